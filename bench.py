@@ -1,0 +1,181 @@
+"""Benchmark of the T-MAE pre-training hot path on MI355X (contract: see the task statement / DESIGN.md).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one full pre-training iteration (VFE -> Siamese SST encoder -> masking -> WCA -> dense decoder ->
+Chamfer -> backward -> Adam one-cycle) over one batch of synthetic 120k-point ONCE-shape frame pairs, inputs
+resident in HBM.  value = frame-pairs/s of the whole job (all ranks).  Rank 0 prints ONE JSON line carrying the
+`roofline` of the dominant hand-written kernel (timed live with HIP events on the launch stream) and the
+`cpu_baseline` (the oracle timed on this box's host cores on one frame pair).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 't-mae_amd'))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16
+VALU_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch-per-gpu', type=int, default=8)        # OPTIMIZATION.BATCH_SIZE_PER_GPU
+    ap.add_argument('--points', type=int, default=120000)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-points', type=int, default=120000)
+    return ap.parse_args()
+
+
+def kernel_roofline(model, batch, amp_dtype, iters=10):
+    """Times the dominant hand-written kernel of the step (the ragged window attention backward of the stage-1
+    previous-frame layers) standalone with HIP events on torch's current stream -- the stream the C ABI launches
+    on -- and prices it by its ALGORITHMIC HBM bytes (q,k,v,out,dout read once, dq,dk,dv written once,
+    + the dense index grid)."""
+    from tmae_amd import ops
+    with torch.no_grad():
+        bd = dict(batch)
+        bd = model.vfe(bd)
+        vc = bd['voxel_coords_prev']
+        ind = vc[:, [0, 2, 3]].int().contiguous()
+        bs = int(bd['batch_size'])
+        grid = ops.index_grid(ind, bs, 468, 468)
+    m, d, H = ind.shape[0], 128, 8
+    dt = amp_dtype or torch.float32
+    es = 2 if dt == torch.bfloat16 else 4
+    qk = torch.randn(m, 2 * d, device=ind.device, dtype=dt).requires_grad_(True)
+    v = torch.randn(m, d, device=ind.device, dtype=dt).requires_grad_(True)
+    tau = torch.ones(1, 1, 1, device=ind.device, requires_grad=True)
+    out = ops.win_attn(qk, v, None, tau, grid, grid, H, bs, 468, 468, False, 0.01)
+    g = torch.randn_like(out)
+    out.backward(g, retain_graph=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        out.backward(g, retain_graph=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    bytes_alg = m * d * es * (3 + 1 + 1 + 3) + m * H * 4 + bs * 468 * 468 * 4
+    achieved = bytes_alg / (ms * 1e-3) / 1e9
+    return {'kernel': 'win_attn_bwd_kernel (stage-1, previous frame)', 'bound': 'hbm', 'achieved': round(achieved, 2),
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': int(m)}
+
+
+def cpu_baseline(n_points):
+    """The oracle (oracle/tmae_oracle.py, a CPU restatement pinned against the reference) timed on this box's
+    host cores: forward + backward of ONE frame pair, fp32, all cores."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import tmae_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.default_model_cfg(3)
+    P = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=0).items()}
+    pts, prv = O.synth_frame_pair(n_points, 1, seed=0)
+    vox = O.voxelize(pts, cfg['point_cloud_range'], cfg['voxel_size'], cfg['grid_size'])
+    noise = np.random.default_rng(0).random(vox['voxel_coords'].shape[0]).astype(np.float32)
+    t0 = time.perf_counter()
+    loss = O.forward_loss(P, pts, prv, noise, 1, cfg)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {'value': round(1.0 / dt, 5), 'unit': 'frame-pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'1 frame pair of {n_points} pts/frame, forward+backward (no optimizer), fp32, {dt:.1f} s'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl')          # RCCL over xGMI
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    from pcdet.models import model_fn_decorator
+    from tmae_amd.train import (SyntheticTemporalDataset, build_model_from_cfg, build_optimizer, build_scheduler,
+                                train_one_step, wrap_ddp)
+    cfg = cfg_from_yaml_file(os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae_ssl.yaml'), EasyDict())
+    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=args.points,
+                                  batch_size=args.batch_per_gpu, rank=rank)
+    torch.manual_seed(0)
+    model = build_model_from_cfg(cfg, ds).to(dev)
+    model.train()
+    ddp = wrap_ddp(model, local_rank)
+    opt = build_optimizer(model, cfg.OPTIMIZATION)
+    sched, _ = build_scheduler(opt, 1000, cfg.OPTIMIZATION.NUM_EPOCHS, -1, cfg.OPTIMIZATION)
+    model_func = model_fn_decorator()
+    amp = torch.bfloat16 if args.dtype == 'bf16' else None
+
+    # synthetic batches, uploaded before the timed region (distinct scans, cycled)
+    nb = min(args.steps + args.warmup, 4)
+    batches = []
+    for i in range(nb):
+        b = ds.batch(i)
+        batches.append({'points': torch.from_numpy(b['points']).to(dev), 'points_prev': torch.from_numpy(b['points_prev']).to(dev),
+                        'batch_size': b['batch_size']})
+
+    def step(i):
+        return train_one_step(ddp, opt, sched, dict(batches[i % nb]), i, model_func, amp_dtype=amp)[0]
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    loss_val = float(loss.detach())
+    assert np.isfinite(loss_val), 'non-finite loss in the timed region'
+
+    if rank == 0:
+        pairs = args.batch_per_gpu * world * args.steps
+        line = {
+            'metric': 'frame-pairs/sec T-MAE pretrain, 120k-pt ONCE scans', 'value': round(pairs / elapsed, 4),
+            'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'configs[1]: ONCE-shape synthetic {args.points}-pt frame-pairs, full 3-stage SST '
+                                   f'encoder + temporal cross-attn + decoder + Chamfer, fwd+bwd+Adam one-cycle',
+                       'batch_per_gpu': args.batch_per_gpu, 'global_batch': args.batch_per_gpu * world,
+                       'parallelism': f'dp{world}', 'grid': '468x468x1', 'final_loss': round(loss_val, 5)},
+        }
+        line['roofline'] = kernel_roofline(model, dict(batches[0]), amp)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.cpu_points)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

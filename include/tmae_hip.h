@@ -1,0 +1,211 @@
+/*
+ * tmae_hip.h -- C ABI of libtmae_hip.so: the MI355X (gfx950) operators of the T-MAE
+ * pre-training hot path.  This is the drop-in boundary (level B4): these
+ * entry points replace what the reference reaches through
+ *   - its in-tree pybind module  sst_ops_cuda   (pcdet/ops/sst_ops/src/sst_ops_api.cpp:6-9)
+ *   - torch_scatter               (pcdet/models/backbones_3d/vfe/temporal_dyn_vfe.py:85,113)
+ *   - torch.unique(dim=0)         (temporal_dyn_vfe.py:72)
+ *   - spconv.pytorch              (pcdet/utils/spconv_utils.py:37-56, SiamWCA_MAE.py:187-193,235)
+ *   - pytorch3d.loss              (pcdet/models/backbones_3d/SiamWCA_MAE.py:163)
+ *   - the padded torch.bmm attention of cosine_msa.py:114-176 + sst_utils.py:118-192
+ *
+ * Conventions (all functions):
+ *   - plain C: device pointers, sizes, one hipStream_t (passed as void*); no torch types.
+ *   - the CALLER owns every buffer (outputs and workspace); nothing is allocated,
+ *     freed or synchronised inside; kernels are enqueued on `stream` and the call returns.
+ *   - return 0 on success, <0 for a bad argument (TMAE_E*), >0 = hipError_t of the launch.
+ *   - `dtype`: 0 = float32, 1 = bfloat16 for feature tensors; index tensors are int32
+ *     unless the name says i64 (the int64 ones mirror the reference's batch_dict keys).
+ *   - thread-safe for distinct streams + distinct workspaces.
+ */
+#ifndef TMAE_HIP_H
+#define TMAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMAE_OK 0
+#define TMAE_EARG (-1)   /* null pointer / negative size / unsupported shape */
+#define TMAE_EWS (-2)    /* workspace too small */
+#define TMAE_EDTYPE (-3) /* unsupported dtype */
+
+#define TMAE_F32 0
+#define TMAE_BF16 1
+
+/* library identification; returns ABI version (bumped on any signature change). */
+int tmae_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * A1  dynamic voxelisation.   Replaces get_in_range_mask (pcdet/utils/common_utils.py:66-76)
+ * + boolean compaction + torch.unique(dim=0, return_inverse) (temporal_dyn_vfe.py:67-72).
+ * points [n,5] f32 rows (b,x,y,z,i).  Outputs sized for the worst case n / n_cells:
+ *   points_out [n,5], point_coords_i64 [n,4] (b,z,y,x), inverse_i64 [n], voxel_coords_i64 [n,4]
+ *   (lexicographically sorted (b,z,y,x), exactly what unique(dim=0) yields),
+ *   counts [2+batch] device int32: {n_kept, n_voxels, voxels of sample 0, 1, ...}.
+ * Coordinates use IEEE fp32 subtract + divide and truncation toward zero (bit-exact). */
+size_t tmae_voxelize_workspace(int64_t n, int batch, int gx, int gy, int gz);
+int tmae_voxelize(const float* points, int64_t n, int batch,
+                  float rmin_x, float rmin_y, float rmin_z, float vs_x, float vs_y, float vs_z,
+                  int gx, int gy, int gz,
+                  float* points_out, int64_t* point_coords_i64, int64_t* inverse_i64,
+                  int64_t* voxel_coords_i64, int32_t* counts,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* CSR of points per voxel in ascending point order (stable): perm [n] point ids grouped by
+ * voxel, offsets [m+1].  Canonical form of the atomic order in sst_ops_gpu.cu:14-28. */
+size_t tmae_segment_csr_workspace(int64_t n, int64_t m);
+int tmae_segment_csr(const int64_t* inverse_i64, int64_t n, int64_t m,
+                     int32_t* perm, int32_t* offsets, void* ws, size_t ws_bytes, void* stream);
+
+/* A5  sst_ops.get_inner_win_inds (pcdet/ops/sst_ops/sst_ops_utils.py:5-12 ->
+ * sst_ops_gpu.cu:14-20): running index of each element inside its group; canonical =
+ * stable rank in element order.  group ids in [0, num_groups). */
+size_t tmae_ingroup_rank_workspace(int64_t n, int64_t num_groups);
+int tmae_ingroup_rank(const int64_t* group_i64, int64_t n, int64_t num_groups, int64_t* out_i64,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* A2  fused voxel mean (torch_scatter.scatter mean, temporal_dyn_vfe.py:85) + the 10 point
+ * features [f_center(3) | x y z i | f_cluster(3)] (temporal_dyn_vfe.py:88-109).
+ * points [n,5] (kept points), point_coords_i64 [n,4], inverse [n]; CSR from tmae_segment_csr.
+ * Outputs voxel_mean [m,4] f32, feats [n,10] f32. */
+int tmae_vfe_point_features(const float* points, const int64_t* point_coords_i64,
+                            const int64_t* inverse_i64, const int32_t* perm, const int32_t* offsets,
+                            int64_t n, int64_t m,
+                            float rmin_x, float rmin_y, float rmin_z, float vs_x, float vs_y, float vs_z,
+                            float* voxel_mean, float* feats, void* stream);
+
+/* torch_scatter.scatter_max (temporal_dyn_vfe.py:113): out[v,c] = max over the voxel's points,
+ * argmax[v,c] = first point (ascending id) attaining it.  x [n,c]; backward routes the
+ * gradient to the argmax rows (dx fully written, no pre-zeroing needed). */
+int tmae_segment_max_fwd(const void* x, int dtype, int64_t n, int64_t m, int c,
+                         const int32_t* perm, const int32_t* offsets,
+                         void* out, int32_t* argmax, void* stream);
+int tmae_segment_max_bwd(const void* dout, int dtype, int64_t n, int64_t m, int c,
+                         const int64_t* inverse_i64, const int32_t* argmax, void* dx, void* stream);
+
+/* A12  sst_ops.group_inner_inds (sst_ops_utils.py:15-27 -> sst_ops_gpu.cu:22-39) fused with the
+ * target normalisation of SiamWCA_MAE.target_assigner (SiamWCA_MAE.py:134-141):
+ * group_inds_i64 [m,k] = first k point ids per voxel (point order), cyclic repeat when fewer;
+ * gt [m,k,3] = xyz[group_inds] - voxel centre ((coord+0.5)*vs+rmin, common_utils.py:130-145). */
+int tmae_group_points(const float* points, const int64_t* voxel_coords_i64,
+                      const int32_t* perm, const int32_t* offsets, int64_t m, int k,
+                      float rmin_x, float rmin_y, float rmin_z, float vs_x, float vs_y, float vs_z,
+                      int64_t* group_inds_i64, float* gt, void* stream);
+
+/* A3  random masking with injected noise (common_utils.py:49-63, SiamWCA_MAE.py:166-182).
+ * noise [m] f32 >= 0 in voxel order, sample_offsets [batch+1] device int32 (voxel rows are
+ * grouped by sample).  keep the int(L*keep_frac) smallest-noise voxels of each sample
+ * (ties by lower index, = stable argsort).  mask [m] f32 (1 = removed),
+ * vis_index [m] int32: compacted ids of kept voxels (first n_vis entries), n_vis device int32. */
+size_t tmae_random_mask_workspace(int64_t m, int batch);
+int tmae_random_mask(const float* noise, const int32_t* sample_offsets, int64_t m, int batch,
+                     double keep_frac, float* mask, int32_t* vis_index, int32_t* n_vis,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* Dense index grid of a sparse tensor: grid [batch*ny*nx] int32 = row id or -1.
+ * indices [m,3] int32 (b,y,x) (the spconv SparseConvTensor.indices layout, SiamWCA_MAE.py:187-193). */
+int tmae_index_grid(const int32_t* indices, int64_t m, int batch, int ny, int nx,
+                    int32_t* grid, void* stream);
+
+/* A4/A10  window partition + region batching (SSTInputLayer.forward spt_backbone.py:137-184;
+ * get_window_coors sst_utils.py:6-58; drop_single_shift spt_backbone.py:47-71;
+ * get_flat2win_inds sst_utils.py:79-107; joint two-frame variant
+ * SSTInputLayer_Temporal.drop_single_shift_ref_to_prv SiamWCA.py:65-140).
+ * grid = dense index grid of this frame, grid_other = the other frame's grid or NULL
+ * (single-frame).  do_shift 0: windows offset by a full window, 1: by half (sst_utils.py:29-36).
+ * levels: n_levels rows {max_tokens, lower, upper}.  Per-voxel outputs [m]:
+ *   batch_win_inds_i64, coors_in_win_i64 [m,3] (z,y,x), inner_i32 (stable rank in window),
+ *   level_i32, keep_u8, flat2win_i64 (= rank_of_window_in_level*max_tokens + inner; -1 if dropped).
+ *   win_per_level [n_levels] device int32 = number of kept windows per level. */
+size_t tmae_window_bucket_workspace(int batch, int ny, int nx, int wy, int wx, int n_levels);
+int tmae_window_bucket(const int32_t* indices, int64_t m, const int32_t* grid, const int32_t* grid_other,
+                       int batch, int ny, int nx, int wy, int wx, int do_shift,
+                       const int32_t* levels_host, int n_levels,
+                       int64_t* batch_win_inds_i64, int64_t* coors_in_win_i64, int32_t* inner_i32,
+                       int32_t* level_i32, uint8_t* keep_u8, int64_t* flat2win_i64,
+                       int32_t* win_per_level, void* ws, size_t ws_bytes, void* stream);
+
+/* A6+A7  ragged window cosine attention (replaces flat2window/window2flat sst_utils.py:118-192 and
+ * _scaled_cosine_attention cosine_msa.py:114-176).  One workgroup per (window, head group); the
+ * window's tokens are read straight from the dense index grids, so there is no padding and no
+ * per-level loop.  q [mq, ldq], k/v [mk, ldk/ldv] already projected (heads contiguous: head h =
+ * columns [h*dh, (h+1)*dh)); per-head L2 normalisation (eps 1e-12), logits / max(tau, tau_min),
+ * softmax over the window's keys, P.V.  Self-attention: grid_k == grid_q.  Cross-attention
+ * (wca_block.py:26-67): grid_q = current frame, grid_k = previous frame; query tokens whose
+ * window has no key get a zero row (they are not "kept", wca_block.py:93-96).
+ * lse [mq, nhead] f32 is saved for the backward.  dh in {16, 32}; 8x8 windows. */
+int tmae_win_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                      int dtype, int64_t mq, int64_t mk, int nhead, int dh,
+                      const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx,
+                      int do_shift, const float* tau, float tau_min,
+                      void* out, int64_t ldo, float* lse, void* stream);
+/* Backward.  dq/dk/dv are fully written for every token that sits in an attended window and
+ * zero-filled otherwise.  dtau_partial [n_windows*nhead/heads_per_block] f32 partial sums of
+ * d loss / d max(tau,tau_min) (summed by the caller; n entries = tmae_win_attn_num_blocks). */
+int64_t tmae_win_attn_num_blocks(int batch, int ny, int nx, int nhead, int dh);
+int tmae_win_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                      const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
+                      int dtype, int64_t mq, int64_t mk, int nhead, int dh,
+                      const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx,
+                      int do_shift, const float* tau, float tau_min,
+                      void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                      float* dtau_partial, void* stream);
+
+/* SSTInputLayer.get_pos_embed (spt_backbone.py:186-224) fused with the q = k = x + pos add of
+ * WindowAttention.forward (sst_basic_block.py:41-44): out[r,:] = x[r,:] + pos_table[cell(r),:], where
+ * cell(r) = ((y+sy)%wy)*wx + (x+sx)%wx is the token's position inside its (shifted) window and
+ * pos_table [wy*wx, d] f32 holds the sin/cos embedding of every in-window position (built once per
+ * width by the host from the reference formula).  indices [m,3] int32 (b,y,x). */
+int tmae_add_pos_embed(const void* x, int dtype, int64_t m, int d, const int32_t* indices,
+                       int wy, int wx, int do_shift, const float* pos_table, void* out, void* stream);
+
+/* A9  2-D sparse convolution rulebook (spconv SparseConv2d k3 s2 p1 / SubMConv2d k3;
+ * spt_backbone.py:280-304).
+ * down_outputs: active output sites of the strided conv, lexicographic (b,y,x):
+ *   out_grid [batch*oy*ox] int32 row ids (-1 inactive), out_indices [<=batch*oy*ox,3], n_out device. */
+size_t tmae_spconv_down_outputs_workspace(int batch, int oy, int ox);
+int tmae_spconv_down_outputs(const int32_t* grid_in, int batch, int ny, int nx, int oy, int ox,
+                             int32_t* out_grid, int32_t* out_indices, int32_t* n_out,
+                             void* ws, size_t ws_bytes, void* stream);
+/* neighbour tables.  nbr [m_out,9]: input row read by output o at tap t=ky*3+kx (or -1):
+ * input site = (oy*stride-1+ky, ox*stride-1+kx).  nbr_t [m_in,9]: output row that reads input i
+ * at tap t (or -1) -- the transposed rulebook used by the data gradient. */
+int tmae_spconv_neighbors(const int32_t* out_indices, int64_t m_out, const int32_t* grid_in,
+                          int batch, int ny, int nx, int stride, int32_t* nbr, void* stream);
+int tmae_spconv_neighbors_t(const int32_t* in_indices, int64_t m_in, const int32_t* grid_out,
+                            int batch, int oy, int ox, int stride, int32_t* nbr_t, void* stream);
+/* gather-GEMM form: cols [m_out, 9*c] = rows of feat selected by nbr (zeros where -1), to be
+ * multiplied by the [cout, 9*c] view of the spconv-2 weight [cout,3,3,cin]; and its adjoint
+ * din [m_in, c] = sum_t dcols[nbr_t[i,t], t*c:(t+1)*c]. */
+int tmae_spconv_gather(const void* feat, int dtype, int64_t m_in, int c, const int32_t* nbr,
+                       int64_t m_out, void* cols, void* stream);
+int tmae_spconv_gather_t(const void* dcols, int dtype, int64_t m_out, int c, const int32_t* nbr_t,
+                         int64_t m_in, void* din, void* stream);
+
+/* SparseConvTensor.dense() (SiamWCA_MAE.py:235) in channels-last: out [batch,ny,nx,c], zeros at
+ * inactive sites; and its adjoint / the decoder-feature gather (SiamWCA_MAE.py:308-312):
+ * rows [m,c] = dense[b,y,x,:]. */
+int tmae_sparse_to_dense(const void* feat, int dtype, int64_t m, int c, const int32_t* grid,
+                         int batch, int ny, int nx, void* out, void* stream);
+int tmae_dense_gather(const void* dense, int dtype, int batch, int ny, int nx, int c,
+                      const int32_t* indices, int64_t m, void* rows, void* stream);
+
+/* A13  pytorch3d.loss.chamfer_distance(pred, gt, weights) (SiamWCA_MAE.py:154-164; v0.7.1 defaults):
+ * per voxel: cx = mean_i min_j |p_i-g_j|^2, cy = mean_j min_i |g_j-p_i|^2.  One wavefront per voxel,
+ * one gt point per lane (ng <= 64, np <= 64).  per_voxel [m] = w*(cx+cy); idx_x [m,np] / idx_y [m,ng]
+ * int8 nearest ids saved for the backward.  loss = sum(per_voxel)/sum(w) is finished by the caller. */
+int tmae_chamfer_fwd(const float* pred, const float* gt, const float* weights, int64_t m, int np, int ng,
+                     float* per_voxel, int8_t* idx_x, int8_t* idx_y, void* stream);
+/* dpred [m,np,3] = scale[0] * w * (2/np (p_i - g_nn(i)) + 2/ng sum_{j: nn(j)=i} (p_i - g_j)). */
+int tmae_chamfer_bwd(const float* pred, const float* gt, const float* weights, const int8_t* idx_x,
+                     const int8_t* idx_y, const float* scale, int64_t m, int np, int ng,
+                     float* dpred, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMAE_HIP_H */

@@ -89,7 +89,15 @@ def main():
     ref = R.load_reference()
     ocfg = O.default_model_cfg(3)
     V, B, cfg = R.build_reference_model(3, seed=0)
-    perturb([V, B], seed=1, tau=0.3)
+    # weights come from the oracle's seeded initialiser so tests can regenerate them without the reference
+    P3 = O.init_params(ocfg, seed=3)
+    for n_, t_ in P3.items():
+        if n_.endswith('tau'):
+            t_.fill_(0.3)
+    mk_ = V.load_state_dict({k[4:]: v for k, v in P3.items() if k.startswith('vfe.')}, strict=False)
+    assert not mk_.unexpected_keys
+    mk_ = B.load_state_dict({k[12:]: v for k, v in P3.items() if k.startswith('backbone_3d.')}, strict=False)
+    assert not mk_.unexpected_keys and all('running' in k or 'num_batches' in k for k in mk_.missing_keys)
     V.train(), B.train()
 
     # ---- state_dict contract (names + shapes), SURVEY 8b-B1
@@ -296,7 +304,7 @@ def main():
     check('enc dx', xo.grad, x.grad, 1e-3)
     gW = blk.encoder_blocks[1].encoder_list[1].win_attn.self_attn.in_proj_weight.grad
     check('enc dW', po['backbone_3d.sst_blocks.0.encoder_blocks.1.encoder_list.1.win_attn.self_attn.in_proj_weight'].grad, gW, 1e-3)
-    f8 = dict(coords=c, x=x.detach(), gout=gout, y=y.detach(), dx=x.grad, dW_last_in_proj=gW,
+    f8 = dict(param_seed=3, tau=np.float32(0.3), coords=c, x=x.detach(), gout=gout, y=y.detach(), dx=x.grad, dW_last_in_proj=gW,
               dtau_first=blk.encoder_blocks[0].encoder_list[0].win_attn.self_attn.tau.grad)
     B.zero_grad()
     # WCA block (cross): cur = subset

@@ -1,0 +1,74 @@
+"""Build libtmae_hip.so (gfx950) in-tree: hipcc per .hip file, then one link.
+
+    python t-mae_amd/build.py [--force] [--verbose]
+
+The shared object lands in t-mae_amd/tmae_amd/lib/ (git-ignored, but it travels with the tree to the
+GPU box).  hipcc cross-compiles gfx950 without a GPU.
+"""
+import argparse
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, 'build')
+LIBDIR = os.path.join(HERE, 'tmae_amd', 'lib')
+LIB = os.path.join(LIBDIR, 'libtmae_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
+         '-fvisibility=default', '-I', os.path.join(HERE, '..', 'include')]
+
+
+def _newer(src, dst, extra=()):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(s) > t for s in (src,) + tuple(extra))
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+    hdrs = tuple(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + (
+        os.path.join(HERE, '..', 'include', 'tmae_hip.h'),)
+    jobs = []
+    for s in srcs:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + '.o')
+        if force or _newer(src, obj, hdrs):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        if verbose:
+            cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return src, r.returncode, r.stdout + r.stderr
+
+    failed = False
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        for src, rc, out in ex.map(cc, jobs):
+            if rc != 0 or verbose:
+                print(f'--- {os.path.basename(src)} (rc={rc})\n{out}', file=sys.stderr)
+            failed |= rc != 0
+    if failed:
+        raise RuntimeError('hipcc failed')
+    objs = [os.path.join(OBJ, s[:-4] + '.o') for s in srcs]
+    if jobs or force or not os.path.exists(LIB):
+        r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs,
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stdout + r.stderr, file=sys.stderr)
+            raise RuntimeError('link failed')
+    return LIB
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--force', action='store_true')
+    ap.add_argument('--verbose', action='store_true')
+    a = ap.parse_args()
+    print(build(a.force, a.verbose))

@@ -1,0 +1,109 @@
+// A13: Chamfer distance between the predicted (<=64) and real (<=64) points of every voxel.
+// One wavefront per voxel: lane j holds gt point j; the 16 predictions are broadcast one at a time, the
+// pred->gt minimum is a wave reduction, the gt->pred minimum a per-lane running minimum.  Brute force,
+// everything in registers; HBM traffic is the algorithmic minimum (each point read once).
+#include "common.h"
+
+__device__ __forceinline__ void wave_argmin(float& d, int& idx) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float od = __shfl_xor(d, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (od < d || (od == d && oi < idx)) { d = od; idx = oi; }
+  }
+}
+
+__global__ __launch_bounds__(256) void chamfer_fwd_kernel(const float* __restrict__ pred,
+                                                         const float* __restrict__ gt,
+                                                         const float* __restrict__ weights, int64_t m, int np,
+                                                         int ng, float* __restrict__ per_voxel,
+                                                         int8_t* __restrict__ idx_x, int8_t* __restrict__ idx_y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= m) return;
+  const float w = weights[v];
+  if (w == 0.f) {                       // unmasked voxel: contributes nothing (weights = mask, SiamWCA_MAE.py:163)
+    if (lane == 0) per_voxel[v] = 0.f;
+    return;
+  }
+  float gx = 0.f, gy = 0.f, gz = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+  if (lane < ng) { const float* g = gt + (v * ng + lane) * 3; gx = g[0]; gy = g[1]; gz = g[2]; }
+  if (lane < np) { const float* p = pred + (v * np + lane) * 3; px = p[0]; py = p[1]; pz = p[2]; }
+  float best = INFINITY;
+  int besti = 0;
+  float cx_sum = 0.f;
+  for (int i = 0; i < np; ++i) {
+    const float ax = __shfl(px, i, 64), ay = __shfl(py, i, 64), az = __shfl(pz, i, 64);
+    const float dx = ax - gx, dy = ay - gy, dz = az - gz;
+    float d = (lane < ng) ? (dx * dx + dy * dy + dz * dz) : INFINITY;
+    if (d < best) { best = d; besti = i; }
+    int j = lane;
+    wave_argmin(d, j);
+    cx_sum += d;
+    if (lane == i) idx_x[v * np + i] = (int8_t)j;
+  }
+  if (lane < ng) idx_y[v * ng + lane] = (int8_t)besti;
+  const float cy_sum = wave_sum(lane < ng ? best : 0.f);
+  if (lane == 0) per_voxel[v] = w * (cx_sum / (float)np + cy_sum / (float)ng);
+}
+
+__global__ __launch_bounds__(256) void chamfer_bwd_kernel(const float* __restrict__ pred,
+                                                         const float* __restrict__ gt,
+                                                         const float* __restrict__ weights,
+                                                         const int8_t* __restrict__ idx_x,
+                                                         const int8_t* __restrict__ idx_y,
+                                                         const float* __restrict__ scale, int64_t m, int np, int ng,
+                                                         float* __restrict__ dpred) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= m) return;
+  const float w = weights[v];
+  if (w == 0.f) {
+    if (lane < np) { float* d = dpred + (v * np + lane) * 3; d[0] = 0.f; d[1] = 0.f; d[2] = 0.f; }
+    return;
+  }
+  float gx = 0.f, gy = 0.f, gz = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+  int iy = -1, ix = 0;
+  if (lane < ng) { const float* g = gt + (v * ng + lane) * 3; gx = g[0]; gy = g[1]; gz = g[2]; iy = idx_y[v * ng + lane]; }
+  if (lane < np) { const float* p = pred + (v * np + lane) * 3; px = p[0]; py = p[1]; pz = p[2]; ix = idx_x[v * np + lane]; }
+  // pred -> gt term: 2/np (p_i - g_nn(i))
+  const float nx_ = __shfl(gx, ix, 64), ny_ = __shfl(gy, ix, 64), nz_ = __shfl(gz, ix, 64);
+  const float a = 2.0f / (float)np, b = 2.0f / (float)ng;
+  float ax = a * (px - nx_), ay = a * (py - ny_), az = a * (pz - nz_);
+  // gt -> pred term: 2/ng sum_{j: nn(j) = i} (p_i - g_j)
+  for (int j = 0; j < ng; ++j) {
+    const int tgt = __shfl(iy, j, 64);
+    const float jx = __shfl(gx, j, 64), jy = __shfl(gy, j, 64), jz = __shfl(gz, j, 64);
+    if (tgt == lane) { ax += b * (px - jx); ay += b * (py - jy); az += b * (pz - jz); }
+  }
+  if (lane < np) {
+    const float s = scale[0] * w;
+    float* d = dpred + (v * np + lane) * 3;
+    d[0] = s * ax; d[1] = s * ay; d[2] = s * az;
+  }
+}
+
+int tmae_chamfer_fwd(const float* pred, const float* gt, const float* weights, int64_t m, int np, int ng,
+                     float* per_voxel, int8_t* idx_x, int8_t* idx_y, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m < 0 || np <= 0 || np > 64 || ng <= 0 || ng > 64) return TMAE_EARG;
+  if (m == 0) return TMAE_OK;
+  if (!pred || !gt || !weights || !per_voxel || !idx_x || !idx_y) return TMAE_EARG;
+  hipLaunchKernelGGL(chamfer_fwd_kernel, dim3(tmae_cdiv(m, 4)), dim3(256), 0, stream, pred, gt, weights, m, np, ng,
+                     per_voxel, idx_x, idx_y);
+  return tmae_launch_status();
+}
+
+int tmae_chamfer_bwd(const float* pred, const float* gt, const float* weights, const int8_t* idx_x,
+                     const int8_t* idx_y, const float* scale, int64_t m, int np, int ng, float* dpred,
+                     void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m < 0 || np <= 0 || np > 64 || ng <= 0 || ng > 64) return TMAE_EARG;
+  if (m == 0) return TMAE_OK;
+  if (!pred || !gt || !weights || !idx_x || !idx_y || !scale || !dpred) return TMAE_EARG;
+  hipLaunchKernelGGL(chamfer_bwd_kernel, dim3(tmae_cdiv(m, 4)), dim3(256), 0, stream, pred, gt, weights, idx_x, idx_y,
+                     scale, m, np, ng, dpred);
+  return tmae_launch_status();
+}
+
+int tmae_abi_version(void) { return 1; }

@@ -1,0 +1,62 @@
+// Shared helpers for the gfx950 kernels of libtmae_hip.so (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/tmae_hip.h"
+
+#define TMAE_WAVE 64
+
+static inline int tmae_launch_status() { return (int)hipGetLastError(); }
+static inline size_t tmae_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline unsigned tmae_cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// Carves 256-byte aligned sub-buffers out of the caller's workspace.
+struct WsCarver {
+  char* base;
+  size_t size, used;
+  bool ok;
+  WsCarver(void* p, size_t n) : base((char*)p), size(n), used(0), ok(p != nullptr || n == 0) {}
+  template <class T>
+  T* take(size_t count) {
+    size_t bytes = tmae_align(count * sizeof(T));
+    if (!ok || used + bytes > size) { ok = false; return nullptr; }
+    T* r = (T*)(base + used);
+    used += bytes;
+    return r;
+  }
+};
+
+// ---- element type helpers (feature tensors are f32 or bf16; arithmetic is f32) --------------
+template <class T> __device__ __forceinline__ float ld_f(const T* p);
+template <> __device__ __forceinline__ float ld_f<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld_f<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+template <class T> __device__ __forceinline__ void st_f(T* p, float v);
+template <> __device__ __forceinline__ void st_f<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+
+__device__ __forceinline__ float bf16_bits_to_f(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// ---- wave reductions ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- device-wide exclusive scan of int32 (three small launches per level) ----------------------
+// out[i] = sum_{j<i} in[i];  *total (device, optional) = sum of all.  in != out.
+size_t tmae_scan_i32_workspace(int64_t n);
+int tmae_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total, void* ws, size_t ws_bytes,
+                  hipStream_t stream);

@@ -1,0 +1,412 @@
+// A1/A2/A5/A12: dynamic voxelisation, point->voxel CSR, VFE point features, segment max,
+// per-voxel point grouping.  All of these are HBM/latency bound index kernels: one pass over the
+// points with coalesced row reads; uniqueness comes from a dense occupancy grid (the pillar grid is
+// only batch*468*468 cells, L2-resident) + prefix sums instead of a 4-column int64 row sort.
+#include "common.h"
+#include <hipcub/hipcub.hpp>
+
+// ------------------------------------------------------------------------------------------------
+// voxelize
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ pts, int64_t n, int batch,
+                                                     float rx, float ry, float rz, float vx, float vy, float vz,
+                                                     int gx, int gy, int gz, int32_t* __restrict__ flag,
+                                                     int32_t* __restrict__ key) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* p = pts + i * 5;
+  // IEEE fp32 subtract + divide, truncation toward zero (common_utils.py:74); no reciprocal, no fma.
+  float qx = __fdiv_rn(__fsub_rn(p[1], rx), vx);
+  float qy = __fdiv_rn(__fsub_rn(p[2], ry), vy);
+  float qz = __fdiv_rn(__fsub_rn(p[3], rz), vz);
+  float fb = p[0];
+  bool ok = (qx > -1.0f) && (qy > -1.0f) && (qz > -1.0f) && (qx < (float)gx) && (qy < (float)gy) &&
+            (qz < (float)gz) && (fb > -1.0f) && (fb < (float)batch);
+  int k = 0;
+  if (ok) {
+    int cx = (int)qx, cy = (int)qy, cz = (int)qz, b = (int)fb;   // trunc; (-1,0) -> 0 is kept (A-1)
+    k = ((b * gz + cz) * gy + cy) * gx + cx;
+  }
+  flag[i] = ok ? 1 : 0;
+  key[i] = k;
+}
+
+__global__ __launch_bounds__(256) void vox_compact_kernel(const float* __restrict__ pts, int64_t n,
+                                                         const int32_t* __restrict__ flag,
+                                                         const int32_t* __restrict__ pos,
+                                                         const int32_t* __restrict__ key, int gx, int gy, int gz,
+                                                         float* __restrict__ pts_out, int64_t* __restrict__ pc,
+                                                         int32_t* __restrict__ keyc, int32_t* __restrict__ occ) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  const int64_t j = pos[i];
+  const float* p = pts + i * 5;
+  float* o = pts_out + j * 5;
+  o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; o[4] = p[4];
+  const int k = key[i];
+  int cx = k % gx, t = k / gx;
+  int cy = t % gy; t /= gy;
+  int cz = t % gz, b = t / gz;
+  int64_t* c = pc + j * 4;
+  c[0] = b; c[1] = cz; c[2] = cy; c[3] = cx;
+  keyc[j] = k;
+  occ[k] = 1;
+}
+
+__global__ __launch_bounds__(256) void vox_emit_kernel(const int32_t* __restrict__ occ,
+                                                      const int32_t* __restrict__ rank, int64_t cells, int gx,
+                                                      int gy, int gz, int64_t* __restrict__ vc) {
+  int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= cells || !occ[k]) return;
+  int64_t* c = vc + (int64_t)rank[k] * 4;
+  int kk = (int)k;
+  int cx = kk % gx, t = kk / gx;
+  int cy = t % gy; t /= gy;
+  c[0] = t / gz; c[1] = t % gz; c[2] = cy; c[3] = cx;
+}
+
+__global__ __launch_bounds__(256) void vox_inverse_kernel(const int32_t* __restrict__ keyc,
+                                                         const int32_t* __restrict__ rank,
+                                                         const int32_t* __restrict__ counts, int64_t n,
+                                                         int64_t* __restrict__ inverse) {
+  int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n || j >= counts[0]) return;
+  inverse[j] = rank[keyc[j]];
+}
+
+__global__ void vox_counts_kernel(const int32_t* occ, const int32_t* rank, int64_t cells, int batch,
+                                  int cells_per_sample, int32_t* counts) {
+  int b = threadIdx.x;
+  if (b < batch) {
+    int64_t lo = (int64_t)b * cells_per_sample, hi = lo + cells_per_sample;
+    int end = (hi < cells) ? rank[hi] : (rank[cells - 1] + occ[cells - 1]);
+    counts[2 + b] = end - rank[lo];
+  }
+}
+
+size_t tmae_voxelize_workspace(int64_t n, int batch, int gx, int gy, int gz) {
+  int64_t cells = (int64_t)batch * gx * gy * gz;
+  return 4 * tmae_align((size_t)n * 4) + 2 * tmae_align((size_t)cells * 4) + tmae_scan_i32_workspace(n) +
+         tmae_scan_i32_workspace(cells) + 4096;
+}
+
+int tmae_voxelize(const float* points, int64_t n, int batch, float rx, float ry, float rz, float vx, float vy,
+                  float vz, int gx, int gy, int gz, float* points_out, int64_t* point_coords, int64_t* inverse,
+                  int64_t* voxel_coords, int32_t* counts, void* wsp, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || batch <= 0 || gx <= 0 || gy <= 0 || gz <= 0 || !counts) return TMAE_EARG;
+  int64_t cells = (int64_t)batch * gx * gy * gz;
+  if (cells >= (1ll << 31) || n >= (1ll << 31)) return TMAE_EARG;
+  if (n > 0 && (!points || !points_out || !point_coords || !inverse || !voxel_coords)) return TMAE_EARG;
+  WsCarver ws(wsp, ws_bytes);
+  int32_t* flag = ws.take<int32_t>((size_t)n);
+  int32_t* pos = ws.take<int32_t>((size_t)n);
+  int32_t* key = ws.take<int32_t>((size_t)n);
+  int32_t* keyc = ws.take<int32_t>((size_t)n);
+  int32_t* occ = ws.take<int32_t>((size_t)cells);
+  int32_t* rank = ws.take<int32_t>((size_t)cells);
+  size_t s1 = tmae_scan_i32_workspace(n), s2 = tmae_scan_i32_workspace(cells);
+  char* scan1 = ws.take<char>(s1);
+  char* scan2 = ws.take<char>(s2);
+  if (!ws.ok) return TMAE_EWS;
+  hipMemsetAsync(occ, 0, (size_t)cells * 4, stream);
+  if (n > 0)
+    hipLaunchKernelGGL(vox_key_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, points, n, batch, rx, ry, rz,
+                       vx, vy, vz, gx, gy, gz, flag, key);
+  int r = tmae_scan_i32(flag, pos, n, counts + 0, scan1, s1, stream);
+  if (r) return r;
+  if (n > 0)
+    hipLaunchKernelGGL(vox_compact_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, points, n, flag, pos, key,
+                       gx, gy, gz, points_out, point_coords, keyc, occ);
+  r = tmae_scan_i32(occ, rank, cells, counts + 1, scan2, s2, stream);
+  if (r) return r;
+  hipLaunchKernelGGL(vox_emit_kernel, dim3(tmae_cdiv(cells, 256)), dim3(256), 0, stream, occ, rank, cells, gx, gy, gz,
+                     voxel_coords);
+  if (n > 0)
+    hipLaunchKernelGGL(vox_inverse_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, keyc, rank, counts, n,
+                       inverse);
+  hipLaunchKernelGGL(vox_counts_kernel, dim3(1), dim3(tmae_align(batch, 64)), 0, stream, occ, rank, cells, batch,
+                     gx * gy * gz, counts);
+  return tmae_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// point -> group CSR (stable) and in-group rank
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void csr_keys_kernel(const int64_t* __restrict__ g, int64_t n,
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                      int32_t* __restrict__ cnt) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t k = (uint32_t)g[i];
+  keys[i] = k;
+  vals[i] = (uint32_t)i;
+  atomicAdd(cnt + k, 1);   // integer count: deterministic
+}
+
+__global__ __launch_bounds__(256) void copy_u32_i32_kernel(const uint32_t* a, int32_t* b, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) b[i] = (int32_t)a[i];
+}
+
+static int bits_for(int64_t m) {
+  int b = 1;
+  while (b < 32 && (1ll << b) < m) ++b;
+  return b;
+}
+
+static size_t sort_temp_bytes(int64_t n, int bits) {
+  size_t bytes = 0;
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                                    (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, bits,
+                                                    (hipStream_t)0);
+  if (e != hipSuccess || bytes == 0) {
+    (void)hipGetLastError();
+    bytes = (size_t)n * 16 + (1u << 20);   // no device to ask (CPU-only host): generous bound
+  }
+  return bytes;
+}
+
+size_t tmae_segment_csr_workspace(int64_t n, int64_t m) {
+  return 4 * tmae_align((size_t)n * 4) + tmae_align((size_t)(m + 1) * 4) + tmae_scan_i32_workspace(m + 1) +
+         tmae_align(sort_temp_bytes(n, bits_for(m))) + 4096;
+}
+
+// keys_sorted (optional out) receives the sorted group ids
+static int csr_build(const int64_t* g, int64_t n, int64_t m, int32_t* perm, int32_t* offsets, uint32_t** keys_sorted,
+                     void* wsp, size_t ws_bytes, hipStream_t stream) {
+  if (n < 0 || m < 0 || n >= (1ll << 31) || m >= (1ll << 31) || !offsets) return TMAE_EARG;
+  if (n > 0 && (!g || !perm)) return TMAE_EARG;
+  WsCarver ws(wsp, ws_bytes);
+  uint32_t* k_in = ws.take<uint32_t>((size_t)n);
+  uint32_t* k_out = ws.take<uint32_t>((size_t)n);
+  uint32_t* v_in = ws.take<uint32_t>((size_t)n);
+  uint32_t* v_out = ws.take<uint32_t>((size_t)n);
+  int32_t* cnt = ws.take<int32_t>((size_t)m + 1);
+  size_t sb = tmae_scan_i32_workspace(m + 1);
+  char* scanws = ws.take<char>(sb);
+  const int bits = bits_for(m);
+  size_t tb = sort_temp_bytes(n, bits);
+  char* temp = ws.take<char>(tb);
+  if (!ws.ok) return TMAE_EWS;
+  hipMemsetAsync(cnt, 0, (size_t)(m + 1) * 4, stream);
+  if (n > 0) {
+    hipLaunchKernelGGL(csr_keys_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, g, n, k_in, v_in, cnt);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, tb, k_in, k_out, v_in, v_out, (int)n, 0, bits, stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(copy_u32_i32_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, v_out, perm, n);
+  }
+  int r = tmae_scan_i32(cnt, offsets, m + 1, nullptr, scanws, sb, stream);   // offsets[m] = n
+  if (r) return r;
+  if (keys_sorted) *keys_sorted = k_out;
+  return tmae_launch_status();
+}
+
+int tmae_segment_csr(const int64_t* inverse, int64_t n, int64_t m, int32_t* perm, int32_t* offsets, void* ws,
+                     size_t ws_bytes, void* stream) {
+  return csr_build(inverse, n, m, perm, offsets, nullptr, ws, ws_bytes, (hipStream_t)stream);
+}
+
+__global__ __launch_bounds__(256) void rank_emit_kernel(const uint32_t* __restrict__ keys_sorted,
+                                                       const int32_t* __restrict__ perm,
+                                                       const int32_t* __restrict__ offsets, int64_t n,
+                                                       int64_t* __restrict__ out) {
+  int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  out[perm[j]] = j - offsets[keys_sorted[j]];
+}
+
+size_t tmae_ingroup_rank_workspace(int64_t n, int64_t num_groups) {
+  return tmae_segment_csr_workspace(n, num_groups) + tmae_align((size_t)n * 4) +
+         tmae_align((size_t)(num_groups + 1) * 4);
+}
+
+int tmae_ingroup_rank(const int64_t* group, int64_t n, int64_t num_groups, int64_t* out, void* wsp, size_t ws_bytes,
+                      void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || num_groups < 0 || (n > 0 && (!group || !out))) return TMAE_EARG;
+  if (n == 0) return TMAE_OK;
+  WsCarver ws(wsp, ws_bytes);
+  int32_t* perm = ws.take<int32_t>((size_t)n);
+  int32_t* offsets = ws.take<int32_t>((size_t)num_groups + 1);
+  if (!ws.ok) return TMAE_EWS;
+  uint32_t* ks = nullptr;
+  int r = csr_build(group, n, num_groups, perm, offsets, &ks, ws.base + ws.used, ws.size - ws.used, stream);
+  if (r) return r;
+  hipLaunchKernelGGL(rank_emit_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, ks, perm, offsets, n, out);
+  return tmae_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// VFE point features
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict__ pts,
+                                                        const int32_t* __restrict__ perm,
+                                                        const int32_t* __restrict__ offsets, int64_t m,
+                                                        float* __restrict__ mean) {
+  int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= m) return;
+  const int lo = offsets[v], hi = offsets[v + 1];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int j = lo; j < hi; ++j) {            // ascending point id: deterministic sum
+    const float* p = pts + (int64_t)perm[j] * 5;
+    s0 += p[1]; s1 += p[2]; s2 += p[3]; s3 += p[4];
+  }
+  const float c = (float)max(hi - lo, 1);
+  float* o = mean + v * 4;
+  o[0] = __fdiv_rn(s0, c); o[1] = __fdiv_rn(s1, c); o[2] = __fdiv_rn(s2, c); o[3] = __fdiv_rn(s3, c);
+}
+
+__global__ __launch_bounds__(256) void point_feat_kernel(const float* __restrict__ pts,
+                                                        const int64_t* __restrict__ pc,
+                                                        const int64_t* __restrict__ inv,
+                                                        const float* __restrict__ mean, int64_t n, float rx, float ry,
+                                                        float rz, float vx, float vy, float vz,
+                                                        float* __restrict__ feats) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* p = pts + i * 5;
+  const int64_t* c = pc + i * 4;
+  const float* mu = mean + inv[i] * 4;
+  const float x = p[1], y = p[2], z = p[3];
+  // f_center = p - ((coord + 0.5) * vs + rmin): separate fp32 roundings as in temporal_dyn_vfe.py:93-96
+  const float ccx = __fadd_rn(__fmul_rn(__fadd_rn((float)c[3], 0.5f), vx), rx);
+  const float ccy = __fadd_rn(__fmul_rn(__fadd_rn((float)c[2], 0.5f), vy), ry);
+  const float ccz = __fadd_rn(__fmul_rn(__fadd_rn((float)c[1], 0.5f), vz), rz);
+  float* f = feats + i * 10;
+  f[0] = x - ccx; f[1] = y - ccy; f[2] = z - ccz;
+  f[3] = x; f[4] = y; f[5] = z; f[6] = p[4];
+  f[7] = x - mu[0]; f[8] = y - mu[1]; f[9] = z - mu[2];
+}
+
+int tmae_vfe_point_features(const float* points, const int64_t* pc, const int64_t* inverse, const int32_t* perm,
+                            const int32_t* offsets, int64_t n, int64_t m, float rx, float ry, float rz, float vx,
+                            float vy, float vz, float* voxel_mean, float* feats, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || m < 0) return TMAE_EARG;
+  if (n == 0 || m == 0) return TMAE_OK;
+  if (!points || !pc || !inverse || !perm || !offsets || !voxel_mean || !feats) return TMAE_EARG;
+  hipLaunchKernelGGL(voxel_mean_kernel, dim3(tmae_cdiv(m, 256)), dim3(256), 0, stream, points, perm, offsets, m,
+                     voxel_mean);
+  hipLaunchKernelGGL(point_feat_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, points, pc, inverse,
+                     voxel_mean, n, rx, ry, rz, vx, vy, vz, feats);
+  return tmae_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// segment max (one wavefront per voxel, channels across lanes -> coalesced row reads)
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void segmax_fwd_kernel(const T* __restrict__ x, int64_t m, int c,
+                                                        const int32_t* __restrict__ perm,
+                                                        const int32_t* __restrict__ offsets, T* __restrict__ out,
+                                                        int32_t* __restrict__ argmax) {
+  const int lane = threadIdx.x & 63;
+  int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= m) return;
+  const int lo = offsets[v], hi = offsets[v + 1];
+  for (int ch = lane; ch < c; ch += 64) {
+    float best = -INFINITY;
+    int arg = -1;
+    for (int j = lo; j < hi; ++j) {
+      const int row = perm[j];
+      const float val = ld_f<T>(x + (int64_t)row * c + ch);
+      if (val > best || arg < 0) { best = val; arg = row; }
+    }
+    if (arg < 0) best = 0.f;
+    st_f<T>(out + v * c + ch, best);
+    argmax[v * c + ch] = arg;
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void segmax_bwd_kernel(const T* __restrict__ dout, int64_t n, int c,
+                                                        const int64_t* __restrict__ inv,
+                                                        const int32_t* __restrict__ argmax, T* __restrict__ dx) {
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * c) return;
+  const int64_t p = e / c;
+  const int ch = (int)(e - p * c);
+  const int64_t v = inv[p];
+  const bool hit = argmax[v * c + ch] == (int)p;
+  if (hit) dx[e] = dout[v * c + ch];
+  else st_f<T>(dx + e, 0.f);
+}
+
+int tmae_segment_max_fwd(const void* x, int dtype, int64_t n, int64_t m, int c, const int32_t* perm,
+                         const int32_t* offsets, void* out, int32_t* argmax, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || m < 0 || c <= 0) return TMAE_EARG;
+  if (m == 0) return TMAE_OK;
+  if (!x || !perm || !offsets || !out || !argmax) return TMAE_EARG;
+  dim3 grid(tmae_cdiv(m, 4)), block(256);
+  if (dtype == TMAE_F32)
+    hipLaunchKernelGGL(segmax_fwd_kernel<float>, grid, block, 0, stream, (const float*)x, m, c, perm, offsets,
+                       (float*)out, argmax);
+  else if (dtype == TMAE_BF16)
+    hipLaunchKernelGGL(segmax_fwd_kernel<__hip_bfloat16>, grid, block, 0, stream, (const __hip_bfloat16*)x, m, c,
+                       perm, offsets, (__hip_bfloat16*)out, argmax);
+  else
+    return TMAE_EDTYPE;
+  return tmae_launch_status();
+}
+
+int tmae_segment_max_bwd(const void* dout, int dtype, int64_t n, int64_t m, int c, const int64_t* inverse,
+                         const int32_t* argmax, void* dx, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || m < 0 || c <= 0) return TMAE_EARG;
+  if (n == 0) return TMAE_OK;
+  if (!dout || !inverse || !argmax || !dx) return TMAE_EARG;
+  dim3 grid(tmae_cdiv(n * c, 256)), block(256);
+  if (dtype == TMAE_F32)
+    hipLaunchKernelGGL(segmax_bwd_kernel<float>, grid, block, 0, stream, (const float*)dout, n, c, inverse, argmax,
+                       (float*)dx);
+  else if (dtype == TMAE_BF16)
+    hipLaunchKernelGGL(segmax_bwd_kernel<__hip_bfloat16>, grid, block, 0, stream, (const __hip_bfloat16*)dout, n, c,
+                       inverse, argmax, (__hip_bfloat16*)dx);
+  else
+    return TMAE_EDTYPE;
+  return tmae_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// group_inner_inds + normalised gt points
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_points_kernel(const float* __restrict__ pts,
+                                                          const int64_t* __restrict__ vc,
+                                                          const int32_t* __restrict__ perm,
+                                                          const int32_t* __restrict__ offsets, int64_t m, int k,
+                                                          float rx, float ry, float rz, float vx, float vy, float vz,
+                                                          int64_t* __restrict__ ginds, float* __restrict__ gt) {
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= m * k) return;
+  const int64_t v = e / k;
+  const int t = (int)(e - v * k);
+  const int lo = offsets[v], cnt = offsets[v + 1] - lo;
+  int64_t idx = -1;
+  float gx_ = 0.f, gy_ = 0.f, gz_ = 0.f;
+  if (cnt > 0) {
+    idx = perm[lo + (t < cnt ? t : t % cnt)];          // cyclic repeat, sst_ops_gpu.cu:30-39
+    const float* p = pts + idx * 5;
+    const int64_t* c = vc + v * 4;
+    const float cx = __fadd_rn(__fmul_rn(__fadd_rn((float)c[3], 0.5f), vx), rx);
+    const float cy = __fadd_rn(__fmul_rn(__fadd_rn((float)c[2], 0.5f), vy), ry);
+    const float cz = __fadd_rn(__fmul_rn(__fadd_rn((float)c[1], 0.5f), vz), rz);
+    gx_ = p[1] - cx; gy_ = p[2] - cy; gz_ = p[3] - cz;
+  }
+  if (ginds) ginds[e] = idx;
+  float* g = gt + e * 3;
+  g[0] = gx_; g[1] = gy_; g[2] = gz_;
+}
+
+int tmae_group_points(const float* points, const int64_t* voxel_coords, const int32_t* perm, const int32_t* offsets,
+                      int64_t m, int k, float rx, float ry, float rz, float vx, float vy, float vz,
+                      int64_t* group_inds, float* gt, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m < 0 || k <= 0) return TMAE_EARG;
+  if (m == 0) return TMAE_OK;
+  if (!points || !voxel_coords || !perm || !offsets || !gt) return TMAE_EARG;
+  hipLaunchKernelGGL(group_points_kernel, dim3(tmae_cdiv(m * k, 256)), dim3(256), 0, stream, points, voxel_coords,
+                     perm, offsets, m, k, rx, ry, rz, vx, vy, vz, group_inds, gt);
+  return tmae_launch_status();
+}

@@ -1,0 +1,76 @@
+"""ctypes binding of libtmae_hip.so (the C ABI of include/tmae_hip.h).
+
+There is NO fallback: if the shared object is missing the import fails loudly, and every call checks the
+library's return code.  Pointers are raw device addresses (tensor.data_ptr()), the stream is the HIP stream
+of torch.cuda.current_stream() -- PyTorch is only the allocator / stream provider here.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libtmae_hip.so')
+
+P, I, L, F, D, Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/tmae_hip.h one to one
+SIGNATURES = {
+    'tmae_abi_version': (I, []),
+    'tmae_voxelize_workspace': (Z, [L, I, I, I, I]),
+    'tmae_voxelize': (I, [P, L, I, F, F, F, F, F, F, I, I, I, P, P, P, P, P, P, Z, P]),
+    'tmae_segment_csr_workspace': (Z, [L, L]),
+    'tmae_segment_csr': (I, [P, L, L, P, P, P, Z, P]),
+    'tmae_ingroup_rank_workspace': (Z, [L, L]),
+    'tmae_ingroup_rank': (I, [P, L, L, P, P, Z, P]),
+    'tmae_vfe_point_features': (I, [P, P, P, P, P, L, L, F, F, F, F, F, F, P, P, P]),
+    'tmae_segment_max_fwd': (I, [P, I, L, L, I, P, P, P, P, P]),
+    'tmae_segment_max_bwd': (I, [P, I, L, L, I, P, P, P, P]),
+    'tmae_group_points': (I, [P, P, P, P, L, I, F, F, F, F, F, F, P, P, P]),
+    'tmae_random_mask_workspace': (Z, [L, I]),
+    'tmae_random_mask': (I, [P, P, L, I, D, P, P, P, P, Z, P]),
+    'tmae_index_grid': (I, [P, L, I, I, I, P, P]),
+    'tmae_window_bucket_workspace': (Z, [I, I, I, I, I, I]),
+    'tmae_window_bucket': (I, [P, L, P, P, I, I, I, I, I, I, P, I, P, P, P, P, P, P, P, P, Z, P]),
+    'tmae_win_attn_fwd': (I, [P, L, P, L, P, L, I, L, L, I, I, P, P, I, I, I, I, P, F, P, L, P, P]),
+    'tmae_win_attn_num_blocks': (L, [I, I, I, I, I]),
+    'tmae_win_attn_bwd': (I, [P, L, P, L, P, L, P, L, P, L, P, I, L, L, I, I, P, P, I, I, I, I, P, F,
+                              P, L, P, L, P, L, P, P]),
+    'tmae_add_pos_embed': (I, [P, I, L, I, P, I, I, I, P, P, P]),
+    'tmae_spconv_down_outputs_workspace': (Z, [I, I, I]),
+    'tmae_spconv_down_outputs': (I, [P, I, I, I, I, I, P, P, P, P, Z, P]),
+    'tmae_spconv_neighbors': (I, [P, L, P, I, I, I, I, P, P]),
+    'tmae_spconv_neighbors_t': (I, [P, L, P, I, I, I, I, P, P]),
+    'tmae_spconv_gather': (I, [P, I, L, I, P, L, P, P]),
+    'tmae_spconv_gather_t': (I, [P, I, L, I, P, L, P, P]),
+    'tmae_sparse_to_dense': (I, [P, I, L, I, P, I, I, I, P, P]),
+    'tmae_dense_gather': (I, [P, I, I, I, I, I, P, L, P, P]),
+    'tmae_chamfer_fwd': (I, [P, P, P, L, I, I, P, P, P, P]),
+    'tmae_chamfer_bwd': (I, [P, P, P, P, P, P, L, I, I, P, P]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f'{LIB_PATH} not found: build the HIP extension first (python t-mae_amd/build.py, or '
+        f'__graft_entry__.build()).  tmae_amd has no CPU / eager fallback.')
+
+lib = C.CDLL(LIB_PATH)
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here = header and library out of sync
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+ABI_VERSION = 1
+if lib.tmae_abi_version() != ABI_VERSION:
+    raise ImportError('libtmae_hip.so ABI version mismatch; rebuild with t-mae_amd/build.py')
+
+
+class TmaeHipError(RuntimeError):
+    pass
+
+
+_ERR = {-1: 'bad argument', -2: 'workspace too small', -3: 'unsupported dtype'}
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = _ERR.get(rc, f'hipError_t {rc}' if rc > 0 else f'error {rc}')
+        raise TmaeHipError(f'{what}: {msg}')

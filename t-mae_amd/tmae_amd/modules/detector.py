@@ -1,0 +1,116 @@
+"""Detector template + TMAE detector with the reference's registry contract.
+
+Mirror of pcdet/models/detectors/detector3d_template.py:15-100,365-451 and t_mae.py:4-34: modules are looked
+up by NAME in per-package registries, called in order on ``batch_dict``; train mode returns
+``({'loss': loss}, tb_dict, disp_dict)``.  Checkpoints are ``{'model_state': state_dict, ...}``.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+
+class Detector3DTemplate(nn.Module):
+    def __init__(self, model_cfg, num_class, dataset, logger=None):
+        super().__init__()
+        self.model_cfg, self.num_class, self.dataset, self.logger = model_cfg, num_class, dataset, logger
+        self.class_names = dataset.class_names
+        self.register_buffer('global_step', torch.LongTensor(1).zero_())
+        self.module_topology = ['vfe', 'backbone_3d']        # the topology entries on the T-MAE path
+
+    @property
+    def mode(self):
+        return 'TRAIN' if self.training else 'TEST'
+
+    def update_global_step(self):
+        self.global_step += 1
+
+    def build_networks(self):
+        info = {
+            'module_list': [],
+            'num_rawpoint_features': self.dataset.point_feature_encoder.num_point_features,
+            'num_point_features': self.dataset.point_feature_encoder.num_point_features,
+            'grid_size': self.dataset.grid_size,
+            'point_cloud_range': self.dataset.point_cloud_range,
+            'voxel_size': self.dataset.voxel_size,
+        }
+        for name in self.module_topology:
+            module, info = getattr(self, 'build_%s' % name)(model_info_dict=info)
+            self.add_module(name, module)
+        for unsupported in ('MAP_TO_BEV', 'PFE', 'BACKBONE_2D', 'DENSE_HEAD', 'POINT_HEAD', 'ROI_HEAD', 'IMG_BACKBONE'):
+            if self.model_cfg.get(unsupported, None) is not None:
+                raise NotImplementedError(f'MODEL.{unsupported}: outside the T-MAE pre-training hot path (SURVEY 8f)')
+        return info['module_list']
+
+    def build_vfe(self, model_info_dict):
+        from . import registry
+        if self.model_cfg.get('VFE', None) is None:
+            return None, model_info_dict
+        m = registry.VFE[self.model_cfg.VFE.NAME](
+            model_cfg=self.model_cfg.VFE, num_point_features=model_info_dict['num_rawpoint_features'],
+            point_cloud_range=model_info_dict['point_cloud_range'], voxel_size=model_info_dict['voxel_size'],
+            grid_size=model_info_dict['grid_size'])
+        model_info_dict['num_point_features'] = m.get_output_feature_dim()
+        model_info_dict['module_list'].append(m)
+        return m, model_info_dict
+
+    def build_backbone_3d(self, model_info_dict):
+        from . import registry
+        if self.model_cfg.get('BACKBONE_3D', None) is None:
+            return None, model_info_dict
+        m = registry.BACKBONES_3D[self.model_cfg.BACKBONE_3D.NAME](
+            model_cfg=self.model_cfg.BACKBONE_3D, input_channels=model_info_dict['num_point_features'],
+            grid_size=model_info_dict['grid_size'], voxel_size=model_info_dict['voxel_size'],
+            point_cloud_range=model_info_dict['point_cloud_range'])
+        model_info_dict['module_list'].append(m)
+        model_info_dict['num_point_features'] = m.num_point_features
+        return m, model_info_dict
+
+    def forward(self, **kwargs):
+        raise NotImplementedError
+
+    # ---- checkpoints (detector3d_template.py:398-451; train_utils.py:245-270)
+    def load_params_from_file(self, filename, logger=None, to_cpu=False):
+        if not os.path.isfile(filename):
+            raise FileNotFoundError(filename)
+        ckpt = torch.load(filename, map_location='cpu' if to_cpu else None, weights_only=False)
+        state = ckpt['model_state']
+        own = self.state_dict()
+        update = {k: v for k, v in state.items() if k in own and own[k].shape == v.shape}
+        own.update(update)
+        self.load_state_dict(own)
+        if logger is not None:
+            for k in own:
+                if k not in update:
+                    logger.info('Not updated weight %s: %s' % (k, str(own[k].shape)))
+            logger.info('==> Done (loaded %d/%d)' % (len(update), len(own)))
+
+    def load_params_with_optimizer(self, filename, to_cpu=False, optimizer=None, logger=None):
+        ckpt = torch.load(filename, map_location='cpu' if to_cpu else None, weights_only=False)
+        self.load_state_dict(ckpt['model_state'])
+        if optimizer is not None and ckpt.get('optimizer_state') is not None:
+            optimizer.load_state_dict(ckpt['optimizer_state'])
+        return ckpt.get('it', 0.0), ckpt.get('epoch', -1)
+
+
+class TMAE(Detector3DTemplate):
+    def __init__(self, model_cfg, num_class, dataset, logger=None):
+        super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset, logger=logger)
+        self.module_list = self.build_networks()
+
+    def forward(self, batch_dict):
+        for cur_module in self.module_list:
+            batch_dict = cur_module(batch_dict)
+        if self.training:
+            loss, tb_dict, disp_dict = self.get_training_loss()
+            return {'loss': loss}, tb_dict, disp_dict
+        return self.post_processing(batch_dict)
+
+    def post_processing(self, batch_dict):
+        return {}, {}
+
+    def get_training_loss(self):
+        loss_rpn, tb_dict = self.backbone_3d.get_loss()
+        # the reference calls loss.item() here (t_mae.py:31): a host sync per step; keep the tensor instead
+        tb_dict = {'loss_rpn': loss_rpn.detach(), **tb_dict}
+        return loss_rpn, tb_dict, {}

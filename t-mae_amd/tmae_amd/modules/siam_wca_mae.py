@@ -1,0 +1,141 @@
+"""SiamWCA_MAE: Siamese SST encoder + window cross-attention + dense BEV decoder + Chamfer loss.
+
+Host-side mirror of pcdet/models/backbones_3d/SiamWCA_MAE.py (same constructor kwargs, batch_dict keys,
+``forward_ret_dict`` and parameter names) over the HIP operators of tmae_amd.ops.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .sparse import SparseConvTensor
+from .sst import SSTBlockV1, WCABlock
+
+
+class SiamWCA_MAE(nn.Module):
+    def __init__(self, model_cfg, input_channels, grid_size, voxel_size, point_cloud_range, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.grid_size = [int(v) for v in grid_size]
+        self.voxel_size = [float(v) for v in voxel_size]
+        self.point_cloud_range = [float(v) for v in point_cloud_range]
+        self.sparse_shape = [self.grid_size[1], self.grid_size[0]]           # (ny, nx)
+
+        self.mask_cfg = model_cfg.get('MASK_CONFIG', None)
+        self.mask_ratio = self.mask_cfg.RATIO if self.mask_cfg is not None else 0.0
+        if model_cfg.get('ASYMMETRIC', False) and model_cfg.ASYMMETRIC.get('ENABLED', False):
+            raise NotImplementedError('ASYMMETRIC encoders are not used by the shipped T-MAE configs')
+
+        in_channels = input_channels
+        self.sst_blocks = nn.ModuleList()
+        for cfg in model_cfg.SST_BLOCK_LIST:
+            self.sst_blocks.append(SSTBlockV1(cfg, in_channels, cfg.NAME))
+            in_channels = cfg.ENCODER.D_MODEL
+        self.wca_blocks = nn.ModuleList()
+        for cfg in model_cfg.SST_BLOCK_LIST:
+            self.wca_blocks.append(WCABlock(cfg, cfg.ENCODER.D_MODEL, cfg.NAME))
+
+        in_channels = 0
+        self.decoder_deblocks = nn.ModuleList()
+        self.deblock_strides = []
+        for src in model_cfg.FEATURES_SOURCE:
+            c = model_cfg.FUSE_LAYER[src]
+            self.decoder_deblocks.append(nn.Sequential(
+                nn.ConvTranspose2d(c.NUM_FILTER, c.NUM_UPSAMPLE_FILTER, c.UPSAMPLE_STRIDE, stride=c.UPSAMPLE_STRIDE,
+                                   bias=False),
+                nn.BatchNorm2d(c.NUM_UPSAMPLE_FILTER, eps=1e-3, momentum=0.01),
+                nn.ReLU(inplace=True)))
+            in_channels += c.NUM_UPSAMPLE_FILTER
+            self.deblock_strides.append(c.UPSAMPLE_STRIDE)
+        n_src = len(self.decoder_deblocks)
+        self.decoder_conv_out = nn.Sequential(
+            nn.Conv2d(in_channels, in_channels // n_src, 3, padding=1, bias=False),
+            nn.BatchNorm2d(in_channels // n_src, eps=1e-3, momentum=0.01),
+            nn.ReLU(inplace=True))
+        in_channels = in_channels // n_src
+        self.decoder_pred = nn.Linear(in_channels, self.mask_cfg.NUM_PRD_POINTS * 3, bias=True)
+        self.forward_ret_dict = {}
+        self.num_point_features = in_channels
+
+    # ------------------------------------------------------------------ masking (SiamWCA_MAE.py:166-182)
+    def mask_voxels(self, all_voxel_features, all_voxel_coords, batch_size, voxels_per_sample, noise=None):
+        m = all_voxel_coords.shape[0]
+        dev = all_voxel_coords.device
+        if noise is None:
+            noise = torch.rand(m, device=dev)
+        offs = np.concatenate([[0], np.cumsum(voxels_per_sample)]).astype(np.int32)
+        keep_frac = 1 - self.mask_ratio
+        n_vis = int(sum(int(L * keep_frac) for L in voxels_per_sample))        # known on the host: no sync
+        mask, vis_index, _ = ops.random_mask(noise, torch.from_numpy(offs).to(dev), batch_size, keep_frac)
+        vis = vis_index[:n_vis].long()
+        return all_voxel_features[vis], all_voxel_coords[vis], mask
+
+    # ------------------------------------------------------------------ encoder (SiamWCA_MAE.py:184-218)
+    def sparse_encode(self, voxel_features, voxel_coords, batch_size, previous_sstblock=False):
+        x = SparseConvTensor(voxel_features, voxel_coords[:, [0, 2, 3]].int().contiguous(), self.sparse_shape,
+                             batch_size)
+        feats, strides = {}, {}
+        for i, blk in enumerate(self.sst_blocks):                   # Siamese: the same weights for both frames
+            x = blk(x)
+            feats[f'x_conv{i + 1}'] = x
+            strides[f'x_conv{i + 1}'] = self.sparse_shape[0] // x.spatial_shape[0]
+        return feats, strides
+
+    def sparse_cross_attn(self, feats, feats_prev, dtime=0):
+        for i, blk in enumerate(self.wca_blocks):
+            feats[f'x_conv{i + 1}'] = blk(feats[f'x_conv{i + 1}'], feats_prev[f'x_conv{i + 1}'], dtime)
+        return feats
+
+    # ------------------------------------------------------------------ decoder (SiamWCA_MAE.py:231-253)
+    def dense_conv(self, feats, strides):
+        ups, out_strides = [], []
+        for i, src in enumerate(self.model_cfg.FEATURES_SOURCE):
+            d = feats[src].dense()                                   # [B,C,Y,X], channels-last memory
+            ups.append(self.decoder_deblocks[i](d))
+            out_strides.append(strides[src] // self.model_cfg.FUSE_LAYER[src].UPSAMPLE_STRIDE)
+        spatial = self.decoder_conv_out(torch.cat(ups, dim=1))
+        return spatial, out_strides[0]
+
+    # ------------------------------------------------------------------ targets (SiamWCA_MAE.py:124-152)
+    def target_assigner(self, batch_dict):
+        voxel_features = batch_dict['voxel_features']
+        voxel_coords = batch_dict['voxel_coords']
+        perm, offsets = batch_dict['point_csr']
+        _, gt = ops.group_points(batch_dict['points'], voxel_coords, perm, offsets, self.mask_cfg.NUM_GT_POINTS,
+                                 self.point_cloud_range, self.voxel_size, want_inds=False)
+        pred = self.decoder_pred(voxel_features).view(voxel_features.shape[0], -1, 3)
+        return {'pred_points': pred, 'gt_points': gt, 'mask': batch_dict['voxel_mae_mask']}
+
+    def get_loss(self, tb_dict=None):
+        tb_dict = {} if tb_dict is None else tb_dict
+        r = self.forward_ret_dict
+        loss, _ = ops.chamfer_distance(r['pred_points'].float(), r['gt_points'], weights=r['mask'])
+        return loss, tb_dict
+
+    # ------------------------------------------------------------------ forward (SiamWCA_MAE.py:255-322)
+    def forward(self, batch_dict):
+        bs = int(batch_dict['batch_size'])
+        feats_prev, strides_prev = self.sparse_encode(batch_dict['voxel_features_prev'],
+                                                      batch_dict['voxel_coords_prev'], bs, previous_sstblock=True)
+        all_feats, all_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
+        vis_feats, vis_coords, mask = self.mask_voxels(all_feats, all_coords, bs, batch_dict['voxels_per_sample'],
+                                                      batch_dict.get('mae_noise', None))
+        batch_dict['voxel_mae_mask'] = mask
+        feats, strides = self.sparse_encode(vis_feats, vis_coords, bs)
+        feats = self.sparse_cross_attn(feats, feats_prev, dtime=batch_dict.get('dt', 0))
+        spatial, spatial_stride = self.dense_conv(feats, strides)
+        batch_dict['multi_scale_3d_features'] = feats
+        batch_dict['multi_scale_3d_strides'] = strides
+        batch_dict['spatial_features'] = spatial
+        batch_dict['spatial_features_stride'] = spatial_stride
+        assert spatial.shape[0] == bs and spatial.shape[2] == self.grid_size[1] and spatial.shape[3] == self.grid_size[0]
+
+        all_ind = all_coords[:, [0, 2, 3]].int().contiguous()
+        grid_all = ops.index_grid(all_ind, bs, self.sparse_shape[0], self.sparse_shape[1])
+        nhwc = spatial.permute(0, 2, 3, 1)
+        pyramid = ops.dense_gather(nhwc, grid_all, all_ind)         # decoder feature at EVERY current voxel
+        batch_dict.update({
+            'voxel_features': pyramid, 'voxel_coords': all_coords,
+            'voxel_shuffle_inds': torch.arange(all_coords.shape[0], device=all_coords.device, dtype=torch.long)})
+        self.forward_ret_dict = self.target_assigner(batch_dict)
+        return batch_dict

@@ -1,0 +1,127 @@
+"""Sparse tensor + 2-D sparse convolution modules with the call shapes of spconv.pytorch that the
+reference uses (SparseConvTensor, SubMConv2d, SparseConv2d, SparseSequential; pcdet/utils/spconv_utils.py:28-56,
+SiamWCA_MAE.py:187-193) -- implemented on the HIP rulebook / gather kernels, not on spconv.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class SparseConvTensor:
+    """features [m,c]; indices [m,3] int32 (b,y,x), lexicographically ordered; spatial_shape (ny,nx)."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, cache=None):
+        self.features = features
+        self.indices = indices.int().contiguous() if indices.dtype != torch.int32 else indices.contiguous()
+        self.spatial_shape = [int(spatial_shape[0]), int(spatial_shape[1])]
+        self.batch_size = int(batch_size)
+        self._grid = grid
+        self._cache = cache if cache is not None else {}      # rulebooks keyed by conv kind, shared by replace_feature
+
+    @property
+    def grid(self):
+        """Dense row-index grid [batch*ny*nx] int32 (built once per index set)."""
+        if self._grid is None:
+            self._grid = ops.index_grid(self.indices, self.batch_size, *self.spatial_shape)
+        return self._grid
+
+    def replace_feature(self, new_features):
+        return SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self._grid, self._cache)
+
+    def dense_nhwc(self):
+        ny, nx = self.spatial_shape
+        return ops.sparse_to_dense(self.features, self.grid, self.indices, self.batch_size, ny, nx)
+
+    def dense(self):
+        """[batch, c, ny, nx] (channels-last memory), zeros at inactive sites (SiamWCA_MAE.py:235)."""
+        return self.dense_nhwc().permute(0, 3, 1, 2)
+
+
+class SparseModule(nn.Module):
+    pass
+
+
+class SparseConvolution(SparseModule):
+    """3x3 conv, weight in the spconv-2 layout [cout, kh, kw, cin] (detector3d_template.py:373-383)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=False, indice_key=None,
+                 subm=False):
+        super().__init__()
+        if kernel_size != 3 or bias:
+            raise NotImplementedError('the T-MAE path only uses 3x3 bias-free sparse convs')
+        if not subm and not (stride == 2 and padding == 1):
+            raise NotImplementedError('strided sparse conv: only k3 s2 p1 (spt_backbone.py:280-284)')
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.subm, self.stride, self.indice_key = subm, stride, indice_key
+        self.weight = nn.Parameter(torch.empty(out_channels, 3, 3, in_channels))
+        nn.init.kaiming_uniform_(self.weight.view(out_channels, -1), a=5 ** 0.5)
+
+    def forward(self, x: SparseConvTensor):
+        ny, nx = x.spatial_shape
+        if self.subm:
+            rb = x._cache.get('subm')
+            if rb is None:
+                nbr = ops.spconv_neighbors(x.indices, x.grid, x.batch_size, ny, nx, 1)
+                rb = (nbr, nbr.flip(1).contiguous())              # transposed rulebook of a subm conv = flipped taps
+                x._cache['subm'] = rb
+            y = ops.sparse_conv(x.features, self.weight, rb[0], rb[1])
+            return x.replace_feature(y)
+        rb = x._cache.get('down')
+        if rb is None:
+            out_grid, out_ind, n_out, (oy, ox) = ops.spconv_down_outputs(x.grid, x.batch_size, ny, nx)
+            m_out = int(n_out.item())                               # one host sync per strided conv (output count)
+            out_ind = out_ind[:m_out]
+            nbr = ops.spconv_neighbors(out_ind, x.grid, x.batch_size, ny, nx, 2)
+            nbr_t = ops.spconv_neighbors_t(x.indices, out_grid, x.batch_size, oy, ox, 2)
+            rb = (nbr, nbr_t, out_ind, out_grid, (oy, ox))
+            x._cache['down'] = rb
+        nbr, nbr_t, out_ind, out_grid, oshape = rb
+        y = ops.sparse_conv(x.features, self.weight, nbr, nbr_t)
+        return SparseConvTensor(y, out_ind, oshape, x.batch_size, out_grid)
+
+
+class SubMConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, bias=False, indice_key=None, **kw):
+        super().__init__(in_channels, out_channels, kernel_size, bias=bias, indice_key=indice_key, subm=True)
+
+
+class SparseConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=False, indice_key=None, **kw):
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=bias,
+                         indice_key=indice_key)
+
+
+class SparseSequential(SparseModule):
+    """Children named '0','1',... like spconv.SparseSequential; dense modules act on .features."""
+
+    def __init__(self, *mods):
+        super().__init__()
+        for i, m in enumerate(mods):
+            self.add_module(str(i), m)
+
+    def forward(self, x):
+        for m in self._modules.values():
+            if isinstance(m, SparseModule):
+                x = m(x)
+            else:
+                x = x.replace_feature(m(x.features))
+        return x
+
+
+def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0, conv_type='subm',
+                   norm_fn=None, dim=2):
+    """conv + norm + ReLU (pcdet/utils/spconv_utils.py:37-56)."""
+    assert dim == 2
+    if conv_type == 'subm':
+        conv = SubMConv2d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key)
+    elif conv_type == 'spconv':
+        conv = SparseConv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False,
+                            indice_key=indice_key)
+    else:
+        raise NotImplementedError(conv_type)
+    return SparseSequential(conv, norm_fn(out_channels), nn.ReLU())
+
+
+def replace_feature(out, new_features):
+    return out.replace_feature(new_features)

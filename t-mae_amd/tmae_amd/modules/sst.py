@@ -1,0 +1,284 @@
+"""SST encoder stage (SSTBlockV1) and window cross-attention stage (WCABlock) on ragged window attention.
+
+Host-side mirror of pcdet/models/backbones_3d/spt_backbone.py:11-353, SiamWCA.py:21-447,
+model_utils/{sst_basic_block,wca_block,cosine_msa}.py: same module tree and parameter names
+(``encoder_blocks.{j}.encoder_list.{k}.win_attn.self_attn.{in_proj_weight,in_proj_bias,tau,out_proj.*}`` ...),
+so reference checkpoints load unchanged.  What differs is the execution: there is no SSTInputLayer
+bucketing into padded [windows, T, C] tensors, no per-drop-level Python loop and no host sync -- one
+dense index grid per sparse tensor and one ragged attention launch per layer.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .sparse import SparseConvTensor, post_act_block
+
+
+def pos_embed_table(feat_dim, window_shape, pos_temperature, normalize_pos=False):
+    """Sin/cos embedding of every in-window position, [wy*wx, feat_dim] float32 (cell = y*wx + x).
+    Formula of SSTInputLayer.get_pos_embed (spt_backbone.py:186-224)."""
+    wx, wy = int(window_shape[0]), int(window_shape[1])
+    ys, xs = torch.meshgrid(torch.arange(wy), torch.arange(wx), indexing='ij')
+    y = ys.reshape(-1) - wy / 2
+    x = xs.reshape(-1) - wx / 2
+    if normalize_pos:
+        x = x / wx * 2 * 3.1415
+        y = y / wy * 2 * 3.1415
+    pos_length = feat_dim // 2
+    inv_freq = torch.arange(pos_length, dtype=torch.float32)
+    inv_freq = pos_temperature ** (2 * torch.div(inv_freq, 2, rounding_mode='floor') / pos_length)
+    ex = x[:, None] / inv_freq[None, :]
+    ey = y[:, None] / inv_freq[None, :]
+    ex = torch.stack([ex[:, ::2].sin(), ex[:, 1::2].cos()], dim=-1).flatten(1)
+    ey = torch.stack([ey[:, ::2].sin(), ey[:, 1::2].cos()], dim=-1).flatten(1)
+    table = torch.cat([ex, ey], dim=-1).float().contiguous()
+    assert table.shape == (wx * wy, feat_dim)
+    return table
+
+
+class CosineMultiheadAttention(nn.Module):
+    """Parameter container with nn.MultiheadAttention's names (cosine_msa.py:441-458): packed in-proj,
+    out_proj, learnable temperature tau (1,1,1) clamped at tau_min."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0, tau_min=0.01, cosine=True, non_shared_tau=False):
+        super().__init__()
+        if dropout != 0.0 or not cosine or non_shared_tau:
+            raise NotImplementedError('T-MAE configs use cosine attention, shared tau, dropout 0')
+        self.embed_dim, self.num_heads, self.tau_min = embed_dim, num_heads, tau_min
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.tau = nn.Parameter(torch.ones(1, 1, 1))
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+
+class WindowPlan:
+    """Everything a stage's attention layers need about one sparse index set: indices, dense grid, shape."""
+
+    def __init__(self, sp: SparseConvTensor):
+        self.indices, self.grid = sp.indices, sp.grid
+        self.batch, (self.ny, self.nx) = sp.batch_size, sp.spatial_shape
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, d_model, nhead, dropout, layer_cfg):
+        super().__init__()
+        self.nhead = nhead
+        if not layer_cfg.get('cosine', False):
+            raise NotImplementedError('non-cosine window attention is not on the T-MAE path')
+        self.self_attn = CosineMultiheadAttention(d_model, nhead, dropout=dropout,
+                                                  tau_min=layer_cfg.get('tau_min', 0.01),
+                                                  non_shared_tau=layer_cfg.get('non_shared_tau', False))
+
+    def forward(self, x, plan, pos_table, window_shape, shift):
+        """q = k = x + pos, v = x (sst_basic_block.py:22-54), windows of `shift` read from plan.grid."""
+        a = self.self_attn
+        d = a.embed_dim
+        xp = ops.add_pos_embed(x, plan.indices, pos_table, window_shape, shift)
+        qk = F.linear(xp, a.in_proj_weight[:2 * d], a.in_proj_bias[:2 * d])
+        v = F.linear(x, a.in_proj_weight[2 * d:], a.in_proj_bias[2 * d:])
+        o = ops.win_attn(qk, v, None, a.tau, plan.grid, plan.grid, self.nhead, plan.batch, plan.ny, plan.nx,
+                         shift, a.tau_min)
+        return a.out_proj(o)
+
+
+class WindowCrossAttention(nn.Module):
+    def __init__(self, d_model, nhead, dropout, layer_cfg):
+        super().__init__()
+        self.nhead = nhead
+        if not layer_cfg.get('cosine', False):
+            raise NotImplementedError('non-cosine window attention is not on the T-MAE path')
+        self.cross_attn = CosineMultiheadAttention(d_model, nhead, dropout=dropout,
+                                                   tau_min=layer_cfg.get('tau_min', 0.01),
+                                                   non_shared_tau=layer_cfg.get('non_shared_tau', False))
+
+    def forward(self, x, plan, x_prv, plan_prv, pos_table, window_shape, shift):
+        """q = cur + pos, k = prev + pos_prev, v = prev (wca_block.py:26-67).  Query tokens whose window is
+        empty in the previous frame come back as zero rows (= not in keep_inds, wca_block.py:93-96)."""
+        a = self.cross_attn
+        d = a.embed_dim
+        w, b = a.in_proj_weight, a.in_proj_bias
+        q = F.linear(ops.add_pos_embed(x, plan.indices, pos_table, window_shape, shift), w[:d], b[:d])
+        k = F.linear(ops.add_pos_embed(x_prv, plan_prv.indices, pos_table, window_shape, shift), w[d:2 * d], b[d:2 * d])
+        v = F.linear(x_prv, w[2 * d:], b[2 * d:])
+        return ops.win_attn(q, k, v, a.tau, plan.grid, plan_prv.grid, self.nhead, plan.batch, plan.ny, plan.nx,
+                            shift, a.tau_min)
+
+
+def _activation(name):
+    if name == 'gelu':
+        return F.gelu
+    if name == 'relu':
+        return F.relu
+    raise RuntimeError(f'activation should be relu/gelu, not {name}.')
+
+
+class _EncoderTail(nn.Module):
+    """linear1/linear2/norm1/norm2 shared by the self and cross layers (post-norm, dropout 0)."""
+
+    def __init__(self, d_model, dim_feedforward, activation):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.activation = _activation(activation)
+
+    def tail(self, src):
+        src = self.norm1(src)
+        src2 = self.linear2(self.activation(self.linear1(src)))
+        return self.norm2(src + src2)
+
+
+class EncoderLayer(_EncoderTail):
+    """sst_basic_block.EncoderLayer (sst_basic_block.py:57-84)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward, dropout, activation, layer_cfg):
+        super().__init__(d_model, dim_feedforward, activation)
+        self.win_attn = WindowAttention(d_model, nhead, dropout, layer_cfg)
+
+    def forward(self, src, plan, pos_table, window_shape, shift):
+        src = src + self.win_attn(src, plan, pos_table, window_shape, shift)
+        return self.tail(src)
+
+
+class BasicShiftBlockV2(nn.Module):
+    """Two encoder layers: shift 0 then shift 1 (sst_basic_block.py:87-114)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward, dropout, activation, layer_cfg):
+        super().__init__()
+        self.encoder_list = nn.ModuleList([EncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, layer_cfg)
+                                           for _ in range(2)])
+
+    def forward(self, src, plan, pos_table, window_shape):
+        for i, layer in enumerate(self.encoder_list):
+            src = layer(src, plan, pos_table, window_shape, i == 1)
+        return src
+
+
+class WCAEncoderLayer(_EncoderTail):
+    """wca_block.EncoderLayer (wca_block.py:70-103)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward, dropout, activation, layer_cfg):
+        super().__init__(d_model, dim_feedforward, activation)
+        self.win_attn = WindowCrossAttention(d_model, nhead, dropout, layer_cfg)
+
+    def forward(self, src, plan, src_prv, plan_prv, pos_table, window_shape, shift, kept):
+        a = self.win_attn.cross_attn
+        o = self.win_attn(src, plan, src_prv, plan_prv, pos_table, window_shape, shift)
+        # src[keep] += out_proj(attn): kept = query rows whose window also holds previous-frame tokens
+        # (the out-proj bias must not reach the other rows)
+        upd = a.out_proj(o) * kept
+        return self.tail(src + upd)
+
+
+class BasicShiftBlock_WCA(nn.Module):
+    """Two cross layers, shift 0 then shift 1 (wca_block.py:106-145)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward, dropout, activation, layer_cfg):
+        super().__init__()
+        self.encoder_list = nn.ModuleList([WCAEncoderLayer(d_model, nhead, dim_feedforward, dropout, activation,
+                                                           layer_cfg) for _ in range(2)])
+
+    def forward(self, src, plan, src_prv, plan_prv, pos_table, window_shape, kept_list):
+        for i, layer in enumerate(self.encoder_list):
+            src = layer(src, plan, src_prv, plan_prv, pos_table, window_shape, i == 1, kept_list[i])
+        return src
+
+
+def _check_preprocess(pre):
+    ws = pre.WINDOW_SHAPE
+    if list(ws) != [8, 8, 1]:
+        raise NotImplementedError('window attention kernels are built for 8x8x1 windows (t_mae_ssl.yaml:61)')
+    if pre.get('SHUFFLE_VOXELS', False):
+        raise NotImplementedError('SHUFFLE_VOXELS is False in the T-MAE configs')
+    if pre.get('NORMALIZE_POS', False):
+        raise NotImplementedError('NORMALIZE_POS is False in the T-MAE configs')
+    top = max(int(v['max_tokens']) for v in pre.DROP_INFO['train'].values())
+    if top < ws[0] * ws[1]:
+        # SURVEY A-6: with max_tokens >= window cells no voxel is ever dropped and the ragged kernel is exact
+        raise NotImplementedError('DROP_INFO must keep every token of a window (max_tokens >= 64)')
+
+
+class SSTBlockV1(nn.Module):
+    """conv_down -> NUM_BLOCKS x BasicShiftBlockV2 -> residual -> conv_out (spt_backbone.py:267-353)."""
+
+    def __init__(self, model_cfg, input_channels, indice_key, **kwargs):
+        super().__init__()
+        if kwargs.get('half_channels', False):
+            raise NotImplementedError('ASYMMETRIC/HALF_CHANNELS is not used by the shipped T-MAE configs')
+        self.model_cfg = model_cfg
+        enc = model_cfg.ENCODER
+        d_model, stride = enc.D_MODEL, enc.STRIDE
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.conv_down = None
+        if stride > 1:
+            self.conv_down = post_act_block(input_channels, d_model, 3, norm_fn=norm_fn, stride=stride, padding=1,
+                                            indice_key=f'{indice_key}_spconv', conv_type='spconv', dim=2)
+        _check_preprocess(model_cfg.PREPROCESS)
+        self.window_shape = list(model_cfg.PREPROCESS.WINDOW_SHAPE)
+        self.encoder_blocks = nn.ModuleList([
+            BasicShiftBlockV2(d_model, enc.NHEAD, enc.DIM_FEEDFORWARD, enc.DROPOUT, enc.ACTIVATION, enc.LAYER_CFG)
+            for _ in range(enc.NUM_BLOCKS)])
+        self.conv_out = post_act_block(d_model, d_model, 3, norm_fn=norm_fn, indice_key=f'{indice_key}_subm', dim=2)
+        self.register_buffer('pos_table', pos_embed_table(d_model, self.window_shape,
+                                                          model_cfg.PREPROCESS.POS_TEMPERATURE), persistent=False)
+
+    def encoder_forward(self, sp: SparseConvTensor):
+        """SSTBlockV1.encoder_forward (spt_backbone.py:314-340) on the ragged layout."""
+        plan = WindowPlan(sp)
+        out = sp.features
+        for block in self.encoder_blocks:
+            out = block(out, plan, self.pos_table, self.window_shape)
+        return out
+
+    def forward(self, sp: SparseConvTensor):
+        if self.conv_down is not None:
+            sp = self.conv_down(sp)
+        x = sp.features
+        out = self.encoder_forward(sp)
+        sp = sp.replace_feature(x + out.to(x.dtype))
+        return self.conv_out(sp)
+
+
+class WCABlock(nn.Module):
+    """Temporal window cross-attention stage (SiamWCA.py:272-447): one BasicShiftBlock_WCA (NUM_BLOCKS is
+    forced to 1 there, :294-296), residual, subm conv_out."""
+
+    def __init__(self, model_cfg, input_channels, indice_key, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        enc = model_cfg.ENCODER
+        d_model = enc.D_MODEL
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        _check_preprocess(model_cfg.PREPROCESS)
+        self.window_shape = list(model_cfg.PREPROCESS.WINDOW_SHAPE)
+        self.drop_info = {int(k): dict(v) for k, v in model_cfg.PREPROCESS.DROP_INFO['train'].items()}
+        self.encoder_blocks = nn.ModuleList([
+            BasicShiftBlock_WCA(d_model, enc.NHEAD, enc.DIM_FEEDFORWARD, enc.DROPOUT, enc.ACTIVATION, enc.LAYER_CFG)])
+        self.conv_out = post_act_block(d_model, d_model, 3, norm_fn=norm_fn, indice_key=f'{indice_key}_subm', dim=2)
+        self.register_buffer('pos_table', pos_embed_table(d_model, self.window_shape,
+                                                          model_cfg.PREPROCESS.POS_TEMPERATURE), persistent=False)
+
+    def encoder_forward(self, sp: SparseConvTensor, sp_prev: SparseConvTensor):
+        """WCABlock.encoder_forward (SiamWCA.py:342-396): joint bucketing of the two frames, two cross layers."""
+        plan, plan_prv = WindowPlan(sp), WindowPlan(sp_prev)
+        assert sp.spatial_shape == sp_prev.spatial_shape
+        x = sp.features
+        kept = []
+        for shift in (False, True):
+            wb = ops.window_bucket(plan.indices, plan.grid, plan_prv.grid, plan.batch, plan.ny, plan.nx,
+                                   self.window_shape, shift, self.drop_info)
+            kept.append(wb['keep'].view(-1, 1).to(x.dtype))
+        return self.encoder_blocks[0](x, plan, sp_prev.features, plan_prv, self.pos_table, self.window_shape, kept)
+
+    def forward(self, sp: SparseConvTensor, sp_prev: SparseConvTensor, dtime=0):
+        x = sp.features
+        res = self.encoder_forward(sp, sp_prev)
+        sp = sp.replace_feature(x + res.to(x.dtype))
+        return self.conv_out(sp)

@@ -1,0 +1,476 @@
+"""Python operator layer over the C ABI (include/tmae_hip.h): thin wrappers + autograd Functions.
+
+Mirrors the operator surface the reference reaches through sst_ops_utils / torch_scatter / spconv /
+pytorch3d -- same argument meaning, but every call lands in a hand-written gfx950 kernel.
+No tensor math happens here besides allocation and dense GEMMs handed to hipBLASLt via torch.
+"""
+import torch
+
+from .. import _lib
+from .._lib import lib, check
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise TypeError(f'tmae_amd ops support float32 / bfloat16 features, got {t.dtype}')
+
+
+def _ws(nbytes, device):
+    return torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+
+
+def _need_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError('tmae_amd ops run on the GPU only (no CPU fallback)')
+
+
+def compute_dtype(t):
+    """dtype a feature op should run in: the autocast dtype when autocast is on, else the input's."""
+    if torch.is_autocast_enabled('cuda'):
+        return torch.get_autocast_dtype('cuda')
+    return t.dtype if t.dtype in (torch.float32, torch.bfloat16) else torch.float32
+
+
+# ----------------------------------------------------------------------------- voxelisation (A1)
+
+def voxelize_launch(points, batch_size, pc_range, voxel_size, grid_size):
+    """Enqueue the voxelisation of one frame; returns worst-case buffers + device counts (no sync).
+    Replaces get_in_range_mask + unique(dim=0) (temporal_dyn_vfe.py:67-72)."""
+    _need_cuda(points)
+    pts = points.contiguous().float()
+    n = pts.shape[0]
+    gx, gy, gz = (int(v) for v in grid_size)
+    dev = pts.device
+    out = dict(
+        points=torch.empty((n, 5), dtype=torch.float32, device=dev),
+        point_coords=torch.empty((n, 4), dtype=torch.int64, device=dev),
+        inverse=torch.empty((n,), dtype=torch.int64, device=dev),
+        voxel_coords=torch.empty((min(n, batch_size * gx * gy * gz), 4), dtype=torch.int64, device=dev),
+        counts=torch.zeros((2 + batch_size,), dtype=torch.int32, device=dev),
+    )
+    wsb = lib.tmae_voxelize_workspace(n, batch_size, gx, gy, gz)
+    ws = _ws(wsb, dev)
+    r, vs = [float(v) for v in pc_range[:3]], [float(v) for v in voxel_size]
+    check(lib.tmae_voxelize(_p(pts), n, batch_size, r[0], r[1], r[2], vs[0], vs[1], vs[2], gx, gy, gz,
+                            _p(out['points']), _p(out['point_coords']), _p(out['inverse']),
+                            _p(out['voxel_coords']), _p(out['counts']), _p(ws), wsb, _s()), 'tmae_voxelize')
+    return out
+
+
+def voxelize_finish(out, counts_host):
+    n_kept, m = int(counts_host[0]), int(counts_host[1])
+    return dict(points=out['points'][:n_kept], point_coords=out['point_coords'][:n_kept],
+                inverse=out['inverse'][:n_kept], voxel_coords=out['voxel_coords'][:m],
+                voxels_per_sample=[int(v) for v in counts_host[2:]])
+
+
+def voxelize(points, batch_size, pc_range, voxel_size, grid_size):
+    out = voxelize_launch(points, batch_size, pc_range, voxel_size, grid_size)
+    return voxelize_finish(out, out['counts'].cpu())
+
+
+def segment_csr(inverse, m):
+    """Stable point->voxel CSR: perm [n] int32, offsets [m+1] int32."""
+    _need_cuda(inverse)
+    n = inverse.shape[0]
+    perm = torch.empty((n,), dtype=torch.int32, device=inverse.device)
+    offsets = torch.empty((m + 1,), dtype=torch.int32, device=inverse.device)
+    wsb = lib.tmae_segment_csr_workspace(n, m)
+    ws = _ws(wsb, inverse.device)
+    check(lib.tmae_segment_csr(_p(inverse), n, m, _p(perm), _p(offsets), _p(ws), wsb, _s()), 'tmae_segment_csr')
+    return perm, offsets
+
+
+def get_inner_win_inds(group_inds):
+    """sst_ops_utils.get_inner_win_inds (pcdet/ops/sst_ops/sst_ops_utils.py:5-12): running index of each
+    element in its group; deterministic (stable rank), unlike the reference's atomic order."""
+    _need_cuda(group_inds)
+    g = group_inds.contiguous().long()
+    n = g.shape[0]
+    out = torch.empty_like(g)
+    if n == 0:
+        return out
+    ng = int(g.max().item()) + 1          # the reference syncs here as well (sst_ops.cpp:26)
+    wsb = lib.tmae_ingroup_rank_workspace(n, ng)
+    ws = _ws(wsb, g.device)
+    check(lib.tmae_ingroup_rank(_p(g), n, ng, _p(out), _p(ws), wsb, _s()), 'tmae_ingroup_rank')
+    return out
+
+
+def vfe_point_features(points, point_coords, inverse, perm, offsets, m, pc_range, voxel_size):
+    n = points.shape[0]
+    mean = torch.empty((m, 4), dtype=torch.float32, device=points.device)
+    feats = torch.empty((n, 10), dtype=torch.float32, device=points.device)
+    r, vs = [float(v) for v in pc_range[:3]], [float(v) for v in voxel_size]
+    check(lib.tmae_vfe_point_features(_p(points), _p(point_coords), _p(inverse), _p(perm), _p(offsets), n, m,
+                                      r[0], r[1], r[2], vs[0], vs[1], vs[2], _p(mean), _p(feats), _s()),
+          'tmae_vfe_point_features')
+    return mean, feats
+
+
+class _SegmentMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, inverse, perm, offsets, m):
+        x = x.contiguous()
+        n, c = x.shape
+        out = torch.empty((m, c), dtype=x.dtype, device=x.device)
+        argmax = torch.empty((m, c), dtype=torch.int32, device=x.device)
+        check(lib.tmae_segment_max_fwd(_p(x), _dt(x), n, m, c, _p(perm), _p(offsets), _p(out), _p(argmax), _s()),
+              'tmae_segment_max_fwd')
+        ctx.save_for_backward(inverse, argmax)
+        ctx.n = n
+        ctx.mark_non_differentiable(argmax)
+        return out, argmax
+
+    @staticmethod
+    def backward(ctx, dout, _):
+        inverse, argmax = ctx.saved_tensors
+        dout = dout.contiguous()
+        m, c = dout.shape
+        dx = torch.empty((ctx.n, c), dtype=dout.dtype, device=dout.device)
+        check(lib.tmae_segment_max_bwd(_p(dout), _dt(dout), ctx.n, m, c, _p(inverse), _p(argmax), _p(dx), _s()),
+              'tmae_segment_max_bwd')
+        return dx, None, None, None, None
+
+
+def scatter_max(src, inverse, perm, offsets, m):
+    """torch_scatter.scatter_max(src, index, dim=0) -> (out, argmax) (temporal_dyn_vfe.py:113)."""
+    return _SegmentMax.apply(src, inverse, perm, offsets, m)
+
+
+def group_points(points, voxel_coords, perm, offsets, k, pc_range, voxel_size, want_inds=True):
+    """sst_ops_utils.group_inner_inds + centre normalisation (SiamWCA_MAE.py:134-141)."""
+    m = voxel_coords.shape[0]
+    dev = points.device
+    ginds = torch.empty((m, k), dtype=torch.int64, device=dev) if want_inds else None
+    gt = torch.empty((m, k, 3), dtype=torch.float32, device=dev)
+    r, vs = [float(v) for v in pc_range[:3]], [float(v) for v in voxel_size]
+    check(lib.tmae_group_points(_p(points), _p(voxel_coords), _p(perm), _p(offsets), m, k, r[0], r[1], r[2],
+                                vs[0], vs[1], vs[2], _p(ginds), _p(gt), _s()), 'tmae_group_points')
+    return ginds, gt
+
+
+# ----------------------------------------------------------------------------- masking (A3)
+
+def random_mask(noise, sample_offsets, batch_size, keep_frac):
+    """random_masking with injected noise (common_utils.py:49-63).  Returns mask [m] f32 (1 = removed),
+    vis_index [m] int32 (first n_vis valid), n_vis (device int32 tensor)."""
+    _need_cuda(noise)
+    m = noise.shape[0]
+    dev = noise.device
+    mask = torch.empty((m,), dtype=torch.float32, device=dev)
+    vis = torch.empty((m,), dtype=torch.int32, device=dev)
+    n_vis = torch.zeros((1,), dtype=torch.int32, device=dev)
+    wsb = lib.tmae_random_mask_workspace(m, batch_size)
+    ws = _ws(wsb, dev)
+    check(lib.tmae_random_mask(_p(noise.contiguous().float()), _p(sample_offsets), m, batch_size, float(keep_frac),
+                               _p(mask), _p(vis), _p(n_vis), _p(ws), wsb, _s()), 'tmae_random_mask')
+    return mask, vis, n_vis
+
+
+# ----------------------------------------------------------------------------- windows (A4/A5/A10)
+
+def index_grid(indices, batch_size, ny, nx):
+    """Dense row-index grid [batch*ny*nx] int32 (-1 = inactive) of a sparse tensor's indices [m,3] (b,y,x)."""
+    _need_cuda(indices)
+    assert indices.dtype == torch.int32 and indices.is_contiguous()
+    grid = torch.empty((batch_size * ny * nx,), dtype=torch.int32, device=indices.device)
+    check(lib.tmae_index_grid(_p(indices), indices.shape[0], batch_size, ny, nx, _p(grid), _s()), 'tmae_index_grid')
+    return grid
+
+
+def window_bucket(indices, grid, grid_other, batch_size, ny, nx, window_shape, do_shift, drop_info):
+    """Window partition + region batching of one shift (spt_backbone.py:47-71,137-184; sst_utils.py:6-107;
+    joint two-frame form SiamWCA.py:65-140 when grid_other is given)."""
+    import ctypes as C
+    m = indices.shape[0]
+    dev = indices.device
+    wx, wy = int(window_shape[0]), int(window_shape[1])
+    lv = sorted(drop_info.items())
+    arr = (C.c_int32 * (3 * len(lv)))()
+    for i, (_, info) in enumerate(lv):
+        arr[3 * i], arr[3 * i + 1], arr[3 * i + 2] = info['max_tokens'], info['drop_range'][0], info['drop_range'][1]
+    out = dict(
+        batch_win_inds=torch.empty((m,), dtype=torch.int64, device=dev),
+        coors_in_win=torch.empty((m, 3), dtype=torch.int64, device=dev),
+        inner=torch.empty((m,), dtype=torch.int32, device=dev),
+        level=torch.empty((m,), dtype=torch.int32, device=dev),
+        keep=torch.empty((m,), dtype=torch.uint8, device=dev),
+        flat2win=torch.empty((m,), dtype=torch.int64, device=dev),
+        win_per_level=torch.zeros((len(lv),), dtype=torch.int32, device=dev),
+    )
+    wsb = lib.tmae_window_bucket_workspace(batch_size, ny, nx, wy, wx, len(lv))
+    ws = _ws(wsb, dev)
+    check(lib.tmae_window_bucket(_p(indices), m, _p(grid), _p(grid_other), batch_size, ny, nx, wy, wx,
+                                 1 if do_shift else 0, C.cast(arr, C.c_void_p), len(lv),
+                                 _p(out['batch_win_inds']), _p(out['coors_in_win']), _p(out['inner']),
+                                 _p(out['level']), _p(out['keep']), _p(out['flat2win']), _p(out['win_per_level']),
+                                 _p(ws), wsb, _s()), 'tmae_window_bucket')
+    return out
+
+
+class _AddPos(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, indices, table, wy, wx, do_shift):
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        check(lib.tmae_add_pos_embed(_p(x), _dt(x), x.shape[0], x.shape[1], _p(indices), wy, wx,
+                                     1 if do_shift else 0, _p(table), _p(out), _s()), 'tmae_add_pos_embed')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None, None, None
+
+
+def add_pos_embed(x, indices, table, window_shape, do_shift):
+    """x + pos_embed(coors_in_win) (spt_backbone.py:186-224 + sst_basic_block.py:41-44)."""
+    return _AddPos.apply(x, indices, table, int(window_shape[1]), int(window_shape[0]), bool(do_shift))
+
+
+# ----------------------------------------------------------------------------- attention (A6/A7)
+
+class _WinAttn(torch.autograd.Function):
+    """Ragged window cosine attention over projected q/k/v.
+    Self mode (c is None): a = packed [m,2d] (q|k) from one GEMM over x+pos, b = v [m,d].
+    Cross mode: a = q [mq,d], b = k [mk,d], c = v [mk,d]."""
+
+    @staticmethod
+    def _ptrs(a, b, c, d):
+        es = a.element_size()
+        if c is None:
+            return (a.data_ptr(), 2 * d, a.data_ptr() + d * es, 2 * d, b.data_ptr(), d)
+        return (a.data_ptr(), d, b.data_ptr(), d, c.data_ptr(), d)
+
+    @staticmethod
+    def forward(ctx, a, b, c, tau, grid_q, grid_k, nhead, batch, ny, nx, do_shift, tau_min):
+        a, b = a.contiguous(), b.contiguous()
+        assert a.dtype == b.dtype
+        if c is None:
+            d = b.shape[1]
+            mq = mk = a.shape[0]
+        else:
+            c = c.contiguous()
+            assert c.dtype == a.dtype
+            d = a.shape[1]
+            mq, mk = a.shape[0], b.shape[0]
+        dh = d // nhead
+        q, ldq, k, ldk, v, ldv = _WinAttn._ptrs(a, b, c, d)
+        tau32 = tau.detach().reshape(-1).float().contiguous()
+        out = torch.empty((mq, d), dtype=a.dtype, device=a.device)
+        lse = torch.empty((mq, nhead), dtype=torch.float32, device=a.device)
+        check(lib.tmae_win_attn_fwd(q, ldq, k, ldk, v, ldv, _dt(a), mq, mk, nhead, dh, _p(grid_q), _p(grid_k),
+                                    batch, ny, nx, 1 if do_shift else 0, _p(tau32), float(tau_min), _p(out), d,
+                                    _p(lse), _s()), 'tmae_win_attn_fwd')
+        ctx.cross = c is not None
+        ctx.save_for_backward(a, b, c if c is not None else b, tau32, grid_q, grid_k, out, lse)
+        ctx.meta = (d, nhead, dh, batch, ny, nx, do_shift, tau_min, mq, mk, tau.shape, tau.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b, c, tau32, grid_q, grid_k, out, lse = ctx.saved_tensors
+        d, nhead, dh, batch, ny, nx, do_shift, tau_min, mq, mk, tshape, tdtype = ctx.meta
+        if not ctx.cross:
+            c = None
+        dout = dout.contiguous()
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        dc = torch.empty_like(c) if c is not None else None
+        q, ldq, k, ldk, v, ldv = _WinAttn._ptrs(a, b, c, d)
+        dq, lddq, dk, lddk, dv, lddv = _WinAttn._ptrs(da, db, dc, d)
+        nblk = lib.tmae_win_attn_num_blocks(batch, ny, nx, nhead, dh)
+        part = torch.empty((nblk,), dtype=torch.float32, device=a.device)
+        check(lib.tmae_win_attn_bwd(q, ldq, k, ldk, v, ldv, _p(out), d, _p(dout), d, _p(lse), _dt(a), mq, mk,
+                                    nhead, dh, _p(grid_q), _p(grid_k), batch, ny, nx, 1 if do_shift else 0,
+                                    _p(tau32), float(tau_min), dq, lddq, dk, lddk, dv, lddv, _p(part), _s()),
+              'tmae_win_attn_bwd')
+        # d/d tau of logits = cos / max(tau, tau_min): -(1/tau_c) * sum dS*s, zero in the clamped branch
+        tau_c = tau32.clamp(min=tau_min)
+        dtau = (-(part.sum() / tau_c) * (tau32 >= tau_min).float()).reshape(tshape).to(tdtype)
+        return da, db, dc, dtau, None, None, None, None, None, None, None, None
+
+
+def win_attn(a, b, c, tau, grid_q, grid_k, nhead, batch, ny, nx, do_shift, tau_min):
+    return _WinAttn.apply(a, b, c, tau, grid_q, grid_k, nhead, batch, ny, nx, do_shift, tau_min)
+
+
+# ----------------------------------------------------------------------------- sparse conv (A9)
+
+def spconv_down_outputs(grid_in, batch, ny, nx):
+    """Active output sites of SparseConv2d(k3,s2,p1): (out_grid, out_indices[worst case], n_out dev, (oy,ox))."""
+    oy, ox = (ny + 2 - 3) // 2 + 1, (nx + 2 - 3) // 2 + 1
+    dev = grid_in.device
+    out_grid = torch.empty((batch * oy * ox,), dtype=torch.int32, device=dev)
+    out_ind = torch.empty((batch * oy * ox, 3), dtype=torch.int32, device=dev)
+    n_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+    wsb = lib.tmae_spconv_down_outputs_workspace(batch, oy, ox)
+    ws = _ws(wsb, dev)
+    check(lib.tmae_spconv_down_outputs(_p(grid_in), batch, ny, nx, oy, ox, _p(out_grid), _p(out_ind), _p(n_out),
+                                       _p(ws), wsb, _s()), 'tmae_spconv_down_outputs')
+    return out_grid, out_ind, n_out, (oy, ox)
+
+
+def spconv_neighbors(out_indices, grid_in, batch, ny, nx, stride):
+    m = out_indices.shape[0]
+    nbr = torch.empty((m, 9), dtype=torch.int32, device=out_indices.device)
+    check(lib.tmae_spconv_neighbors(_p(out_indices), m, _p(grid_in), batch, ny, nx, stride, _p(nbr), _s()),
+          'tmae_spconv_neighbors')
+    return nbr
+
+
+def spconv_neighbors_t(in_indices, grid_out, batch, oy, ox, stride):
+    m = in_indices.shape[0]
+    nbr_t = torch.empty((m, 9), dtype=torch.int32, device=in_indices.device)
+    check(lib.tmae_spconv_neighbors_t(_p(in_indices), m, _p(grid_out), batch, oy, ox, stride, _p(nbr_t), _s()),
+          'tmae_spconv_neighbors_t')
+    return nbr_t
+
+
+def _gather9(feat, nbr):
+    m_out = nbr.shape[0]
+    c = feat.shape[1]
+    cols = torch.empty((m_out, 9 * c), dtype=feat.dtype, device=feat.device)
+    check(lib.tmae_spconv_gather(_p(feat), _dt(feat), feat.shape[0], c, _p(nbr), m_out, _p(cols), _s()),
+          'tmae_spconv_gather')
+    return cols
+
+
+class _SparseConv(torch.autograd.Function):
+    """out[o] = sum_t W[:,t,:] in[nbr[o,t]] as gather + one GEMM; weight [cout,3,3,cin] (spconv-2 layout)."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, nbr, nbr_t):
+        cdt = compute_dtype(feat)
+        f = feat.to(cdt).contiguous()
+        w = weight.to(cdt).reshape(weight.shape[0], -1)
+        cols = _gather9(f, nbr)
+        out = cols @ w.t()
+        ctx.save_for_backward(f, w, nbr, nbr_t)
+        ctx.wshape, ctx.wdtype, ctx.fdtype = weight.shape, weight.dtype, feat.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        f, w, nbr, nbr_t = ctx.saved_tensors
+        dout = dout.to(f.dtype).contiguous()
+        dcols = dout @ w                                              # [m_out, 9*cin]
+        din = torch.empty_like(f)
+        check(lib.tmae_spconv_gather_t(_p(dcols), _dt(dcols), dout.shape[0], f.shape[1], _p(nbr_t), f.shape[0],
+                                       _p(din), _s()), 'tmae_spconv_gather_t')
+        del dcols
+        cols = _gather9(f, nbr)                                       # recomputed: cheaper than keeping 9x rows
+        dw = (dout.t() @ cols).reshape(ctx.wshape).to(ctx.wdtype)
+        return din.to(ctx.fdtype), dw, None, None
+
+
+def sparse_conv(feat, weight, nbr, nbr_t):
+    return _SparseConv.apply(feat, weight, nbr, nbr_t)
+
+
+# ----------------------------------------------------------------------------- dense <-> sparse (A11/A12)
+
+class _ToDense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, grid, indices, batch, ny, nx):
+        feat = feat.contiguous()
+        c = feat.shape[1]
+        out = torch.empty((batch, ny, nx, c), dtype=feat.dtype, device=feat.device)
+        check(lib.tmae_sparse_to_dense(_p(feat), _dt(feat), feat.shape[0], c, _p(grid), batch, ny, nx, _p(out),
+                                       _s()), 'tmae_sparse_to_dense')
+        ctx.save_for_backward(indices)
+        ctx.meta = (batch, ny, nx, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (indices,) = ctx.saved_tensors
+        batch, ny, nx, c = ctx.meta
+        dout = dout.contiguous()
+        rows = torch.empty((indices.shape[0], c), dtype=dout.dtype, device=dout.device)
+        check(lib.tmae_dense_gather(_p(dout), _dt(dout), batch, ny, nx, c, _p(indices), indices.shape[0], _p(rows),
+                                    _s()), 'tmae_dense_gather')
+        return rows, None, None, None, None, None
+
+
+def sparse_to_dense(feat, grid, indices, batch, ny, nx):
+    """SparseConvTensor.dense() in channels-last: [batch, ny, nx, c] (SiamWCA_MAE.py:235)."""
+    return _ToDense.apply(feat, grid, indices, batch, ny, nx)
+
+
+class _DenseGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dense, grid, indices):
+        dense = dense.contiguous()                       # [batch, ny, nx, c]
+        batch, ny, nx, c = dense.shape
+        m = indices.shape[0]
+        rows = torch.empty((m, c), dtype=dense.dtype, device=dense.device)
+        check(lib.tmae_dense_gather(_p(dense), _dt(dense), batch, ny, nx, c, _p(indices), m, _p(rows), _s()),
+              'tmae_dense_gather')
+        ctx.save_for_backward(grid)
+        ctx.meta = (batch, ny, nx, c)
+        return rows
+
+    @staticmethod
+    def backward(ctx, drows):
+        (grid,) = ctx.saved_tensors
+        batch, ny, nx, c = ctx.meta
+        drows = drows.contiguous()
+        out = torch.empty((batch, ny, nx, c), dtype=drows.dtype, device=drows.device)
+        check(lib.tmae_sparse_to_dense(_p(drows), _dt(drows), drows.shape[0], c, _p(grid), batch, ny, nx, _p(out),
+                                       _s()), 'tmae_sparse_to_dense')
+        return out, None, None
+
+
+def dense_gather(dense_nhwc, grid, indices):
+    """rows[r] = dense[b,y,x,:] for the (unique) sites in indices (SiamWCA_MAE.py:308-312)."""
+    return _DenseGather.apply(dense_nhwc, grid, indices)
+
+
+# ----------------------------------------------------------------------------- Chamfer (A13)
+
+class _Chamfer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, weights):
+        pred = pred.contiguous().float()
+        gt = gt.contiguous().float()
+        w = weights.contiguous().float()
+        m, np_, _ = pred.shape
+        ng = gt.shape[1]
+        dev = pred.device
+        per = torch.empty((m,), dtype=torch.float32, device=dev)
+        ix = torch.empty((m, np_), dtype=torch.int8, device=dev)
+        iy = torch.empty((m, ng), dtype=torch.int8, device=dev)
+        check(lib.tmae_chamfer_fwd(_p(pred), _p(gt), _p(w), m, np_, ng, _p(per), _p(ix), _p(iy), _s()),
+              'tmae_chamfer_fwd')
+        wsum = w.sum()
+        inv = torch.where(wsum > 0, 1.0 / wsum.clamp(min=1e-30), torch.zeros_like(wsum))
+        ctx.save_for_backward(pred, gt, w, ix, iy, inv)
+        return per.sum() * inv
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gt, w, ix, iy, inv = ctx.saved_tensors
+        m, np_, _ = pred.shape
+        scale = (g.float() * inv).reshape(1).contiguous()
+        dpred = torch.empty_like(pred)
+        check(lib.tmae_chamfer_bwd(_p(pred), _p(gt), _p(w), _p(ix), _p(iy), _p(scale), m, np_, gt.shape[1],
+                                   _p(dpred), _s()), 'tmae_chamfer_bwd')
+        return dpred, None, None
+
+
+def chamfer_distance(pred, gt, weights=None):
+    """pytorch3d.loss.chamfer_distance(x, y, weights=) -> (loss, None) (SiamWCA_MAE.py:163)."""
+    if weights is None:
+        weights = torch.ones(pred.shape[0], device=pred.device)
+    return _Chamfer.apply(pred, gt, weights), None

@@ -1,0 +1,40 @@
+"""One training step of the T-MAE pre-training loop (tools/train_utils/train_utils.py:59-100) and the
+data-parallel wrapper (tools/train.py:283-289): one process per GPU, DDP over RCCL ('nccl' on ROCm),
+bf16 autocast (no GradScaler needed), decoupled-decay Adam one-cycle."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def build_model_from_cfg(cfg, dataset, logger=None):
+    from pcdet.models import build_network
+    return build_network(model_cfg=cfg.MODEL, num_class=len(cfg.CLASS_NAMES), dataset=dataset, logger=logger)
+
+
+def wrap_ddp(model, local_rank):
+    """Frame-pair data parallel: gradients (11.8 M params, 47 MB fp32) are all-reduced bucket-wise during
+    backward; BatchNorm statistics stay per-rank (SYNC_BN off in the shipped configs)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return model
+    if next(model.parameters()).is_cuda:
+        return torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=True,
+                                                         gradient_as_bucket_view=True, bucket_cap_mb=64)
+    return torch.nn.parallel.DistributedDataParallel(model)
+
+
+def train_one_step(model, optimizer, scheduler, batch_dict, it, model_func, amp_dtype=torch.bfloat16,
+                   grad_norm_clip=None):
+    """lr_scheduler.step -> zero_grad -> autocast forward -> backward (DDP all-reduce overlaps) ->
+    [clip, non-AMP branch only: train_utils.py:88-93] -> optimizer.step."""
+    if scheduler is not None:
+        scheduler.step(it)
+    optimizer.zero_grad(set_to_none=True)
+    use_amp = amp_dtype is not None
+    with torch.autocast('cuda', dtype=amp_dtype if use_amp else torch.bfloat16, enabled=use_amp):
+        loss, tb_dict, disp_dict = model_func(model, batch_dict)
+    loss.backward()
+    if not use_amp and grad_norm_clip:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm_clip)
+    optimizer.step()
+    return loss, tb_dict, disp_dict

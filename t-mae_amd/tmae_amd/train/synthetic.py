@@ -1,0 +1,57 @@
+"""Deterministic synthetic ONCE-shape two-frame scans: log-uniform radius, uniform azimuth,
+ground-hugging z, uniform intensity; cropped to |x|,|y| <= 74.88 like mask_points_by_range
+(pcdet/utils/common_utils.py:124-127); previous frame = current translated by (0.5, 0.1) m and re-cropped.
+Batches follow the collate layout of the reference (pcdet/datasets/dataset.py:203-208): rows
+[batch_idx, x, y, z, intensity] float32 under the keys points / points_prev, plus batch_size."""
+import numpy as np
+
+
+def synth_frame_pair(n_points, batch_size, seed, shift=(0.5, 0.1), limit=74.88):
+    cur, prv = [], []
+    for b in range(batch_size):
+        rng = np.random.default_rng(seed * 64 + b)
+        r = np.exp(rng.uniform(np.log(2.0), np.log(105.0), n_points))
+        th = rng.uniform(0, 2 * np.pi, n_points)
+        x, y = r * np.cos(th), r * np.sin(th)
+        z = rng.normal(-1.7, 0.3, n_points) + 3 * rng.uniform(0, 1, n_points) ** 4
+        it = rng.uniform(0, 1, n_points)
+        pts = np.stack([np.full(n_points, b), x, y, z, it], axis=1).astype(np.float32)
+        keep = (np.abs(pts[:, 1]) <= limit) & (np.abs(pts[:, 2]) <= limit)
+        cur.append(pts[keep])
+        q = pts.copy()
+        q[:, 1] += np.float32(shift[0])
+        q[:, 2] += np.float32(shift[1])
+        keep = (np.abs(q[:, 1]) <= limit) & (np.abs(q[:, 2]) <= limit)
+        prv.append(q[keep])
+    return np.concatenate(cur), np.concatenate(prv)
+
+
+class _PointFeatureEncoder:
+    num_point_features = 5        # x, y, z, intensity, group_id (once_temporal_dataset.yaml POINT_FEATURE_ENCODING)
+
+
+class SyntheticTemporalDataset:
+    """Stands where ONCETemporalDataset stands for build_network: exposes class_names,
+    point_feature_encoder.num_point_features, grid_size, point_cloud_range, voxel_size
+    (detector3d_template.py:22,46-53) and yields collated batches."""
+
+    def __init__(self, dataset_cfg, class_names, n_points=120000, batch_size=8, rank=0, length=1 << 30):
+        self.class_names = class_names
+        self.point_feature_encoder = _PointFeatureEncoder()
+        self.point_cloud_range = np.array(dataset_cfg.POINT_CLOUD_RANGE, dtype=np.float32)
+        vs = None
+        for p in dataset_cfg.DATA_PROCESSOR:
+            if p.NAME == 'calculate_grid_size':
+                vs = p.VOXEL_SIZE
+        self.voxel_size = list(vs)
+        g = (self.point_cloud_range[3:6] - self.point_cloud_range[0:3]) / np.array(vs)
+        self.grid_size = np.round(g).astype(np.int64)          # data_processor.py:166-171
+        self.n_points, self.batch_size, self.rank, self.length = n_points, batch_size, rank, length
+
+    def __len__(self):
+        return self.length
+
+    def batch(self, iteration):
+        pts, prv = synth_frame_pair(self.n_points, self.batch_size, 1000 * self.rank + iteration,
+                                    limit=float(self.point_cloud_range[3]))
+        return {'points': pts, 'points_prev': prv, 'batch_size': self.batch_size}

@@ -1,0 +1,51 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, 't-mae_amd'), os.path.join(ROOT, 'oracle'), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+CFG_YAML = os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae_ssl.yaml')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+
+
+def load_cfg(num_stages=3):
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    cfg = cfg_from_yaml_file(CFG_YAML, EasyDict())
+    if num_stages < 3:
+        b = cfg.MODEL.BACKBONE_3D
+        b.SST_BLOCK_LIST = b.SST_BLOCK_LIST[:num_stages]
+        b.FEATURES_SOURCE = b.FEATURES_SOURCE[:num_stages]
+    return cfg
+
+
+def build_product_model(num_stages=3, params=None, device='cpu', n_points=1000, batch_size=2):
+    """TMAE through the pcdet registry path; `params` = oracle-style state dict (reference key names)."""
+    from pcdet.models import build_network
+    from tmae_amd.train import SyntheticTemporalDataset
+    cfg = load_cfg(num_stages)
+    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=n_points, batch_size=batch_size)
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
+    if params is not None:
+        res = model.load_state_dict(params, strict=False)
+        assert not res.unexpected_keys, res.unexpected_keys
+        assert all('running_' in k or 'num_batches' in k or k == 'global_step' for k in res.missing_keys), res.missing_keys
+    return model.to(device), cfg, ds
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    import tmae_oracle
+    return tmae_oracle

@@ -1,0 +1,113 @@
+"""CPU: the C-ABI library loads and exports every symbol include/tmae_hip.h declares (no compute calls),
+the host-side mirror of the pcdet API resolves, and the module tree reproduces the reference's state_dict."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, build_product_model, golden, load_cfg
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'tmae_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(tmae_\w+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tmae_amd import _lib
+    syms = _declared_symbols()
+    assert len(syms) >= 30
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f'{s} declared in tmae_hip.h but not exported'
+    assert set(syms) == set(_lib.SIGNATURES), set(syms) ^ set(_lib.SIGNATURES)
+    assert lib.tmae_abi_version() == _lib.ABI_VERSION
+
+
+def test_ops_refuse_cpu_tensors():
+    from tmae_amd import ops
+    with pytest.raises(RuntimeError, match='GPU only'):
+        ops.voxelize(torch.zeros(4, 5), 1, [-1, -1, -1, 1, 1, 1], [1, 1, 1], [2, 2, 2])
+    with pytest.raises(RuntimeError, match='GPU only'):
+        ops.get_inner_win_inds(torch.zeros(4, dtype=torch.long))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, 't-mae_amd')
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(d, f)).read()
+                assert 'tmae_oracle' not in src and 'ref_import' not in src, os.path.join(d, f)
+
+
+def test_config_api():
+    from pcdet.config import EasyDict, cfg_from_list
+    cfg = load_cfg(3)
+    assert cfg.MODEL.NAME == 'TMAE' and cfg.MODEL.VFE.NAME == 'TemporalDynVFE'
+    assert cfg.DATA_CONFIG.DATASET == 'ONCETemporalDataset'                  # from _BASE_CONFIG_
+    assert cfg.DATA_CONFIG.POINT_CLOUD_RANGE[0] == -74.88                    # override of the base
+    assert isinstance(cfg.MODEL.BACKBONE_3D.SST_BLOCK_LIST[0], EasyDict)
+    cfg_from_list(['OPTIMIZATION.LR', '0.001', 'MODEL.BACKBONE_3D.MASK_CONFIG.RATIO', '0.5'], cfg)
+    assert cfg.OPTIMIZATION.LR == 0.001 and cfg.MODEL.BACKBONE_3D.MASK_CONFIG.RATIO == 0.5
+    with pytest.raises(AssertionError):
+        cfg_from_list(['MODEL.NOPE', '1'], cfg)
+
+
+def test_registry_and_state_dict_contract():
+    from pcdet.models import detectors, backbones_3d
+    from pcdet.models.backbones_3d import vfe
+    assert {'TMAE', 'CenterPoint'} <= set(detectors.__all__)
+    assert {'SiamWCA_MAE', 'SiamWCA'} <= set(backbones_3d.__all__)
+    assert 'TemporalDynVFE' in vfe.__all__
+    with pytest.raises(NotImplementedError):
+        backbones_3d.__all__['SiamWCA']()
+    model, cfg, ds = build_product_model(3)
+    assert list(ds.grid_size) == [468, 468, 1]
+    g = golden('F0_state_dict_contract')
+    ref = {str(n): str(s) for n, s in zip(g['names'], g['shapes'])}
+    mine = {k: str(tuple(v.shape)) for k, v in model.state_dict().items() if k != 'global_step'}
+    assert mine == ref
+    assert sum(p.numel() for p in model.parameters()) == 11793218
+    assert 'global_step' in model.state_dict()
+
+
+def test_one_cycle_schedule_and_decoupled_decay():
+    from tmae_amd.train import AdamOneCycle, OneCycle
+    p = torch.nn.Parameter(torch.ones(3))
+    opt = AdamOneCycle([p], wd=0.01)
+    sch = OneCycle(opt, 100, 3e-3, [0.95, 0.85], 10, 0.4)
+    assert abs(opt.lr - 3e-4) < 1e-12 and abs(opt.mom - 0.95) < 1e-12
+    sch.step(40)
+    assert abs(opt.lr - 3e-3) < 1e-9 and abs(opt.mom - 0.85) < 1e-9
+    sch.step(99)
+    assert opt.lr < 1e-5
+    sch.step(10)
+    lr = opt.lr
+    p.grad = torch.zeros(3)
+    opt.step()                                                               # zero grad: only the decay acts
+    np.testing.assert_allclose(p.detach().numpy(), np.full(3, 1 - 0.01 * lr), rtol=1e-6)
+
+
+def test_pos_table_matches_golden():
+    from tmae_amd.modules.sst import pos_embed_table
+    g = golden('F6_pos_embed')
+    for d in (128, 256):
+        t = pos_embed_table(d, [8, 8, 1], 1000).numpy()
+        ciw = g['coors_in_win']
+        np.testing.assert_allclose(t[ciw[:, 1] * 8 + ciw[:, 2]], g[f'pos_{d}'], atol=1e-6)
+
+
+def test_synthetic_dataset_shards_by_rank():
+    from tmae_amd.train import SyntheticTemporalDataset
+    cfg = load_cfg(3)
+    a = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=500, batch_size=2, rank=0).batch(0)
+    b = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=500, batch_size=2, rank=1).batch(0)
+    a2 = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=500, batch_size=2, rank=0).batch(0)
+    assert np.array_equal(a['points'], a2['points']) and not np.array_equal(a['points'][:50], b['points'][:50])
+    assert a['points'].dtype == np.float32 and a['points'].shape[1] == 5
+    assert np.abs(a['points'][:, 1:3]).max() <= 74.88

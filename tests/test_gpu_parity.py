@@ -1,0 +1,512 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (tmae_amd.ops -> libtmae_hip.so), against
+ (1) the golden vectors captured from the reference (tests/golden),
+ (2) the CPU oracle on seeded inputs,
+ (3) size-independent properties at BASELINE configuration sizes.
+Bars: bit-exact for every integer / index / mask output; stated fp tolerances otherwise."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import build_product_model, golden
+
+pytestmark = pytest.mark.gpu
+
+PCR = [-74.88, -74.88, -5.0, 74.88, 74.88, 3.0]
+VS = [0.32, 0.32, 8.0]
+GRID = [468, 468, 1]
+DROP = {0: dict(max_tokens=16, drop_range=(0, 16)), 1: dict(max_tokens=32, drop_range=(16, 32)),
+        2: dict(max_tokens=64, drop_range=(32, 100000))}
+
+
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    return torch.device('cuda:0')
+
+
+def cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    return t if dtype is None else t.to(dtype)
+
+
+def test_native_library_is_loaded():
+    from tmae_amd import _lib
+    assert _lib.lib.tmae_abi_version() == 1
+    maps = open('/proc/self/maps').read()
+    assert 'libtmae_hip.so' in maps
+
+
+# ------------------------------------------------------------------------------------------ A1 / A2 / A5 / A12
+
+def test_voxelize_golden_bit_exact():
+    from tmae_amd import ops
+    g = golden('F1_F2_voxelize_vfe')
+    v = ops.voxelize(cu(g['points']), 2, PCR, VS, GRID)
+    assert np.array_equal(v['points'].cpu().numpy(), g['points_kept'])
+    assert np.array_equal(v['point_coords'].cpu().numpy(), g['point_coords'])
+    assert np.array_equal(v['voxel_coords'].cpu().numpy(), g['voxel_coords'])
+    assert np.array_equal(v['inverse'].cpu().numpy(), g['inverse'])
+    vc = g['voxel_coords']
+    assert v['voxels_per_sample'] == [int((vc[:, 0] == b).sum()) for b in range(2)]
+
+
+def test_voxelize_edge_and_empty(oracle):
+    from tmae_amd import ops
+    v = ops.voxelize(torch.zeros((0, 5), device=dev()), 2, PCR, VS, GRID)
+    assert v['points'].shape[0] == 0 and v['voxel_coords'].shape[0] == 0 and v['voxels_per_sample'] == [0, 0]
+    far = np.array([[0, 500., 0, 0, 1], [1, 0, -300., 0, 1], [0, 0, 0, 50., 1]], np.float32)
+    v = ops.voxelize(cu(far), 2, PCR, VS, GRID)
+    assert v['points'].shape[0] == 0 and v['voxel_coords'].shape[0] == 0
+    rng = np.random.default_rng(0)
+    # points exactly on voxel boundaries and range edges: the fp32 divide must round like the reference
+    k = rng.integers(0, 469, (4000, 2))
+    pts = np.zeros((4000, 5), np.float32)
+    pts[:, 0] = rng.integers(0, 2, 4000)
+    pts[:, 1] = np.float32(-74.88) + k[:, 0].astype(np.float32) * np.float32(0.32)
+    pts[:, 2] = np.float32(-74.88) + k[:, 1].astype(np.float32) * np.float32(0.32)
+    pts[:, 3] = rng.uniform(-14, 4, 4000)
+    o = oracle.voxelize(pts, PCR, VS, GRID)
+    v = ops.voxelize(cu(pts), 2, PCR, VS, GRID)
+    assert np.array_equal(v['point_coords'].cpu().numpy(), o['point_coords'])
+    assert np.array_equal(v['voxel_coords'].cpu().numpy(), o['voxel_coords'])
+    assert np.array_equal(v['inverse'].cpu().numpy(), o['inverse'])
+
+
+def test_ingroup_rank_and_csr(oracle):
+    from tmae_amd import ops
+    rng = np.random.default_rng(1)
+    for n, ng in ((1, 1), (1000, 7), (50000, 3000), (200000, 60000)):
+        g = rng.integers(0, ng, n)
+        r = ops.get_inner_win_inds(cu(g))
+        assert np.array_equal(r.cpu().numpy(), oracle.stable_ingroup_rank(g))
+        m = int(g.max()) + 1
+        perm, off = ops.segment_csr(cu(g), m)
+        perm, off = perm.cpu().numpy(), off.cpu().numpy()
+        assert off[0] == 0 and off[-1] == n and np.array_equal(np.diff(off), np.bincount(g, minlength=m))
+        assert np.array_equal(perm, np.argsort(g, kind='stable'))
+    assert ops.get_inner_win_inds(torch.zeros(0, dtype=torch.long, device=dev())).shape[0] == 0
+
+
+def test_sst_ops_utils_api(oracle):
+    """The reference's operator module surface (pcdet/ops/sst_ops/sst_ops_utils.py:5-27)."""
+    from pcdet.ops.sst_ops import sst_ops_utils
+    rng = np.random.default_rng(2)
+    inv = rng.integers(0, 300, 2000)
+    inv[:300] = np.arange(300)
+    pts = rng.normal(size=(2000, 3)).astype(np.float32)
+    out = sst_ops_utils.group_inner_inds(cu(pts), cu(inv), 8)
+    table = oracle.group_inner_inds(inv, 300, 8)
+    assert np.array_equal(out.cpu().numpy(), pts[table])
+    r = sst_ops_utils.get_inner_win_inds(cu(inv))
+    assert np.array_equal(r.cpu().numpy(), oracle.stable_ingroup_rank(inv))
+
+
+def test_vfe_features_golden():
+    g = golden('F1_F2_voxelize_vfe')
+    params = {k.replace('__', '.'): torch.from_numpy(g[k]) for k in g.files if k.startswith('vfe__')}
+    model, _, _ = build_product_model(3, params=params, device=dev())
+    model.train()
+    bd = {'points': cu(g['points']), 'points_prev': cu(g['points']), 'batch_size': 2}
+    bd = model.vfe(bd)
+    for suffix in ('', '_prev'):
+        np.testing.assert_allclose(bd['voxel_features' + suffix].detach().cpu().numpy(), g['voxel_features'], atol=1e-5)
+        assert np.array_equal(bd['voxel_coords' + suffix].cpu().numpy(), g['voxel_coords'])
+
+
+def test_segment_max_backward(oracle):
+    from tmae_amd import ops
+    rng = np.random.default_rng(3)
+    inv = rng.integers(0, 500, 4000)
+    inv[:500] = np.arange(500)
+    x = rng.normal(size=(4000, 128)).astype(np.float32)
+    for dt, tol in ((torch.float32, 0.0), (torch.bfloat16, 0.0)):
+        xt = cu(x, dt).requires_grad_(True)
+        perm, off = ops.segment_csr(cu(inv), 500)
+        out, arg = ops.scatter_max(xt, cu(inv), perm, off, 500)
+        xo = xt.detach().float().cpu().requires_grad_(True)
+        ref = oracle.segment_max(xo, torch.from_numpy(inv), 500)
+        assert torch.equal(out.detach().float().cpu(), ref.detach())
+        gout = torch.randn(500, 128)
+        out.backward(cu(gout.numpy(), dt))
+        ref.backward(gout.to(dt).float())
+        assert torch.equal(xt.grad.float().cpu(), xo.grad)                  # no ties in random data
+
+
+def test_group_points_and_chamfer(oracle):
+    from tmae_amd import ops
+    rng = np.random.default_rng(4)
+    pts, _ = oracle.synth_frame_pair(6000, 2, seed=9)
+    v = ops.voxelize(cu(pts), 2, PCR, VS, GRID)
+    m = v['voxel_coords'].shape[0]
+    perm, off = ops.segment_csr(v['inverse'], m)
+    ginds, gt = ops.group_points(v['points'], v['voxel_coords'], perm, off, 64, PCR, VS)
+    table = oracle.group_inner_inds(v['inverse'].cpu().numpy(), m, 64)
+    assert np.array_equal(ginds.cpu().numpy(), table)
+    gt_ref = torch.from_numpy(v['points'].cpu().numpy()[:, 1:4])[torch.from_numpy(table)] - \
+        oracle.voxel_centers(v['voxel_coords'].cpu().numpy()[:, 1:], VS, PCR).unsqueeze(1)
+    np.testing.assert_allclose(gt.cpu().numpy(), gt_ref.numpy(), atol=1e-6)
+    pred = torch.from_numpy(rng.normal(0, 0.3, (m, 16, 3)).astype(np.float32))
+    w = torch.from_numpy((rng.random(m) < 0.75).astype(np.float32))
+    pg = pred.clone().to(dev()).requires_grad_(True)
+    loss, _ = ops.chamfer_distance(pg, gt, weights=w.to(dev()))
+    loss.backward()
+    po = pred.clone().requires_grad_(True)
+    lo = oracle.chamfer_distance(po, gt_ref, w)
+    lo.backward()
+    assert abs(float(loss) - float(lo)) < 1e-5                               # north-star: Chamfer within 1e-4
+    np.testing.assert_allclose(pg.grad.cpu().numpy(), po.grad.numpy(), atol=1e-7)
+    z, _ = ops.chamfer_distance(pg.detach(), gt, weights=torch.zeros(m, device=dev()))
+    assert float(z) == 0.0
+
+
+# ------------------------------------------------------------------------------------------ A3
+
+def test_mask_golden_and_ties(oracle):
+    from tmae_amd import ops
+    g = golden('F3_mask')
+    vc = g['voxel_coords']
+    per = [int((vc[:, 0] == b).sum()) for b in range(2)]
+    offs = torch.tensor([0, per[0], per[0] + per[1]], dtype=torch.int32, device=dev())
+    mask, vis, nvis = ops.random_mask(cu(g['noise']), offs, 2, 1 - float(g['mask_ratio']))
+    assert np.array_equal(mask.cpu().numpy(), g['mask'])
+    n = int(nvis.item())
+    assert n == sum(int(L * 0.25) for L in per)
+    assert np.array_equal(vis[:n].cpu().numpy(), np.nonzero(g['mask'] == 0)[0])
+    # heavy ties: quantised noise; ties broken by index like a stable argsort
+    rng = np.random.default_rng(5)
+    noise = (rng.integers(0, 7, 5000) / 8).astype(np.float32)
+    offs = torch.tensor([0, 1800, 5000], dtype=torch.int32, device=dev())
+    mask, _, _ = ops.random_mask(cu(noise), offs, 2, 0.25)
+    ref = np.concatenate([oracle.random_masking_from_noise(noise[:1800], 0.75), oracle.random_masking_from_noise(noise[1800:], 0.75)])
+    assert np.array_equal(mask.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------------------------------ A4 / A10
+
+def _bucket(coords4, grid_n, other4=None, shift=False, batch=3):
+    from tmae_amd import ops
+    ind = cu(coords4[:, [0, 2, 3]], torch.int32).contiguous()
+    grid = ops.index_grid(ind, batch, grid_n, grid_n)
+    gother = None
+    if other4 is not None:
+        gother = ops.index_grid(cu(other4[:, [0, 2, 3]], torch.int32).contiguous(), batch, grid_n, grid_n)
+    return ops.window_bucket(ind, grid, gother, batch, grid_n, grid_n, [8, 8, 1], shift, DROP)
+
+
+def test_window_partition_golden():
+    g = golden('F4_window_partition')
+    for grid_n in (468, 234, 117):
+        for s in (0, 1):
+            wb = _bucket(g[f'coords_{grid_n}'], grid_n, shift=s == 1)
+            assert np.array_equal(wb['batch_win_inds'].cpu().numpy(), g[f'bwi_{grid_n}_s{s}'])
+            assert np.array_equal(wb['coors_in_win'].cpu().numpy(), g[f'ciw_{grid_n}_s{s}'])
+
+
+def test_bucketing_golden_single_and_temporal(oracle):
+    g = golden('F5_bucketing')
+    c = g['A_coords']
+    for s in (0, 1):
+        wb = _bucket(c, 468, shift=s == 1)
+        lvl = wb['level'].cpu().numpy()
+        assert np.array_equal(lvl, g[f'A_lvl_s{s}'])
+        assert wb['keep'].cpu().numpy().all()                                # SURVEY A-6: nothing is dropped
+        assert np.array_equal(wb['inner'].cpu().numpy(), oracle.stable_ingroup_rank(g[f'A_bwi_s{s}']))
+        f2w = wb['flat2win'].cpu().numpy()
+        for dl in (0, 1, 2):
+            assert np.array_equal(f2w[lvl == dl], g[f'A_f2w_s{s}_l{dl}'])
+            nwin = int(g[f'A_kpm_s{s}_l{dl}'].shape[0])
+            assert int(wb['win_per_level'][dl]) == nwin
+    cur, prv = g['T_coords_cur'], g['T_coords_prv']
+    for s in (0, 1):
+        for tag, a, b in (('cur', cur, prv), ('prv', prv, cur)):
+            wb = _bucket(a, 468, other4=b, shift=s == 1)
+            keep = wb['keep'].cpu().numpy().astype(bool)
+            assert np.array_equal(np.nonzero(keep)[0], g[f'T_{tag}_voxel_keep_inds_s{s}'])
+            assert np.array_equal(wb['level'].cpu().numpy()[keep], g[f'T_{tag}_voxel_drop_level_s{s}'])
+            assert np.array_equal(wb['batch_win_inds'].cpu().numpy()[keep], g[f'T_{tag}_batch_win_inds_s{s}'])
+            assert np.array_equal(wb['coors_in_win'].cpu().numpy()[keep], g[f'T_{tag}_coors_in_win_s{s}'])
+            f2w, lvl = wb['flat2win'].cpu().numpy(), wb['level'].cpu().numpy()
+            for dl in (0, 1, 2):
+                key = f'T_{tag}_f2w_s{s}_l{dl}'
+                if key in g.files:
+                    assert np.array_equal(f2w[keep & (lvl == dl)], g[key])
+                else:
+                    assert not (keep & (lvl == dl)).any()
+
+
+# ------------------------------------------------------------------------------------------ A6 / A7
+
+def _place(lens, base_b=0):
+    """Tokens of window w (t < lens[w]) at cell (t//8, t%8) of window (1 + w//50, 1 + w%50); returns
+    coords [(b,y,x)] sorted lexicographically and row id of every (w,t)."""
+    items = []
+    for w, L in enumerate(lens):
+        wy, wx = w // 50, w % 50
+        for t in range(int(L)):
+            items.append((base_b, wy * 8 + t // 8, wx * 8 + t % 8, w, t))
+    items.sort()
+    coords = np.array([(b, y, x) for b, y, x, _, _ in items], dtype=np.int32).reshape(-1, 3)
+    row = {(w, t): i for i, (_, _, _, w, t) in enumerate(items)}
+    return coords, row
+
+
+def _rows(padded, lens, row):
+    """padded [T, nW, E] -> ragged [M, E]."""
+    out = np.zeros((len(row), padded.shape[2]), np.float32)
+    for (w, t), i in row.items():
+        out[i] = padded[t, w]
+    return out
+
+
+@pytest.mark.parametrize('case', [0, 1, 2, 3])
+def test_attention_golden_fwd_bwd(case):
+    """Real reference CosineMultiheadAttention outputs/grads (F7) vs the ragged HIP kernel, fp32."""
+    from tmae_amd import ops
+    g = golden('F7_attention')
+    pre = f'c{case}_'
+    E, H, T, nW, cross = [int(v) for v in g[pre + 'meta']]
+    W = cu(g[pre + 'w_in_proj_weight']).requires_grad_(True)
+    bias = cu(g[pre + 'w_in_proj_bias'])
+    Wo, bo = cu(g[pre + 'w_out_proj__weight']), cu(g[pre + 'w_out_proj__bias'])
+    tau = cu(g[pre + 'w_tau']).requires_grad_(True)
+    klens = (~g[pre + 'kpm']).sum(1)
+    qlens = g[pre + 'qlens']
+    kc, krow = _place(klens)
+    qc, qrow = _place(qlens) if cross else (kc, krow)
+    gq = ops.index_grid(cu(qc), 1, 468, 468)
+    gk = ops.index_grid(cu(kc), 1, 468, 468)
+    Xq = cu(_rows(g[pre + 'q'], qlens, qrow)).requires_grad_(True)
+    Xv = cu(_rows(g[pre + 'v'], klens, krow)).requires_grad_(True)
+    if cross:
+        Xk = cu(_rows(g[pre + 'k'], klens, krow)).requires_grad_(True)
+        q = F.linear(Xq, W[:E], bias[:E])
+        k = F.linear(Xk, W[E:2 * E], bias[E:2 * E])
+        v = F.linear(Xv, W[2 * E:], bias[2 * E:])
+        o = ops.win_attn(q, k, v, tau, gq, gk, H, 1, 468, 468, False, 0.01)
+    else:
+        qk = F.linear(Xq, W[:2 * E], bias[:2 * E])
+        v = F.linear(Xv, W[2 * E:], bias[2 * E:])
+        o = ops.win_attn(qk, v, None, tau, gq, gk, H, 1, 468, 468, False, 0.01)
+    out = F.linear(o, Wo, bo)
+    (out * cu(_rows(g[pre + 'gout'], qlens, qrow))).sum().backward()
+    tol = 2e-5 if float(g[pre + 'tau']) >= 0.05 else 2e-4                  # logits reach +-100 at the tau clamp
+    np.testing.assert_allclose(out.detach().cpu().numpy(), _rows(g[pre + 'out'], qlens, qrow), atol=tol)
+    np.testing.assert_allclose(Xq.grad.cpu().numpy(), _rows(g[pre + 'dq'], qlens, qrow), atol=3e-4)
+    np.testing.assert_allclose(Xv.grad.cpu().numpy(), _rows(g[pre + 'dv'], klens, krow), atol=3e-4)
+    if cross:
+        np.testing.assert_allclose(Xk.grad.cpu().numpy(), _rows(g[pre + 'dk'], klens, krow), atol=3e-4)
+    dtau = g[pre + 'dtau']
+    np.testing.assert_allclose(tau.grad.cpu().numpy(), dtau, atol=1e-3 * max(1.0, float(np.abs(dtau).max())))
+    np.testing.assert_allclose(W.grad.cpu().numpy(), g[pre + 'd_in_proj_weight'], atol=1e-3)
+
+
+def test_attention_bf16_and_softmax_property():
+    """bf16 I/O (fp32 softmax/normalise) stays within bf16 tolerance of the fp32 kernel; with V = 1 every
+    attended row must come back as exactly-normalised ones (rows of P sum to 1) -- at stage-1 size."""
+    from tmae_amd import ops
+    rng = np.random.default_rng(7)
+    n = 40000
+    c = np.unique(np.stack([rng.integers(0, 2, n), rng.integers(0, 468, n), rng.integers(0, 468, n)], 1), axis=0)
+    ind = cu(c, torch.int32)
+    grid = ops.index_grid(ind, 2, 468, 468)
+    m = len(c)
+    tau = torch.full((1, 1, 1), 0.07, device=dev())
+    for d, H in ((128, 8), (256, 8)):
+        qk = torch.randn(m, 2 * d, device=dev())
+        v = torch.randn(m, d, device=dev())
+        for shift in (False, True):
+            o32 = ops.win_attn(qk, v, None, tau, grid, grid, H, 2, 468, 468, shift, 0.01)
+            o16 = ops.win_attn(qk.bfloat16(), v.bfloat16(), None, tau, grid, grid, H, 2, 468, 468, shift, 0.01)
+            err = (o16.float() - o32).abs().max().item()
+            assert err < 0.25 and (o16.float() - o32).abs().mean().item() < 2e-2, err
+            ones = ops.win_attn(qk, torch.ones_like(v), None, tau, grid, grid, H, 2, 468, 468, shift, 0.01)
+            assert (ones - 1).abs().max().item() < 1e-5
+
+
+def test_encoder_blocks_golden(oracle):
+    """F8: SSTBlockV1 encoder (4 layers) and the WCA block (2 cross layers), outputs + input grads, fp32."""
+    from tmae_amd.modules.sparse import SparseConvTensor
+    g = golden('F8_encoder_blocks')
+    cfg = oracle.default_model_cfg(3)
+    P = oracle.init_params(cfg, seed=int(g['param_seed']))
+    for n, t in P.items():
+        if n.endswith('tau'):
+            t.fill_(float(g['tau']))
+    model, _, _ = build_product_model(3, params=P, device=dev())
+    model.train()
+    blk = model.backbone_3d.sst_blocks[0]
+    c = g['coords']
+    x = cu(g['x']).requires_grad_(True)
+    sp = SparseConvTensor(x, cu(c[:, [0, 2, 3]], torch.int32), [468, 468], 3)
+    y = blk.encoder_forward(sp)
+    (y * cu(g['gout'])).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g['y'], atol=2e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g['dx'], atol=1e-3)
+    gW = blk.encoder_blocks[1].encoder_list[1].win_attn.self_attn.in_proj_weight.grad
+    np.testing.assert_allclose(gW.cpu().numpy(), g['dW_last_in_proj'], atol=1e-3)
+    gt = blk.encoder_blocks[0].encoder_list[0].win_attn.self_attn.tau.grad
+    np.testing.assert_allclose(gt.cpu().numpy(), g['dtau_first'], atol=1e-3 * max(1.0, float(np.abs(g['dtau_first']).max())))
+    wb = model.backbone_3d.wca_blocks[0]
+    cc = g['w_coords_cur']
+    xc = cu(g['w_xc']).requires_grad_(True)
+    xp = cu(g['w_xp']).requires_grad_(True)
+    spc = SparseConvTensor(xc, cu(cc[:, [0, 2, 3]], torch.int32), [468, 468], 3)
+    spp = SparseConvTensor(xp, cu(c[:, [0, 2, 3]], torch.int32), [468, 468], 3)
+    yc = wb.encoder_forward(spc, spp)
+    (yc * cu(g['w_gout'])).sum().backward()
+    np.testing.assert_allclose(yc.detach().cpu().numpy(), g['w_y'], atol=2e-4)
+    np.testing.assert_allclose(xc.grad.cpu().numpy(), g['w_dxc'], atol=1e-3)
+    np.testing.assert_allclose(xp.grad.cpu().numpy(), g['w_dxp'], atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------ A9 / A11
+
+def test_sparse_conv_golden_and_dense(oracle):
+    from tmae_amd.modules.sparse import SparseConvTensor, SubMConv2d, SparseConv2d
+    g = golden('F9_sparse_conv')
+    ind = g['indices']
+    feat = cu(g['feat']).requires_grad_(True)
+    sp = SparseConvTensor(feat, cu(ind, torch.int32), [468, 468], 3)
+    subm = SubMConv2d(16, 24, 3).to(dev())
+    down = SparseConv2d(16, 24, 3, stride=2, padding=1).to(dev())
+    with torch.no_grad():
+        subm.weight.copy_(cu(g['weight'])), down.weight.copy_(cu(g['weight']))
+    ys = subm(sp)
+    np.testing.assert_allclose(ys.features.detach().cpu().numpy(), g['subm_out'], atol=1e-5)
+    yd = down(sp)
+    assert yd.spatial_shape == [234, 234]
+    assert np.array_equal(yd.indices.cpu().numpy(), g['down_indices'])        # lexicographic output order
+    np.testing.assert_allclose(yd.features.detach().cpu().numpy(), g['down_out'], atol=1e-5)
+    # gradients against autograd through a dense conv on the densified input
+    go_s, go_d = torch.randn_like(ys.features), torch.randn_like(yd.features)
+    (ys.features * go_s).sum().backward(retain_graph=True)
+    gs_feat, gs_w = feat.grad.clone(), subm.weight.grad.clone()
+    feat.grad = None
+    (yd.features * go_d).sum().backward()
+    gd_feat, gd_w = feat.grad.clone(), down.weight.grad.clone()
+    fo = torch.from_numpy(g['feat']).requires_grad_(True)
+    wo = torch.from_numpy(g['weight']).requires_grad_(True)
+    dense = oracle.to_dense(fo, ind, (468, 468), 3)
+    wd = wo.permute(0, 3, 1, 2)
+    r1 = F.conv2d(dense, wd, padding=1).permute(0, 2, 3, 1)[ind[:, 0], ind[:, 1], ind[:, 2]]
+    (r1 * go_s.cpu()).sum().backward()
+    np.testing.assert_allclose(gs_feat.cpu().numpy(), fo.grad.numpy(), atol=1e-4)
+    np.testing.assert_allclose(gs_w.cpu().numpy(), wo.grad.numpy(), atol=1e-3)
+    fo.grad, wo.grad = None, None
+    oi = g['down_indices']
+    dense = oracle.to_dense(fo, ind, (468, 468), 3)
+    r2 = F.conv2d(dense, wo.permute(0, 3, 1, 2), stride=2, padding=1).permute(0, 2, 3, 1)[oi[:, 0], oi[:, 1], oi[:, 2]]
+    (r2 * go_d.cpu()).sum().backward()
+    np.testing.assert_allclose(gd_feat.cpu().numpy(), fo.grad.numpy(), atol=1e-4)
+    np.testing.assert_allclose(gd_w.cpu().numpy(), wo.grad.numpy(), atol=1e-3)
+
+
+def test_dense_roundtrip_full_grid():
+    from tmae_amd import ops
+    rng = np.random.default_rng(8)
+    c = np.unique(np.stack([rng.integers(0, 4, 150000), rng.integers(0, 468, 150000), rng.integers(0, 468, 150000)], 1), axis=0)
+    ind = cu(c, torch.int32)
+    grid = ops.index_grid(ind, 4, 468, 468)
+    for dt in (torch.float32, torch.bfloat16):
+        f = torch.randn(len(c), 128, device=dev()).to(dt).requires_grad_(True)
+        d = ops.sparse_to_dense(f, grid, ind, 4, 468, 468)
+        assert d.shape == (4, 468, 468, 128)
+        assert torch.equal(ops.dense_gather(d, grid, ind), f)                # dense -> rows is the exact inverse
+        assert float(d.float().abs().sum()) == pytest.approx(float(f.detach().float().abs().sum()), rel=1e-3)
+        w = torch.randn_like(d)
+        (d * w).sum().backward()
+        assert torch.equal(f.grad, ops.dense_gather(w, grid, ind).to(dt))
+
+
+# ------------------------------------------------------------------------------------------ end to end
+
+def _run_product(model, pts, prv, noise, bs, amp=None):
+    bd = {'points': cu(pts), 'points_prev': cu(prv), 'batch_size': bs, 'mae_noise': cu(noise)}
+    model.zero_grad()
+    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp is not None):
+        ret, tb, _ = model(bd)
+    ret['loss'].backward()
+    return ret['loss'], bd
+
+
+@pytest.mark.parametrize('name,nst', [('F11_e2e_1stage', 1), ('F10_e2e_3stage', 3)])
+def test_e2e_golden_and_oracle(oracle, name, nst):
+    """Whole step (VFE -> Siamese encoder -> masking -> WCA -> decoder -> Chamfer) in fp32 vs the reference's
+    captured loss / mask / predictions / grad norms, and per-parameter gradients vs the CPU oracle."""
+    g = golden(name)
+    cfg = oracle.default_model_cfg(nst)
+    P = oracle.init_params(cfg, seed=int(g['param_seed']))
+    for n, t in P.items():
+        if n.endswith('tau'):
+            t.fill_(float(g['tau']))
+    bs = int(g['batch_size'])
+    model, _, _ = build_product_model(nst, params=P, device=dev())
+    model.train()
+    loss, bd = _run_product(model, g['points'], g['points_prev'], g['noise'], bs)
+    assert abs(float(loss) - float(g['loss'])) < 1e-4, (float(loss), float(g['loss']))   # north-star bar
+    assert np.array_equal(bd['voxel_mae_mask'].cpu().numpy(), g['mask'])
+    assert np.array_equal(bd['voxel_coords'].cpu().numpy(), g['voxel_coords'])
+    pred = model.backbone_3d.forward_ret_dict['pred_points']
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g['pred_points'], atol=2e-4)
+    sf = bd['spatial_features'].detach().double()
+    assert float(sf.sum()) == pytest.approx(float(g['spatial_checksum']), rel=1e-4, abs=1.0)
+    assert float(sf.abs().sum()) == pytest.approx(float(g['spatial_abs_checksum']), rel=1e-4)
+    names = [str(n) for n in g['grad_names']]
+    grads = dict(model.named_parameters())
+    for n, gn in zip(names, g['grad_norms']):
+        assert abs(float(grads[n].grad.norm()) - gn) <= 5e-3 * max(1.0, gn), n
+    counts = dict(zip([str(s) for s in g['stage_count_names']], g['stage_counts']))
+    feats = bd['multi_scale_3d_features']
+    for si in range(nst):
+        assert feats[f'x_conv{si + 1}'].features.shape[0] == counts[f'cur_M{si}']
+    # per-parameter gradients against the oracle (CPU, same inputs)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lo = oracle.forward_loss(Pg, g['points'], g['points_prev'], g['noise'], bs, cfg)
+    lo.backward()
+    assert abs(float(lo) - float(loss)) < 1e-4
+    for n in names:
+        a, b = grads[n].grad.cpu(), Pg[n].grad
+        assert (a - b).abs().max().item() <= 5e-3 * max(1.0, b.abs().max().item()), n
+
+
+def test_e2e_bf16_autocast_close_to_fp32(oracle):
+    g = golden('F10_e2e_3stage')
+    cfg = oracle.default_model_cfg(3)
+    P = oracle.init_params(cfg, seed=int(g['param_seed']))
+    model, _, _ = build_product_model(3, params=P, device=dev())
+    model.train()
+    loss, _ = _run_product(model, g['points'], g['points_prev'], g['noise'], int(g['batch_size']), amp=True)
+    l32, _ = _run_product(model, g['points'], g['points_prev'], g['noise'], int(g['batch_size']))
+    assert torch.isfinite(loss) and abs(float(loss) - float(l32)) < 0.05 * max(1.0, abs(float(l32)))
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_full_size_properties(oracle):
+    """BASELINE config-2 sizes (120k-point frames, batch 2): size-independent properties of the index path."""
+    from tmae_amd import ops
+    pts, prv = oracle.synth_frame_pair(120000, 2, seed=1)
+    v = ops.voxelize(cu(pts), 2, PCR, VS, GRID)
+    vc, inv, pc = v['voxel_coords'], v['inverse'], v['point_coords']
+    assert torch.equal(vc[inv], pc)                                          # every point maps to its own voxel
+    key = (vc[:, 0] * 468 + vc[:, 2]) * 468 + vc[:, 3]
+    assert (key[1:] > key[:-1]).all()                                        # sorted, unique
+    assert sum(v['voxels_per_sample']) == vc.shape[0]
+    assert torch.unique(inv).numel() == vc.shape[0]
+    o = oracle.voxelize(pts, PCR, VS, GRID)
+    assert np.array_equal(vc.cpu().numpy(), o['voxel_coords']) and np.array_equal(inv.cpu().numpy(), o['inverse'])
+    m = vc.shape[0]
+    per = v['voxels_per_sample']
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(per)]), dtype=torch.int32, device=dev())
+    noise = torch.rand(m, device=dev())
+    mask, vis, nvis = ops.random_mask(noise, offs, 2, 0.25)
+    assert int(nvis) == sum(int(L * 0.25) for L in per) == int((mask == 0).sum())
+    ref = oracle.mask_voxels(vc.cpu().numpy(), noise.cpu().numpy(), 0.75, 2)
+    assert np.array_equal(mask.cpu().numpy(), ref)
+    ind = vc[:, [0, 2, 3]].int().contiguous()
+    grid = ops.index_grid(ind, 2, 468, 468)
+    for s in (False, True):
+        wb = ops.window_bucket(ind, grid, None, 2, 468, 468, [8, 8, 1], s, DROP)
+        bwi, _ = oracle.get_window_coors(vc.cpu().numpy(), (468, 468, 1), (8, 8, 1), s)
+        assert np.array_equal(wb['batch_win_inds'].cpu().numpy(), bwi)
+        assert np.array_equal(wb['inner'].cpu().numpy(), oracle.stable_ingroup_rank(bwi))
+        assert int(wb['win_per_level'].sum()) == len(np.unique(bwi))
