@@ -137,8 +137,17 @@ def main():
     def step(i):
         return train_one_step(ddp, opt, sched, dict(batches[i % nb]), i, model_func, amp_dtype=amp)[0]
 
+    def log(msg):
+        if rank == 0:
+            print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+    log(f'model on {dev}, {nb} synthetic batches resident ({int(batches[0]["points"].shape[0])} + '
+        f'{int(batches[0]["points_prev"].shape[0])} points each); warm-up ...')
     for i in range(args.warmup):
+        tw = time.perf_counter()
         step(i)
+        torch.cuda.synchronize()
+        log(f'warm-up step {i}: {time.perf_counter() - tw:.2f} s')
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -168,8 +177,10 @@ def main():
                        'batch_per_gpu': args.batch_per_gpu, 'global_batch': args.batch_per_gpu * world,
                        'parallelism': f'dp{world}', 'grid': '468x468x1', 'final_loss': round(loss_val, 5)},
         }
+        log(f'timed region done: {1e3 * elapsed / args.steps:.1f} ms/step; timing the dominant kernel ...')
         line['roofline'] = kernel_roofline(model, dict(batches[0]), amp)
         if world == 1 and not args.no_cpu_baseline:
+            log('timing the CPU oracle on one frame pair (cpu_baseline) ...')
             line['cpu_baseline'] = cpu_baseline(args.cpu_points)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -358,15 +358,11 @@ def main():
          subm_pairs=np.array([len(p[0]) for p in pairs]), down_pairs=np.array([len(p[0]) for p in pairs2]))
 
     # ---- F10 / F11 end-to-end, 1-stage (config C1 reading) and 3-stage, small clouds
-    for tag, nst, npts, bs in (('F11_e2e_1stage', 1, 3000, 2), ('F10_e2e_3stage', 3, 2500, 2)):
+    for tag, nst, npts, bs in (('F11_e2e_1stage', 1, 6000, 2), ('F10_e2e_3stage', 3, 5000, 2)):
         print(tag)
         c1 = O.default_model_cfg(nst)
         Vn, Bn, _ = R.build_reference_model(nst, seed=0)
-        P = O.init_params(c1, seed=7)
-        with torch.no_grad():
-            for n_, t_ in P.items():
-                if n_.endswith('tau'):
-                    t_.fill_(0.2)
+        P = O.init_params(c1, seed=7, tau=0.2, pred_scale=0.1)
         missing = Vn.load_state_dict({k[4:]: v for k, v in P.items() if k.startswith('vfe.')}, strict=False)
         assert not missing.unexpected_keys
         missing = Bn.load_state_dict({k[12:]: v for k, v in P.items() if k.startswith('backbone_3d.')}, strict=False)
@@ -404,7 +400,7 @@ def main():
             counts[f'prev_M{si}'] = len(cap[f'prev_stage{si}']['indices'])
             counts[f'cur_M{si}'] = len(cap[f'cur_stage{si}']['indices'])
             assert counts[f'prev_M{si}'] == len(bd['multi_scale_3d_features'][f'x_conv{si + 1}'].indices) or True
-        save(tag, n_points=npts, batch_size=bs, data_seed=21, param_seed=7, tau=np.float32(0.2),
+        save(tag, n_points=npts, batch_size=bs, data_seed=21, param_seed=7, tau=np.float32(0.2), pred_scale=np.float32(0.1),
              points=pts, points_prev=pts_prev, noise=noise, loss=loss.detach(),
              mask=bd['voxel_mae_mask'], pred_points=Bn.forward_ret_dict['pred_points'].detach(),
              voxel_coords=vc, grad_names=np.array(list(gn.keys())), grad_norms=np.array(list(gn.values())),

@@ -307,6 +307,7 @@ int tmae_win_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
                       int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
                       int batch, int ny, int nx, int do_shift, const float* tau, float tau_min, void* out, int64_t ldo,
                       float* lse, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   int r = attn_check(mq, mk, nhead, dh, batch, ny, nx);
   if (r) return r;
@@ -332,6 +333,7 @@ int tmae_win_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
                       int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
                       int batch, int ny, int nx, int do_shift, const float* tau, float tau_min, void* dq, int64_t lddq,
                       void* dk, int64_t lddk, void* dv, int64_t lddv, float* dtau_partial, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   int r = attn_check(mq, mk, nhead, dh, batch, ny, nx);
   if (r) return r;

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void chamfer_bwd_kernel(const float* __restric
 
 int tmae_chamfer_fwd(const float* pred, const float* gt, const float* weights, int64_t m, int np, int ng,
                      float* per_voxel, int8_t* idx_x, int8_t* idx_y, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || np <= 0 || np > 64 || ng <= 0 || ng > 64) return TMAE_EARG;
   if (m == 0) return TMAE_OK;
@@ -97,6 +98,7 @@ int tmae_chamfer_fwd(const float* pred, const float* gt, const float* weights, i
 int tmae_chamfer_bwd(const float* pred, const float* gt, const float* weights, const int8_t* idx_x,
                      const int8_t* idx_y, const float* scale, int64_t m, int np, int ng, float* dpred,
                      void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || np <= 0 || np > 64 || ng <= 0 || ng > 64) return TMAE_EARG;
   if (m == 0) return TMAE_OK;

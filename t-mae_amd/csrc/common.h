@@ -38,6 +38,23 @@ template <> __device__ __forceinline__ void st_f<__hip_bfloat16>(__hip_bfloat16*
 
 __device__ __forceinline__ float bf16_bits_to_f(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 
+// ---- correctly-rounded single fp32 ops that the compiler may NOT contract into an fma.  hipcc defaults to
+// -ffp-contract=fast and HIP's __fmul_rn/__fadd_rn are plain operators, so parity-critical arithmetic
+// (voxel indices, voxel centres: the reference rounds every op separately) goes through these.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+__device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
+
 // ---- wave reductions ---------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

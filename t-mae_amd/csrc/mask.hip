@@ -97,6 +97,7 @@ size_t tmae_random_mask_workspace(int64_t m, int batch) {
 
 int tmae_random_mask(const float* noise, const int32_t* sample_offsets, int64_t m, int batch, double keep_frac,
                      float* mask, int32_t* vis_index, int32_t* n_vis, void* wsp, size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || batch <= 0 || !sample_offsets || !n_vis || m >= (1ll << 31)) return TMAE_EARG;
   if (m > 0 && (!noise || !mask || !vis_index)) return TMAE_EARG;

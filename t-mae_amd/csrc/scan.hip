@@ -83,6 +83,7 @@ static int scan_rec(const int32_t* in, int32_t* out, int64_t n, WsCarver& ws, hi
 
 int tmae_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total, void* wsp, size_t ws_bytes,
                   hipStream_t stream) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   if (n < 0 || (n > 0 && (!in || !out))) return TMAE_EARG;
   if (n > 0) {
     WsCarver ws(wsp, ws_bytes);

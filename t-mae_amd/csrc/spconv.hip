@@ -51,6 +51,7 @@ size_t tmae_spconv_down_outputs_workspace(int batch, int oy, int ox) {
 
 int tmae_spconv_down_outputs(const int32_t* grid_in, int batch, int ny, int nx, int oy, int ox, int32_t* out_grid,
                              int32_t* out_indices, int32_t* n_out, void* wsp, size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (!grid_in || !out_grid || !out_indices || !n_out || batch <= 0 || ny <= 0 || nx <= 0) return TMAE_EARG;
   if (oy != (ny + 2 - 3) / 2 + 1 || ox != (nx + 2 - 3) / 2 + 1) return TMAE_EARG;
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256) void nbr_t_kernel(const int32_t* __restrict__ 
 
 int tmae_spconv_neighbors(const int32_t* out_indices, int64_t m_out, const int32_t* grid_in, int batch, int ny,
                           int nx, int stride, int32_t* nbr, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (m_out < 0 || batch <= 0 || ny <= 0 || nx <= 0 || (stride != 1 && stride != 2)) return TMAE_EARG;
   if (m_out == 0) return TMAE_OK;
@@ -113,6 +115,7 @@ int tmae_spconv_neighbors(const int32_t* out_indices, int64_t m_out, const int32
 
 int tmae_spconv_neighbors_t(const int32_t* in_indices, int64_t m_in, const int32_t* grid_out, int batch, int oy,
                             int ox, int stride, int32_t* nbr_t, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (m_in < 0 || batch <= 0 || oy <= 0 || ox <= 0 || (stride != 1 && stride != 2)) return TMAE_EARG;
   if (m_in == 0) return TMAE_OK;
@@ -169,6 +172,7 @@ static int esize(int dtype) { return dtype == TMAE_F32 ? 4 : (dtype == TMAE_BF16
 
 int tmae_spconv_gather(const void* feat, int dtype, int64_t m_in, int c, const int32_t* nbr, int64_t m_out,
                        void* cols, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   const int es = esize(dtype);
   if (!es) return TMAE_EDTYPE;
@@ -183,6 +187,7 @@ int tmae_spconv_gather(const void* feat, int dtype, int64_t m_in, int c, const i
 
 int tmae_spconv_gather_t(const void* dcols, int dtype, int64_t m_out, int c, const int32_t* nbr_t, int64_t m_in,
                          void* din, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   const int es = esize(dtype);
   if (!es) return TMAE_EDTYPE;
@@ -232,6 +237,7 @@ __global__ __launch_bounds__(256) void dense_gather_kernel(const char* __restric
 
 int tmae_sparse_to_dense(const void* feat, int dtype, int64_t m, int c, const int32_t* grid, int batch, int ny,
                          int nx, void* out, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   const int es = esize(dtype);
   if (!es) return TMAE_EDTYPE;
@@ -245,6 +251,7 @@ int tmae_sparse_to_dense(const void* feat, int dtype, int64_t m, int c, const in
 
 int tmae_dense_gather(const void* dense, int dtype, int batch, int ny, int nx, int c, const int32_t* indices,
                       int64_t m, void* rows, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   const int es = esize(dtype);
   if (!es) return TMAE_EDTYPE;

@@ -16,9 +16,9 @@ __global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ 
   if (i >= n) return;
   const float* p = pts + i * 5;
   // IEEE fp32 subtract + divide, truncation toward zero (common_utils.py:74); no reciprocal, no fma.
-  float qx = __fdiv_rn(__fsub_rn(p[1], rx), vx);
-  float qy = __fdiv_rn(__fsub_rn(p[2], ry), vy);
-  float qz = __fdiv_rn(__fsub_rn(p[3], rz), vz);
+  float qx = div_rn(sub_rn(p[1], rx), vx);
+  float qy = div_rn(sub_rn(p[2], ry), vy);
+  float qz = div_rn(sub_rn(p[3], rz), vz);
   float fb = p[0];
   bool ok = (qx > -1.0f) && (qy > -1.0f) && (qz > -1.0f) && (qx < (float)gx) && (qy < (float)gy) &&
             (qz < (float)gz) && (fb > -1.0f) && (fb < (float)batch);
@@ -93,6 +93,7 @@ size_t tmae_voxelize_workspace(int64_t n, int batch, int gx, int gy, int gz) {
 int tmae_voxelize(const float* points, int64_t n, int batch, float rx, float ry, float rz, float vx, float vy,
                   float vz, int gx, int gy, int gz, float* points_out, int64_t* point_coords, int64_t* inverse,
                   int64_t* voxel_coords, int32_t* counts, void* wsp, size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || batch <= 0 || gx <= 0 || gy <= 0 || gz <= 0 || !counts) return TMAE_EARG;
   int64_t cells = (int64_t)batch * gx * gy * gz;
@@ -204,6 +205,7 @@ static int csr_build(const int64_t* g, int64_t n, int64_t m, int32_t* perm, int3
 
 int tmae_segment_csr(const int64_t* inverse, int64_t n, int64_t m, int32_t* perm, int32_t* offsets, void* ws,
                      size_t ws_bytes, void* stream) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   return csr_build(inverse, n, m, perm, offsets, nullptr, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -223,6 +225,7 @@ size_t tmae_ingroup_rank_workspace(int64_t n, int64_t num_groups) {
 
 int tmae_ingroup_rank(const int64_t* group, int64_t n, int64_t num_groups, int64_t* out, void* wsp, size_t ws_bytes,
                       void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || num_groups < 0 || (n > 0 && (!group || !out))) return TMAE_EARG;
   if (n == 0) return TMAE_OK;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   for (int j = lo; j < hi; ++j) {            // ascending point id: deterministic sum
     const float* p = pts + (int64_t)perm[j] * 5;
-    s0 += p[1]; s1 += p[2]; s2 += p[3]; s3 += p[4];
+    s0 = add_rn(s0, p[1]); s1 = add_rn(s1, p[2]); s2 = add_rn(s2, p[3]); s3 = add_rn(s3, p[4]);
   }
   const float c = (float)max(hi - lo, 1);
   float* o = mean + v * 4;
@@ -270,18 +273,19 @@ __global__ __launch_bounds__(256) void point_feat_kernel(const float* __restrict
   const float* mu = mean + inv[i] * 4;
   const float x = p[1], y = p[2], z = p[3];
   // f_center = p - ((coord + 0.5) * vs + rmin): separate fp32 roundings as in temporal_dyn_vfe.py:93-96
-  const float ccx = __fadd_rn(__fmul_rn(__fadd_rn((float)c[3], 0.5f), vx), rx);
-  const float ccy = __fadd_rn(__fmul_rn(__fadd_rn((float)c[2], 0.5f), vy), ry);
-  const float ccz = __fadd_rn(__fmul_rn(__fadd_rn((float)c[1], 0.5f), vz), rz);
+  const float ccx = add_rn(mul_rn(add_rn((float)c[3], 0.5f), vx), rx);
+  const float ccy = add_rn(mul_rn(add_rn((float)c[2], 0.5f), vy), ry);
+  const float ccz = add_rn(mul_rn(add_rn((float)c[1], 0.5f), vz), rz);
   float* f = feats + i * 10;
-  f[0] = x - ccx; f[1] = y - ccy; f[2] = z - ccz;
+  f[0] = sub_rn(x, ccx); f[1] = sub_rn(y, ccy); f[2] = sub_rn(z, ccz);
   f[3] = x; f[4] = y; f[5] = z; f[6] = p[4];
-  f[7] = x - mu[0]; f[8] = y - mu[1]; f[9] = z - mu[2];
+  f[7] = sub_rn(x, mu[0]); f[8] = sub_rn(y, mu[1]); f[9] = sub_rn(z, mu[2]);
 }
 
 int tmae_vfe_point_features(const float* points, const int64_t* pc, const int64_t* inverse, const int32_t* perm,
                             const int32_t* offsets, int64_t n, int64_t m, float rx, float ry, float rz, float vx,
                             float vy, float vz, float* voxel_mean, float* feats, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || m < 0) return TMAE_EARG;
   if (n == 0 || m == 0) return TMAE_OK;
@@ -335,6 +339,7 @@ __global__ __launch_bounds__(256) void segmax_bwd_kernel(const T* __restrict__ d
 
 int tmae_segment_max_fwd(const void* x, int dtype, int64_t n, int64_t m, int c, const int32_t* perm,
                          const int32_t* offsets, void* out, int32_t* argmax, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || m < 0 || c <= 0) return TMAE_EARG;
   if (m == 0) return TMAE_OK;
@@ -353,6 +358,7 @@ int tmae_segment_max_fwd(const void* x, int dtype, int64_t n, int64_t m, int c, 
 
 int tmae_segment_max_bwd(const void* dout, int dtype, int64_t n, int64_t m, int c, const int64_t* inverse,
                          const int32_t* argmax, void* dx, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || m < 0 || c <= 0) return TMAE_EARG;
   if (n == 0) return TMAE_OK;
@@ -389,10 +395,10 @@ __global__ __launch_bounds__(256) void group_points_kernel(const float* __restri
     idx = perm[lo + (t < cnt ? t : t % cnt)];          // cyclic repeat, sst_ops_gpu.cu:30-39
     const float* p = pts + idx * 5;
     const int64_t* c = vc + v * 4;
-    const float cx = __fadd_rn(__fmul_rn(__fadd_rn((float)c[3], 0.5f), vx), rx);
-    const float cy = __fadd_rn(__fmul_rn(__fadd_rn((float)c[2], 0.5f), vy), ry);
-    const float cz = __fadd_rn(__fmul_rn(__fadd_rn((float)c[1], 0.5f), vz), rz);
-    gx_ = p[1] - cx; gy_ = p[2] - cy; gz_ = p[3] - cz;
+    const float cx = add_rn(mul_rn(add_rn((float)c[3], 0.5f), vx), rx);
+    const float cy = add_rn(mul_rn(add_rn((float)c[2], 0.5f), vy), ry);
+    const float cz = add_rn(mul_rn(add_rn((float)c[1], 0.5f), vz), rz);
+    gx_ = sub_rn(p[1], cx); gy_ = sub_rn(p[2], cy); gz_ = sub_rn(p[3], cz);
   }
   if (ginds) ginds[e] = idx;
   float* g = gt + e * 3;
@@ -402,6 +408,7 @@ __global__ __launch_bounds__(256) void group_points_kernel(const float* __restri
 int tmae_group_points(const float* points, const int64_t* voxel_coords, const int32_t* perm, const int32_t* offsets,
                       int64_t m, int k, float rx, float ry, float rz, float vx, float vy, float vz,
                       int64_t* group_inds, float* gt, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || k <= 0) return TMAE_EARG;
   if (m == 0) return TMAE_OK;

@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const int32_t* __rest
 }
 
 int tmae_index_grid(const int32_t* indices, int64_t m, int batch, int ny, int nx, int32_t* grid, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || batch <= 0 || ny <= 0 || nx <= 0 || !grid || (m > 0 && !indices)) return TMAE_EARG;
   hipMemsetAsync(grid, 0xFF, (size_t)batch * ny * nx * 4, stream);
@@ -132,6 +133,7 @@ int tmae_window_bucket(const int32_t* indices, int64_t m, const int32_t* grid, c
                        int ny, int nx, int wy, int wx, int do_shift, const int32_t* levels_host, int n_levels,
                        int64_t* bwi, int64_t* ciw, int32_t* inner, int32_t* level, uint8_t* keep, int64_t* f2w,
                        int32_t* win_per_level, void* wsp, size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || batch <= 0 || ny <= 0 || nx <= 0 || wy <= 0 || wx <= 0 || wy * wx > 64 || !grid || !levels_host ||
       n_levels <= 0 || n_levels > MAX_LEVELS || !inner || !win_per_level || (m > 0 && !indices))
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(256) void add_pos_kernel(const T* __restrict__ x, i
 
 int tmae_add_pos_embed(const void* x, int dtype, int64_t m, int d, const int32_t* indices, int wy, int wx,
                        int do_shift, const float* pos_table, void* out, void* stream_) {
+  (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || d <= 0 || wy <= 0 || wx <= 0) return TMAE_EARG;
   if (m == 0) return TMAE_OK;

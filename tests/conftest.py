@@ -31,7 +31,7 @@ def load_cfg(num_stages=3):
     return cfg
 
 
-def build_product_model(num_stages=3, params=None, device='cpu', n_points=1000, batch_size=2):
+def build_product_model(num_stages=3, params=None, device='cpu', n_points=1000, batch_size=2, partial=False):
     """TMAE through the pcdet registry path; `params` = oracle-style state dict (reference key names)."""
     from pcdet.models import build_network
     from tmae_amd.train import SyntheticTemporalDataset
@@ -41,7 +41,8 @@ def build_product_model(num_stages=3, params=None, device='cpu', n_points=1000, 
     if params is not None:
         res = model.load_state_dict(params, strict=False)
         assert not res.unexpected_keys, res.unexpected_keys
-        assert all('running_' in k or 'num_batches' in k or k == 'global_step' for k in res.missing_keys), res.missing_keys
+        assert partial or all('running_' in k or 'num_batches' in k or k == 'global_step' for k in res.missing_keys), \
+            res.missing_keys
     return model.to(device), cfg, ds
 
 

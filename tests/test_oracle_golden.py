@@ -111,10 +111,8 @@ def test_f7_attention(oracle):
 def test_f8_encoder_blocks(oracle):
     g = golden('F8_encoder_blocks')
     cfg = oracle.default_model_cfg(3)
-    P = oracle.init_params(cfg, seed=int(g['param_seed']))
-    for n, t in P.items():
-        if n.endswith('tau'):
-            t.fill_(float(g['tau']))
+    P = oracle.init_params(cfg, seed=int(g['param_seed']), tau=float(g['tau']),
+                           pred_scale=float(g['pred_scale']) if 'pred_scale' in g.files else 1.0)
     x = torch.from_numpy(g['x']).requires_grad_(True)
     y = oracle.sst_encoder(x, g['coords'], (468, 468, 1), P, 'backbone_3d.sst_blocks.0.', cfg['stages'][0], cfg)
     (y * torch.from_numpy(g['gout'])).sum().backward()
@@ -152,10 +150,8 @@ def test_f9_sparse_conv_vs_dense(oracle):
 def _e2e(oracle, name, nst):
     g = golden(name)
     cfg = oracle.default_model_cfg(nst)
-    P = oracle.init_params(cfg, seed=int(g['param_seed']))
-    for n, t in P.items():
-        if n.endswith('tau'):
-            t.fill_(float(g['tau']))
+    P = oracle.init_params(cfg, seed=int(g['param_seed']), tau=float(g['tau']),
+                           pred_scale=float(g['pred_scale']) if 'pred_scale' in g.files else 1.0)
     P = {k: v.requires_grad_(True) for k, v in P.items()}
     cap = {}
     loss = oracle.forward_loss(P, g['points'], g['points_prev'], g['noise'], int(g['batch_size']), cfg, cap)
