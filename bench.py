@@ -83,7 +83,11 @@ def cpu_baseline(n_points):
     host cores: forward + backward of ONE frame pair, fp32, all cores."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import tmae_oracle as O
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))          # the 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(cores)
     cfg = O.default_model_cfg(3)
     P = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=0).items()}

@@ -7,6 +7,9 @@ of torch.cuda.current_stream() -- PyTorch is only the allocator / stream provide
 import ctypes as C
 import os
 
+import torch  # noqa: F401  MUST precede the CDLL below: torch bundles its own libamdhip64.so.7; loading ours first
+#                     would put a second HIP runtime in the process (torch's pointers/streams would be foreign to it)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libtmae_hip.so')
 
