@@ -205,6 +205,16 @@ int tmae_chamfer_bwd(const float* pred, const float* gt, const float* weights, c
                      const int8_t* idx_y, const float* scale, int64_t m, int np, int ng,
                      float* dpred, void* stream);
 
+/* Weight / bias gradient of the token-list Linear layers (replaces the autograd of torch.nn.functional.linear as
+ * called from cosine_msa.py:47-62,431, sst_basic_block.py:81, wca_block.py:99 and of the gather-GEMM sparse conv):
+ *   dw [n,k] f32 = sum_m dy[m,n] * x[m,k];   db [n] f32 = sum_m dy[m,n]  (db may be NULL).
+ * dy [m, >=n] and x [m, >=k] are bf16 with row strides ldy / ldx (elements, multiples of 8, 16-byte aligned bases);
+ * n, k multiples of 8.  Token axis split over ~1k workgroups, MFMA 16x16x32 with transposed LDS reads, fp32 slabs
+ * in the workspace summed in a fixed order (deterministic). */
+size_t tmae_linear_wgrad_workspace(int64_t m, int n, int k);
+int tmae_linear_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k,
+                      float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,178 @@
+// Weight / bias gradient of a Linear over a token list:  dW[n,k] = sum_m dY[m,n] * X[m,k],  db[n] = sum_m dY[m,n].
+//
+// Why a kernel of our own: on this path M is 1e5..4e5 tokens while N,K <= 512, so the output is a few tiles and
+// the library GEMM runs on a handful of workgroups (measured 15-130 TFLOP/s, 0.25-0.7 TB/s; profiles/).  The work
+// is one streaming pass over dY and X, so the bound is HBM.  Here the token axis is split over ~1k workgroups; each
+// streams its 32-row slices of dY and X through LDS once (16-byte coalesced loads, double buffered) and contracts
+// them on the matrix cores.  The contraction index (token m) is the ROW index of both operands, i.e. both MFMA
+// operands are needed "transposed"; gfx950's ds_read_b64_tr_b16 delivers exactly that from a row-major LDS image
+// (XOR-swizzled so the transposed reads are bank-conflict free), so no transposed copy is ever materialised.
+// Partial [N,K] blocks go to fp32 slabs (plain stores) and a second tiny kernel sums the slabs in a fixed order:
+// deterministic, no atomics.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WG_BN 128   // output rows (n) per workgroup
+#define WG_BK 128   // output cols (k) per workgroup
+#define WG_MS 32    // tokens per step = one 16x16x32 MFMA k-step
+
+// byte offset of 16-byte chunk `ch` (0..15) of row `row` in a [rows][128 x bf16] LDS image; the XOR makes both the
+// row-wise b128 stores and the transposed b64 reads of 16x16x32 operands conflict free (guide T10, layout (b)).
+__device__ __forceinline__ int tile_off(int row, int ch) {
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+__device__ __forceinline__ s16x4 tr_read(const char* lds_ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_ptr);
+}
+
+// fragment (8 consecutive tokens 8g..8g+7 for column cb*16 + (lane&15)) of a [32][128] image
+__device__ __forceinline__ bf16x8 load_frag(const char* img, int cb, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const s16x4 lo = tr_read(img + tile_off(8 * g + q, 2 * cb + (p >> 1)) + 8 * (p & 1));
+  const s16x4 hi = tr_read(img + tile_off(8 * g + 4 + q, 2 * cb + (p >> 1)) + 8 * (p & 1));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return *reinterpret_cast<bf16x8*>(&v);
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
+                                                   const __hip_bfloat16* __restrict__ X, int64_t ldx, int64_t M,
+                                                   int N, int K, int rows_per_split, float* __restrict__ slab_w,
+                                                   float* __restrict__ slab_b) {
+  __shared__ __attribute__((aligned(16))) char lds[2][2][WG_MS * 256];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w >> 1, wk = w & 1;
+  const int n0 = blockIdx.x * WG_BN, k0 = blockIdx.y * WG_BK, s = blockIdx.z;
+  const int64_t m_begin = (int64_t)s * rows_per_split;
+  const int64_t m_end = min(M, m_begin + (int64_t)rows_per_split);
+  const int steps = m_end > m_begin ? (int)((m_end - m_begin + WG_MS - 1) / WG_MS) : 0;
+  const bool want_bias = (slab_b != nullptr) && blockIdx.y == 0 && wk == 0;     // wave-uniform
+
+  uint4 ry[2], rx[2];
+  auto gload = [&](int step) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+      const int64_t m = m_begin + (int64_t)step * WG_MS + row;
+      const int cy = n0 + ch * 8, cx = k0 + ch * 8;
+      ry[i] = (m < m_end && cy < N) ? *reinterpret_cast<const uint4*>(dY + m * ldy + cy) : make_uint4(0, 0, 0, 0);
+      rx[i] = (m < m_end && cx < K) ? *reinterpret_cast<const uint4*>(X + m * ldx + cx) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lwrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+      *reinterpret_cast<uint4*>(&lds[buf][0][tile_off(row, ch)]) = ry[i];
+      *reinterpret_cast<uint4*>(&lds[buf][1][tile_off(row, ch)]) = rx[i];
+    }
+  };
+
+  f32x4 acc[4][4], accb[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
+  const bf16x8 ones = *reinterpret_cast<bf16x8*>(&ones_s);
+
+  if (steps > 0) {
+    gload(0);
+    lwrite(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < steps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < steps) gload(st + 1);
+    bf16x8 fa[4], fb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      fa[t] = load_frag(lds[buf][0], wn * 4 + t, lane);
+      fb[t] = load_frag(lds[buf][1], wk * 4 + t, lane);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    if (want_bias) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
+    }
+    if (st + 1 < steps) lwrite(buf ^ 1);
+    __syncthreads();
+  }
+  // C layout of mfma_f32_16x16x*: lane holds rows 4*(lane>>4)+r, column lane&15
+  const int g = lane >> 4, ci = lane & 15;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + (wn * 4 + a) * 16 + 4 * g + r;
+      if (n >= N) continue;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int k = k0 + (wk * 4 + b) * 16 + ci;
+        if (k < K) slab_w[((int64_t)s * N + n) * K + k] = acc[a][b][r];
+      }
+      if (want_bias && ci == 0) slab_b[(int64_t)s * N + n] = accb[a][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int64_t count,
+                                                          float* __restrict__ out) {
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  float acc = 0.f;
+  for (int s = 0; s < splits; ++s) acc += slab[(int64_t)s * count + e];     // fixed order: deterministic
+  out[e] = acc;
+}
+
+static void wgrad_plan(int64_t m, int n, int k, int& splits, int& rows_per_split) {
+  const int nb = ((n + WG_BN - 1) / WG_BN) * ((k + WG_BK - 1) / WG_BK);
+  int64_t s = (768 + nb - 1) / nb;                        // ~3 workgroups per CU in flight
+  const int64_t max_s = (m + 255) / 256;                  // at least 8 steps per workgroup
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  int64_t rows = (m + s - 1) / s;
+  rows = (rows + WG_MS - 1) / WG_MS * WG_MS;
+  if (rows < WG_MS) rows = WG_MS;
+  splits = (int)((m + rows - 1) / rows);
+  if (splits < 1) splits = 1;
+  rows_per_split = (int)rows;
+}
+
+size_t tmae_linear_wgrad_workspace(int64_t m, int n, int k) {
+  int splits, rows;
+  wgrad_plan(m, n, k, splits, rows);
+  return tmae_align((size_t)splits * n * k * 4) + tmae_align((size_t)splits * n * 4) + 1024;
+}
+
+int tmae_linear_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k, float* dw,
+                      float* db, void* wsp, size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m < 0 || n <= 0 || k <= 0 || !dw || (n % 8) || (k % 8) || (ldy % 8) || (ldx % 8)) return TMAE_EARG;
+  if (m > 0 && (!dy || !x)) return TMAE_EARG;
+  if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return TMAE_EARG;
+  int splits, rows;
+  wgrad_plan(m, n, k, splits, rows);
+  WsCarver ws(wsp, ws_bytes);
+  float* slab_w = ws.take<float>((size_t)splits * n * k);
+  float* slab_b = ws.take<float>((size_t)splits * n);
+  if (!ws.ok) return TMAE_EWS;
+  dim3 grid((n + WG_BN - 1) / WG_BN, (k + WG_BK - 1) / WG_BK, splits);
+  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, stream, (const __hip_bfloat16*)dy, ldy,
+                     (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab_w, db ? slab_b : (float*)nullptr);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tmae_cdiv((int64_t)n * k, 256)), dim3(256), 0, stream, slab_w, splits,
+                     (int64_t)n * k, dw);
+  if (db)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, slab_b, splits, (int64_t)n,
+                       db);
+  return tmae_launch_status();
+}

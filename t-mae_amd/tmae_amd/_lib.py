@@ -48,6 +48,8 @@ SIGNATURES = {
     'tmae_dense_gather': (I, [P, I, I, I, I, I, P, L, P, P]),
     'tmae_chamfer_fwd': (I, [P, P, P, L, I, I, P, P, P, P]),
     'tmae_chamfer_bwd': (I, [P, P, P, P, P, P, L, I, I, P, P]),
+    'tmae_linear_wgrad_workspace': (Z, [L, I, I]),
+    'tmae_linear_wgrad': (I, [P, L, P, L, L, I, I, P, P, P, Z, P]),
 }
 
 if not os.path.exists(LIB_PATH):

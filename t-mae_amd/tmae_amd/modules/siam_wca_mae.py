@@ -103,7 +103,7 @@ class SiamWCA_MAE(nn.Module):
         perm, offsets = batch_dict['point_csr']
         _, gt = ops.group_points(batch_dict['points'], voxel_coords, perm, offsets, self.mask_cfg.NUM_GT_POINTS,
                                  self.point_cloud_range, self.voxel_size, want_inds=False)
-        pred = self.decoder_pred(voxel_features).view(voxel_features.shape[0], -1, 3)
+        pred = ops.linear(voxel_features, self.decoder_pred.weight, self.decoder_pred.bias).view(voxel_features.shape[0], -1, 3)
         return {'pred_points': pred, 'gt_points': gt, 'mask': batch_dict['voxel_mae_mask']}
 
     def get_loss(self, tb_dict=None):

@@ -80,11 +80,11 @@ class WindowAttention(nn.Module):
         a = self.self_attn
         d = a.embed_dim
         xp = ops.add_pos_embed(x, plan.indices, pos_table, window_shape, shift)
-        qk = F.linear(xp, a.in_proj_weight[:2 * d], a.in_proj_bias[:2 * d])
-        v = F.linear(x, a.in_proj_weight[2 * d:], a.in_proj_bias[2 * d:])
+        qk = ops.linear(xp, a.in_proj_weight[:2 * d], a.in_proj_bias[:2 * d])
+        v = ops.linear(x, a.in_proj_weight[2 * d:], a.in_proj_bias[2 * d:])
         o = ops.win_attn(qk, v, None, a.tau, plan.grid, plan.grid, self.nhead, plan.batch, plan.ny, plan.nx,
                          shift, a.tau_min)
-        return a.out_proj(o)
+        return ops.linear(o, a.out_proj.weight, a.out_proj.bias)
 
 
 class WindowCrossAttention(nn.Module):
@@ -103,9 +103,10 @@ class WindowCrossAttention(nn.Module):
         a = self.cross_attn
         d = a.embed_dim
         w, b = a.in_proj_weight, a.in_proj_bias
-        q = F.linear(ops.add_pos_embed(x, plan.indices, pos_table, window_shape, shift), w[:d], b[:d])
-        k = F.linear(ops.add_pos_embed(x_prv, plan_prv.indices, pos_table, window_shape, shift), w[d:2 * d], b[d:2 * d])
-        v = F.linear(x_prv, w[2 * d:], b[2 * d:])
+        q = ops.linear(ops.add_pos_embed(x, plan.indices, pos_table, window_shape, shift), w[:d], b[:d])
+        k = ops.linear(ops.add_pos_embed(x_prv, plan_prv.indices, pos_table, window_shape, shift), w[d:2 * d],
+                       b[d:2 * d])
+        v = ops.linear(x_prv, w[2 * d:], b[2 * d:])
         return ops.win_attn(q, k, v, a.tau, plan.grid, plan_prv.grid, self.nhead, plan.batch, plan.ny, plan.nx,
                             shift, a.tau_min)
 
@@ -131,7 +132,8 @@ class _EncoderTail(nn.Module):
 
     def tail(self, src):
         src = self.norm1(src)
-        src2 = self.linear2(self.activation(self.linear1(src)))
+        h = self.activation(ops.linear(src, self.linear1.weight, self.linear1.bias))
+        src2 = ops.linear(h, self.linear2.weight, self.linear2.bias)
         return self.norm2(src + src2)
 
 
@@ -173,7 +175,7 @@ class WCAEncoderLayer(_EncoderTail):
         o = self.win_attn(src, plan, src_prv, plan_prv, pos_table, window_shape, shift)
         # src[keep] += out_proj(attn): kept = query rows whose window also holds previous-frame tokens
         # (the out-proj bias must not reach the other rows)
-        upd = a.out_proj(o) * kept
+        upd = ops.linear(o, a.out_proj.weight, a.out_proj.bias) * kept
         return self.tail(src + upd)
 
 

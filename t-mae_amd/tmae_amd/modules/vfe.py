@@ -61,7 +61,9 @@ class TemporalDynVFE(VFETemplate):
         vox['perm'], vox['offsets'] = perm, offsets
         _, feats = ops.vfe_point_features(vox['points'], vox['point_coords'], vox['inverse'], perm, offsets, m,
                                           self.point_cloud_range, self.voxel_size)
-        x = self.dvfe_mlps[0](feats)
+        x = feats
+        for layer in self.dvfe_mlps[0]:
+            x = ops.linear(x, layer.weight, None) if isinstance(layer, nn.Linear) else layer(x)
         x_max, _ = ops.scatter_max(x, vox['inverse'], perm, offsets, m)
         return x_max
 

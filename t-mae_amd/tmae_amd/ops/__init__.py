@@ -42,6 +42,67 @@ def compute_dtype(t):
     return t.dtype if t.dtype in (torch.float32, torch.bfloat16) else torch.float32
 
 
+# ----------------------------------------------------------------------------- token-list Linear
+
+def linear_wgrad(dy, x, want_bias=True):
+    """dW [n,k] f32 = dy^T @ x, db [n] f32 = column sums of dy; dy [m,n], x [m,k] bf16 (row-major, last dim
+    contiguous).  One streaming pass, token axis split over the chip (csrc/wgrad.hip)."""
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(1) == 1 and x.stride(1) == 1
+    m, n = dy.shape
+    k = x.shape[1]
+    dw = torch.empty((n, k), dtype=torch.float32, device=dy.device)
+    db = torch.empty((n,), dtype=torch.float32, device=dy.device) if want_bias else None
+    wsb = lib.tmae_linear_wgrad_workspace(m, n, k)
+    ws = _ws(wsb, dy.device)
+    check(lib.tmae_linear_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), m, n, k, _p(dw), _p(db), _p(ws), wsb, _s()),
+          'tmae_linear_wgrad')
+    return dw, db
+
+
+def _wgrad_ok(dy, x):
+    return (dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0
+            and dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0
+            and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and dy.shape[0] >= 4096)
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b over a long token list.  Forward and dX are plain library GEMMs (they stream at HBM rate);
+    the weight / bias gradient -- a reduction over 1e5+ tokens into a few tiles -- is our split-token MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        cdt = compute_dtype(x)
+        x_c = x.to(cdt)
+        w_c = weight.to(cdt)
+        y = torch.nn.functional.linear(x_c, w_c, None if bias is None else bias.to(cdt))
+        ctx.save_for_backward(x_c, w_c)
+        ctx.has_bias = bias is not None
+        ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_c, w_c = ctx.saved_tensors
+        xdt, wdt, bdt = ctx.dtypes
+        dy = dy.to(x_c.dtype)
+        if dy.stride(-1) != 1:
+            dy = dy.contiguous()
+        dx = (dy @ w_c).to(xdt) if ctx.needs_input_grad[0] else None
+        if _wgrad_ok(dy, x_c):
+            dw, db = linear_wgrad(dy, x_c, ctx.has_bias)
+        else:
+            dw = dy.t() @ x_c
+            db = dy.sum(0) if ctx.has_bias else None
+        return dx, dw.to(wdt), (db.to(bdt) if ctx.has_bias else None)
+
+
+def linear(x, weight, bias=None):
+    """torch.nn.functional.linear with the token-split weight-gradient kernel (2-D inputs on the GPU)."""
+    if x.is_cuda and x.dim() == 2:
+        return _Linear.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 # ----------------------------------------------------------------------------- voxelisation (A1)
 
 def voxelize_launch(points, batch_size, pc_range, voxel_size, grid_size):
@@ -370,7 +431,11 @@ class _SparseConv(torch.autograd.Function):
                                        _p(din), _s()), 'tmae_spconv_gather_t')
         del dcols
         cols = _gather9(f, nbr)                                       # recomputed: cheaper than keeping 9x rows
-        dw = (dout.t() @ cols).reshape(ctx.wshape).to(ctx.wdtype)
+        if _wgrad_ok(dout, cols):
+            dw = linear_wgrad(dout, cols, want_bias=False)[0]
+        else:
+            dw = dout.t() @ cols
+        dw = dw.reshape(ctx.wshape).to(ctx.wdtype)
         return din.to(ctx.fdtype), dw, None, None
 
 
