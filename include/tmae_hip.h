@@ -215,6 +215,18 @@ size_t tmae_linear_wgrad_workspace(int64_t m, int n, int k);
 int tmae_linear_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k,
                       float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
 
+/* Fused residual add + LayerNorm of the post-norm encoder layers (EncoderLayer.forward sst_basic_block.py:77-84,
+ * wca_block.py:93-102): y = LN(a + b) * gamma + beta, eps inside the sqrt, biased variance (nn.LayerNorm).
+ * a, b (b may be NULL), y, xsum [m,d] in `dtype`; d in {128, 256}; xsum (may be NULL) receives a + b for the
+ * backward; mean / rstd [m] f32.  Statistics are taken in fp32 over the stored (rounded) sum. */
+int tmae_add_layernorm_fwd(const void* a, const void* b, int dtype, int64_t m, int d, const float* gamma,
+                           const float* beta, float eps, void* xsum, void* y, float* mean, float* rstd, void* stream);
+/* dx [m,d] = gradient wrt (a + b); dgamma / dbeta [d] f32 (two-stage fixed-order column sums). */
+size_t tmae_layernorm_bwd_workspace(int64_t m, int d);
+int tmae_layernorm_bwd(const void* dy, const void* x, int dtype, int64_t m, int d, const float* mean,
+                       const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                       void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,11 +130,12 @@ class _EncoderTail(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.activation = _activation(activation)
 
-    def tail(self, src):
-        src = self.norm1(src)
+    def tail(self, src, attn):
+        """src = LN1(src + attn); src = LN2(src + linear2(act(linear1(src)))) -- both adds fused into the norms."""
+        src = ops.add_layer_norm(src, attn, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         h = self.activation(ops.linear(src, self.linear1.weight, self.linear1.bias))
         src2 = ops.linear(h, self.linear2.weight, self.linear2.bias)
-        return self.norm2(src + src2)
+        return ops.add_layer_norm(src, src2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
 
 
 class EncoderLayer(_EncoderTail):
@@ -145,8 +146,7 @@ class EncoderLayer(_EncoderTail):
         self.win_attn = WindowAttention(d_model, nhead, dropout, layer_cfg)
 
     def forward(self, src, plan, pos_table, window_shape, shift):
-        src = src + self.win_attn(src, plan, pos_table, window_shape, shift)
-        return self.tail(src)
+        return self.tail(src, self.win_attn(src, plan, pos_table, window_shape, shift))
 
 
 class BasicShiftBlockV2(nn.Module):
@@ -176,7 +176,7 @@ class WCAEncoderLayer(_EncoderTail):
         # src[keep] += out_proj(attn): kept = query rows whose window also holds previous-frame tokens
         # (the out-proj bias must not reach the other rows)
         upd = ops.linear(o, a.out_proj.weight, a.out_proj.bias) * kept
-        return self.tail(src + upd)
+        return self.tail(src, upd)
 
 
 class BasicShiftBlock_WCA(nn.Module):

@@ -103,6 +103,50 @@ def linear(x, weight, bias=None):
     return torch.nn.functional.linear(x, weight, bias)
 
 
+class _AddLayerNorm(torch.autograd.Function):
+    """y = LayerNorm(a + b): one fused pass forward, one backward (+ fixed-order gamma/beta sums)."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, bias, eps):
+        cdt = compute_dtype(a)
+        a_c = a.to(cdt).contiguous()
+        b_c = None if b is None else b.to(cdt).contiguous()
+        m, d = a_c.shape
+        y = torch.empty_like(a_c)
+        xs = torch.empty_like(a_c) if b_c is not None else None
+        mean = torch.empty((m,), dtype=torch.float32, device=a.device)
+        rstd = torch.empty((m,), dtype=torch.float32, device=a.device)
+        g32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        check(lib.tmae_add_layernorm_fwd(_p(a_c), _p(b_c), _dt(a_c), m, d, _p(g32), _p(b32), float(eps), _p(xs), _p(y),
+                                         _p(mean), _p(rstd), _s()), 'tmae_add_layernorm_fwd')
+        ctx.save_for_backward(xs if xs is not None else a_c, mean, rstd, g32)
+        ctx.meta = (a.dtype, None if b is None else b.dtype, weight.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, g32 = ctx.saved_tensors
+        adt, bdt, wdt, btdt = ctx.meta
+        dy = dy.to(x.dtype).contiguous()
+        m, d = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty((d,), dtype=torch.float32, device=x.device)
+        db = torch.empty((d,), dtype=torch.float32, device=x.device)
+        wsb = lib.tmae_layernorm_bwd_workspace(m, d)
+        ws = _ws(wsb, x.device)
+        check(lib.tmae_layernorm_bwd(_p(dy), _p(x), _dt(x), m, d, _p(mean), _p(rstd), _p(g32), _p(dx), _p(dg), _p(db),
+                                     _p(ws), wsb, _s()), 'tmae_layernorm_bwd')
+        return dx.to(adt), (None if bdt is None else dx.to(bdt)), dg.to(wdt), db.to(btdt), None
+
+
+def add_layer_norm(a, b, weight, bias, eps=1e-5):
+    """LayerNorm(a + b) (b may be None) with nn.LayerNorm semantics; fused HIP kernel for d in {128, 256}."""
+    if a.is_cuda and a.dim() == 2 and a.shape[1] in (128, 256):
+        return _AddLayerNorm.apply(a, b, weight, bias, eps)
+    x = a if b is None else a + b
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+
+
 # ----------------------------------------------------------------------------- voxelisation (A1)
 
 def voxelize_launch(points, batch_size, pc_range, voxel_size, grid_size):

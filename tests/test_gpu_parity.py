@@ -405,6 +405,37 @@ def test_linear_wgrad_kernel_vs_torch():
     assert (g1[2] - b.grad).abs().max().item() <= 1e-2 * float(b.grad.abs().max())
 
 
+def test_add_layernorm_kernel_vs_torch():
+    from tmae_amd import ops
+    torch.manual_seed(1)
+    for d in (128, 256):
+        for m in (1, 777, 40000):
+            a = torch.randn(m, d, device=dev())
+            b = torch.randn(m, d, device=dev()) * 0.5
+            w = (1 + 0.1 * torch.randn(d, device=dev())).requires_grad_(True)
+            bb = (0.1 * torch.randn(d, device=dev())).requires_grad_(True)
+            go = torch.randn(m, d, device=dev())
+            for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 6e-2)):
+                a1, b1 = a.to(dt).clone().requires_grad_(True), b.to(dt).clone().requires_grad_(True)
+                y = ops.add_layer_norm(a1, b1, w, bb, 1e-5)
+                y.backward(go.to(dt))
+                g_mine = (a1.grad.float().clone(), b1.grad.float().clone(), w.grad.clone(), bb.grad.clone())
+                w.grad = bb.grad = None
+                a2, b2 = a.to(dt).float().clone().requires_grad_(True), b.to(dt).float().clone().requires_grad_(True)
+                xs = (a2 + b2) if dt == torch.float32 else (a2 + b2).to(dt).float()
+                y2 = F.layer_norm(xs, (d,), w, bb, 1e-5)
+                y2.backward(go.to(dt).float())
+                assert (y.float() - y2).abs().max().item() <= tol, (d, m, dt)
+                assert (g_mine[0] - a2.grad).abs().max().item() <= tol * 4
+                assert torch.equal(g_mine[0], g_mine[1])
+                sc = max(1.0, float(w.grad.abs().max()))
+                assert (g_mine[2] - w.grad).abs().max().item() <= (1e-3 if dt == torch.float32 else 3e-2) * sc * max(1, m ** 0.5 / 10)
+                assert (g_mine[3] - bb.grad).abs().max().item() <= (1e-3 if dt == torch.float32 else 3e-2) * sc * max(1, m ** 0.5 / 10)
+                w.grad = bb.grad = None
+    y = ops.add_layer_norm(a, None, w, bb, 1e-5)
+    assert (y - F.layer_norm(a, (256,), w, bb, 1e-5)).abs().max().item() < 2e-5
+
+
 # ------------------------------------------------------------------------------------------ A9 / A11
 
 def test_sparse_conv_golden_and_dense(oracle):
