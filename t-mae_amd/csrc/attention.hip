@@ -9,6 +9,7 @@
 // Shapes on this path are tiny (T <= 64, dh 16/32), so the kernel is gather/latency bound, not FLOP
 // bound; see DESIGN.md for the roofline.
 #include "common.h"
+#include <stdlib.h>
 
 #define WIN 8          // window edge (cells); 8x8 = 64 cells = one wavefront
 #define ROWPAD 4       // LDS row padding (floats): keeps 16-byte alignment, breaks the power-of-two stride
@@ -284,6 +285,20 @@ __global__ __launch_bounds__(64 * (64 / DH)) void win_attn_bwd_kernel(
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// bf16 runs on the MFMA kernels of attention_mfma.hip; TMAE_ATTN_IMPL=valu forces the fp32-VALU kernels (A/B runs)
+int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                           int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
+                           int batch, int ny, int nx, int do_shift, const float* tau, float tau_min, void* out,
+                           int64_t ldo, float* lse, hipStream_t stream);
+static bool use_mfma() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TMAE_ATTN_IMPL");
+    v = (e && e[0] == 'v') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 static inline void attn_dims(int ny, int nx, int& Wy, int& Wx) {
   Wy = (ny + WIN - 1) / WIN + 1;
   Wx = (nx + WIN - 1) / WIN + 1;
@@ -322,7 +337,13 @@ int tmae_win_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
   hipLaunchKernelGGL((win_attn_fwd_kernel<T, DH>), grid, block, 0, stream, (const T*)q, ldq, (const T*)k, ldk,       \
                      (const T*)v, ldv, nhead, grid_q, grid_k, ny, nx, Wy, Wx, s, s, tau, tau_min, (T*)out, ldo, lse)
   if (dtype == TMAE_F32) { if (dh == 16) FWD(float, 16); else FWD(float, 32); }
-  else if (dtype == TMAE_BF16) { if (dh == 16) FWD(__hip_bfloat16, 16); else FWD(__hip_bfloat16, 32); }
+  else if (dtype == TMAE_BF16) {
+    if (use_mfma() && nhead % 4 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && !((uintptr_t)q & 15) &&
+        !((uintptr_t)k & 15) && !((uintptr_t)v & 15))
+      return tmae_win_attn_fwd_mfma(q, ldq, k, ldk, v, ldv, mq, mk, nhead, dh, grid_q, grid_k, batch, ny, nx, do_shift,
+                                    tau, tau_min, out, ldo, lse, stream);
+    if (dh == 16) FWD(__hip_bfloat16, 16); else FWD(__hip_bfloat16, 32);
+  }
   else return TMAE_EDTYPE;
 #undef FWD
   return tmae_launch_status();

@@ -1,0 +1,230 @@
+// A6/A7 (bf16 path): ragged window cosine attention on the matrix cores.
+//
+// One wavefront per (8x8 window, head); 4 heads per workgroup.  The window's tokens come from the dense index
+// grids (see attention.hip); its <=64 queries / keys are cut into 16-row tiles.
+//   S^T = K-hat . Q-hat^T   16x16x32 (dh 32) / 16x16x16 (dh 16) MFMA, operands loaded straight from the token rows
+//                           (the contraction index is the contiguous channel axis: plain 16-/8-byte row reads),
+//                           L2-normalised and scaled by 1/max(tau,tau_min) in registers before the bf16 cast.
+//   softmax                  in registers: the "swapped" product leaves one query per lane column, its keys in the
+//                            4 accumulator rows x 4 lane groups, so max / sum are 2 cross-lane steps (fp32).
+//   O = P . V                16x16x16 MFMA; P is taken from the accumulators as-is (their layout IS the A-operand
+//                            layout), V comes from a row-major LDS image through ds_read_b64_tr_b16.
+// No padding to 16/32/64-token levels, no key masks in memory, nothing of size T x T leaves the registers.
+#include "common.h"
+
+#define WIN 8
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ s16x4 tr_read4(const char* lds_ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_ptr);
+}
+__device__ __forceinline__ short f2bf(float v) {
+  __hip_bfloat16 b = __float2bfloat16(v);
+  return *reinterpret_cast<short*>(&b);
+}
+__device__ __forceinline__ float bf2f(short s) { return __uint_as_float(((unsigned)(unsigned short)s) << 16); }
+
+// Row fragment of a token: channels [FR*g, FR*g+FR) of head `hoff`, FR = 8 (dh 32) or 4 (dh 16), as floats.
+template <int FR>
+__device__ __forceinline__ void load_row_frag(const __hip_bfloat16* base, int64_t ld, int tok, int hoff, int g,
+                                              float* f) {
+  if (tok < 0) {
+#pragma unroll
+    for (int j = 0; j < FR; ++j) f[j] = 0.f;
+    return;
+  }
+  const __hip_bfloat16* p = base + (int64_t)tok * ld + hoff + FR * g;
+  if constexpr (FR == 8) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(w[j] << 16); f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
+  } else {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xFFFF0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xFFFF0000u);
+  }
+}
+
+// L2-normalise a token row that is spread over the 4 lane groups (same lane&15), times `scale`.
+template <int FR>
+__device__ __forceinline__ void normalize_frag(float* f, float scale) {
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < FR; ++j) ss += f[j] * f[j];
+  ss += __shfl_xor(ss, 16, 64);
+  ss += __shfl_xor(ss, 32, 64);
+  const float inv = scale / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+  for (int j = 0; j < FR; ++j) f[j] *= inv;
+}
+
+template <int DH> struct Frag;
+template <> struct Frag<32> { typedef s16x8 T; };
+template <> struct Frag<16> { typedef s16x4 T; };
+
+template <int FR>
+__device__ __forceinline__ typename Frag<FR * 4>::T pack_frag(const float* f) {
+  typename Frag<FR * 4>::T r;
+#pragma unroll
+  for (int j = 0; j < FR; ++j) r[j] = f2bf(f[j]);
+  return r;
+}
+
+__device__ __forceinline__ f32x4 mfma_s(const s16x8& a, const s16x8& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_s(const s16x4& a, const s16x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
+    const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
+    const __hip_bfloat16* __restrict__ v, int64_t ldv, int nhead, const int32_t* __restrict__ grid_q,
+    const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx, int sy, int sx,
+    const float* __restrict__ tau, float tau_min, __hip_bfloat16* __restrict__ out, int64_t ldo,
+    float* __restrict__ lse) {
+  constexpr int FR = DH / 4;                 // channels per lane in a row fragment
+  constexpr int CT = DH / 16;                // 16-channel output tiles
+  constexpr int RB = DH * 2 + 16;            // V image row pitch (bytes): 16-byte aligned, off the power of two
+  typedef typename Frag<DH>::T frag_t;
+  __shared__ int toks[2][64];
+  __shared__ __attribute__((aligned(16))) char vimg[4][64 * RB];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+  const int head = blockIdx.y * 4 + w, hoff = head * DH;
+  // window tokens (every wave computes the same; wave 0 publishes the compacted lists)
+  const int64_t dw = blockIdx.x;
+  const int wcy = (int)(dw % Wy), wcx = (int)((dw / Wy) % Wx), b = (int)(dw / ((int64_t)Wy * Wx));
+  const int y = wcy * WIN - sy + (lane >> 3), x = wcx * WIN - sx + (lane & 7);
+  const bool in = y >= 0 && y < ny && x >= 0 && x < nx;
+  const int64_t cell = ((int64_t)b * ny + y) * nx + x;
+  const int tq = in ? grid_q[cell] : -1, tk = in ? grid_k[cell] : -1;
+  const unsigned long long mq = __ballot(tq >= 0), mk = __ballot(tk >= 0);
+  if (mq == 0ull) return;
+  const int Tq = __popcll(mq), Tk = __popcll(mk);
+  if (Tk == 0) {                              // cross-attention window without keys: zero rows (not "kept")
+    if (tq >= 0) {
+      __hip_bfloat16* o = out + (int64_t)tq * ldo + hoff;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) o[c] = __float2bfloat16(0.f);
+      lse[(int64_t)tq * nhead + head] = 0.f;
+    }
+    return;
+  }
+  if (w == 0) {
+    if (tq >= 0) toks[0][__popcll(mq & ((1ull << lane) - 1ull))] = tq;
+    if (tk >= 0) toks[1][__popcll(mk & ((1ull << lane) - 1ull))] = tk;
+  }
+  // stage this head's V rows (row = key slot) for the transposed reads
+  if (tk >= 0) {
+    const int slot = __popcll(mk & ((1ull << lane) - 1ull));
+    const uint4* src = reinterpret_cast<const uint4*>(v + (int64_t)tk * ldv + hoff);
+    uint4* dst = reinterpret_cast<uint4*>(&vimg[w][slot * RB]);
+#pragma unroll
+    for (int c = 0; c < DH / 8; ++c) dst[c] = src[c];
+  }
+  if (lane >= Tk) {                          // rows no key writes: zero them (P is 0 there, but 0 * garbage = NaN)
+    uint4* dst = reinterpret_cast<uint4*>(&vimg[w][lane * RB]);
+#pragma unroll
+    for (int c = 0; c < DH / 8; ++c) dst[c] = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  const int nq = (Tq + 15) >> 4, nk = (Tk + 15) >> 4;
+  const float inv_tau = 1.0f / fmaxf(tau[0], tau_min);
+  // K-hat fragments of every key tile stay in registers
+  frag_t kf[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    float f[FR];
+    const int slot = kt * 16 + i;
+    load_row_frag<FR>(k, ldk, (kt < nk && slot < Tk) ? toks[1][slot] : -1, hoff, g, f);
+    normalize_frag<FR>(f, 1.0f);
+    kf[kt] = pack_frag<FR>(f);
+  }
+  // V fragments (B operand of P.V): [key tile][channel tile], 4 keys x 1 channel per lane
+  s16x4 vf[4][CT];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      vf[kt][ct] = tr_read4(&vimg[w][(kt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3)]);
+
+  for (int qt = 0; qt < nq; ++qt) {
+    float f[FR];
+    const int qslot = qt * 16 + i;
+    load_row_frag<FR>(q, ldq, qslot < Tq ? toks[0][qslot] : -1, hoff, g, f);
+    normalize_frag<FR>(f, inv_tau);
+    const frag_t qf = pack_frag<FR>(f);
+    f32x4 st[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      st[kt] = mfma_s(kf[kt], qf, f32x4{0.f, 0.f, 0.f, 0.f});      // S^T tile: rows = keys 4g+r, col = query i
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (kt * 16 + 4 * g + r >= Tk) st[kt][r] = -INFINITY;
+        mx = fmaxf(mx, st[kt][r]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float l = 0.f;
+    s16x4 pf[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(st[kt][r] - mx);
+        l += p;
+        pf[kt][r] = f2bf(p);
+      }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float invl = 1.0f / l;
+    f32x4 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) o[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf[kt], vf[kt][ct], o[ct], 0, 0, 0);
+    }
+    // O tile: rows = queries 4g+r, col = channel i
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qs = qt * 16 + 4 * g + r;
+      const float il = __shfl(invl, 4 * g + r, 64);
+      if (qs < Tq) {
+        __hip_bfloat16* op = out + (int64_t)toks[0][qs] * ldo + hoff + i;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) op[ct * 16] = __float2bfloat16(o[ct][r] * il);
+      }
+    }
+    if (g == 0 && qslot < Tq) lse[(int64_t)toks[0][qslot] * nhead + head] = mx + __logf(l);
+  }
+}
+
+int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                           int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
+                           int batch, int ny, int nx, int do_shift, const float* tau, float tau_min, void* out,
+                           int64_t ldo, float* lse, hipStream_t stream) {
+  if (nhead % 4 || (dh != 16 && dh != 32)) return TMAE_EARG;
+  // 16-byte row fragments / V rows: bases and pitches must keep every head slice 16-byte aligned
+  if ((ldq % 8) || (ldk % 8) || (ldv % 8) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15))
+    return TMAE_EARG;
+  const int Wy = (ny + WIN - 1) / WIN + 1, Wx = (nx + WIN - 1) / WIN + 1;
+  const int s = do_shift ? WIN / 2 : WIN;
+  dim3 grid((unsigned)((int64_t)batch * Wy * Wx), (unsigned)(nhead / 4));
+  if (dh == 32)
+    hipLaunchKernelGGL(win_attn_fwd_mfma_kernel<32>, grid, dim3(256), 0, stream, (const __hip_bfloat16*)q, ldq,
+                       (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v, ldv, nhead, grid_q, grid_k, ny, nx, Wy,
+                       Wx, s, s, tau, tau_min, (__hip_bfloat16*)out, ldo, lse);
+  else
+    hipLaunchKernelGGL(win_attn_fwd_mfma_kernel<16>, grid, dim3(256), 0, stream, (const __hip_bfloat16*)q, ldq,
+                       (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v, ldv, nhead, grid_q, grid_k, ny, nx, Wy,
+                       Wx, s, s, tau, tau_min, (__hip_bfloat16*)out, ldo, lse);
+  return (int)hipGetLastError();
+}

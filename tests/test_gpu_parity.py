@@ -330,6 +330,9 @@ def test_attention_bf16_and_softmax_property():
             assert err < 0.25 and (o16.float() - o32).abs().mean().item() < 2e-2, err
             ones = ops.win_attn(qk, torch.ones_like(v), None, tau, grid, grid, H, 2, 468, 468, shift, 0.01)
             assert (ones - 1).abs().max().item() < 1e-5
+            ones16 = ops.win_attn(qk.bfloat16(), torch.ones_like(v).bfloat16(), None, tau, grid, grid, H, 2, 468, 468,
+                                  shift, 0.01)
+            assert torch.isfinite(ones16.float()).all() and (ones16.float() - 1).abs().max().item() < 1.5e-2
 
 
 def test_encoder_blocks_golden(oracle):
