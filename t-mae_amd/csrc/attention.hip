@@ -290,6 +290,11 @@ int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
                            int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
                            int batch, int ny, int nx, int do_shift, const float* tau, float tau_min, void* out,
                            int64_t ldo, float* lse, hipStream_t stream);
+int tmae_win_attn_bwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                           const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, int nhead,
+                           int dh, const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx,
+                           int do_shift, const float* tau, float tau_min, void* dq, int64_t lddq, void* dk,
+                           int64_t lddk, void* dv, int64_t lddv, float* dtau_partial, hipStream_t stream);
 static bool use_mfma() {
   static int v = -1;
   if (v < 0) {
@@ -371,7 +376,14 @@ int tmae_win_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
                      (const T*)v, ldv, (const T*)out, ldo, (const T*)dout, lddo, lse, nhead, grid_q, grid_k, ny, nx, \
                      Wy, Wx, s, s, tau, tau_min, (T*)dq, lddq, (T*)dk, lddk, (T*)dv, lddv, dtau_partial)
   if (dtype == TMAE_F32) { if (dh == 16) BWD(float, 16); else BWD(float, 32); }
-  else if (dtype == TMAE_BF16) { if (dh == 16) BWD(__hip_bfloat16, 16); else BWD(__hip_bfloat16, 32); }
+  else if (dtype == TMAE_BF16) {
+    const bool al = !(ldq % 8) && !(ldk % 8) && !(ldv % 8) && !(ldo % 8) && !(lddo % 8) && !((uintptr_t)q & 15) &&
+                    !((uintptr_t)k & 15) && !((uintptr_t)v & 15) && !((uintptr_t)out & 15) && !((uintptr_t)dout & 15);
+    if (use_mfma() && nhead % 4 == 0 && al && mq > 0 && mk > 0)
+      return tmae_win_attn_bwd_mfma(q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, lse, nhead, dh, grid_q, grid_k, batch,
+                                    ny, nx, do_shift, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, dtau_partial, stream);
+    if (dh == 16) BWD(__hip_bfloat16, 16); else BWD(__hip_bfloat16, 32);
+  }
   else return TMAE_EDTYPE;
 #undef BWD
   return tmae_launch_status();

@@ -228,3 +228,273 @@ int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
                        Wx, s, s, tau, tau_min, (__hip_bfloat16*)out, ldo, lse);
   return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// backward (bf16): P is recomputed from the saved log-sum-exp in BOTH orientations, because the five products
+// need the T x T factor once with the query on the lane column (dQ-hat = dS.K-hat) and once with the key on it
+// (dV = P^T.dO, dK-hat = dS^T.Q-hat) -- recomputing two tiny MFMAs is cheaper than any cross-lane transpose.
+// The right-hand factors (K-hat, Q-hat/tau, dO) are row-major LDS images read with ds_read_b64_tr_b16.
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
+    const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
+    const __hip_bfloat16* __restrict__ v, int64_t ldv, const __hip_bfloat16* __restrict__ outp, int64_t ldo,
+    const __hip_bfloat16* __restrict__ dout, int64_t lddo, const float* __restrict__ lse, int nhead,
+    const int32_t* __restrict__ grid_q, const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx, int sy,
+    int sx, const float* __restrict__ tau, float tau_min, __hip_bfloat16* __restrict__ dq, int64_t lddq,
+    __hip_bfloat16* __restrict__ dk, int64_t lddk, __hip_bfloat16* __restrict__ dv, int64_t lddv,
+    float* __restrict__ dtau_partial) {
+  constexpr int FR = DH / 4;
+  constexpr int CT = DH / 16;
+  constexpr int RB = DH * 2 + 16;
+  typedef typename Frag<DH>::T frag_t;
+  __shared__ int toks[2][64];
+  __shared__ __attribute__((aligned(16))) char kimg[4][64 * RB];   // K-hat
+  __shared__ __attribute__((aligned(16))) char qimg[4][64 * RB];   // Q-hat / tau_c
+  __shared__ __attribute__((aligned(16))) char gimg[4][64 * RB];   // dO
+  __shared__ float qnorm[4][64], knorm[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
+  const int head = blockIdx.y * 4 + w, hoff = head * DH;
+  const int64_t dw = blockIdx.x;
+  const int wcy = (int)(dw % Wy), wcx = (int)((dw / Wy) % Wx), b = (int)(dw / ((int64_t)Wy * Wx));
+  const int y = wcy * WIN - sy + (lane >> 3), x = wcx * WIN - sx + (lane & 7);
+  const bool in = y >= 0 && y < ny && x >= 0 && x < nx;
+  const int64_t cell = ((int64_t)b * ny + y) * nx + x;
+  const int tq = in ? grid_q[cell] : -1, tk = in ? grid_k[cell] : -1;
+  const unsigned long long mq = __ballot(tq >= 0), mk = __ballot(tk >= 0);
+  const int Tq = __popcll(mq), Tk = __popcll(mk);
+  float* dtp = dtau_partial + dw * nhead + head;
+  if (Tq == 0 || Tk == 0) {
+    if (lane == 0) *dtp = 0.f;
+    if (Tq > 0 && tq >= 0) {
+      __hip_bfloat16* p = dq + (int64_t)tq * lddq + hoff;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) p[c] = __float2bfloat16(0.f);
+    }
+    if (Tk > 0 && tk >= 0 && grid_q != grid_k) {
+      __hip_bfloat16* p1 = dk + (int64_t)tk * lddk + hoff;
+      __hip_bfloat16* p2 = dv + (int64_t)tk * lddv + hoff;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) { p1[c] = __float2bfloat16(0.f); p2[c] = __float2bfloat16(0.f); }
+    }
+    return;
+  }
+  const float inv_tau = 1.0f / fmaxf(tau[0], tau_min);
+  if (w == 0) {
+    if (tq >= 0) toks[0][__popcll(mq & ((1ull << lane) - 1ull))] = tq;
+    if (tk >= 0) toks[1][__popcll(mk & ((1ull << lane) - 1ull))] = tk;
+  }
+  // ---- stage the row-major images: every lane owns the row of its own token (or zero-fills a dead row)
+  {
+    float r[DH];
+    const int qslot = (tq >= 0) ? __popcll(mq & ((1ull << lane) - 1ull)) : -1;
+    const int kslot = (tk >= 0) ? __popcll(mk & ((1ull << lane) - 1ull)) : -1;
+    if (tk >= 0) {
+      const __hip_bfloat16* src = k + (int64_t)tk * ldk + hoff;
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) { r[c] = __bfloat162float(src[c]); ss += r[c] * r[c]; }
+      const float nrm = fmaxf(sqrtf(ss), 1e-12f), inv = 1.0f / nrm;
+      knorm[w][kslot] = nrm;
+      short* dst = reinterpret_cast<short*>(&kimg[w][kslot * RB]);
+#pragma unroll
+      for (int c = 0; c < DH; ++c) dst[c] = f2bf(r[c] * inv);
+    }
+    if (tq >= 0) {
+      const __hip_bfloat16* src = q + (int64_t)tq * ldq + hoff;
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) { r[c] = __bfloat162float(src[c]); ss += r[c] * r[c]; }
+      const float nrm = fmaxf(sqrtf(ss), 1e-12f), inv = inv_tau / nrm;
+      qnorm[w][qslot] = nrm;
+      short* dst = reinterpret_cast<short*>(&qimg[w][qslot * RB]);
+#pragma unroll
+      for (int c = 0; c < DH; ++c) dst[c] = f2bf(r[c] * inv);
+      const uint4* gsrc = reinterpret_cast<const uint4*>(dout + (int64_t)tq * lddo + hoff);
+      uint4* gdst = reinterpret_cast<uint4*>(&gimg[w][qslot * RB]);
+#pragma unroll
+      for (int c = 0; c < DH / 8; ++c) gdst[c] = gsrc[c];
+    }
+    if (lane >= Tk) {
+      uint4* d0 = reinterpret_cast<uint4*>(&kimg[w][lane * RB]);
+#pragma unroll
+      for (int c = 0; c < DH / 8; ++c) d0[c] = make_uint4(0, 0, 0, 0);
+    }
+    if (lane >= Tq) {
+      uint4* d1 = reinterpret_cast<uint4*>(&qimg[w][lane * RB]);
+      uint4* d2 = reinterpret_cast<uint4*>(&gimg[w][lane * RB]);
+#pragma unroll
+      for (int c = 0; c < DH / 8; ++c) { d1[c] = make_uint4(0, 0, 0, 0); d2[c] = make_uint4(0, 0, 0, 0); }
+    }
+  }
+  __syncthreads();
+  const int nq = (Tq + 15) >> 4, nk = (Tk + 15) >> 4;
+  // row fragments of K-hat (from the image: already normalised + rounded) and V (from global), per key tile
+  frag_t kf[4], vr[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int slot = kt * 16 + i;
+    kf[kt] = *reinterpret_cast<const frag_t*>(&kimg[w][slot * RB + FR * g * 2]);
+    float f[FR];
+    load_row_frag<FR>(v, ldv, (kt < nk && slot < Tk) ? toks[1][slot] : -1, hoff, g, f);
+    vr[kt] = pack_frag<FR>(f);
+  }
+  f32x4 dKa[4][CT], dVa[4][CT];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { dKa[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dVa[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  float dtau_acc = 0.f;
+
+  for (int qt = 0; qt < nq; ++qt) {
+    const int qslot = qt * 16 + i;
+    const bool qok = qslot < Tq;
+    const int qtok = qok ? toks[0][qslot] : -1;
+    const frag_t qf = *reinterpret_cast<const frag_t*>(&qimg[w][qslot * RB + FR * g * 2]);
+    const frag_t gf = *reinterpret_cast<const frag_t*>(&gimg[w][qslot * RB + FR * g * 2]);
+    // D = dO . O and LSE of query i (swapped orientation) -> shuffled copies for queries 4g+r (unswapped)
+    float of[FR], gfl[FR];
+    load_row_frag<FR>(outp, ldo, qtok, hoff, g, of);
+#pragma unroll
+    for (int j = 0; j < FR; ++j) gfl[j] = bf2f(gf[j]);
+    float dsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < FR; ++j) dsum += of[j] * gfl[j];
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+    const float lse_i = qok ? lse[(int64_t)qtok * nhead + head] : 0.f;
+    float lse_r[4], d_r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { lse_r[r] = __shfl(lse_i, 4 * g + r, 64); d_r[r] = __shfl(dsum, 4 * g + r, 64); }
+    // transposed right-hand fragments of this query tile
+    s16x4 trQ[CT], trG[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int off = (qt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3);
+      trQ[ct] = tr_read4(&qimg[w][off]);
+      trG[ct] = tr_read4(&gimg[w][off]);
+    }
+    f32x4 dQa[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) dQa[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      if (kt < nk) {
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        // swapped: rows = keys 4g+r of this tile, column = query i
+        const f32x4 sT = mfma_s(kf[kt], qf, z);
+        const f32x4 dPT = mfma_s(vr[kt], gf, z);
+        s16x4 dsT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = qok && (kt * 16 + 4 * g + r < Tk);
+          const float p = ok ? __expf(sT[r] - lse_i) : 0.f;
+          const float ds = p * (dPT[r] - dsum);
+          dtau_acc += ok ? ds * sT[r] : 0.f;
+          dsT[r] = f2bf(ds);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const s16x4 trK = tr_read4(&kimg[w][(kt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3)]);
+          dQa[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsT, trK, dQa[ct], 0, 0, 0);
+        }
+        // unswapped: rows = queries 4g+r, column = key i
+        const f32x4 sU = mfma_s(qf, kf[kt], z);
+        const f32x4 dPU = mfma_s(gf, vr[kt], z);
+        s16x4 pU, dsU;
+        const bool kok = kt * 16 + i < Tk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = kok && (qt * 16 + 4 * g + r < Tq);
+          const float p = ok ? __expf(sU[r] - lse_r[r]) : 0.f;
+          pU[r] = f2bf(p);
+          dsU[r] = f2bf(p * (dPU[r] - d_r[r]));
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          dVa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pU, trG[ct], dVa[kt][ct], 0, 0, 0);
+          dKa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsU, trQ[ct], dKa[kt][ct], 0, 0, 0);
+        }
+      }
+    }
+    // dq = (dq-hat - q-hat (q-hat . dq-hat)) / |q| ; accumulators: rows = queries 4g+r, column = channel ct*16+i
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qs = qt * 16 + 4 * g + r;
+      float qh[CT], dqh[CT], dot = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        qh[ct] = bf2f(*reinterpret_cast<const short*>(&qimg[w][qs * RB + (ct * 16 + i) * 2])) * (1.0f / inv_tau);
+        dqh[ct] = dQa[ct][r] * inv_tau;
+        dot += qh[ct] * dqh[ct];
+      }
+      dot += __shfl_xor(dot, 1, 64);
+      dot += __shfl_xor(dot, 2, 64);
+      dot += __shfl_xor(dot, 4, 64);
+      dot += __shfl_xor(dot, 8, 64);
+      if (qs < Tq) {
+        const float nrm = qnorm[w][qs];
+        if (nrm <= 1e-12f) dot = 0.f;
+        const float inv = 1.0f / nrm;
+        __hip_bfloat16* p = dq + (int64_t)toks[0][qs] * lddq + hoff + i;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) p[ct * 16] = __float2bfloat16((dqh[ct] - qh[ct] * dot) * inv);
+      }
+    }
+  }
+  dtau_acc = wave_sum(dtau_acc);
+  if (lane == 0) *dtp = dtau_acc;
+  // ---- dk, dv: rows = keys 4g+r of tile kt, column = channel ct*16+i
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    if (kt < nk) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ks = kt * 16 + 4 * g + r;
+        float kh[CT], dot = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          kh[ct] = bf2f(*reinterpret_cast<const short*>(&kimg[w][ks * RB + (ct * 16 + i) * 2]));
+          dot += kh[ct] * dKa[kt][ct][r];
+        }
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        dot += __shfl_xor(dot, 4, 64);
+        dot += __shfl_xor(dot, 8, 64);
+        if (ks < Tk) {
+          const float nrm = knorm[w][ks];
+          if (nrm <= 1e-12f) dot = 0.f;
+          const float inv = 1.0f / nrm;
+          const int tokk = toks[1][ks];
+          __hip_bfloat16* p1 = dk + (int64_t)tokk * lddk + hoff + i;
+          __hip_bfloat16* p2 = dv + (int64_t)tokk * lddv + hoff + i;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            p1[ct * 16] = __float2bfloat16((dKa[kt][ct][r] - kh[ct] * dot) * inv);
+            p2[ct * 16] = __float2bfloat16(dVa[kt][ct][r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+int tmae_win_attn_bwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                           const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, int nhead,
+                           int dh, const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx,
+                           int do_shift, const float* tau, float tau_min, void* dq, int64_t lddq, void* dk,
+                           int64_t lddk, void* dv, int64_t lddv, float* dtau_partial, hipStream_t stream) {
+  if (nhead % 4 || (dh != 16 && dh != 32)) return TMAE_EARG;
+  const int Wy = (ny + WIN - 1) / WIN + 1, Wx = (nx + WIN - 1) / WIN + 1;
+  const int s = do_shift ? WIN / 2 : WIN;
+  dim3 grid((unsigned)((int64_t)batch * Wy * Wx), (unsigned)(nhead / 4));
+#define BWDM(DH)                                                                                                      \
+  hipLaunchKernelGGL(win_attn_bwd_mfma_kernel<DH>, grid, dim3(256), 0, stream, (const __hip_bfloat16*)q, ldq,         \
+                     (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v, ldv, (const __hip_bfloat16*)out, ldo,   \
+                     (const __hip_bfloat16*)dout, lddo, lse, nhead, grid_q, grid_k, ny, nx, Wy, Wx, s, s, tau, tau_min, \
+                     (__hip_bfloat16*)dq, lddq, (__hip_bfloat16*)dk, lddk, (__hip_bfloat16*)dv, lddv, dtau_partial)
+  if (dh == 32) BWDM(32); else BWDM(16);
+#undef BWDM
+  return (int)hipGetLastError();
+}
+

@@ -335,6 +335,50 @@ def test_attention_bf16_and_softmax_property():
             assert torch.isfinite(ones16.float()).all() and (ones16.float() - 1).abs().max().item() < 1.5e-2
 
 
+def test_attention_mfma_bf16_fwd_bwd_vs_fp32_kernel():
+    """The bf16 MFMA kernels (forward + backward) against the fp32 kernels (which the golden tests pin to the
+    reference) on the same inputs: self- and cross-attention, dh 16 and 32, both shifts, tau at and above the clamp."""
+    from tmae_amd import ops
+    rng = np.random.default_rng(11)
+
+    def cloud(n, b):
+        c = np.unique(np.stack([rng.integers(0, b, n), rng.integers(0, 234, n), rng.integers(0, 234, n)], 1), axis=0)
+        dense = np.stack(np.meshgrid(np.arange(40, 72), np.arange(40, 72), indexing='ij'), -1).reshape(-1, 2)
+        dense = dense[rng.random(len(dense)) < 0.7]
+        c = np.unique(np.concatenate([c, np.concatenate([np.zeros((len(dense), 1), np.int64), dense], 1)]), axis=0)
+        return cu(c, torch.int32)
+
+    def rel(a, b):
+        return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+
+    for d, H, tauv, cross in ((128, 8, 0.3, False), (256, 8, 1.0, False), (256, 8, 0.05, True), (128, 8, 0.005, True)):
+        indq = cloud(15000, 2)
+        indk = cloud(30000, 2) if cross else indq
+        gq = ops.index_grid(indq, 2, 234, 234)
+        gk = ops.index_grid(indk, 2, 234, 234) if cross else gq
+        mq, mk = indq.shape[0], indk.shape[0]
+        for shift in (False, True):
+            res = {}
+            base = [torch.randn(mq, 2 * d if not cross else d, device=dev()), torch.randn(mk, d, device=dev()),
+                    torch.randn(mk, d, device=dev()) if cross else None]
+            go = torch.randn(mq, d, device=dev())
+            for dt in (torch.float32, torch.bfloat16):
+                a, b_, c_ = [None if t is None else t.to(dt).clone().requires_grad_(True) for t in base]
+                tau = torch.full((1, 1, 1), tauv, device=dev(), requires_grad=True)
+                o = ops.win_attn(a, b_, c_, tau, gq, gk, H, 2, 234, 234, shift, 0.01)
+                o.backward(go.to(dt))
+                res[dt] = (o.detach(), a.grad, b_.grad, None if c_ is None else c_.grad, tau.grad)
+            f, h = res[torch.float32], res[torch.bfloat16]
+            assert all(torch.isfinite(t.float()).all() for t in h if t is not None)
+            lim = 0.03 if tauv >= 0.05 else 0.12          # logits reach +-100 at the clamp: bf16 logit error ~0.4
+            assert rel(h[0], f[0]) < lim, ('out', d, cross, shift, rel(h[0], f[0]))
+            assert rel(h[1], f[1]) < 2 * lim, ('da', d, cross, shift, rel(h[1], f[1]))
+            assert rel(h[2], f[2]) < 2 * lim, ('db', d, cross, shift, rel(h[2], f[2]))
+            if cross:
+                assert rel(h[3], f[3]) < 2 * lim, ('dc', d, cross, shift, rel(h[3], f[3]))
+            assert abs(float(h[4]) - float(f[4])) <= 3 * lim * max(1.0, abs(float(f[4]))), ('dtau', float(h[4]), float(f[4]))
+
+
 def test_encoder_blocks_golden(oracle):
     """F8: SSTBlockV1 encoder (4 layers) and the WCA block (2 cross layers), outputs + input grads, fp32."""
     from tmae_amd.modules.sparse import SparseConvTensor
