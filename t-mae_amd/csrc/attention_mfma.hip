@@ -74,6 +74,18 @@ __device__ __forceinline__ typename Frag<FR * 4>::T pack_frag(const float* f) {
   return r;
 }
 
+// hi/lo split of an fp32 fragment into two bf16 fragments (f ~= hi + lo): three MFMAs (hi.hi + hi.lo + lo.hi) give
+// the cosine logits to ~2^-16 relative instead of bf16's 2^-8 -- they are divided by tau >= 0.01 before the exp.
+template <int FR>
+__device__ __forceinline__ void split_frag(const float* f, typename Frag<FR * 4>::T& hi, typename Frag<FR * 4>::T& lo) {
+#pragma unroll
+  for (int j = 0; j < FR; ++j) {
+    const short h = f2bf(f[j]);
+    hi[j] = h;
+    lo[j] = f2bf(f[j] - bf2f(h));
+  }
+}
+
 __device__ __forceinline__ f32x4 mfma_s(const s16x8& a, const s16x8& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
 }
@@ -136,14 +148,14 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
   const int nq = (Tq + 15) >> 4, nk = (Tk + 15) >> 4;
   const float inv_tau = 1.0f / fmaxf(tau[0], tau_min);
   // K-hat fragments of every key tile stay in registers
-  frag_t kf[4];
+  frag_t kf[4], kl[4];
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     float f[FR];
     const int slot = kt * 16 + i;
     load_row_frag<FR>(k, ldk, (kt < nk && slot < Tk) ? toks[1][slot] : -1, hoff, g, f);
     normalize_frag<FR>(f, 1.0f);
-    kf[kt] = pack_frag<FR>(f);
+    split_frag<FR>(f, kf[kt], kl[kt]);
   }
   // V fragments (B operand of P.V): [key tile][channel tile], 4 keys x 1 channel per lane
   s16x4 vf[4][CT];
@@ -158,12 +170,15 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
     const int qslot = qt * 16 + i;
     load_row_frag<FR>(q, ldq, qslot < Tq ? toks[0][qslot] : -1, hoff, g, f);
     normalize_frag<FR>(f, inv_tau);
-    const frag_t qf = pack_frag<FR>(f);
+    frag_t qf, ql;
+    split_frag<FR>(f, qf, ql);
     f32x4 st[4];
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      st[kt] = mfma_s(kf[kt], qf, f32x4{0.f, 0.f, 0.f, 0.f});      // S^T tile: rows = keys 4g+r, col = query i
+      st[kt] = mfma_s(kl[kt], qf, f32x4{0.f, 0.f, 0.f, 0.f});      // S^T tile: rows = keys 4g+r, col = query i
+      st[kt] = mfma_s(kf[kt], ql, st[kt]);
+      st[kt] = mfma_s(kf[kt], qf, st[kt]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (kt * 16 + 4 * g + r >= Tk) st[kt][r] = -INFINITY;
@@ -330,13 +345,16 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
   __syncthreads();
   const int nq = (Tq + 15) >> 4, nk = (Tk + 15) >> 4;
   // row fragments of K-hat (from the image: already normalised + rounded) and V (from global), per key tile
-  frag_t kf[4], vr[4];
+  frag_t kf[4], kl[4], vr[4];
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     const int slot = kt * 16 + i;
-    kf[kt] = *reinterpret_cast<const frag_t*>(&kimg[w][slot * RB + FR * g * 2]);
+    const int tokk = (kt < nk && slot < Tk) ? toks[1][slot] : -1;
     float f[FR];
-    load_row_frag<FR>(v, ldv, (kt < nk && slot < Tk) ? toks[1][slot] : -1, hoff, g, f);
+    load_row_frag<FR>(k, ldk, tokk, hoff, g, f);
+    normalize_frag<FR>(f, 1.0f);
+    split_frag<FR>(f, kf[kt], kl[kt]);           // hi part == the kimg row (same rounding)
+    load_row_frag<FR>(v, ldv, tokk, hoff, g, f);
     vr[kt] = pack_frag<FR>(f);
   }
   f32x4 dKa[4][CT], dVa[4][CT];
@@ -350,7 +368,13 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
     const int qslot = qt * 16 + i;
     const bool qok = qslot < Tq;
     const int qtok = qok ? toks[0][qslot] : -1;
-    const frag_t qf = *reinterpret_cast<const frag_t*>(&qimg[w][qslot * RB + FR * g * 2]);
+    frag_t qf, ql;
+    {
+      float f[FR];
+      load_row_frag<FR>(q, ldq, qtok, hoff, g, f);
+      normalize_frag<FR>(f, inv_tau);
+      split_frag<FR>(f, qf, ql);
+    }
     const frag_t gf = *reinterpret_cast<const frag_t*>(&gimg[w][qslot * RB + FR * g * 2]);
     // D = dO . O and LSE of query i (swapped orientation) -> shuffled copies for queries 4g+r (unswapped)
     float of[FR], gfl[FR];
@@ -382,7 +406,9 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
       if (kt < nk) {
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
         // swapped: rows = keys 4g+r of this tile, column = query i
-        const f32x4 sT = mfma_s(kf[kt], qf, z);
+        f32x4 sT = mfma_s(kl[kt], qf, z);
+        sT = mfma_s(kf[kt], ql, sT);
+        sT = mfma_s(kf[kt], qf, sT);
         const f32x4 dPT = mfma_s(vr[kt], gf, z);
         s16x4 dsT;
 #pragma unroll
@@ -399,7 +425,9 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
           dQa[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsT, trK, dQa[ct], 0, 0, 0);
         }
         // unswapped: rows = queries 4g+r, column = key i
-        const f32x4 sU = mfma_s(qf, kf[kt], z);
+        f32x4 sU = mfma_s(ql, kf[kt], z);
+        sU = mfma_s(qf, kl[kt], sU);
+        sU = mfma_s(qf, kf[kt], sU);
         const f32x4 dPU = mfma_s(gf, vr[kt], z);
         s16x4 pU, dsU;
         const bool kok = kt * 16 + i < Tk;

@@ -99,19 +99,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
+// one workgroup per 16 columns: 16 column lanes x 16 row lanes walk the partial rows, then a fixed-order LDS tree
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblocks, int d,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= 2 * d) return;
-  const int which = e / d, c = e % d;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + cl;                 // column in [0, 2d)
   float acc = 0.f;
-  for (int b = 0; b < nblocks; ++b) acc += part[((int64_t)b * 2 + which) * d + c];
-  (which == 0 ? dgamma : dbeta)[c] = acc;
+  if (e < 2 * d)
+    for (int b = rl; b < nblocks; b += 16) acc += part[(int64_t)b * 2 * d + e];
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && e < 2 * d) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][cl];
+    if (e < d) dgamma[e] = t; else dbeta[e - d] = t;
+  }
 }
 
 static int ln_grid(int64_t m) {
   int64_t g = (m + 31) / 32;            // >= 8 rows per wave
-  if (g > 1024) g = 1024;
+  if (g > 512) g = 512;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -157,7 +166,7 @@ int tmae_layernorm_bwd(const void* dy, const void* x, int dtype, int64_t m, int 
   else if (dtype == TMAE_BF16) { if (d == 128) BWD(__hip_bfloat16, 2); else BWD(__hip_bfloat16, 4); }
   else return TMAE_EDTYPE;
 #undef BWD
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(tmae_cdiv(2 * d, 256)), dim3(256), 0, stream, part, nb, d, dgamma,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(tmae_cdiv(2 * d, 16)), dim3(256), 0, stream, part, nb, d, dgamma,
                      dbeta);
   return tmae_launch_status();
 }

@@ -41,15 +41,17 @@ __device__ __forceinline__ bf16x8 load_frag(const char* img, int cb, int lane) {
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
                                                    const __hip_bfloat16* __restrict__ X, int64_t ldx, int64_t M,
-                                                   int N, int K, int rows_per_split, float* __restrict__ slab_w,
-                                                   float* __restrict__ slab_b) {
+                                                   int N, int K, int rows_per_split, float* __restrict__ slab,
+                                                   int64_t count, bool has_bias) {
   __shared__ __attribute__((aligned(16))) char lds[2][2][WG_MS * 256];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w >> 1, wk = w & 1;
   const int n0 = blockIdx.x * WG_BN, k0 = blockIdx.y * WG_BK, s = blockIdx.z;
   const int64_t m_begin = (int64_t)s * rows_per_split;
   const int64_t m_end = min(M, m_begin + (int64_t)rows_per_split);
   const int steps = m_end > m_begin ? (int)((m_end - m_begin + WG_MS - 1) / WG_MS) : 0;
-  const bool want_bias = (slab_b != nullptr) && blockIdx.y == 0 && wk == 0;     // wave-uniform
+  const bool want_bias = has_bias && blockIdx.y == 0 && wk == 0;     // wave-uniform
+  float* __restrict__ slab_w = slab + (int64_t)s * count;
+  float* __restrict__ slab_b = slab_w + (int64_t)N * K;
 
   uint4 ry[2], rx[2];
   auto gload = [&](int step) {
@@ -117,25 +119,43 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const __hip_bfloat16* __rest
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int k = k0 + (wk * 4 + b) * 16 + ci;
-        if (k < K) slab_w[((int64_t)s * N + n) * K + k] = acc[a][b][r];
+        if (k < K) slab_w[(int64_t)n * K + k] = acc[a][b][r];
       }
-      if (want_bias && ci == 0) slab_b[(int64_t)s * N + n] = accb[a][r];
+      if (want_bias && ci == 0) slab_b[n] = accb[a][r];
     }
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int64_t count,
-                                                          float* __restrict__ out) {
-  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// Slab reduction, two levels, both in a fixed order (deterministic).  Level 1: block (x, y) sums the slabs
+// y, y+RG, y+2RG, ... for 1024 consecutive elements (float4 per thread) into part[y]; level 2 sums the RG parts.
+#define WG_RG 8
+__global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restrict__ slab, int splits, int64_t count,
+                                                           float* __restrict__ part) {
+  const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= count) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = blockIdx.y; s < splits; s += WG_RG) {
+    const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)s * count + e);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * count + e) = acc;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restrict__ part, int64_t count, int n, int k,
+                                                           float* __restrict__ dw, float* __restrict__ db) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= count) return;
   float acc = 0.f;
-  for (int s = 0; s < splits; ++s) acc += slab[(int64_t)s * count + e];     // fixed order: deterministic
-  out[e] = acc;
+#pragma unroll
+  for (int y = 0; y < WG_RG; ++y) acc += part[(int64_t)y * count + e];
+  const int64_t nk = (int64_t)n * k;
+  if (e < nk) dw[e] = acc;
+  else if (db && e < nk + n) db[e - nk] = acc;
 }
 
 static void wgrad_plan(int64_t m, int n, int k, int& splits, int& rows_per_split) {
   const int nb = ((n + WG_BN - 1) / WG_BN) * ((k + WG_BK - 1) / WG_BK);
-  int64_t s = (768 + nb - 1) / nb;                        // ~3 workgroups per CU in flight
+  int64_t s = (512 + nb - 1) / nb;                        // ~2 workgroups per CU in flight
   const int64_t max_s = (m + 255) / 256;                  // at least 8 steps per workgroup
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -147,10 +167,13 @@ static void wgrad_plan(int64_t m, int n, int k, int& splits, int& rows_per_split
   rows_per_split = (int)rows;
 }
 
+// slab row = [n*k weight partials | n bias partials | pad to a multiple of 4 floats]
+static int64_t slab_count(int n, int k) { return (((int64_t)n * k + n) + 3) / 4 * 4; }
+
 size_t tmae_linear_wgrad_workspace(int64_t m, int n, int k) {
   int splits, rows;
   wgrad_plan(m, n, k, splits, rows);
-  return tmae_align((size_t)splits * n * k * 4) + tmae_align((size_t)splits * n * 4) + 1024;
+  return tmae_align((size_t)splits * slab_count(n, k) * 4) + tmae_align((size_t)WG_RG * slab_count(n, k) * 4) + 1024;
 }
 
 int tmae_linear_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k, float* dw,
@@ -162,17 +185,18 @@ int tmae_linear_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, i
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return TMAE_EARG;
   int splits, rows;
   wgrad_plan(m, n, k, splits, rows);
+  const int64_t count = slab_count(n, k);
   WsCarver ws(wsp, ws_bytes);
-  float* slab_w = ws.take<float>((size_t)splits * n * k);
-  float* slab_b = ws.take<float>((size_t)splits * n);
+  float* slab = ws.take<float>((size_t)splits * count);
+  float* part = ws.take<float>((size_t)WG_RG * count);
   if (!ws.ok) return TMAE_EWS;
+  // without a bias the slabs' bias columns stay unwritten; the reduction discards those sums
   dim3 grid((n + WG_BN - 1) / WG_BN, (k + WG_BK - 1) / WG_BK, splits);
   hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, stream, (const __hip_bfloat16*)dy, ldy,
-                     (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab_w, db ? slab_b : (float*)nullptr);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tmae_cdiv((int64_t)n * k, 256)), dim3(256), 0, stream, slab_w, splits,
-                     (int64_t)n * k, dw);
-  if (db)
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, slab_b, splits, (int64_t)n,
-                       db);
+                     (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr);
+  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(tmae_cdiv(count / 4, 256), WG_RG), dim3(256), 0, stream, slab, splits,
+                     count, part);
+  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(tmae_cdiv(count, 256)), dim3(256), 0, stream, part, count, n, k, dw,
+                     db);
   return tmae_launch_status();
 }
