@@ -51,15 +51,17 @@ __device__ __forceinline__ void load_row_frag(const __hip_bfloat16* base, int64_
 
 // L2-normalise a token row that is spread over the 4 lane groups (same lane&15), times `scale`.
 template <int FR>
-__device__ __forceinline__ void normalize_frag(float* f, float scale) {
+__device__ __forceinline__ float normalize_frag(float* f, float scale) {
   float ss = 0.f;
 #pragma unroll
   for (int j = 0; j < FR; ++j) ss += f[j] * f[j];
   ss += __shfl_xor(ss, 16, 64);
   ss += __shfl_xor(ss, 32, 64);
-  const float inv = scale / fmaxf(sqrtf(ss), 1e-12f);
+  const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+  const float inv = scale / nrm;
 #pragma unroll
   for (int j = 0; j < FR; ++j) f[j] *= inv;
+  return nrm;                                   // max(|x|, eps) of the whole row
 }
 
 template <int DH> struct Frag;
@@ -151,11 +153,16 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
   frag_t kf[4], kl[4];
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
-    float f[FR];
     const int slot = kt * 16 + i;
-    load_row_frag<FR>(k, ldk, (kt < nk && slot < Tk) ? toks[1][slot] : -1, hoff, g, f);
-    normalize_frag<FR>(f, 1.0f);
-    split_frag<FR>(f, kf[kt], kl[kt]);
+    if (kt < nk) {                                   // wave-uniform
+      float f[FR];
+      load_row_frag<FR>(k, ldk, slot < Tk ? toks[1][slot] : -1, hoff, g, f);
+      normalize_frag<FR>(f, 1.0f);
+      split_frag<FR>(f, kf[kt], kl[kt]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < FR; ++j) { kf[kt][j] = 0; kl[kt][j] = 0; }
+    }
   }
   // V fragments (B operand of P.V): [key tile][channel tile], 4 keys x 1 channel per lane
   s16x4 vf[4][CT];
@@ -176,9 +183,12 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      st[kt] = mfma_s(kl[kt], qf, f32x4{0.f, 0.f, 0.f, 0.f});      // S^T tile: rows = keys 4g+r, col = query i
-      st[kt] = mfma_s(kf[kt], ql, st[kt]);
-      st[kt] = mfma_s(kf[kt], qf, st[kt]);
+      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt < nk) {
+        st[kt] = mfma_s(kl[kt], qf, st[kt]);                       // S^T tile: rows = keys 4g+r, col = query i
+        st[kt] = mfma_s(kf[kt], ql, st[kt]);
+        st[kt] = mfma_s(kf[kt], qf, st[kt]);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (kt * 16 + 4 * g + r >= Tk) st[kt][r] = -INFINITY;
@@ -205,7 +215,8 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
     for (int ct = 0; ct < CT; ++ct) {
       o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) o[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf[kt], vf[kt][ct], o[ct], 0, 0, 0);
+      for (int kt = 0; kt < 4; ++kt)
+        if (kt < nk) o[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf[kt], vf[kt][ct], o[ct], 0, 0, 0);
     }
     // O tile: rows = queries 4g+r, col = channel i
 #pragma unroll
@@ -299,64 +310,45 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
     if (tq >= 0) toks[0][__popcll(mq & ((1ull << lane) - 1ull))] = tq;
     if (tk >= 0) toks[1][__popcll(mk & ((1ull << lane) - 1ull))] = tk;
   }
-  // ---- stage the row-major images: every lane owns the row of its own token (or zero-fills a dead row)
-  {
-    float r[DH];
-    const int qslot = (tq >= 0) ? __popcll(mq & ((1ull << lane) - 1ull)) : -1;
-    const int kslot = (tk >= 0) ? __popcll(mk & ((1ull << lane) - 1ull)) : -1;
-    if (tk >= 0) {
-      const __hip_bfloat16* src = k + (int64_t)tk * ldk + hoff;
-      float ss = 0.f;
-#pragma unroll
-      for (int c = 0; c < DH; ++c) { r[c] = __bfloat162float(src[c]); ss += r[c] * r[c]; }
-      const float nrm = fmaxf(sqrtf(ss), 1e-12f), inv = 1.0f / nrm;
-      knorm[w][kslot] = nrm;
-      short* dst = reinterpret_cast<short*>(&kimg[w][kslot * RB]);
-#pragma unroll
-      for (int c = 0; c < DH; ++c) dst[c] = f2bf(r[c] * inv);
-    }
-    if (tq >= 0) {
-      const __hip_bfloat16* src = q + (int64_t)tq * ldq + hoff;
-      float ss = 0.f;
-#pragma unroll
-      for (int c = 0; c < DH; ++c) { r[c] = __bfloat162float(src[c]); ss += r[c] * r[c]; }
-      const float nrm = fmaxf(sqrtf(ss), 1e-12f), inv = inv_tau / nrm;
-      qnorm[w][qslot] = nrm;
-      short* dst = reinterpret_cast<short*>(&qimg[w][qslot * RB]);
-#pragma unroll
-      for (int c = 0; c < DH; ++c) dst[c] = f2bf(r[c] * inv);
-      const uint4* gsrc = reinterpret_cast<const uint4*>(dout + (int64_t)tq * lddo + hoff);
-      uint4* gdst = reinterpret_cast<uint4*>(&gimg[w][qslot * RB]);
-#pragma unroll
-      for (int c = 0; c < DH / 8; ++c) gdst[c] = gsrc[c];
-    }
-    if (lane >= Tk) {
-      uint4* d0 = reinterpret_cast<uint4*>(&kimg[w][lane * RB]);
-#pragma unroll
-      for (int c = 0; c < DH / 8; ++c) d0[c] = make_uint4(0, 0, 0, 0);
-    }
-    if (lane >= Tq) {
-      uint4* d1 = reinterpret_cast<uint4*>(&qimg[w][lane * RB]);
-      uint4* d2 = reinterpret_cast<uint4*>(&gimg[w][lane * RB]);
-#pragma unroll
-      for (int c = 0; c < DH / 8; ++c) { d1[c] = make_uint4(0, 0, 0, 0); d2[c] = make_uint4(0, 0, 0, 0); }
-    }
-  }
-  __syncthreads();
+  __syncthreads();                                   // token lists visible
   const int nq = (Tq + 15) >> 4, nk = (Tk + 15) >> 4;
-  // row fragments of K-hat (from the image: already normalised + rounded) and V (from global), per key tile
+  // ---- stage the row-major LDS images from 16-byte row fragments: lane (g,i) owns chunk g of row tile*16+i.
+  //      Slots beyond T get zero fragments, so every row of every image is defined.
   frag_t kf[4], kl[4], vr[4];
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     const int slot = kt * 16 + i;
-    const int tokk = (kt < nk && slot < Tk) ? toks[1][slot] : -1;
-    float f[FR];
-    load_row_frag<FR>(k, ldk, tokk, hoff, g, f);
-    normalize_frag<FR>(f, 1.0f);
-    split_frag<FR>(f, kf[kt], kl[kt]);           // hi part == the kimg row (same rounding)
-    load_row_frag<FR>(v, ldv, tokk, hoff, g, f);
-    vr[kt] = pack_frag<FR>(f);
+    if (kt < nk) {                                   // wave-uniform: most windows hold a single 16-token tile
+      const int tokk = slot < Tk ? toks[1][slot] : -1;
+      float f[FR];
+      load_row_frag<FR>(k, ldk, tokk, hoff, g, f);
+      const float nrm = normalize_frag<FR>(f, 1.0f);
+      split_frag<FR>(f, kf[kt], kl[kt]);
+      if (g == 0) knorm[w][slot] = nrm;
+      load_row_frag<FR>(v, ldv, tokk, hoff, g, f);
+      vr[kt] = pack_frag<FR>(f);
+    } else {
+#pragma unroll
+      for (int j = 0; j < FR; ++j) { kf[kt][j] = 0; kl[kt][j] = 0; vr[kt][j] = 0; }
+    }
+    *reinterpret_cast<frag_t*>(&kimg[w][slot * RB + FR * g * 2]) = kf[kt];
   }
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const int slot = qt * 16 + i;
+    if (qt < nq) {
+      const int tokq = slot < Tq ? toks[0][slot] : -1;
+      float f[FR];
+      load_row_frag<FR>(q, ldq, tokq, hoff, g, f);
+      const float nrm = normalize_frag<FR>(f, inv_tau);
+      *reinterpret_cast<frag_t*>(&qimg[w][slot * RB + FR * g * 2]) = pack_frag<FR>(f);
+      if (g == 0) qnorm[w][slot] = nrm;
+      load_row_frag<FR>(dout, lddo, tokq, hoff, g, f);
+      *reinterpret_cast<frag_t*>(&gimg[w][slot * RB + FR * g * 2]) = pack_frag<FR>(f);   // exact: bf16 -> f32 -> bf16
+    }
+    // tiles >= nq are never read: the q loop and its transposed reads stop at nq
+  }
+  __syncthreads();
   f32x4 dKa[4][CT], dVa[4][CT];
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt)

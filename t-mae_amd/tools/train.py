@@ -1,0 +1,110 @@
+"""Pre-training driver with the reference's CLI surface (tools/train.py:35-149: --cfg_file --batch_size --epochs
+--launcher --amp --set --ckpt --extra_tag ...) for MODEL.NAME == TMAE.  One process per GPU; `--launcher pytorch`
+reads the torchrun environment and uses RCCL ('nccl') for the gradient all-reduce.  The real ONCE loader is out
+of scope: `--synthetic` feeds deterministic ONCE-shape frame pairs."""
+import argparse
+import os
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from pcdet.config import cfg, cfg_from_list, cfg_from_yaml_file, log_config_to_file  # noqa: E402
+from pcdet.models import build_network, model_fn_decorator  # noqa: E402
+from pcdet.utils import common_utils  # noqa: E402
+from tmae_amd.train import (SyntheticTemporalDataset, build_optimizer, build_scheduler, train_one_step,  # noqa: E402
+                            wrap_ddp)
+
+
+def parse_config():
+    p = argparse.ArgumentParser(description='T-MAE pre-training on MI355X')
+    p.add_argument('--cfg_file', type=str, required=True)
+    p.add_argument('--batch_size', type=int, default=None, help='total batch size (split over GPUs, train.py:163-169)')
+    p.add_argument('--epochs', type=int, default=None)
+    p.add_argument('--workers', type=int, default=4)
+    p.add_argument('--extra_tag', type=str, default='default')
+    p.add_argument('--ckpt', type=str, default=None)
+    p.add_argument('--pretrained_model', type=str, default=None)
+    p.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
+    p.add_argument('--local_rank', type=int, default=0)
+    p.add_argument('--amp', action='store_true', help='bf16 autocast (the reference: fp16 + GradScaler)')
+    p.add_argument('--fix_random_seed', action='store_true')
+    p.add_argument('--ckpt_save_interval', type=int, default=1)
+    p.add_argument('--max_ckpt_save_num', type=int, default=30)
+    p.add_argument('--set', dest='set_cfgs', default=None, nargs=argparse.REMAINDER)
+    p.add_argument('--synthetic', action='store_true')
+    p.add_argument('--synthetic_points', type=int, default=120000)
+    p.add_argument('--iters_per_epoch', type=int, default=100)
+    p.add_argument('--output_dir', type=str, default=None)
+    args = p.parse_args()
+    cfg_from_yaml_file(args.cfg_file, cfg)
+    cfg.TAG = Path(args.cfg_file).stem
+    if args.set_cfgs is not None:
+        cfg_from_list(args.set_cfgs, cfg)
+    return args, cfg
+
+
+def save_checkpoint(model, optimizer, epoch, it, path):
+    """{'epoch','it','model_state','optimizer_state','version'} (train_utils.py:245-270)."""
+    m = model.module if hasattr(model, 'module') else model
+    state = {k: v.cpu() for k, v in m.state_dict().items()}
+    torch.save({'epoch': epoch, 'it': it, 'model_state': state, 'optimizer_state': optimizer.state_dict(),
+                'version': 'tmae_amd'}, path)
+
+
+def main():
+    args, cfg = parse_config()
+    if args.launcher == 'pytorch':
+        world, rank = common_utils.init_dist_pytorch(backend='nccl')
+        local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    else:
+        world, rank, local_rank = 1, 0, 0
+        torch.cuda.set_device(0)
+    bs = cfg.OPTIMIZATION.BATCH_SIZE_PER_GPU if args.batch_size is None else args.batch_size // world
+    epochs = cfg.OPTIMIZATION.NUM_EPOCHS if args.epochs is None else args.epochs
+    if args.fix_random_seed:
+        common_utils.set_random_seed(666 + rank)
+    out = Path(args.output_dir or (Path(cfg.ROOT_DIR) / 'output' / cfg.TAG / args.extra_tag))
+    (out / 'ckpt').mkdir(parents=True, exist_ok=True)
+    logger = common_utils.create_logger(out / f'log_train_{time.strftime("%Y%m%d-%H%M%S")}.txt', rank=rank)
+    log_config_to_file(cfg, logger=logger)
+    if not args.synthetic:
+        raise NotImplementedError('the ONCE two-frame dataloader is outside this hot path (SURVEY 8f-2); use --synthetic')
+    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=args.synthetic_points, batch_size=bs, rank=rank)
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds, logger).cuda()
+    opt = build_optimizer(model, cfg.OPTIMIZATION)
+    start_epoch = it = 0
+    if args.pretrained_model:
+        model.load_params_from_file(args.pretrained_model, logger=logger)
+    if args.ckpt:
+        it, start_epoch = model.load_params_with_optimizer(args.ckpt, optimizer=opt, logger=logger)
+        start_epoch += 1
+    model.train()
+    ddp = wrap_ddp(model, local_rank)
+    sched, _ = build_scheduler(opt, args.iters_per_epoch, epochs, -1, cfg.OPTIMIZATION)
+    model_func = model_fn_decorator()
+    amp = torch.bfloat16 if args.amp else None
+    for epoch in range(start_epoch, epochs):
+        t0 = time.time()
+        for i in range(args.iters_per_epoch):
+            batch = ds.batch(epoch * args.iters_per_epoch + i)
+            loss, tb, _ = train_one_step(ddp, opt, sched, batch, it, model_func, amp_dtype=amp,
+                                         grad_norm_clip=cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+            it += 1
+            if rank == 0 and (i % 10 == 0 or i == args.iters_per_epoch - 1):
+                logger.info(f'epoch {epoch} it {i}/{args.iters_per_epoch} loss {float(loss):.5f} lr {opt.lr:.2e}')
+        if rank == 0:
+            logger.info(f'epoch {epoch} done in {time.time() - t0:.1f} s '
+                        f'({bs * world * args.iters_per_epoch / (time.time() - t0):.1f} frame-pairs/s incl. data gen)')
+            if (epoch + 1) % args.ckpt_save_interval == 0:
+                save_checkpoint(ddp, opt, epoch, it, out / 'ckpt' / f'checkpoint_epoch_{epoch + 1}.pth')
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
