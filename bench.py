@@ -54,13 +54,14 @@ def kernel_roofline(model, batch, amp_dtype, iters=10):
         ind = vc[:, [0, 2, 3]].int().contiguous()
         bs = int(bd['batch_size'])
         grid = ops.index_grid(ind, bs, 468, 468)
+        wl = ops.window_worklist(grid, grid, bs, 468, 468, False)
     m, d, H = ind.shape[0], 128, 8
     dt = amp_dtype or torch.float32
     es = 2 if dt == torch.bfloat16 else 4
     qk = torch.randn(m, 2 * d, device=ind.device, dtype=dt).requires_grad_(True)
     v = torch.randn(m, d, device=ind.device, dtype=dt).requires_grad_(True)
     tau = torch.ones(1, 1, 1, device=ind.device, requires_grad=True)
-    out = ops.win_attn(qk, v, None, tau, grid, grid, H, bs, 468, 468, False, 0.01)
+    out = ops.win_attn(qk, v, None, tau, grid, grid, H, bs, 468, 468, False, 0.01, worklist=wl)
     g = torch.randn_like(out)
     out.backward(g, retain_graph=True)
     torch.cuda.synchronize()
@@ -73,7 +74,7 @@ def kernel_roofline(model, batch, amp_dtype, iters=10):
     ms = e0.elapsed_time(e1) / iters
     bytes_alg = m * d * es * (3 + 1 + 1 + 3) + m * H * 4 + bs * 468 * 468 * 4
     achieved = bytes_alg / (ms * 1e-3) / 1e9
-    return {'kernel': 'win_attn_bwd_kernel (stage-1, previous frame)', 'bound': 'hbm', 'achieved': round(achieved, 2),
+    return {'kernel': 'win_attn_bwd_mfma_kernel<16,{1,2,4}> (stage-1 self-attention backward, previous frame; 3 class launches)', 'bound': 'hbm', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': int(m)}
 

@@ -142,7 +142,7 @@ int tmae_win_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
                       int dtype, int64_t mq, int64_t mk, int nhead, int dh,
                       const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx,
                       int do_shift, const float* tau, float tau_min,
-                      void* out, int64_t ldo, float* lse, void* stream);
+                      void* out, int64_t ldo, float* lse, const int32_t* worklist, void* stream);
 /* Backward.  dq/dk/dv are fully written for every token that sits in an attended window and
  * zero-filled otherwise.  dtau_partial [n_windows*nhead/heads_per_block] f32 partial sums of
  * d loss / d max(tau,tau_min) (summed by the caller; n entries = tmae_win_attn_num_blocks). */
@@ -153,7 +153,18 @@ int tmae_win_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
                       const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx,
                       int do_shift, const float* tau, float tau_min,
                       void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
-                      float* dtau_partial, void* stream);
+                      float* dtau_partial, const int32_t* worklist, void* stream);
+
+/* Window work lists -- the reference's region batching (drop levels 16/32/64 tokens, spt_backbone.py:47-71,
+ * t_mae_ssl.yaml:63-67) as three index lists instead of padded tensors: windows of one shift that hold both queries
+ * and keys, binned by the 16-token tiles they need.  worklist [tmae_window_worklist_size()] int32:
+ * [0..2] counts, [4 + c*nwin + j] dense window ids of class c.  Passed to tmae_win_attn_fwd/bwd (bf16 path) it
+ * selects kernel instantiations sized for the class; tokens of windows that are in no list (no key / no query in the
+ * other frame) are then NOT written: the caller pre-zeroes out / dq / dk / dv and dtau_partial.  NULL = one
+ * worst-case kernel over all dense windows. */
+size_t tmae_window_worklist_size(int batch, int ny, int nx);
+int tmae_window_worklist(const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx, int do_shift,
+                         int32_t* worklist, void* stream);
 
 /* SSTInputLayer.get_pos_embed (spt_backbone.py:186-224) fused with the q = k = x + pos add of
  * WindowAttention.forward (sst_basic_block.py:41-44): out[r,:] = x[r,:] + pos_table[cell(r),:], where

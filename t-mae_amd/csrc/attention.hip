@@ -289,12 +289,13 @@ __global__ __launch_bounds__(64 * (64 / DH)) void win_attn_bwd_kernel(
 int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                            int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
                            int batch, int ny, int nx, int do_shift, const float* tau, float tau_min, void* out,
-                           int64_t ldo, float* lse, hipStream_t stream);
+                           int64_t ldo, float* lse, const int32_t* worklist, hipStream_t stream);
 int tmae_win_attn_bwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                           const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, int nhead,
-                           int dh, const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx,
-                           int do_shift, const float* tau, float tau_min, void* dq, int64_t lddq, void* dk,
-                           int64_t lddk, void* dv, int64_t lddv, float* dtau_partial, hipStream_t stream);
+                           const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, int64_t mq,
+                           int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k, int batch,
+                           int ny, int nx, int do_shift, const float* tau, float tau_min, void* dq, int64_t lddq,
+                           void* dk, int64_t lddk, void* dv, int64_t lddv, float* dtau_partial,
+                           const int32_t* worklist, hipStream_t stream);
 static bool use_mfma() {
   static int v = -1;
   if (v < 0) {
@@ -326,7 +327,7 @@ static int attn_check(int64_t mq, int64_t mk, int nhead, int dh, int batch, int 
 int tmae_win_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, int dtype,
                       int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
                       int batch, int ny, int nx, int do_shift, const float* tau, float tau_min, void* out, int64_t ldo,
-                      float* lse, void* stream_) {
+                      float* lse, const int32_t* worklist, void* stream_) {
   (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   int r = attn_check(mq, mk, nhead, dh, batch, ny, nx);
@@ -346,7 +347,7 @@ int tmae_win_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
     if (use_mfma() && nhead % 4 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && !((uintptr_t)q & 15) &&
         !((uintptr_t)k & 15) && !((uintptr_t)v & 15))
       return tmae_win_attn_fwd_mfma(q, ldq, k, ldk, v, ldv, mq, mk, nhead, dh, grid_q, grid_k, batch, ny, nx, do_shift,
-                                    tau, tau_min, out, ldo, lse, stream);
+                                    tau, tau_min, out, ldo, lse, worklist, stream);
     if (dh == 16) FWD(__hip_bfloat16, 16); else FWD(__hip_bfloat16, 32);
   }
   else return TMAE_EDTYPE;
@@ -358,7 +359,8 @@ int tmae_win_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
                       const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, int dtype,
                       int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
                       int batch, int ny, int nx, int do_shift, const float* tau, float tau_min, void* dq, int64_t lddq,
-                      void* dk, int64_t lddk, void* dv, int64_t lddv, float* dtau_partial, void* stream_) {
+                      void* dk, int64_t lddk, void* dv, int64_t lddv, float* dtau_partial, const int32_t* worklist,
+                      void* stream_) {
   (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   int r = attn_check(mq, mk, nhead, dh, batch, ny, nx);
@@ -380,8 +382,9 @@ int tmae_win_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
     const bool al = !(ldq % 8) && !(ldk % 8) && !(ldv % 8) && !(ldo % 8) && !(lddo % 8) && !((uintptr_t)q & 15) &&
                     !((uintptr_t)k & 15) && !((uintptr_t)v & 15) && !((uintptr_t)out & 15) && !((uintptr_t)dout & 15);
     if (use_mfma() && nhead % 4 == 0 && al && mq > 0 && mk > 0)
-      return tmae_win_attn_bwd_mfma(q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, lse, nhead, dh, grid_q, grid_k, batch,
-                                    ny, nx, do_shift, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, dtau_partial, stream);
+      return tmae_win_attn_bwd_mfma(q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, lse, mq, mk, nhead, dh, grid_q, grid_k,
+                                    batch, ny, nx, do_shift, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, dtau_partial,
+                                    worklist, stream);
     if (dh == 16) BWD(__hip_bfloat16, 16); else BWD(__hip_bfloat16, 32);
   }
   else return TMAE_EDTYPE;

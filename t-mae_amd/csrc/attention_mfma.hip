@@ -95,23 +95,104 @@ __device__ __forceinline__ f32x4 mfma_s(const s16x4& a, const s16x4& b, f32x4 c)
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 
-template <int DH>
+// ------------------------------------------------------------------------------------------------
+// window work lists: the windows that hold both queries and keys, binned by the number of 16-token tiles they
+// need (class 0: <=16 tokens, 1: <=32, 2: <=64).  This is the reference's "region batching" (drop levels
+// 16/32/64, spt_backbone.py:47-71) reduced to three index lists -- no padded tensors.  The class selects a kernel
+// instantiation whose LDS images / register tiles are sized for it, so the ~85 % of windows with <=16 tokens run
+// at 4x the occupancy of a worst-case (64-token) workgroup.  layout: wl[0..2] = counts, wl[4 + c*nwin + j] = ids.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void win_class_kernel(const int32_t* __restrict__ grid_q,
+                                                       const int32_t* __restrict__ grid_k, int batch, int ny, int nx,
+                                                       int Wy, int Wx, int sy, int sx, int8_t* __restrict__ cls) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwin = (int64_t)batch * Wy * Wx;
+  const int64_t dw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (dw >= nwin) return;
+  const int wcy = (int)(dw % Wy), wcx = (int)((dw / Wy) % Wx), b = (int)(dw / ((int64_t)Wy * Wx));
+  const int y = wcy * WIN - sy + (lane >> 3), x = wcx * WIN - sx + (lane & 7);
+  const bool in = y >= 0 && y < ny && x >= 0 && x < nx;
+  const int64_t cell = ((int64_t)b * ny + y) * nx + x;
+  const int tq = in ? grid_q[cell] : -1, tk = in ? grid_k[cell] : -1;
+  const int Tq = __popcll(__ballot(tq >= 0)), Tk = __popcll(__ballot(tk >= 0));
+  if (lane == 0) {
+    const int t = max(Tq, Tk);
+    cls[dw] = (Tq > 0 && Tk > 0) ? (int8_t)(t <= 16 ? 0 : (t <= 32 ? 1 : 2)) : (int8_t)-1;
+  }
+}
+
+// compaction: one thread per window; a wave reserves its range with ONE atomic per class (list order only affects
+// scheduling, never results)
+__global__ __launch_bounds__(256) void win_worklist_kernel(const int8_t* __restrict__ cls, int64_t nwin,
+                                                          int32_t* __restrict__ wl) {
+  const int lane = threadIdx.x & 63;
+  const int64_t dw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = dw < nwin ? (int)cls[dw] : -1;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const unsigned long long m = __ballot(c == k);
+    if (m == 0ull) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(wl + k, __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (c == k) wl[4 + (int64_t)k * nwin + base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)dw;
+  }
+}
+
+size_t tmae_window_worklist_size(int batch, int ny, int nx) {
+  const int Wy = (ny + WIN - 1) / WIN + 1, Wx = (nx + WIN - 1) / WIN + 1;
+  const size_t nwin = (size_t)batch * Wy * Wx;
+  return 4 + 3 * nwin + (nwin + 3) / 4;                 // counts | three lists | class bytes (scratch)
+}
+
+int tmae_window_worklist(const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx, int do_shift,
+                         int32_t* worklist, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!grid_q || !grid_k || !worklist || batch <= 0 || ny <= 0 || nx <= 0) return TMAE_EARG;
+  const int Wy = (ny + WIN - 1) / WIN + 1, Wx = (nx + WIN - 1) / WIN + 1;
+  const int s = do_shift ? WIN / 2 : WIN;
+  const int64_t nwin = (int64_t)batch * Wy * Wx;
+  int8_t* cls = reinterpret_cast<int8_t*>(worklist + 4 + 3 * nwin);
+  hipMemsetAsync(worklist, 0, 16, stream);
+  hipLaunchKernelGGL(win_class_kernel, dim3(tmae_cdiv(nwin, 4)), dim3(256), 0, stream, grid_q, grid_k, batch, ny, nx,
+                     Wy, Wx, s, s, cls);
+  hipLaunchKernelGGL(win_worklist_kernel, dim3(tmae_cdiv(nwin, 256)), dim3(256), 0, stream, cls, nwin, worklist);
+  return (int)hipGetLastError();
+}
+
+// resolves the window of this workgroup; returns false when the block has nothing to do
+__device__ __forceinline__ bool pick_window(const int32_t* __restrict__ wl, int cls, int64_t nwin, int64_t& dw) {
+  if (wl) {
+    if ((int)blockIdx.x >= wl[cls]) return false;
+    dw = wl[4 + (int64_t)cls * nwin + blockIdx.x];
+  } else {
+    dw = blockIdx.x;
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int DH, int NT>
 __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
     const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
     const __hip_bfloat16* __restrict__ v, int64_t ldv, int nhead, const int32_t* __restrict__ grid_q,
     const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx, int sy, int sx,
     const float* __restrict__ tau, float tau_min, __hip_bfloat16* __restrict__ out, int64_t ldo,
-    float* __restrict__ lse) {
+    float* __restrict__ lse, const int32_t* __restrict__ wl, int cls, int64_t nwin) {
   constexpr int FR = DH / 4;                 // channels per lane in a row fragment
   constexpr int CT = DH / 16;                // 16-channel output tiles
   constexpr int RB = DH * 2 + 16;            // V image row pitch (bytes): 16-byte aligned, off the power of two
+  constexpr int ROWS = NT * 16;
   typedef typename Frag<DH>::T frag_t;
   __shared__ int toks[2][64];
-  __shared__ __attribute__((aligned(16))) char vimg[4][64 * RB];
+  __shared__ __attribute__((aligned(16))) char vimg[4][ROWS * RB];
+  int64_t dw;
+  if (!pick_window(wl, cls, nwin, dw)) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
   const int head = blockIdx.y * 4 + w, hoff = head * DH;
-  // window tokens (every wave computes the same; wave 0 publishes the compacted lists)
-  const int64_t dw = blockIdx.x;
   const int wcy = (int)(dw % Wy), wcx = (int)((dw / Wy) % Wx), b = (int)(dw / ((int64_t)Wy * Wx));
   const int y = wcy * WIN - sy + (lane >> 3), x = wcx * WIN - sx + (lane & 7);
   const bool in = y >= 0 && y < ny && x >= 0 && x < nx;
@@ -120,7 +201,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
   const unsigned long long mq = __ballot(tq >= 0), mk = __ballot(tk >= 0);
   if (mq == 0ull) return;
   const int Tq = __popcll(mq), Tk = __popcll(mk);
-  if (Tk == 0) {                              // cross-attention window without keys: zero rows (not "kept")
+  if (Tk == 0) {                              // (dense launch only) cross-attention window without keys: zero rows
     if (tq >= 0) {
       __hip_bfloat16* o = out + (int64_t)tq * ldo + hoff;
 #pragma unroll
@@ -133,135 +214,151 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
     if (tq >= 0) toks[0][__popcll(mq & ((1ull << lane) - 1ull))] = tq;
     if (tk >= 0) toks[1][__popcll(mk & ((1ull << lane) - 1ull))] = tk;
   }
-  // stage this head's V rows (row = key slot) for the transposed reads
-  if (tk >= 0) {
-    const int slot = __popcll(mk & ((1ull << lane) - 1ull));
-    const uint4* src = reinterpret_cast<const uint4*>(v + (int64_t)tk * ldv + hoff);
-    uint4* dst = reinterpret_cast<uint4*>(&vimg[w][slot * RB]);
-#pragma unroll
-    for (int c = 0; c < DH / 8; ++c) dst[c] = src[c];
-  }
-  if (lane >= Tk) {                          // rows no key writes: zero them (P is 0 there, but 0 * garbage = NaN)
-    uint4* dst = reinterpret_cast<uint4*>(&vimg[w][lane * RB]);
-#pragma unroll
-    for (int c = 0; c < DH / 8; ++c) dst[c] = make_uint4(0, 0, 0, 0);
-  }
   __syncthreads();
   const int nq = (Tq + 15) >> 4, nk = (Tk + 15) >> 4;
   const float inv_tau = 1.0f / fmaxf(tau[0], tau_min);
-  // K-hat fragments of every key tile stay in registers
-  frag_t kf[4], kl[4];
+  // ---- all global row loads are issued here, one dependent round after the token ids
+  frag_t kf[NT], kl[NT], qf[NT], ql[NT];
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
-    const int slot = kt * 16 + i;
-    if (kt < nk) {                                   // wave-uniform
-      float f[FR];
-      load_row_frag<FR>(k, ldk, slot < Tk ? toks[1][slot] : -1, hoff, g, f);
+  for (int t = 0; t < NT; ++t) {
+    const int slot = t * 16 + i;
+    float f[FR];
+    if (t < nk) {                                   // wave-uniform
+      const int tokk = slot < Tk ? toks[1][slot] : -1;
+      load_row_frag<FR>(k, ldk, tokk, hoff, g, f);
       normalize_frag<FR>(f, 1.0f);
-      split_frag<FR>(f, kf[kt], kl[kt]);
+      split_frag<FR>(f, kf[t], kl[t]);
+      load_row_frag<FR>(v, ldv, tokk, hoff, g, f);
+      *reinterpret_cast<frag_t*>(&vimg[w][slot * RB + FR * g * 2]) = pack_frag<FR>(f);
     } else {
 #pragma unroll
-      for (int j = 0; j < FR; ++j) { kf[kt][j] = 0; kl[kt][j] = 0; }
+      for (int j = 0; j < FR; ++j) { kf[t][j] = 0; kl[t][j] = 0; }
+      frag_t z;
+#pragma unroll
+      for (int j = 0; j < FR; ++j) z[j] = 0;
+      *reinterpret_cast<frag_t*>(&vimg[w][slot * RB + FR * g * 2]) = z;     // P is 0 there, but 0 * garbage = NaN
+    }
+    if (t < nq) {
+      load_row_frag<FR>(q, ldq, slot < Tq ? toks[0][slot] : -1, hoff, g, f);
+      normalize_frag<FR>(f, inv_tau);
+      split_frag<FR>(f, qf[t], ql[t]);
     }
   }
+  __syncthreads();
   // V fragments (B operand of P.V): [key tile][channel tile], 4 keys x 1 channel per lane
-  s16x4 vf[4][CT];
+  s16x4 vf[NT][CT];
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
+  for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
       vf[kt][ct] = tr_read4(&vimg[w][(kt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3)]);
 
-  for (int qt = 0; qt < nq; ++qt) {
-    float f[FR];
-    const int qslot = qt * 16 + i;
-    load_row_frag<FR>(q, ldq, qslot < Tq ? toks[0][qslot] : -1, hoff, g, f);
-    normalize_frag<FR>(f, inv_tau);
-    frag_t qf, ql;
-    split_frag<FR>(f, qf, ql);
-    f32x4 st[4];
-    float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kt < nk) {
-        st[kt] = mfma_s(kl[kt], qf, st[kt]);                       // S^T tile: rows = keys 4g+r, col = query i
-        st[kt] = mfma_s(kf[kt], ql, st[kt]);
-        st[kt] = mfma_s(kf[kt], qf, st[kt]);
+  for (int qt = 0; qt < NT; ++qt) {
+    if (qt < nq) {
+      const int qslot = qt * 16 + i;
+      f32x4 st[NT];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (kt < nk) {
+          st[kt] = mfma_s(kl[kt], qf[qt], st[kt]);                   // S^T tile: rows = keys 4g+r, col = query i
+          st[kt] = mfma_s(kf[kt], ql[qt], st[kt]);
+          st[kt] = mfma_s(kf[kt], qf[qt], st[kt]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (kt * 16 + 4 * g + r >= Tk) st[kt][r] = -INFINITY;
+          mx = fmaxf(mx, st[kt][r]);
+        }
       }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float l = 0.f;
+      s16x4 pf[NT];
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(st[kt][r] - mx);
+          l += p;
+          pf[kt][r] = f2bf(p);
+        }
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const float invl = 1.0f / l;
+      f32x4 o[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+          if (kt < nk) o[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf[kt], vf[kt][ct], o[ct], 0, 0, 0);
+      }
+      // O tile: rows = queries 4g+r, col = channel i
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (kt * 16 + 4 * g + r >= Tk) st[kt][r] = -INFINITY;
-        mx = fmaxf(mx, st[kt][r]);
+        const int qs = qt * 16 + 4 * g + r;
+        const float il = __shfl(invl, 4 * g + r, 64);
+        if (qs < Tq) {
+          __hip_bfloat16* op = out + (int64_t)toks[0][qs] * ldo + hoff + i;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) op[ct * 16] = __float2bfloat16(o[ct][r] * il);
+        }
       }
+      if (g == 0 && qslot < Tq) lse[(int64_t)toks[0][qslot] * nhead + head] = mx + __logf(l);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float l = 0.f;
-    s16x4 pf[4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __expf(st[kt][r] - mx);
-        l += p;
-        pf[kt][r] = f2bf(p);
-      }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float invl = 1.0f / l;
-    f32x4 o[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-        if (kt < nk) o[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf[kt], vf[kt][ct], o[ct], 0, 0, 0);
-    }
-    // O tile: rows = queries 4g+r, col = channel i
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qs = qt * 16 + 4 * g + r;
-      const float il = __shfl(invl, 4 * g + r, 64);
-      if (qs < Tq) {
-        __hip_bfloat16* op = out + (int64_t)toks[0][qs] * ldo + hoff + i;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) op[ct * 16] = __float2bfloat16(o[ct][r] * il);
-      }
-    }
-    if (g == 0 && qslot < Tq) lse[(int64_t)toks[0][qslot] * nhead + head] = mx + __logf(l);
   }
+}
+
+static int64_t class_grid(int cls, int64_t nwin, int64_t mq, int64_t mk) {
+  // class c windows hold > 16*c tokens (c = 1: >= 17, c = 2: >= 33) in one of the two frames
+  const int64_t bound = cls == 0 ? nwin : (mq + mk) / (cls == 1 ? 17 : 33);
+  return bound < nwin ? bound : nwin;
 }
 
 int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                            int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
                            int batch, int ny, int nx, int do_shift, const float* tau, float tau_min, void* out,
-                           int64_t ldo, float* lse, hipStream_t stream) {
+                           int64_t ldo, float* lse, const int32_t* worklist, hipStream_t stream) {
   if (nhead % 4 || (dh != 16 && dh != 32)) return TMAE_EARG;
   // 16-byte row fragments / V rows: bases and pitches must keep every head slice 16-byte aligned
   if ((ldq % 8) || (ldk % 8) || (ldv % 8) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15))
     return TMAE_EARG;
   const int Wy = (ny + WIN - 1) / WIN + 1, Wx = (nx + WIN - 1) / WIN + 1;
   const int s = do_shift ? WIN / 2 : WIN;
-  dim3 grid((unsigned)((int64_t)batch * Wy * Wx), (unsigned)(nhead / 4));
-  if (dh == 32)
-    hipLaunchKernelGGL(win_attn_fwd_mfma_kernel<32>, grid, dim3(256), 0, stream, (const __hip_bfloat16*)q, ldq,
-                       (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v, ldv, nhead, grid_q, grid_k, ny, nx, Wy,
-                       Wx, s, s, tau, tau_min, (__hip_bfloat16*)out, ldo, lse);
-  else
-    hipLaunchKernelGGL(win_attn_fwd_mfma_kernel<16>, grid, dim3(256), 0, stream, (const __hip_bfloat16*)q, ldq,
-                       (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v, ldv, nhead, grid_q, grid_k, ny, nx, Wy,
-                       Wx, s, s, tau, tau_min, (__hip_bfloat16*)out, ldo, lse);
+  const int64_t nwin = (int64_t)batch * Wy * Wx;
+#define FWDM(DH, NT, CLS, GX)                                                                                        \
+  hipLaunchKernelGGL((win_attn_fwd_mfma_kernel<DH, NT>), dim3((unsigned)(GX), (unsigned)(nhead / 4)), dim3(256), 0,  \
+                     stream, (const __hip_bfloat16*)q, ldq, (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v,  \
+                     ldv, nhead, grid_q, grid_k, ny, nx, Wy, Wx, s, s, tau, tau_min, (__hip_bfloat16*)out, ldo, lse,  \
+                     worklist, CLS, nwin)
+  if (!worklist) {
+    if (dh == 32) FWDM(32, 4, 0, nwin); else FWDM(16, 4, 0, nwin);
+  } else {
+    const int64_t g0 = class_grid(0, nwin, mq, mk), g1 = class_grid(1, nwin, mq, mk), g2 = class_grid(2, nwin, mq, mk);
+    if (dh == 32) {
+      if (g0 > 0) FWDM(32, 1, 0, g0);
+      if (g1 > 0) FWDM(32, 2, 1, g1);
+      if (g2 > 0) FWDM(32, 4, 2, g2);
+    } else {
+      if (g0 > 0) FWDM(16, 1, 0, g0);
+      if (g1 > 0) FWDM(16, 2, 1, g1);
+      if (g2 > 0) FWDM(16, 4, 2, g2);
+    }
+  }
+#undef FWDM
   return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward (bf16): P is recomputed from the saved log-sum-exp in BOTH orientations, because the five products
-// need the T x T factor once with the query on the lane column (dQ-hat = dS.K-hat) and once with the key on it
-// (dV = P^T.dO, dK-hat = dS^T.Q-hat) -- recomputing two tiny MFMAs is cheaper than any cross-lane transpose.
-// The right-hand factors (K-hat, Q-hat/tau, dO) are row-major LDS images read with ds_read_b64_tr_b16.
+// backward (bf16): P is recomputed from the saved log-sum-exp with the query on the lane column (what dQ-hat =
+// dS.K-hat needs as its A operand); dV = P^T.dO and dK-hat = dS^T.Q-hat need the key on the lane column, which a
+// 16x16 bf16 tile written with one 8-byte store per lane and read back with ds_read_b64_tr_b16 provides.
+// The right-hand factors (K-hat, Q-hat/tau, dO) are row-major LDS images read with the same transposing read.
 // ------------------------------------------------------------------------------------------------
-template <int DH>
+template <int DH, int NT>
 __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
     const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
     const __hip_bfloat16* __restrict__ v, int64_t ldv, const __hip_bfloat16* __restrict__ outp, int64_t ldo,
@@ -269,19 +366,23 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
     const int32_t* __restrict__ grid_q, const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx, int sy,
     int sx, const float* __restrict__ tau, float tau_min, __hip_bfloat16* __restrict__ dq, int64_t lddq,
     __hip_bfloat16* __restrict__ dk, int64_t lddk, __hip_bfloat16* __restrict__ dv, int64_t lddv,
-    float* __restrict__ dtau_partial) {
+    float* __restrict__ dtau_partial, const int32_t* __restrict__ wl, int cls, int64_t nwin) {
   constexpr int FR = DH / 4;
   constexpr int CT = DH / 16;
   constexpr int RB = DH * 2 + 16;
+  constexpr int ROWS = NT * 16;
   typedef typename Frag<DH>::T frag_t;
   __shared__ int toks[2][64];
-  __shared__ __attribute__((aligned(16))) char kimg[4][64 * RB];   // K-hat
-  __shared__ __attribute__((aligned(16))) char qimg[4][64 * RB];   // Q-hat / tau_c
-  __shared__ __attribute__((aligned(16))) char gimg[4][64 * RB];   // dO
-  __shared__ float qnorm[4][64], knorm[4][64];
+  __shared__ __attribute__((aligned(16))) char kimg[4][ROWS * RB];   // K-hat
+  __shared__ __attribute__((aligned(16))) char qimg[4][ROWS * RB];   // Q-hat / tau_c
+  __shared__ __attribute__((aligned(16))) char gimg[4][ROWS * RB];   // dO
+  __shared__ float qnorm[4][ROWS], knorm[4][ROWS];
+  constexpr int TP = 40;                                              // pitch (bytes) of the 16x16 bf16 transpose tiles
+  __shared__ __attribute__((aligned(16))) char ptile[4][2][16 * TP];
+  int64_t dw;
+  if (!pick_window(wl, cls, nwin, dw)) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
   const int head = blockIdx.y * 4 + w, hoff = head * DH;
-  const int64_t dw = blockIdx.x;
   const int wcy = (int)(dw % Wy), wcx = (int)((dw / Wy) % Wx), b = (int)(dw / ((int64_t)Wy * Wx));
   const int y = wcy * WIN - sy + (lane >> 3), x = wcx * WIN - sx + (lane & 7);
   const bool in = y >= 0 && y < ny && x >= 0 && x < nx;
@@ -290,7 +391,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
   const unsigned long long mq = __ballot(tq >= 0), mk = __ballot(tk >= 0);
   const int Tq = __popcll(mq), Tk = __popcll(mk);
   float* dtp = dtau_partial + dw * nhead + head;
-  if (Tq == 0 || Tk == 0) {
+  if (Tq == 0 || Tk == 0) {                   // (dense launch only) nothing attended here: zero gradients
     if (lane == 0) *dtp = 0.f;
     if (Tq > 0 && tq >= 0) {
       __hip_bfloat16* p = dq + (int64_t)tq * lddq + hoff;
@@ -312,153 +413,137 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
   }
   __syncthreads();                                   // token lists visible
   const int nq = (Tq + 15) >> 4, nk = (Tk + 15) >> 4;
-  // ---- stage the row-major LDS images from 16-byte row fragments: lane (g,i) owns chunk g of row tile*16+i.
-  //      Slots beyond T get zero fragments, so every row of every image is defined.
-  frag_t kf[4], kl[4], vr[4];
+  // ---- every global row load of the workgroup is issued here (one dependent round after the token ids); the
+  //      row-major LDS images are written from the same 16-byte fragments: lane (g,i) owns chunk g of row tile*16+i.
+  frag_t kf[NT], kl[NT], vr[NT], qf[NT], ql[NT], gf[NT];
+  float dsum[NT], lse_i[NT];
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
-    const int slot = kt * 16 + i;
-    if (kt < nk) {                                   // wave-uniform: most windows hold a single 16-token tile
+  for (int t = 0; t < NT; ++t) {
+    const int slot = t * 16 + i;
+    float f[FR];
+    if (t < nk) {                                    // wave-uniform
       const int tokk = slot < Tk ? toks[1][slot] : -1;
-      float f[FR];
       load_row_frag<FR>(k, ldk, tokk, hoff, g, f);
       const float nrm = normalize_frag<FR>(f, 1.0f);
-      split_frag<FR>(f, kf[kt], kl[kt]);
+      split_frag<FR>(f, kf[t], kl[t]);
       if (g == 0) knorm[w][slot] = nrm;
       load_row_frag<FR>(v, ldv, tokk, hoff, g, f);
-      vr[kt] = pack_frag<FR>(f);
+      vr[t] = pack_frag<FR>(f);
     } else {
 #pragma unroll
-      for (int j = 0; j < FR; ++j) { kf[kt][j] = 0; kl[kt][j] = 0; vr[kt][j] = 0; }
+      for (int j = 0; j < FR; ++j) { kf[t][j] = 0; kl[t][j] = 0; vr[t][j] = 0; }
     }
-    *reinterpret_cast<frag_t*>(&kimg[w][slot * RB + FR * g * 2]) = kf[kt];
-  }
-#pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
-    const int slot = qt * 16 + i;
-    if (qt < nq) {
+    *reinterpret_cast<frag_t*>(&kimg[w][slot * RB + FR * g * 2]) = kf[t];
+    dsum[t] = 0.f;
+    lse_i[t] = 0.f;
+    if (t < nq) {
       const int tokq = slot < Tq ? toks[0][slot] : -1;
-      float f[FR];
       load_row_frag<FR>(q, ldq, tokq, hoff, g, f);
       const float nrm = normalize_frag<FR>(f, inv_tau);
-      *reinterpret_cast<frag_t*>(&qimg[w][slot * RB + FR * g * 2]) = pack_frag<FR>(f);
+      split_frag<FR>(f, qf[t], ql[t]);
+      *reinterpret_cast<frag_t*>(&qimg[w][slot * RB + FR * g * 2]) = qf[t];
       if (g == 0) qnorm[w][slot] = nrm;
-      load_row_frag<FR>(dout, lddo, tokq, hoff, g, f);
-      *reinterpret_cast<frag_t*>(&gimg[w][slot * RB + FR * g * 2]) = pack_frag<FR>(f);   // exact: bf16 -> f32 -> bf16
+      float gfl[FR];
+      load_row_frag<FR>(dout, lddo, tokq, hoff, g, gfl);
+      gf[t] = pack_frag<FR>(gfl);                                        // exact: bf16 -> f32 -> bf16
+      *reinterpret_cast<frag_t*>(&gimg[w][slot * RB + FR * g * 2]) = gf[t];
+      load_row_frag<FR>(outp, ldo, tokq, hoff, g, f);
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < FR; ++j) d += f[j] * gfl[j];                   // D = dO . O
+      d += __shfl_xor(d, 16, 64);
+      d += __shfl_xor(d, 32, 64);
+      dsum[t] = d;
+      lse_i[t] = tokq >= 0 ? lse[(int64_t)tokq * nhead + head] : 0.f;
     }
-    // tiles >= nq are never read: the q loop and its transposed reads stop at nq
   }
   __syncthreads();
-  f32x4 dKa[4][CT], dVa[4][CT];
+  f32x4 dKa[NT][CT], dVa[NT][CT];
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
+  for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) { dKa[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dVa[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   float dtau_acc = 0.f;
 
-  for (int qt = 0; qt < nq; ++qt) {
-    const int qslot = qt * 16 + i;
-    const bool qok = qslot < Tq;
-    const int qtok = qok ? toks[0][qslot] : -1;
-    frag_t qf, ql;
-    {
-      float f[FR];
-      load_row_frag<FR>(q, ldq, qtok, hoff, g, f);
-      normalize_frag<FR>(f, inv_tau);
-      split_frag<FR>(f, qf, ql);
-    }
-    const frag_t gf = *reinterpret_cast<const frag_t*>(&gimg[w][qslot * RB + FR * g * 2]);
-    // D = dO . O and LSE of query i (swapped orientation) -> shuffled copies for queries 4g+r (unswapped)
-    float of[FR], gfl[FR];
-    load_row_frag<FR>(outp, ldo, qtok, hoff, g, of);
 #pragma unroll
-    for (int j = 0; j < FR; ++j) gfl[j] = bf2f(gf[j]);
-    float dsum = 0.f;
-#pragma unroll
-    for (int j = 0; j < FR; ++j) dsum += of[j] * gfl[j];
-    dsum += __shfl_xor(dsum, 16, 64);
-    dsum += __shfl_xor(dsum, 32, 64);
-    const float lse_i = qok ? lse[(int64_t)qtok * nhead + head] : 0.f;
-    float lse_r[4], d_r[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { lse_r[r] = __shfl(lse_i, 4 * g + r, 64); d_r[r] = __shfl(dsum, 4 * g + r, 64); }
-    // transposed right-hand fragments of this query tile
-    s16x4 trQ[CT], trG[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const int off = (qt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3);
-      trQ[ct] = tr_read4(&qimg[w][off]);
-      trG[ct] = tr_read4(&gimg[w][off]);
-    }
-    f32x4 dQa[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) dQa[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      if (kt < nk) {
-        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-        // swapped: rows = keys 4g+r of this tile, column = query i
-        f32x4 sT = mfma_s(kl[kt], qf, z);
-        sT = mfma_s(kf[kt], ql, sT);
-        sT = mfma_s(kf[kt], qf, sT);
-        const f32x4 dPT = mfma_s(vr[kt], gf, z);
-        s16x4 dsT;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = qok && (kt * 16 + 4 * g + r < Tk);
-          const float p = ok ? __expf(sT[r] - lse_i) : 0.f;
-          const float ds = p * (dPT[r] - dsum);
-          dtau_acc += ok ? ds * sT[r] : 0.f;
-          dsT[r] = f2bf(ds);
-        }
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const s16x4 trK = tr_read4(&kimg[w][(kt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3)]);
-          dQa[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsT, trK, dQa[ct], 0, 0, 0);
-        }
-        // unswapped: rows = queries 4g+r, column = key i
-        f32x4 sU = mfma_s(ql, kf[kt], z);
-        sU = mfma_s(qf, kl[kt], sU);
-        sU = mfma_s(qf, kf[kt], sU);
-        const f32x4 dPU = mfma_s(gf, vr[kt], z);
-        s16x4 pU, dsU;
-        const bool kok = kt * 16 + i < Tk;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = kok && (qt * 16 + 4 * g + r < Tq);
-          const float p = ok ? __expf(sU[r] - lse_r[r]) : 0.f;
-          pU[r] = f2bf(p);
-          dsU[r] = f2bf(p * (dPU[r] - d_r[r]));
-        }
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          dVa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pU, trG[ct], dVa[kt][ct], 0, 0, 0);
-          dKa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsU, trQ[ct], dKa[kt][ct], 0, 0, 0);
-        }
-      }
-    }
-    // dq = (dq-hat - q-hat (q-hat . dq-hat)) / |q| ; accumulators: rows = queries 4g+r, column = channel ct*16+i
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qs = qt * 16 + 4 * g + r;
-      float qh[CT], dqh[CT], dot = 0.f;
+  for (int qt = 0; qt < NT; ++qt) {
+    if (qt < nq) {
+      const int qslot = qt * 16 + i;
+      const bool qok = qslot < Tq;
+      // transposed right-hand fragments of this query tile
+      s16x4 trQ[CT], trG[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        qh[ct] = bf2f(*reinterpret_cast<const short*>(&qimg[w][qs * RB + (ct * 16 + i) * 2])) * (1.0f / inv_tau);
-        dqh[ct] = dQa[ct][r] * inv_tau;
-        dot += qh[ct] * dqh[ct];
+        const int off = (qt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3);
+        trQ[ct] = tr_read4(&qimg[w][off]);
+        trG[ct] = tr_read4(&gimg[w][off]);
       }
-      dot += __shfl_xor(dot, 1, 64);
-      dot += __shfl_xor(dot, 2, 64);
-      dot += __shfl_xor(dot, 4, 64);
-      dot += __shfl_xor(dot, 8, 64);
-      if (qs < Tq) {
-        const float nrm = qnorm[w][qs];
-        if (nrm <= 1e-12f) dot = 0.f;
-        const float inv = 1.0f / nrm;
-        __hip_bfloat16* p = dq + (int64_t)toks[0][qs] * lddq + hoff + i;
+      f32x4 dQa[CT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) p[ct * 16] = __float2bfloat16((dqh[ct] - qh[ct] * dot) * inv);
+      for (int ct = 0; ct < CT; ++ct) dQa[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        if (kt < nk) {
+          const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+          // swapped: rows = keys 4g+r of this tile, column = query i
+          f32x4 sT = mfma_s(kl[kt], qf[qt], z);
+          sT = mfma_s(kf[kt], ql[qt], sT);
+          sT = mfma_s(kf[kt], qf[qt], sT);
+          const f32x4 dPT = mfma_s(vr[kt], gf[qt], z);
+          s16x4 dsT, pTb;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = qok && (kt * 16 + 4 * g + r < Tk);
+            const float p = ok ? __expf(sT[r] - lse_i[qt]) : 0.f;
+            const float ds = p * (dPT[r] - dsum[qt]);
+            dtau_acc += ok ? ds * sT[r] : 0.f;
+            dsT[r] = f2bf(ds);
+            pTb[r] = f2bf(p);
+          }
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const s16x4 trK = tr_read4(&kimg[w][(kt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3)]);
+            dQa[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsT, trK, dQa[ct], 0, 0, 0);
+          }
+          // the key-on-lane factors for dV / dK-hat: P and dS of this tile transposed through a 16x16 LDS tile
+          // (one 8-byte store + one hardware-transposing read each) instead of recomputing exp() per element
+          *reinterpret_cast<s16x4*>(&ptile[w][0][i * TP + 8 * g]) = pTb;
+          *reinterpret_cast<s16x4*>(&ptile[w][1][i * TP + 8 * g]) = dsT;
+          __builtin_amdgcn_wave_barrier();               // same wave: LDS ops execute in order
+          const int toff = (4 * g + (i >> 2)) * TP + 8 * (i & 3);
+          const s16x4 pU = tr_read4(&ptile[w][0][toff]);   // P^T  [key = i][query 4g+j]
+          const s16x4 dsU = tr_read4(&ptile[w][1][toff]);  // dS^T [key = i][query 4g+j]
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            dVa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pU, trG[ct], dVa[kt][ct], 0, 0, 0);
+            dKa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsU, trQ[ct], dKa[kt][ct], 0, 0, 0);
+          }
+        }
+      }
+      // dq = (dq-hat - q-hat (q-hat . dq-hat)) / |q| ; accumulators: rows = queries 4g+r, column = channel ct*16+i
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qs = qt * 16 + 4 * g + r;
+        float qh[CT], dqh[CT], dot = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          qh[ct] = bf2f(*reinterpret_cast<const short*>(&qimg[w][qs * RB + (ct * 16 + i) * 2])) * (1.0f / inv_tau);
+          dqh[ct] = dQa[ct][r] * inv_tau;
+          dot += qh[ct] * dqh[ct];
+        }
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        dot += __shfl_xor(dot, 4, 64);
+        dot += __shfl_xor(dot, 8, 64);
+        if (qs < Tq) {
+          const float nrm = qnorm[w][qs];
+          if (nrm <= 1e-12f) dot = 0.f;
+          const float inv = 1.0f / nrm;
+          __hip_bfloat16* p = dq + (int64_t)toks[0][qs] * lddq + hoff + i;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) p[ct * 16] = __float2bfloat16((dqh[ct] - qh[ct] * dot) * inv);
+        }
       }
     }
   }
@@ -466,7 +551,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
   if (lane == 0) *dtp = dtau_acc;
   // ---- dk, dv: rows = keys 4g+r of tile kt, column = channel ct*16+i
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
+  for (int kt = 0; kt < NT; ++kt) {
     if (kt < nk) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -500,21 +585,35 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
 }
 
 int tmae_win_attn_bwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
-                           const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, int nhead,
-                           int dh, const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx,
-                           int do_shift, const float* tau, float tau_min, void* dq, int64_t lddq, void* dk,
-                           int64_t lddk, void* dv, int64_t lddv, float* dtau_partial, hipStream_t stream) {
+                           const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, int64_t mq,
+                           int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k, int batch,
+                           int ny, int nx, int do_shift, const float* tau, float tau_min, void* dq, int64_t lddq,
+                           void* dk, int64_t lddk, void* dv, int64_t lddv, float* dtau_partial,
+                           const int32_t* worklist, hipStream_t stream) {
   if (nhead % 4 || (dh != 16 && dh != 32)) return TMAE_EARG;
   const int Wy = (ny + WIN - 1) / WIN + 1, Wx = (nx + WIN - 1) / WIN + 1;
   const int s = do_shift ? WIN / 2 : WIN;
-  dim3 grid((unsigned)((int64_t)batch * Wy * Wx), (unsigned)(nhead / 4));
-#define BWDM(DH)                                                                                                      \
-  hipLaunchKernelGGL(win_attn_bwd_mfma_kernel<DH>, grid, dim3(256), 0, stream, (const __hip_bfloat16*)q, ldq,         \
-                     (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v, ldv, (const __hip_bfloat16*)out, ldo,   \
-                     (const __hip_bfloat16*)dout, lddo, lse, nhead, grid_q, grid_k, ny, nx, Wy, Wx, s, s, tau, tau_min, \
-                     (__hip_bfloat16*)dq, lddq, (__hip_bfloat16*)dk, lddk, (__hip_bfloat16*)dv, lddv, dtau_partial)
-  if (dh == 32) BWDM(32); else BWDM(16);
+  const int64_t nwin = (int64_t)batch * Wy * Wx;
+#define BWDM(DH, NT, CLS, GX)                                                                                        \
+  hipLaunchKernelGGL((win_attn_bwd_mfma_kernel<DH, NT>), dim3((unsigned)(GX), (unsigned)(nhead / 4)), dim3(256), 0,  \
+                     stream, (const __hip_bfloat16*)q, ldq, (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v,  \
+                     ldv, (const __hip_bfloat16*)out, ldo, (const __hip_bfloat16*)dout, lddo, lse, nhead, grid_q,     \
+                     grid_k, ny, nx, Wy, Wx, s, s, tau, tau_min, (__hip_bfloat16*)dq, lddq, (__hip_bfloat16*)dk, lddk, \
+                     (__hip_bfloat16*)dv, lddv, dtau_partial, worklist, CLS, nwin)
+  if (!worklist) {
+    if (dh == 32) BWDM(32, 4, 0, nwin); else BWDM(16, 4, 0, nwin);
+  } else {
+    const int64_t g0 = class_grid(0, nwin, mq, mk), g1 = class_grid(1, nwin, mq, mk), g2 = class_grid(2, nwin, mq, mk);
+    if (dh == 32) {
+      if (g0 > 0) BWDM(32, 1, 0, g0);
+      if (g1 > 0) BWDM(32, 2, 1, g1);
+      if (g2 > 0) BWDM(32, 4, 2, g2);
+    } else {
+      if (g0 > 0) BWDM(16, 1, 0, g0);
+      if (g1 > 0) BWDM(16, 2, 1, g1);
+      if (g2 > 0) BWDM(16, 4, 2, g2);
+    }
+  }
 #undef BWDM
   return (int)hipGetLastError();
 }
-

@@ -33,10 +33,12 @@ SIGNATURES = {
     'tmae_index_grid': (I, [P, L, I, I, I, P, P]),
     'tmae_window_bucket_workspace': (Z, [I, I, I, I, I, I]),
     'tmae_window_bucket': (I, [P, L, P, P, I, I, I, I, I, I, P, I, P, P, P, P, P, P, P, P, Z, P]),
-    'tmae_win_attn_fwd': (I, [P, L, P, L, P, L, I, L, L, I, I, P, P, I, I, I, I, P, F, P, L, P, P]),
+    'tmae_win_attn_fwd': (I, [P, L, P, L, P, L, I, L, L, I, I, P, P, I, I, I, I, P, F, P, L, P, P, P]),
+    'tmae_window_worklist_size': (Z, [I, I, I]),
+    'tmae_window_worklist': (I, [P, P, I, I, I, I, P, P]),
     'tmae_win_attn_num_blocks': (L, [I, I, I, I, I]),
     'tmae_win_attn_bwd': (I, [P, L, P, L, P, L, P, L, P, L, P, I, L, L, I, I, P, P, I, I, I, I, P, F,
-                              P, L, P, L, P, L, P, P]),
+                              P, L, P, L, P, L, P, P, P]),
     'tmae_add_pos_embed': (I, [P, I, L, I, P, I, I, I, P, P, P]),
     'tmae_spconv_down_outputs_workspace': (Z, [I, I, I]),
     'tmae_spconv_down_outputs': (I, [P, I, I, I, I, I, P, P, P, P, Z, P]),
@@ -66,7 +68,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError('libtmae_hip.so ABI version mismatch; rebuild with t-mae_amd/build.py')
 

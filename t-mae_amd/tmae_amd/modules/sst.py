@@ -58,11 +58,21 @@ class CosineMultiheadAttention(nn.Module):
 
 
 class WindowPlan:
-    """Everything a stage's attention layers need about one sparse index set: indices, dense grid, shape."""
+    """Everything a stage's attention layers need about one sparse index set: indices, dense grid, shape, and --
+    built once, shared by all layers of the stage -- the per-shift window work lists (region batching as index
+    lists; `other` = the key frame of the cross-attention stage)."""
 
-    def __init__(self, sp: SparseConvTensor):
+    def __init__(self, sp: SparseConvTensor, other: 'WindowPlan' = None):
         self.indices, self.grid = sp.indices, sp.grid
         self.batch, (self.ny, self.nx) = sp.batch_size, sp.spatial_shape
+        self.key_grid = self.grid if other is None else other.grid
+        self._wl = {}
+
+    def worklist(self, shift):
+        shift = bool(shift)
+        if shift not in self._wl:
+            self._wl[shift] = ops.window_worklist(self.grid, self.key_grid, self.batch, self.ny, self.nx, shift)
+        return self._wl[shift]
 
 
 class WindowAttention(nn.Module):
@@ -83,7 +93,7 @@ class WindowAttention(nn.Module):
         qk = ops.linear(xp, a.in_proj_weight[:2 * d], a.in_proj_bias[:2 * d])
         v = ops.linear(x, a.in_proj_weight[2 * d:], a.in_proj_bias[2 * d:])
         o = ops.win_attn(qk, v, None, a.tau, plan.grid, plan.grid, self.nhead, plan.batch, plan.ny, plan.nx,
-                         shift, a.tau_min)
+                         shift, a.tau_min, worklist=plan.worklist(shift))
         return ops.linear(o, a.out_proj.weight, a.out_proj.bias)
 
 
@@ -108,7 +118,7 @@ class WindowCrossAttention(nn.Module):
                        b[d:2 * d])
         v = ops.linear(x_prv, w[2 * d:], b[2 * d:])
         return ops.win_attn(q, k, v, a.tau, plan.grid, plan_prv.grid, self.nhead, plan.batch, plan.ny, plan.nx,
-                            shift, a.tau_min)
+                            shift, a.tau_min, worklist=plan.worklist(shift))
 
 
 def _activation(name):
@@ -269,7 +279,8 @@ class WCABlock(nn.Module):
 
     def encoder_forward(self, sp: SparseConvTensor, sp_prev: SparseConvTensor):
         """WCABlock.encoder_forward (SiamWCA.py:342-396): joint bucketing of the two frames, two cross layers."""
-        plan, plan_prv = WindowPlan(sp), WindowPlan(sp_prev)
+        plan_prv = WindowPlan(sp_prev)
+        plan = WindowPlan(sp, other=plan_prv)
         assert sp.spatial_shape == sp_prev.spatial_shape
         x = sp.features
         kept = []

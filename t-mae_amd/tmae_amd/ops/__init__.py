@@ -346,6 +346,16 @@ def add_pos_embed(x, indices, table, window_shape, do_shift):
 
 # ----------------------------------------------------------------------------- attention (A6/A7)
 
+def window_worklist(grid_q, grid_k, batch, ny, nx, do_shift):
+    """Index lists of the windows holding both queries and keys, binned by 16-token tile count (the reference's
+    drop levels 16/32/64 as lists, not padded tensors).  Built once per (index set, shift), reused by every layer."""
+    n = lib.tmae_window_worklist_size(batch, ny, nx)
+    wl = torch.empty((n,), dtype=torch.int32, device=grid_q.device)
+    check(lib.tmae_window_worklist(_p(grid_q), _p(grid_k), batch, ny, nx, 1 if do_shift else 0, _p(wl), _s()),
+          'tmae_window_worklist')
+    return wl
+
+
 class _WinAttn(torch.autograd.Function):
     """Ragged window cosine attention over projected q/k/v.
     Self mode (c is None): a = packed [m,2d] (q|k) from one GEMM over x+pos, b = v [m,d].
@@ -359,7 +369,7 @@ class _WinAttn(torch.autograd.Function):
         return (a.data_ptr(), d, b.data_ptr(), d, c.data_ptr(), d)
 
     @staticmethod
-    def forward(ctx, a, b, c, tau, grid_q, grid_k, nhead, batch, ny, nx, do_shift, tau_min):
+    def forward(ctx, a, b, c, tau, grid_q, grid_k, worklist, nhead, batch, ny, nx, do_shift, tau_min):
         a, b = a.contiguous(), b.contiguous()
         assert a.dtype == b.dtype
         if c is None:
@@ -373,41 +383,50 @@ class _WinAttn(torch.autograd.Function):
         dh = d // nhead
         q, ldq, k, ldk, v, ldv = _WinAttn._ptrs(a, b, c, d)
         tau32 = tau.detach().reshape(-1).float().contiguous()
-        out = torch.empty((mq, d), dtype=a.dtype, device=a.device)
-        lse = torch.empty((mq, nhead), dtype=torch.float32, device=a.device)
+        if a.dtype != torch.bfloat16:
+            worklist = None                                  # the fp32 kernels walk the dense windows
+        # with a work list, tokens of windows in no list are not written: start from zeros in cross mode
+        alloc = torch.zeros if (worklist is not None and c is not None) else torch.empty
+        out = alloc((mq, d), dtype=a.dtype, device=a.device)
+        lse = alloc((mq, nhead), dtype=torch.float32, device=a.device)
         check(lib.tmae_win_attn_fwd(q, ldq, k, ldk, v, ldv, _dt(a), mq, mk, nhead, dh, _p(grid_q), _p(grid_k),
                                     batch, ny, nx, 1 if do_shift else 0, _p(tau32), float(tau_min), _p(out), d,
-                                    _p(lse), _s()), 'tmae_win_attn_fwd')
+                                    _p(lse), _p(worklist), _s()), 'tmae_win_attn_fwd')
         ctx.cross = c is not None
-        ctx.save_for_backward(a, b, c if c is not None else b, tau32, grid_q, grid_k, out, lse)
+        ctx.has_wl = worklist is not None
+        ctx.save_for_backward(a, b, c if c is not None else b, tau32, grid_q, grid_k, out, lse,
+                              worklist if worklist is not None else grid_q)
         ctx.meta = (d, nhead, dh, batch, ny, nx, do_shift, tau_min, mq, mk, tau.shape, tau.dtype)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        a, b, c, tau32, grid_q, grid_k, out, lse = ctx.saved_tensors
+        a, b, c, tau32, grid_q, grid_k, out, lse, worklist = ctx.saved_tensors
         d, nhead, dh, batch, ny, nx, do_shift, tau_min, mq, mk, tshape, tdtype = ctx.meta
         if not ctx.cross:
             c = None
+        if not ctx.has_wl:
+            worklist = None
         dout = dout.contiguous()
-        da, db = torch.empty_like(a), torch.empty_like(b)
-        dc = torch.empty_like(c) if c is not None else None
+        alloc = torch.zeros_like if (worklist is not None and c is not None) else torch.empty_like
+        da, db = alloc(a), alloc(b)
+        dc = alloc(c) if c is not None else None
         q, ldq, k, ldk, v, ldv = _WinAttn._ptrs(a, b, c, d)
         dq, lddq, dk, lddk, dv, lddv = _WinAttn._ptrs(da, db, dc, d)
         nblk = lib.tmae_win_attn_num_blocks(batch, ny, nx, nhead, dh)
-        part = torch.empty((nblk,), dtype=torch.float32, device=a.device)
+        part = (torch.zeros if worklist is not None else torch.empty)((nblk,), dtype=torch.float32, device=a.device)
         check(lib.tmae_win_attn_bwd(q, ldq, k, ldk, v, ldv, _p(out), d, _p(dout), d, _p(lse), _dt(a), mq, mk,
                                     nhead, dh, _p(grid_q), _p(grid_k), batch, ny, nx, 1 if do_shift else 0,
-                                    _p(tau32), float(tau_min), dq, lddq, dk, lddk, dv, lddv, _p(part), _s()),
-              'tmae_win_attn_bwd')
+                                    _p(tau32), float(tau_min), dq, lddq, dk, lddk, dv, lddv, _p(part), _p(worklist),
+                                    _s()), 'tmae_win_attn_bwd')
         # d/d tau of logits = cos / max(tau, tau_min): -(1/tau_c) * sum dS*s, zero in the clamped branch
         tau_c = tau32.clamp(min=tau_min)
         dtau = (-(part.sum() / tau_c) * (tau32 >= tau_min).float()).reshape(tshape).to(tdtype)
-        return da, db, dc, dtau, None, None, None, None, None, None, None, None
+        return da, db, dc, dtau, None, None, None, None, None, None, None, None, None
 
 
-def win_attn(a, b, c, tau, grid_q, grid_k, nhead, batch, ny, nx, do_shift, tau_min):
-    return _WinAttn.apply(a, b, c, tau, grid_q, grid_k, nhead, batch, ny, nx, do_shift, tau_min)
+def win_attn(a, b, c, tau, grid_q, grid_k, nhead, batch, ny, nx, do_shift, tau_min, worklist=None):
+    return _WinAttn.apply(a, b, c, tau, grid_q, grid_k, worklist, nhead, batch, ny, nx, do_shift, tau_min)
 
 
 # ----------------------------------------------------------------------------- sparse conv (A9)

@@ -31,7 +31,7 @@ def cu(a, dtype=None):
 
 def test_native_library_is_loaded():
     from tmae_amd import _lib
-    assert _lib.lib.tmae_abi_version() == 1
+    assert _lib.lib.tmae_abi_version() == _lib.ABI_VERSION
     maps = open('/proc/self/maps').read()
     assert 'libtmae_hip.so' in maps
 
@@ -369,6 +369,24 @@ def test_attention_mfma_bf16_fwd_bwd_vs_fp32_kernel():
                 o = ops.win_attn(a, b_, c_, tau, gq, gk, H, 2, 234, 234, shift, 0.01)
                 o.backward(go.bfloat16().to(dt))
                 res[dt] = (o.detach(), a.grad, b_.grad, None if c_ is None else c_.grad, tau.grad)
+                if dt == torch.bfloat16:
+                    # class-binned work lists (what the model uses) must give the dense-window kernel's numbers
+                    wl = ops.window_worklist(gq, gk, 2, 234, 234, shift)
+                    cnt = wl[:3].cpu().numpy()
+                    assert cnt.sum() > 0 and cnt[0] > 0 and cnt[2] > 0          # the fixture populates the classes
+                    a2, b2, c2 = [None if t is None else t.detach().clone().requires_grad_(True) for t in (a, b_, c_)]
+                    tau2 = torch.full((1, 1, 1), tauv, device=dev(), requires_grad=True)
+                    o2 = ops.win_attn(a2, b2, c2, tau2, gq, gk, H, 2, 234, 234, shift, 0.01, worklist=wl)
+                    o2.backward(go.bfloat16().to(dt))
+                    def same(x, y, what):
+                        assert torch.isfinite(x.float()).all() and torch.isfinite(y.float()).all(), what
+                        # same algorithm, different template instantiation: FMA contraction may differ by a bf16 ulp
+                        r = rel(x, y)
+                        assert r < 1e-3, (what, d, cross, shift, r, int((x != y).sum()), x.numel())
+                    same(o2, o, 'out'), same(a2.grad, a.grad, 'da'), same(b2.grad, b_.grad, 'db')
+                    if c2 is not None:
+                        same(c2.grad, c_.grad, 'dc')
+                    assert abs(float(tau2.grad) - float(tau.grad)) <= 1e-4 * max(1.0, abs(float(tau.grad)))
             f, h = res[torch.float32], res[torch.bfloat16]
             assert all(torch.isfinite(t.float()).all() for t in h if t is not None)
             lim = 0.03 if tauv >= 0.05 else 0.12          # logits reach +-100 at the clamp: bf16 logit error ~0.4
