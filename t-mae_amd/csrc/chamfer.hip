@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void chamfer_bwd_kernel(const float* __restric
                                                          const int8_t* __restrict__ idx_y,
                                                          const float* __restrict__ scale, int64_t m, int np, int ng,
                                                          float* __restrict__ dpred) {
+  __shared__ float accs[4][192];
   const int lane = threadIdx.x & 63;
   const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (v >= m) return;
@@ -70,11 +71,22 @@ __global__ __launch_bounds__(256) void chamfer_bwd_kernel(const float* __restric
   const float nx_ = __shfl(gx, ix, 64), ny_ = __shfl(gy, ix, 64), nz_ = __shfl(gz, ix, 64);
   const float a = 2.0f / (float)np, b = 2.0f / (float)ng;
   float ax = a * (px - nx_), ay = a * (py - ny_), az = a * (pz - nz_);
-  // gt -> pred term: 2/ng sum_{j: nn(j) = i} (p_i - g_j)
-  for (int j = 0; j < ng; ++j) {
-    const int tgt = __shfl(iy, j, 64);
-    const float jx = __shfl(gx, j, 64), jy = __shfl(gy, j, 64), jz = __shfl(gz, j, 64);
-    if (tgt == lane) { ax += b * (px - jx); ay += b * (py - jy); az += b * (pz - jz); }
+  // gt -> pred term: 2/ng sum_{j: nn(j) = i} (p_i - g_j): every gt lane adds (p_nn - g_j) into its nearest
+  // prediction's slot of a wave-private LDS accumulator (fixed tree order is not needed: <= 64 adds of similar
+  // magnitude per slot; the adds commute up to fp32 rounding) -- 3 LDS atomics per lane instead of 64 x 4 shuffles
+  {
+    float* acc = &accs[threadIdx.x >> 6][0];
+    for (int e = lane; e < np * 3; e += 64) acc[e] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    const int src = iy >= 0 ? iy : 0;                      // shuffles run with every lane active
+    const float qx = __shfl(px, src, 64), qy = __shfl(py, src, 64), qz = __shfl(pz, src, 64);
+    if (lane < ng && iy >= 0) {
+      atomicAdd(&acc[iy * 3 + 0], qx - gx);
+      atomicAdd(&acc[iy * 3 + 1], qy - gy);
+      atomicAdd(&acc[iy * 3 + 2], qz - gz);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < np) { ax += b * acc[lane * 3]; ay += b * acc[lane * 3 + 1]; az += b * acc[lane * 3 + 2]; }
   }
   if (lane < np) {
     const float s = scale[0] * w;

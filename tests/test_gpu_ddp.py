@@ -1,0 +1,64 @@
+"""GPU (-m gpu): two ranks on the one GPU of the box (gloo transport, CUDA tensors): the full TMAE model under
+DistributedDataParallel -- custom autograd Functions + Siamese weight reuse + DDP hooks -- one optimizer step;
+ranks must end with identical weights and the averaged gradient of the two shards."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    for p in (os.path.join(ROOT, 't-mae_amd'), os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import tmae_oracle as O
+    from conftest import build_product_model
+    from pcdet.models import model_fn_decorator
+    from tmae_amd.train import AdamOneCycle, OneCycle, train_one_step
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(0)
+    P = O.init_params(O.default_model_cfg(1), seed=3, pred_scale=0.1)
+    model, cfg, _ = build_product_model(1, params=P, device=dev)
+    model.train()
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+    opt = AdamOneCycle(model.parameters())
+    sch = OneCycle(opt, 10, 3e-3, [0.95, 0.85], 10, 0.4)
+    pts, prv = O.synth_frame_pair(3000, 2, seed=50 + rank)                 # rank-specific shard
+    noise = torch.rand(100000, generator=torch.Generator().manual_seed(rank))
+    batch = {'points': torch.from_numpy(pts).to(dev), 'points_prev': torch.from_numpy(prv).to(dev), 'batch_size': 2}
+    vox = O.voxelize(pts, [-74.88, -74.88, -5, 74.88, 74.88, 3], [0.32, 0.32, 8], [468, 468, 1])
+    batch['mae_noise'] = noise[:vox['voxel_coords'].shape[0]].to(dev)
+    loss, _, _ = train_one_step(ddp, opt, sch, batch, 0, model_fn_decorator(), amp_dtype=None)
+    g = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu()
+    wts = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+    gl = [torch.zeros_like(g) for _ in range(world)]
+    wl = [torch.zeros_like(wts) for _ in range(world)]
+    dist.all_gather(gl, g)
+    dist.all_gather(wl, wts)
+    q.put((rank, float(loss), bool(torch.equal(gl[0], gl[1])), bool(torch.equal(wl[0], wl[1])),
+           bool(torch.isfinite(g).all()), float(g.norm())))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_full_model_ddp_step():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=500) for _ in range(2))
+    [p.join(120) for p in procs]
+    assert res[0][1] != res[1][1]                        # different shards -> different local losses
+    for rank, loss, same_g, same_w, finite, gn in res:
+        assert finite and gn > 0
+        assert same_g, 'DDP did not leave the same (averaged) gradient on both ranks'
+        assert same_w, 'weights diverged after the optimizer step'
