@@ -42,13 +42,14 @@ int tmae_abi_version(void);
 /* ---------------------------------------------------------------------------------------
  * A1  dynamic voxelisation.   Replaces get_in_range_mask (pcdet/utils/common_utils.py:66-76)
  * + boolean compaction + torch.unique(dim=0, return_inverse) (temporal_dyn_vfe.py:67-72).
- * points [n,5] f32 rows (b,x,y,z,i).  Outputs sized for the worst case n / n_cells:
- *   points_out [n,5], point_coords_i64 [n,4] (b,z,y,x), inverse_i64 [n], voxel_coords_i64 [n,4]
+ * points [n,row] f32 rows (b,x,y,z,features...), row = 1 + point features (5 for ONCE, 6 for Waymo).
+ * Outputs sized for the worst case n / n_cells:
+ *   points_out [n,row], point_coords_i64 [n,4] (b,z,y,x), inverse_i64 [n], voxel_coords_i64 [n,4]
  *   (lexicographically sorted (b,z,y,x), exactly what unique(dim=0) yields),
  *   counts [2+batch] device int32: {n_kept, n_voxels, voxels of sample 0, 1, ...}.
  * Coordinates use IEEE fp32 subtract + divide and truncation toward zero (bit-exact). */
 size_t tmae_voxelize_workspace(int64_t n, int batch, int gx, int gy, int gz);
-int tmae_voxelize(const float* points, int64_t n, int batch,
+int tmae_voxelize(const float* points, int row, int64_t n, int batch,
                   float rmin_x, float rmin_y, float rmin_z, float vs_x, float vs_y, float vs_z,
                   int gx, int gy, int gz,
                   float* points_out, int64_t* point_coords_i64, int64_t* inverse_i64,
@@ -68,11 +69,11 @@ size_t tmae_ingroup_rank_workspace(int64_t n, int64_t num_groups);
 int tmae_ingroup_rank(const int64_t* group_i64, int64_t n, int64_t num_groups, int64_t* out_i64,
                       void* ws, size_t ws_bytes, void* stream);
 
-/* A2  fused voxel mean (torch_scatter.scatter mean, temporal_dyn_vfe.py:85) + the 10 point
- * features [f_center(3) | x y z i | f_cluster(3)] (temporal_dyn_vfe.py:88-109).
- * points [n,5] (kept points), point_coords_i64 [n,4], inverse [n]; CSR from tmae_segment_csr.
- * Outputs voxel_mean [m,4] f32, feats [n,10] f32. */
-int tmae_vfe_point_features(const float* points, const int64_t* point_coords_i64,
+/* A2  fused voxel mean (torch_scatter.scatter mean, temporal_dyn_vfe.py:85) + the F+6 point
+ * features [f_center(3) | x y z i ... (F = row-1) | f_cluster(3)] (temporal_dyn_vfe.py:88-109).
+ * points [n,row] (kept points), point_coords_i64 [n,4], inverse [n]; CSR from tmae_segment_csr.
+ * Outputs voxel_mean [m,F] f32, feats [n,F+6] f32. */
+int tmae_vfe_point_features(const float* points, int row, const int64_t* point_coords_i64,
                             const int64_t* inverse_i64, const int32_t* perm, const int32_t* offsets,
                             int64_t n, int64_t m,
                             float rmin_x, float rmin_y, float rmin_z, float vs_x, float vs_y, float vs_z,
@@ -91,7 +92,7 @@ int tmae_segment_max_bwd(const void* dout, int dtype, int64_t n, int64_t m, int 
  * target normalisation of SiamWCA_MAE.target_assigner (SiamWCA_MAE.py:134-141):
  * group_inds_i64 [m,k] = first k point ids per voxel (point order), cyclic repeat when fewer;
  * gt [m,k,3] = xyz[group_inds] - voxel centre ((coord+0.5)*vs+rmin, common_utils.py:130-145). */
-int tmae_group_points(const float* points, const int64_t* voxel_coords_i64,
+int tmae_group_points(const float* points, int row, const int64_t* voxel_coords_i64,
                       const int32_t* perm, const int32_t* offsets, int64_t m, int k,
                       float rmin_x, float rmin_y, float rmin_z, float vs_x, float vs_y, float vs_z,
                       int64_t* group_inds_i64, float* gt, void* stream);

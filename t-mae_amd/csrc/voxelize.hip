@@ -8,13 +8,13 @@
 // ------------------------------------------------------------------------------------------------
 // voxelize
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ pts, int64_t n, int batch,
+__global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ pts, int row, int64_t n, int batch,
                                                      float rx, float ry, float rz, float vx, float vy, float vz,
                                                      int gx, int gy, int gz, int32_t* __restrict__ flag,
                                                      int32_t* __restrict__ key) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const float* p = pts + i * 5;
+  const float* p = pts + i * row;
   // IEEE fp32 subtract + divide, truncation toward zero (common_utils.py:74); no reciprocal, no fma.
   float qx = div_rn(sub_rn(p[1], rx), vx);
   float qy = div_rn(sub_rn(p[2], ry), vy);
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void vox_key_kernel(const float* __restrict__ 
   key[i] = k;
 }
 
-__global__ __launch_bounds__(256) void vox_compact_kernel(const float* __restrict__ pts, int64_t n,
+__global__ __launch_bounds__(256) void vox_compact_kernel(const float* __restrict__ pts, int row, int64_t n,
                                                          const int32_t* __restrict__ flag,
                                                          const int32_t* __restrict__ pos,
                                                          const int32_t* __restrict__ key, int gx, int gy, int gz,
@@ -40,9 +40,9 @@ __global__ __launch_bounds__(256) void vox_compact_kernel(const float* __restric
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n || !flag[i]) return;
   const int64_t j = pos[i];
-  const float* p = pts + i * 5;
-  float* o = pts_out + j * 5;
-  o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; o[4] = p[4];
+  const float* p = pts + i * row;
+  float* o = pts_out + j * row;
+  for (int c = 0; c < row; ++c) o[c] = p[c];
   const int k = key[i];
   int cx = k % gx, t = k / gx;
   int cy = t % gy; t /= gy;
@@ -90,12 +90,12 @@ size_t tmae_voxelize_workspace(int64_t n, int batch, int gx, int gy, int gz) {
          tmae_scan_i32_workspace(cells) + 4096;
 }
 
-int tmae_voxelize(const float* points, int64_t n, int batch, float rx, float ry, float rz, float vx, float vy,
+int tmae_voxelize(const float* points, int row, int64_t n, int batch, float rx, float ry, float rz, float vx, float vy,
                   float vz, int gx, int gy, int gz, float* points_out, int64_t* point_coords, int64_t* inverse,
                   int64_t* voxel_coords, int32_t* counts, void* wsp, size_t ws_bytes, void* stream_) {
   (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
-  if (n < 0 || batch <= 0 || gx <= 0 || gy <= 0 || gz <= 0 || !counts) return TMAE_EARG;
+  if (n < 0 || batch <= 0 || gx <= 0 || gy <= 0 || gz <= 0 || !counts || row < 4 || row > 16) return TMAE_EARG;
   int64_t cells = (int64_t)batch * gx * gy * gz;
   if (cells >= (1ll << 31) || n >= (1ll << 31)) return TMAE_EARG;
   if (n > 0 && (!points || !points_out || !point_coords || !inverse || !voxel_coords)) return TMAE_EARG;
@@ -112,12 +112,12 @@ int tmae_voxelize(const float* points, int64_t n, int batch, float rx, float ry,
   if (!ws.ok) return TMAE_EWS;
   hipMemsetAsync(occ, 0, (size_t)cells * 4, stream);
   if (n > 0)
-    hipLaunchKernelGGL(vox_key_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, points, n, batch, rx, ry, rz,
+    hipLaunchKernelGGL(vox_key_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, points, row, n, batch, rx, ry, rz,
                        vx, vy, vz, gx, gy, gz, flag, key);
   int r = tmae_scan_i32(flag, pos, n, counts + 0, scan1, s1, stream);
   if (r) return r;
   if (n > 0)
-    hipLaunchKernelGGL(vox_compact_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, points, n, flag, pos, key,
+    hipLaunchKernelGGL(vox_compact_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, points, row, n, flag, pos, key,
                        gx, gy, gz, points_out, point_coords, keyc, occ);
   r = tmae_scan_i32(occ, rank, cells, counts + 1, scan2, s2, stream);
   if (r) return r;
@@ -243,24 +243,33 @@ int tmae_ingroup_rank(const int64_t* group, int64_t n, int64_t num_groups, int64
 // ------------------------------------------------------------------------------------------------
 // VFE point features
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict__ pts,
+#define VFE_MAXF 8
+__global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict__ pts, int row,
                                                         const int32_t* __restrict__ perm,
                                                         const int32_t* __restrict__ offsets, int64_t m,
                                                         float* __restrict__ mean) {
   int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (v >= m) return;
+  const int F = row - 1;
   const int lo = offsets[v], hi = offsets[v + 1];
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s[VFE_MAXF];
+#pragma unroll
+  for (int c = 0; c < VFE_MAXF; ++c) s[c] = 0.f;
   for (int j = lo; j < hi; ++j) {            // ascending point id: deterministic sum
-    const float* p = pts + (int64_t)perm[j] * 5;
-    s0 = add_rn(s0, p[1]); s1 = add_rn(s1, p[2]); s2 = add_rn(s2, p[3]); s3 = add_rn(s3, p[4]);
+    const float* p = pts + (int64_t)perm[j] * row;
+#pragma unroll
+    for (int c = 0; c < VFE_MAXF; ++c)
+      if (c < F) s[c] = add_rn(s[c], p[1 + c]);
   }
-  const float c = (float)max(hi - lo, 1);
-  float* o = mean + v * 4;
-  o[0] = __fdiv_rn(s0, c); o[1] = __fdiv_rn(s1, c); o[2] = __fdiv_rn(s2, c); o[3] = __fdiv_rn(s3, c);
+  const float cnt = (float)max(hi - lo, 1);
+  float* o = mean + v * F;
+#pragma unroll
+  for (int c = 0; c < VFE_MAXF; ++c)
+    if (c < F) o[c] = __fdiv_rn(s[c], cnt);
 }
 
-__global__ __launch_bounds__(256) void point_feat_kernel(const float* __restrict__ pts,
+// feats = [f_center(3) | point features (F) | f_cluster(3)]  (temporal_dyn_vfe.py:88-109)
+__global__ __launch_bounds__(256) void point_feat_kernel(const float* __restrict__ pts, int row,
                                                         const int64_t* __restrict__ pc,
                                                         const int64_t* __restrict__ inv,
                                                         const float* __restrict__ mean, int64_t n, float rx, float ry,
@@ -268,31 +277,32 @@ __global__ __launch_bounds__(256) void point_feat_kernel(const float* __restrict
                                                         float* __restrict__ feats) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const float* p = pts + i * 5;
+  const int F = row - 1;
+  const float* p = pts + i * row;
   const int64_t* c = pc + i * 4;
-  const float* mu = mean + inv[i] * 4;
+  const float* mu = mean + inv[i] * F;
   const float x = p[1], y = p[2], z = p[3];
   // f_center = p - ((coord + 0.5) * vs + rmin): separate fp32 roundings as in temporal_dyn_vfe.py:93-96
   const float ccx = add_rn(mul_rn(add_rn((float)c[3], 0.5f), vx), rx);
   const float ccy = add_rn(mul_rn(add_rn((float)c[2], 0.5f), vy), ry);
   const float ccz = add_rn(mul_rn(add_rn((float)c[1], 0.5f), vz), rz);
-  float* f = feats + i * 10;
+  float* f = feats + i * (F + 6);
   f[0] = sub_rn(x, ccx); f[1] = sub_rn(y, ccy); f[2] = sub_rn(z, ccz);
-  f[3] = x; f[4] = y; f[5] = z; f[6] = p[4];
-  f[7] = sub_rn(x, mu[0]); f[8] = sub_rn(y, mu[1]); f[9] = sub_rn(z, mu[2]);
+  for (int k = 0; k < F; ++k) f[3 + k] = p[1 + k];
+  f[3 + F] = sub_rn(x, mu[0]); f[4 + F] = sub_rn(y, mu[1]); f[5 + F] = sub_rn(z, mu[2]);
 }
 
-int tmae_vfe_point_features(const float* points, const int64_t* pc, const int64_t* inverse, const int32_t* perm,
-                            const int32_t* offsets, int64_t n, int64_t m, float rx, float ry, float rz, float vx,
+int tmae_vfe_point_features(const float* points, int row, const int64_t* pc, const int64_t* inverse,
+                            const int32_t* perm, const int32_t* offsets, int64_t n, int64_t m, float rx, float ry, float rz, float vx,
                             float vy, float vz, float* voxel_mean, float* feats, void* stream_) {
   (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
-  if (n < 0 || m < 0) return TMAE_EARG;
+  if (n < 0 || m < 0 || row < 4 || row - 1 > VFE_MAXF) return TMAE_EARG;
   if (n == 0 || m == 0) return TMAE_OK;
   if (!points || !pc || !inverse || !perm || !offsets || !voxel_mean || !feats) return TMAE_EARG;
-  hipLaunchKernelGGL(voxel_mean_kernel, dim3(tmae_cdiv(m, 256)), dim3(256), 0, stream, points, perm, offsets, m,
+  hipLaunchKernelGGL(voxel_mean_kernel, dim3(tmae_cdiv(m, 256)), dim3(256), 0, stream, points, row, perm, offsets, m,
                      voxel_mean);
-  hipLaunchKernelGGL(point_feat_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, points, pc, inverse,
+  hipLaunchKernelGGL(point_feat_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, points, row, pc, inverse,
                      voxel_mean, n, rx, ry, rz, vx, vy, vz, feats);
   return tmae_launch_status();
 }
@@ -378,7 +388,7 @@ int tmae_segment_max_bwd(const void* dout, int dtype, int64_t n, int64_t m, int 
 // ------------------------------------------------------------------------------------------------
 // group_inner_inds + normalised gt points
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void group_points_kernel(const float* __restrict__ pts,
+__global__ __launch_bounds__(256) void group_points_kernel(const float* __restrict__ pts, int row,
                                                           const int64_t* __restrict__ vc,
                                                           const int32_t* __restrict__ perm,
                                                           const int32_t* __restrict__ offsets, int64_t m, int k,
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(256) void group_points_kernel(const float* __restri
   float gx_ = 0.f, gy_ = 0.f, gz_ = 0.f;
   if (cnt > 0) {
     idx = perm[lo + (t < cnt ? t : t % cnt)];          // cyclic repeat, sst_ops_gpu.cu:30-39
-    const float* p = pts + idx * 5;
+    const float* p = pts + idx * row;
     const int64_t* c = vc + v * 4;
     const float cx = add_rn(mul_rn(add_rn((float)c[3], 0.5f), vx), rx);
     const float cy = add_rn(mul_rn(add_rn((float)c[2], 0.5f), vy), ry);
@@ -405,15 +415,15 @@ __global__ __launch_bounds__(256) void group_points_kernel(const float* __restri
   g[0] = gx_; g[1] = gy_; g[2] = gz_;
 }
 
-int tmae_group_points(const float* points, const int64_t* voxel_coords, const int32_t* perm, const int32_t* offsets,
+int tmae_group_points(const float* points, int row, const int64_t* voxel_coords, const int32_t* perm, const int32_t* offsets,
                       int64_t m, int k, float rx, float ry, float rz, float vx, float vy, float vz,
                       int64_t* group_inds, float* gt, void* stream_) {
   (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
-  if (m < 0 || k <= 0) return TMAE_EARG;
+  if (m < 0 || k <= 0 || row < 4) return TMAE_EARG;
   if (m == 0) return TMAE_OK;
   if (!points || !voxel_coords || !perm || !offsets || !gt) return TMAE_EARG;
-  hipLaunchKernelGGL(group_points_kernel, dim3(tmae_cdiv(m * k, 256)), dim3(256), 0, stream, points, voxel_coords,
+  hipLaunchKernelGGL(group_points_kernel, dim3(tmae_cdiv(m * k, 256)), dim3(256), 0, stream, points, row, voxel_coords,
                      perm, offsets, m, k, rx, ry, rz, vx, vy, vz, group_inds, gt);
   return tmae_launch_status();
 }

@@ -19,15 +19,15 @@ P, I, L, F, D, Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_si
 SIGNATURES = {
     'tmae_abi_version': (I, []),
     'tmae_voxelize_workspace': (Z, [L, I, I, I, I]),
-    'tmae_voxelize': (I, [P, L, I, F, F, F, F, F, F, I, I, I, P, P, P, P, P, P, Z, P]),
+    'tmae_voxelize': (I, [P, I, L, I, F, F, F, F, F, F, I, I, I, P, P, P, P, P, P, Z, P]),
     'tmae_segment_csr_workspace': (Z, [L, L]),
     'tmae_segment_csr': (I, [P, L, L, P, P, P, Z, P]),
     'tmae_ingroup_rank_workspace': (Z, [L, L]),
     'tmae_ingroup_rank': (I, [P, L, L, P, P, Z, P]),
-    'tmae_vfe_point_features': (I, [P, P, P, P, P, L, L, F, F, F, F, F, F, P, P, P]),
+    'tmae_vfe_point_features': (I, [P, I, P, P, P, P, L, L, F, F, F, F, F, F, P, P, P]),
     'tmae_segment_max_fwd': (I, [P, I, L, L, I, P, P, P, P, P]),
     'tmae_segment_max_bwd': (I, [P, I, L, L, I, P, P, P, P]),
-    'tmae_group_points': (I, [P, P, P, P, L, I, F, F, F, F, F, F, P, P, P]),
+    'tmae_group_points': (I, [P, I, P, P, P, L, I, F, F, F, F, F, F, P, P, P]),
     'tmae_random_mask_workspace': (Z, [L, I]),
     'tmae_random_mask': (I, [P, P, L, I, D, P, P, P, P, Z, P]),
     'tmae_index_grid': (I, [P, L, I, I, I, P, P]),
@@ -68,7 +68,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError('libtmae_hip.so ABI version mismatch; rebuild with t-mae_amd/build.py')
 

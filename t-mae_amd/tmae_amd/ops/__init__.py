@@ -154,11 +154,11 @@ def voxelize_launch(points, batch_size, pc_range, voxel_size, grid_size):
     Replaces get_in_range_mask + unique(dim=0) (temporal_dyn_vfe.py:67-72)."""
     _need_cuda(points)
     pts = points.contiguous().float()
-    n = pts.shape[0]
+    n, row = pts.shape
     gx, gy, gz = (int(v) for v in grid_size)
     dev = pts.device
     out = dict(
-        points=torch.empty((n, 5), dtype=torch.float32, device=dev),
+        points=torch.empty((n, row), dtype=torch.float32, device=dev),
         point_coords=torch.empty((n, 4), dtype=torch.int64, device=dev),
         inverse=torch.empty((n,), dtype=torch.int64, device=dev),
         voxel_coords=torch.empty((min(n, batch_size * gx * gy * gz), 4), dtype=torch.int64, device=dev),
@@ -167,7 +167,7 @@ def voxelize_launch(points, batch_size, pc_range, voxel_size, grid_size):
     wsb = lib.tmae_voxelize_workspace(n, batch_size, gx, gy, gz)
     ws = _ws(wsb, dev)
     r, vs = [float(v) for v in pc_range[:3]], [float(v) for v in voxel_size]
-    check(lib.tmae_voxelize(_p(pts), n, batch_size, r[0], r[1], r[2], vs[0], vs[1], vs[2], gx, gy, gz,
+    check(lib.tmae_voxelize(_p(pts), row, n, batch_size, r[0], r[1], r[2], vs[0], vs[1], vs[2], gx, gy, gz,
                             _p(out['points']), _p(out['point_coords']), _p(out['inverse']),
                             _p(out['voxel_coords']), _p(out['counts']), _p(ws), wsb, _s()), 'tmae_voxelize')
     return out
@@ -214,11 +214,11 @@ def get_inner_win_inds(group_inds):
 
 
 def vfe_point_features(points, point_coords, inverse, perm, offsets, m, pc_range, voxel_size):
-    n = points.shape[0]
-    mean = torch.empty((m, 4), dtype=torch.float32, device=points.device)
-    feats = torch.empty((n, 10), dtype=torch.float32, device=points.device)
+    n, row = points.shape
+    mean = torch.empty((m, row - 1), dtype=torch.float32, device=points.device)
+    feats = torch.empty((n, row + 5), dtype=torch.float32, device=points.device)
     r, vs = [float(v) for v in pc_range[:3]], [float(v) for v in voxel_size]
-    check(lib.tmae_vfe_point_features(_p(points), _p(point_coords), _p(inverse), _p(perm), _p(offsets), n, m,
+    check(lib.tmae_vfe_point_features(_p(points), row, _p(point_coords), _p(inverse), _p(perm), _p(offsets), n, m,
                                       r[0], r[1], r[2], vs[0], vs[1], vs[2], _p(mean), _p(feats), _s()),
           'tmae_vfe_point_features')
     return mean, feats
@@ -261,7 +261,7 @@ def group_points(points, voxel_coords, perm, offsets, k, pc_range, voxel_size, w
     ginds = torch.empty((m, k), dtype=torch.int64, device=dev) if want_inds else None
     gt = torch.empty((m, k, 3), dtype=torch.float32, device=dev)
     r, vs = [float(v) for v in pc_range[:3]], [float(v) for v in voxel_size]
-    check(lib.tmae_group_points(_p(points), _p(voxel_coords), _p(perm), _p(offsets), m, k, r[0], r[1], r[2],
+    check(lib.tmae_group_points(_p(points), points.shape[1], _p(voxel_coords), _p(perm), _p(offsets), m, k, r[0], r[1], r[2],
                                 vs[0], vs[1], vs[2], _p(ginds), _p(gt), _s()), 'tmae_group_points')
     return ginds, gt
 

@@ -6,7 +6,7 @@ Batches follow the collate layout of the reference (pcdet/datasets/dataset.py:20
 import numpy as np
 
 
-def synth_frame_pair(n_points, batch_size, seed, shift=(0.5, 0.1), limit=74.88):
+def synth_frame_pair(n_points, batch_size, seed, shift=(0.5, 0.1), limit=74.88, extra_features=0):
     cur, prv = [], []
     for b in range(batch_size):
         rng = np.random.default_rng(seed * 64 + b)
@@ -15,7 +15,8 @@ def synth_frame_pair(n_points, batch_size, seed, shift=(0.5, 0.1), limit=74.88):
         x, y = r * np.cos(th), r * np.sin(th)
         z = rng.normal(-1.7, 0.3, n_points) + 3 * rng.uniform(0, 1, n_points) ** 4
         it = rng.uniform(0, 1, n_points)
-        pts = np.stack([np.full(n_points, b), x, y, z, it], axis=1).astype(np.float32)
+        cols = [np.full(n_points, b), x, y, z, it] + [rng.uniform(0, 1, n_points) for _ in range(extra_features)]
+        pts = np.stack(cols, axis=1).astype(np.float32)          # Waymo-shape scans carry elongation as a 5th feature
         keep = (np.abs(pts[:, 1]) <= limit) & (np.abs(pts[:, 2]) <= limit)
         cur.append(pts[keep])
         q = pts.copy()
@@ -27,7 +28,8 @@ def synth_frame_pair(n_points, batch_size, seed, shift=(0.5, 0.1), limit=74.88):
 
 
 class _PointFeatureEncoder:
-    num_point_features = 5        # x, y, z, intensity, group_id (once_temporal_dataset.yaml POINT_FEATURE_ENCODING)
+    def __init__(self, n):
+        self.num_point_features = n   # ONCE: x, y, z, intensity, group_id = 5 (once_temporal_dataset.yaml); Waymo: 6
 
 
 class SyntheticTemporalDataset:
@@ -35,9 +37,10 @@ class SyntheticTemporalDataset:
     point_feature_encoder.num_point_features, grid_size, point_cloud_range, voxel_size
     (detector3d_template.py:22,46-53) and yields collated batches."""
 
-    def __init__(self, dataset_cfg, class_names, n_points=120000, batch_size=8, rank=0, length=1 << 30):
+    def __init__(self, dataset_cfg, class_names, n_points=120000, batch_size=8, rank=0, length=1 << 30,
+                 num_point_features=5):
         self.class_names = class_names
-        self.point_feature_encoder = _PointFeatureEncoder()
+        self.point_feature_encoder = _PointFeatureEncoder(num_point_features)
         self.point_cloud_range = np.array(dataset_cfg.POINT_CLOUD_RANGE, dtype=np.float32)
         vs = None
         for p in dataset_cfg.DATA_PROCESSOR:
@@ -53,5 +56,6 @@ class SyntheticTemporalDataset:
 
     def batch(self, iteration):
         pts, prv = synth_frame_pair(self.n_points, self.batch_size, 1000 * self.rank + iteration,
-                                    limit=float(self.point_cloud_range[3]))
+                                    limit=float(self.point_cloud_range[3]),
+                                    extra_features=self.point_feature_encoder.num_point_features - 5)
         return {'points': pts, 'points_prev': prv, 'batch_size': self.batch_size}

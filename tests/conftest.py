@@ -31,12 +31,21 @@ def load_cfg(num_stages=3):
     return cfg
 
 
-def build_product_model(num_stages=3, params=None, device='cpu', n_points=1000, batch_size=2, partial=False):
+def build_product_model(num_stages=3, params=None, device='cpu', n_points=1000, batch_size=2, partial=False,
+                        waymo_shape=False):
     """TMAE through the pcdet registry path; `params` = oracle-style state dict (reference key names)."""
     from pcdet.models import build_network
     from tmae_amd.train import SyntheticTemporalDataset
     cfg = load_cfg(num_stages)
-    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=n_points, batch_size=batch_size)
+    npf = 5
+    if waymo_shape:      # BASELINE configs[3]: 5 point features (x,y,z,intensity,elongation), z range [-2,4), 6 m pillars
+        cfg.DATA_CONFIG.POINT_CLOUD_RANGE = [-74.88, -74.88, -2.0, 74.88, 74.88, 4.0]
+        for p in cfg.DATA_CONFIG.DATA_PROCESSOR:
+            if p.NAME == 'calculate_grid_size':
+                p.VOXEL_SIZE = [0.32, 0.32, 6.0]
+        npf = 6
+    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=n_points, batch_size=batch_size,
+                                  num_point_features=npf)
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
     if params is not None:
         res = model.load_state_dict(params, strict=False)

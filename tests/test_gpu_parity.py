@@ -612,6 +612,39 @@ def test_e2e_golden_and_oracle(oracle, name, nst):
         assert (a - b).abs().max().item() <= 5e-3 * max(1.0, b.abs().max().item()), n
 
 
+def test_e2e_waymo_shape_config(oracle):
+    """BASELINE configs[3] shape: 5 point features (VFE input width 11), z range [-2,4), 6 m pillars; same model.
+    (Range +-74.88 -> grid 468: with the dataset yaml's +-75.2 the reference's own decoder cannot concatenate
+    118*4 = 472 with 470.)  Whole step in fp32 vs the CPU oracle."""
+    cfg = oracle.default_model_cfg(3)
+    cfg['point_cloud_range'] = [-74.88, -74.88, -2.0, 74.88, 74.88, 4.0]
+    cfg['voxel_size'] = [0.32, 0.32, 6.0]
+    P = oracle.init_params(cfg, seed=5, num_point_features=5, tau=0.3, pred_scale=0.1)
+    rng = np.random.default_rng(3)
+    pts, prv = oracle.synth_frame_pair(4000, 2, seed=77)
+    pts[:, 3] += 1.5
+    prv[:, 3] += 1.5
+    pts = np.concatenate([pts, rng.uniform(0, 1, (len(pts), 1)).astype(np.float32)], 1)
+    prv = np.concatenate([prv, rng.uniform(0, 1, (len(prv), 1)).astype(np.float32)], 1)
+    vox = oracle.voxelize(pts, cfg['point_cloud_range'], cfg['voxel_size'], cfg['grid_size'])
+    noise = rng.random(vox['voxel_coords'].shape[0]).astype(np.float32)
+    model, _, ds = build_product_model(3, params=P, device=dev(), waymo_shape=True)
+    assert list(ds.grid_size) == [468, 468, 1] and model.vfe.dvfe_mlps[0][0].weight.shape == (64, 11)
+    model.train()
+    loss, bd = _run_product(model, pts, prv, noise, 2)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    cap = {}
+    lo = oracle.forward_loss(Pg, pts, prv, noise, 2, cfg, cap)
+    lo.backward()
+    assert abs(float(lo) - float(loss)) < 1e-4, (float(lo), float(loss))
+    assert np.array_equal(bd['voxel_mae_mask'].cpu().numpy(), cap['mask'])
+    assert np.array_equal(bd['voxel_coords'].cpu().numpy(), cap['vfe_cur']['voxel_coords'])
+    grads = dict(model.named_parameters())
+    for n in ('vfe.dvfe_mlps.0.0.weight', 'backbone_3d.sst_blocks.2.conv_down.0.weight', 'backbone_3d.decoder_pred.weight'):
+        a, b = grads[n].grad.cpu(), Pg[n].grad
+        assert (a - b).abs().max().item() <= 5e-3 * max(1.0, b.abs().max().item()), n
+
+
 def test_e2e_bf16_autocast_close_to_fp32(oracle):
     g = golden('F10_e2e_3stage')
     cfg = oracle.default_model_cfg(3)
