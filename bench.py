@@ -98,9 +98,14 @@ def kernel_roofline(model, batch, amp_dtype, iters=20):
     ms = e0.elapsed_time(e1) / iters
     bytes_alg = m * d * es * (3 + 1 + 1 + 3) + m * H * 4 + bs * 468 * 468 * 4
     achieved = bytes_alg / (ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'round1_attn_bwd_pmc.json')      # rocprofv3 --pmc passes of --probe-only
+    if os.path.exists(pmc) and code == 1:
+        traffic = json.load(open(pmc)).get('traffic_bytes_per_op')
     return {'kernel': 'win_attn_bwd_mfma_kernel<16,NT> (stage-1 self-attention backward, previous frame; the op = its 3 '
                       'tile-class launches NT=1,2,4)', 'bound': 'hbm', 'achieved': round(achieved, 2),
-            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+            'traffic_source': 'profiles/round1_attn_bwd_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': int(m)}
 
 
