@@ -239,6 +239,18 @@ int tmae_layernorm_bwd(const void* dy, const void* x, int dtype, int64_t m, int 
                        const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* BatchNorm1d with batch statistics (+ optional ReLU) over the rows of a token / point list -- the norm of
+ * spconv_utils.post_act_block (pcdet/utils/spconv_utils.py:50-54, eps 1e-3) and of the VFE MLP
+ * (model_utils/network_utils.py:31).  x, y, dy, dx [m,c] in `dtype`, c in {64,128,256}; mean / var (biased) / rstd [c]
+ * f32 are outputs of the forward (the caller updates the running statistics from mean and var*m/(m-1)).
+ * y = relu?((x - mean) * rstd * gamma + beta).  Backward: dx, dgamma, dbeta; the ReLU mask is recomputed from x. */
+size_t tmae_bn_workspace(int64_t m, int c);
+int tmae_bn_relu_fwd(const void* x, int dtype, int64_t m, int c, const float* gamma, const float* beta, float eps,
+                     int relu, void* y, float* mean, float* var, float* rstd, void* ws, size_t ws_bytes, void* stream);
+int tmae_bn_relu_bwd(const void* dy, const void* x, int dtype, int64_t m, int c, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, int relu, void* dx, float* dgamma, float* dbeta,
+                     void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

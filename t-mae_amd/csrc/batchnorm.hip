@@ -1,0 +1,259 @@
+// BatchNorm1d (training statistics) + ReLU over the rows of a token / point list [m, c], forward and backward
+// (spconv_utils.post_act_block: conv + BatchNorm1d(eps 1e-3) + ReLU, pcdet/utils/spconv_utils.py:37-56; the VFE's
+// Linear + BatchNorm1d + ReLU, model_utils/network_utils.py:25-40).  Pure HBM streaming: one wavefront per row,
+// c/64 contiguous channels per lane; column sums are accumulated per lane in registers, per workgroup in LDS, and
+// finished in a fixed order (deterministic, no atomics); the final combination runs in double.
+#include "common.h"
+
+template <class T, int VEC>
+__device__ __forceinline__ void bn_load(const T* p, float* v) {
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) v[i] = ld_f<T>(p + i);
+}
+
+// partial column sums of x and x^2
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t m,
+                                                      float* __restrict__ part /*[grid][2][C]*/) {
+  constexpr int C = VEC * 64;
+  __shared__ float red[4][2][C];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  for (int64_t r = wave; r < m; r += nwaves) {
+    float v[VEC];
+    bn_load<T, VEC>(x + r * C + lane * VEC, v);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { red[w][0][lane * VEC + i] = s1[i]; red[w][1][lane * VEC + i] = s2[i]; }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * C; e += 256) {
+    const int which = e / C, c = e % C;
+    part[(int64_t)blockIdx.x * 2 * C + e] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+  }
+}
+
+// mean / biased variance / rstd per channel from the partials (double accumulation, fixed order)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblocks, int c, int64_t m,
+                                                         float eps, float* __restrict__ mean,
+                                                         float* __restrict__ var, float* __restrict__ rstd) {
+  __shared__ double red[16][17][2];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double a = 0.0, b = 0.0;
+  if (ch < c)
+    for (int k = rl; k < nblocks; k += 16) { a += part[(int64_t)k * 2 * c + ch]; b += part[(int64_t)k * 2 * c + c + ch]; }
+  red[rl][cl][0] = a;
+  red[rl][cl][1] = b;
+  __syncthreads();
+  if (rl == 0 && ch < c) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
+    const double mu = s1 / (double)m;
+    double vr = s2 / (double)m - mu * mu;
+    if (vr < 0.0) vr = 0.0;
+    mean[ch] = (float)mu;
+    var[ch] = (float)vr;
+    rstd[ch] = (float)(1.0 / sqrt(vr + (double)eps));
+  }
+}
+
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int64_t m,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int relu, T* __restrict__ y) {
+  constexpr int C = VEC * 64;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = lane * VEC + i;
+    sc[i] = rstd[ch] * gamma[ch];
+    sh[i] = beta[ch] - mean[ch] * sc[i];
+  }
+  for (int64_t r = wave; r < m; r += nwaves) {
+    float v[VEC];
+    bn_load<T, VEC>(x + r * C + lane * VEC, v);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float z = v[i] * sc[i] + sh[i];
+      if (relu) z = fmaxf(z, 0.f);
+      st_f<T>(y + r * C + lane * VEC + i, z);
+    }
+  }
+}
+
+// partial sums of dz and dz * xhat, dz = dy * (z > 0) with z recomputed from x
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           int64_t m, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int relu,
+                                                           float* __restrict__ part) {
+  constexpr int C = VEC * 64;
+  __shared__ float red[4][2][C];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+  float mu[VEC], rs[VEC], g[VEC], bt[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = lane * VEC + i;
+    mu[i] = mean[ch]; rs[i] = rstd[ch]; g[i] = gamma[ch]; bt[i] = beta[ch];
+    s1[i] = 0.f; s2[i] = 0.f;
+  }
+  for (int64_t r = wave; r < m; r += nwaves) {
+    float v[VEC], d[VEC];
+    bn_load<T, VEC>(x + r * C + lane * VEC, v);
+    bn_load<T, VEC>(dy + r * C + lane * VEC, d);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float xh = (v[i] - mu[i]) * rs[i];
+      const float dz = (relu && !(xh * g[i] + bt[i] > 0.f)) ? 0.f : d[i];
+      s1[i] += dz;
+      s2[i] += dz * xh;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { red[w][0][lane * VEC + i] = s1[i]; red[w][1][lane * VEC + i] = s2[i]; }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * C; e += 256) {
+    const int which = e / C, c = e % C;
+    part[(int64_t)blockIdx.x * 2 * C + e] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int c,
+                                                             float* __restrict__ dbeta, float* __restrict__ dgamma) {
+  __shared__ double red[16][17][2];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double a = 0.0, b = 0.0;
+  if (ch < c)
+    for (int k = rl; k < nblocks; k += 16) { a += part[(int64_t)k * 2 * c + ch]; b += part[(int64_t)k * 2 * c + c + ch]; }
+  red[rl][cl][0] = a;
+  red[rl][cl][1] = b;
+  __syncthreads();
+  if (rl == 0 && ch < c) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
+    dbeta[ch] = (float)s1;
+    dgamma[ch] = (float)s2;
+  }
+}
+
+// dx = gamma * rstd * (dz - dbeta/m - xhat * dgamma/m)
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, int64_t m,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int relu,
+                                                          const float* __restrict__ dbeta,
+                                                          const float* __restrict__ dgamma, T* __restrict__ dx) {
+  constexpr int C = VEC * 64;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  const float invm = 1.0f / (float)m;
+  float mu[VEC], rs[VEC], g[VEC], bt[VEC], a[VEC], b[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int ch = lane * VEC + i;
+    mu[i] = mean[ch]; rs[i] = rstd[ch]; g[i] = gamma[ch]; bt[i] = beta[ch];
+    a[i] = dbeta[ch] * invm; b[i] = dgamma[ch] * invm;
+  }
+  for (int64_t r = wave; r < m; r += nwaves) {
+    float v[VEC], d[VEC];
+    bn_load<T, VEC>(x + r * C + lane * VEC, v);
+    bn_load<T, VEC>(dy + r * C + lane * VEC, d);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float xh = (v[i] - mu[i]) * rs[i];
+      const float dz = (relu && !(xh * g[i] + bt[i] > 0.f)) ? 0.f : d[i];
+      st_f<T>(dx + r * C + lane * VEC + i, g[i] * rs[i] * (dz - a[i] - xh * b[i]));
+    }
+  }
+}
+
+static int bn_grid(int64_t m) {
+  int64_t g = (m + 63) / 64;            // >= 16 rows per wave
+  if (g > 512) g = 512;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+size_t tmae_bn_workspace(int64_t m, int c) { return (size_t)bn_grid(m) * 2 * c * 4 + 256; }
+
+#define BN_DISPATCH(T, KERNEL, ...)                                                              \
+  do {                                                                                            \
+    if (c == 64) hipLaunchKernelGGL((KERNEL<T, 1>), grid, block, 0, stream, __VA_ARGS__);         \
+    else if (c == 128) hipLaunchKernelGGL((KERNEL<T, 2>), grid, block, 0, stream, __VA_ARGS__);   \
+    else hipLaunchKernelGGL((KERNEL<T, 4>), grid, block, 0, stream, __VA_ARGS__);                 \
+  } while (0)
+
+int tmae_bn_relu_fwd(const void* x_, int dtype, int64_t m, int c, const float* gamma, const float* beta, float eps,
+                     int relu, void* y_, float* mean, float* var, float* rstd, void* wsp, size_t ws_bytes,
+                     void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m <= 0 || (c != 64 && c != 128 && c != 256) || !x_ || !gamma || !beta || !y_ || !mean || !var || !rstd)
+    return TMAE_EARG;
+  if (dtype != TMAE_F32 && dtype != TMAE_BF16) return TMAE_EDTYPE;
+  const int nb = bn_grid(m);
+  WsCarver ws(wsp, ws_bytes);
+  float* part = ws.take<float>((size_t)nb * 2 * c);
+  if (!ws.ok) return TMAE_EWS;
+  dim3 grid(nb), block(256);
+  if (dtype == TMAE_F32) {
+    const float* x = (const float*)x_;
+    float* y = (float*)y_;
+    BN_DISPATCH(float, bn_stats_kernel, x, m, part);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, m, eps, mean, var, rstd);
+    BN_DISPATCH(float, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y);
+  } else {
+    const __hip_bfloat16* x = (const __hip_bfloat16*)x_;
+    __hip_bfloat16* y = (__hip_bfloat16*)y_;
+    BN_DISPATCH(__hip_bfloat16, bn_stats_kernel, x, m, part);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, m, eps, mean, var, rstd);
+    BN_DISPATCH(__hip_bfloat16, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y);
+  }
+  return tmae_launch_status();
+}
+
+int tmae_bn_relu_bwd(const void* dy_, const void* x_, int dtype, int64_t m, int c, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, int relu, void* dx_, float* dgamma, float* dbeta, void* wsp,
+                     size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m <= 0 || (c != 64 && c != 128 && c != 256) || !dy_ || !x_ || !mean || !rstd || !gamma || !beta || !dx_ ||
+      !dgamma || !dbeta)
+    return TMAE_EARG;
+  if (dtype != TMAE_F32 && dtype != TMAE_BF16) return TMAE_EDTYPE;
+  const int nb = bn_grid(m);
+  WsCarver ws(wsp, ws_bytes);
+  float* part = ws.take<float>((size_t)nb * 2 * c);
+  if (!ws.ok) return TMAE_EWS;
+  dim3 grid(nb), block(256);
+  if (dtype == TMAE_F32) {
+    const float *dy = (const float*)dy_, *x = (const float*)x_;
+    float* dx = (float*)dx_;
+    BN_DISPATCH(float, bn_bwd_reduce_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, dbeta, dgamma);
+    BN_DISPATCH(float, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, dx);
+  } else {
+    const __hip_bfloat16 *dy = (const __hip_bfloat16*)dy_, *x = (const __hip_bfloat16*)x_;
+    __hip_bfloat16* dx = (__hip_bfloat16*)dx_;
+    BN_DISPATCH(__hip_bfloat16, bn_bwd_reduce_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, dbeta, dgamma);
+    BN_DISPATCH(__hip_bfloat16, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, dx);
+  }
+  return tmae_launch_status();
+}

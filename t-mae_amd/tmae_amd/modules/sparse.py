@@ -101,11 +101,18 @@ class SparseSequential(SparseModule):
             self.add_module(str(i), m)
 
     def forward(self, x):
-        for m in self._modules.values():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
             if isinstance(m, SparseModule):
                 x = m(x)
+            elif isinstance(m, nn.BatchNorm1d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                x = x.replace_feature(ops.batch_norm_relu(x.features, m, relu=True))     # fused BN + ReLU kernels
+                i += 1
             else:
                 x = x.replace_feature(m(x.features))
+            i += 1
         return x
 
 

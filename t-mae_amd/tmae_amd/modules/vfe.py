@@ -62,8 +62,12 @@ class TemporalDynVFE(VFETemplate):
         _, feats = ops.vfe_point_features(vox['points'], vox['point_coords'], vox['inverse'], perm, offsets, m,
                                           self.point_cloud_range, self.voxel_size)
         x = feats
-        for layer in self.dvfe_mlps[0]:
-            x = ops.linear(x, layer.weight, None) if isinstance(layer, nn.Linear) else layer(x)
+        layers = list(self.dvfe_mlps[0])
+        for i, layer in enumerate(layers):
+            if isinstance(layer, nn.Linear):
+                x = ops.linear(x, layer.weight, None)
+            elif isinstance(layer, nn.BatchNorm1d):
+                x = ops.batch_norm_relu(x, layer, relu=True)         # the ReLU that follows is fused
         x_max, _ = ops.scatter_max(x, vox['inverse'], perm, offsets, m)
         return x_max
 

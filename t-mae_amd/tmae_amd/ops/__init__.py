@@ -147,6 +147,58 @@ def add_layer_norm(a, b, weight, bias, eps=1e-5):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 
+class _BatchNormReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, relu):
+        x = x.contiguous()
+        m, c = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+        var, rstd = torch.empty_like(mean), torch.empty_like(mean)
+        g32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        wsb = lib.tmae_bn_workspace(m, c)
+        ws = _ws(wsb, x.device)
+        check(lib.tmae_bn_relu_fwd(_p(x), _dt(x), m, c, _p(g32), _p(b32), float(eps), 1 if relu else 0, _p(y), _p(mean),
+                                   _p(var), _p(rstd), _p(ws), wsb, _s()), 'tmae_bn_relu_fwd')
+        ctx.save_for_backward(x, mean, rstd, g32, b32)
+        ctx.relu = relu
+        ctx.dtypes = (weight.dtype, bias.dtype)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _m, _v):
+        x, mean, rstd, g32, b32 = ctx.saved_tensors
+        dy = dy.to(x.dtype).contiguous()
+        m, c = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty((c,), dtype=torch.float32, device=x.device)
+        db = torch.empty_like(dg)
+        wsb = lib.tmae_bn_workspace(m, c)
+        ws = _ws(wsb, x.device)
+        check(lib.tmae_bn_relu_bwd(_p(dy), _p(x), _dt(x), m, c, _p(mean), _p(rstd), _p(g32), _p(b32),
+                                   1 if ctx.relu else 0, _p(dx), _p(dg), _p(db), _p(ws), wsb, _s()), 'tmae_bn_relu_bwd')
+        return dx, dg.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None
+
+
+def batch_norm_relu(x, bn, relu=True):
+    """nn.BatchNorm1d `bn` (+ ReLU) over the rows of x [m,c]; fused HIP kernels in training mode for c in
+    {64,128,256}; updates bn's running statistics like torch does."""
+    if (x.is_cuda and x.dim() == 2 and bn.training and x.shape[1] in (64, 128, 256) and x.shape[0] > 1
+            and x.dtype in (torch.float32, torch.bfloat16)):
+        y, mean, var = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.eps, relu)
+        if bn.track_running_stats:
+            with torch.no_grad():
+                m = x.shape[0]
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var, alpha=mom * m / (m - 1))
+                bn.num_batches_tracked += 1
+        return y
+    y = bn(x)
+    return torch.relu(y) if relu else y
+
+
 # ----------------------------------------------------------------------------- voxelisation (A1)
 
 def voxelize_launch(points, batch_size, pc_range, voxel_size, grid_size):

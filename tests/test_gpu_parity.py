@@ -502,6 +502,36 @@ def test_add_layernorm_kernel_vs_torch():
     assert (y - F.layer_norm(a, (256,), w, bb, 1e-5)).abs().max().item() < 2e-5
 
 
+def test_batchnorm_relu_kernel_vs_torch():
+    from tmae_amd import ops
+    torch.manual_seed(2)
+    for c in (64, 128, 256):
+        for m in (2, 999, 60000):
+            x = torch.randn(m, c, device=dev()) * 1.5 + 0.3
+            go = torch.randn(m, c, device=dev())
+            for dt, tol in ((torch.float32, 3e-5), (torch.bfloat16, 4e-2)):
+                bn1 = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev())
+                bn2 = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev())
+                with torch.no_grad():
+                    bn1.weight.normal_(1, 0.2), bn1.bias.normal_(0, 0.2)
+                    bn2.load_state_dict(bn1.state_dict())
+                x1 = x.to(dt).clone().requires_grad_(True)
+                y1 = ops.batch_norm_relu(x1, bn1, relu=True)
+                y1.backward(go.to(dt))
+                x2 = x.to(dt).float().clone().requires_grad_(True)
+                y2 = torch.relu(bn2(x2))
+                y2.backward(go.to(dt).float())
+                assert (y1.float() - y2).abs().max().item() <= tol, (c, m, dt)
+                assert (x1.grad.float() - x2.grad).abs().max().item() <= tol * 3 * max(1.0, float(x2.grad.abs().max())), (c, m, dt)
+                sc = max(1.0, float(bn2.weight.grad.abs().max()))
+                lim = (2e-3 if dt == torch.float32 else 5e-2) * sc * max(1.0, m ** 0.5 / 20)
+                assert (bn1.weight.grad - bn2.weight.grad).abs().max().item() <= lim
+                assert (bn1.bias.grad - bn2.bias.grad).abs().max().item() <= lim
+                assert (bn1.running_mean - bn2.running_mean).abs().max().item() < 1e-4
+                assert (bn1.running_var - bn2.running_var).abs().max().item() < 1e-3
+                assert int(bn1.num_batches_tracked) == 1
+
+
 # ------------------------------------------------------------------------------------------ A9 / A11
 
 def test_sparse_conv_golden_and_dense(oracle):
