@@ -227,6 +227,13 @@ size_t tmae_linear_wgrad_workspace(int64_t m, int n, int k);
 int tmae_linear_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k,
                       float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
 
+/* Weight gradient of the 3x3 sparse conv without materialising the gathered [m_out, 9*cin] matrix: the token-split
+ * kernel reads row nbr[o,t] of feat [m_in, cin] (bf16) for the column block of tap t.  dw [cout, 9*cin] f32 = the
+ * spconv-2 weight layout [cout,3,3,cin] flattened; cin a multiple of 128, cout of 8; workspace =
+ * tmae_linear_wgrad_workspace(m_out, cout, 9*cin). */
+int tmae_spconv_wgrad(const void* dy, int64_t ldy, const void* feat, int64_t ldf, const int32_t* nbr, int64_t m_out,
+                      int cout, int cin, float* dw, void* ws, size_t ws_bytes, void* stream);
+
 /* Fused residual add + LayerNorm of the post-norm encoder layers (EncoderLayer.forward sst_basic_block.py:77-84,
  * wca_block.py:93-102): y = LN(a + b) * gamma + beta, eps inside the sqrt, biased variance (nn.LayerNorm).
  * a, b (b may be NULL), y, xsum [m,d] in `dtype`; d in {128, 256}; xsum (may be NULL) receives a + b for the

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
   // ---- every global row load of the workgroup is issued here (one dependent round after the token ids); the
   //      row-major LDS images are written from the same 16-byte fragments: lane (g,i) owns chunk g of row tile*16+i.
   frag_t kf[NT], kl[NT], vr[NT], qf[NT], ql[NT], gf[NT];
-  float dsum[NT], lse_i[NT];
+  float lse_i[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int slot = t * 16 + i;
@@ -434,7 +434,6 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
       for (int j = 0; j < FR; ++j) { kf[t][j] = 0; kl[t][j] = 0; vr[t][j] = 0; }
     }
     *reinterpret_cast<frag_t*>(&kimg[w][slot * RB + FR * g * 2]) = kf[t];
-    dsum[t] = 0.f;
     lse_i[t] = 0.f;
     if (t < nq) {
       const int tokq = slot < Tq ? toks[0][slot] : -1;
@@ -447,13 +446,6 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
       load_row_frag<FR>(dout, lddo, tokq, hoff, g, gfl);
       gf[t] = pack_frag<FR>(gfl);                                        // exact: bf16 -> f32 -> bf16
       *reinterpret_cast<frag_t*>(&gimg[w][slot * RB + FR * g * 2]) = gf[t];
-      load_row_frag<FR>(outp, ldo, tokq, hoff, g, f);
-      float d = 0.f;
-#pragma unroll
-      for (int j = 0; j < FR; ++j) d += f[j] * gfl[j];                   // D = dO . O
-      d += __shfl_xor(d, 16, 64);
-      d += __shfl_xor(d, 32, 64);
-      dsum[t] = d;
       lse_i[t] = tokq >= 0 ? lse[(int64_t)tokq * nhead + head] : 0.f;
     }
   }
@@ -481,6 +473,11 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
       f32x4 dQa[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) dQa[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // pass 1 over the key tiles: logits, probabilities and dP; D_i = sum_j P_ij dP_ij is taken from THESE values
+      // (not from dO . O with the bf16-rounded saved output), so that sum_j dS_ij = 0 holds to fp32 rounding --
+      // the tau gradient sum_ij dS_ij s_ij is a difference of large terms and is biased otherwise
+      f32x4 sTk[NT], pTk[NT], dPk[NT];
+      float dacc = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         if (kt < nk) {
@@ -489,14 +486,28 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
           f32x4 sT = mfma_s(kl[kt], qf[qt], z);
           sT = mfma_s(kf[kt], ql[qt], sT);
           sT = mfma_s(kf[kt], qf[qt], sT);
-          const f32x4 dPT = mfma_s(vr[kt], gf[qt], z);
-          s16x4 dsT, pTb;
+          dPk[kt] = mfma_s(vr[kt], gf[qt], z);
+          sTk[kt] = sT;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool ok = qok && (kt * 16 + 4 * g + r < Tk);
             const float p = ok ? __expf(sT[r] - lse_i[qt]) : 0.f;
-            const float ds = p * (dPT[r] - dsum[qt]);
-            dtau_acc += ok ? ds * sT[r] : 0.f;
+            pTk[kt][r] = p;
+            dacc += p * dPk[kt][r];
+          }
+        }
+      }
+      dacc += __shfl_xor(dacc, 16, 64);
+      dacc += __shfl_xor(dacc, 32, 64);
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        if (kt < nk) {
+          s16x4 dsT, pTb;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = pTk[kt][r];
+            const float ds = p * (dPk[kt][r] - dacc);
+            dtau_acc += (p > 0.f) ? ds * sTk[kt][r] : 0.f;
             dsT[r] = f2bf(ds);
             pTb[r] = f2bf(p);
           }

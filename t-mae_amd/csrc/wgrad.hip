@@ -42,18 +42,37 @@ __device__ __forceinline__ bf16x8 load_frag(const char* img, int cb, int lane) {
 __global__ __launch_bounds__(256) void wgrad_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
                                                    const __hip_bfloat16* __restrict__ X, int64_t ldx, int64_t M,
                                                    int N, int K, int rows_per_split, float* __restrict__ slab,
-                                                   int64_t count, bool has_bias) {
+                                                   int64_t count, bool has_bias, int NB, int KB, int S,
+                                                   const int32_t* __restrict__ nbr, int cin) {
   __shared__ __attribute__((aligned(16))) char lds[2][2][WG_MS * 256];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w >> 1, wk = w & 1;
-  const int n0 = blockIdx.x * WG_BN, k0 = blockIdx.y * WG_BK, s = blockIdx.z;
+  // XCD-aware 1-D grid: block ids are dealt round-robin over the 8 XCDs (speed only, never correctness), so all
+  // (n, k) output blocks of one token chunk s get ids of the same residue: they stream the same dY / X rows at the
+  // same time and share them through that XCD's L2 instead of fetching them once per block from HBM.
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int per_s = NB * KB;
+  const int s = (j / per_s) * 8 + xcd;
+  if (s >= S) return;
+  const int blk = j % per_s;
+  const int n0 = (blk % NB) * WG_BN, kblk = blk / NB, k0 = kblk * WG_BK;
   const int64_t m_begin = (int64_t)s * rows_per_split;
   const int64_t m_end = min(M, m_begin + (int64_t)rows_per_split);
   const int steps = m_end > m_begin ? (int)((m_end - m_begin + WG_MS - 1) / WG_MS) : 0;
-  const bool want_bias = has_bias && blockIdx.y == 0 && wk == 0;     // wave-uniform
+  const bool want_bias = has_bias && kblk == 0 && wk == 0;     // wave-uniform
+  // gathered X (sparse conv): column block k0 lies inside tap k0 / cin; row m reads feature row nbr[m, tap]
+  const int tap = nbr ? k0 / cin : 0, c0 = nbr ? k0 % cin : k0;
   float* __restrict__ slab_w = slab + (int64_t)s * count;
   float* __restrict__ slab_b = slab_w + (int64_t)N * K;
 
   uint4 ry[2], rx[2];
+  int xi[2] = {-1, -1};                 // gathered mode: feature-row ids of the NEXT slice, fetched one step early so
+  auto iload = [&](int step) {          // the row loads never wait on an index load (no dependent round trip)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t m = m_begin + (int64_t)step * WG_MS + ((tid + 256 * i) >> 4);
+      xi[i] = (nbr && m < m_end) ? nbr[m * 9 + tap] : -1;
+    }
+  };
   auto gload = [&](int step) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -61,7 +80,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const __hip_bfloat16* __rest
       const int64_t m = m_begin + (int64_t)step * WG_MS + row;
       const int cy = n0 + ch * 8, cx = k0 + ch * 8;
       ry[i] = (m < m_end && cy < N) ? *reinterpret_cast<const uint4*>(dY + m * ldy + cy) : make_uint4(0, 0, 0, 0);
-      rx[i] = (m < m_end && cx < K) ? *reinterpret_cast<const uint4*>(X + m * ldx + cx) : make_uint4(0, 0, 0, 0);
+      const int64_t xr = nbr ? (int64_t)xi[i] : m;
+      rx[i] = (m < m_end && cx < K && xr >= 0) ? *reinterpret_cast<const uint4*>(X + xr * ldx + c0 + ch * 8)
+                                              : make_uint4(0, 0, 0, 0);
     }
   };
   auto lwrite = [&](int buf) {
@@ -84,13 +105,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const __hip_bfloat16* __rest
   const bf16x8 ones = *reinterpret_cast<bf16x8*>(&ones_s);
 
   if (steps > 0) {
+    iload(0);
     gload(0);
+    if (steps > 1) iload(1);
     lwrite(0);
   }
   __syncthreads();
   for (int st = 0; st < steps; ++st) {
     const int buf = st & 1;
     if (st + 1 < steps) gload(st + 1);
+    if (st + 2 < steps) iload(st + 2);
     bf16x8 fa[4], fb[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -155,9 +179,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
 
 static void wgrad_plan(int64_t m, int n, int k, int& splits, int& rows_per_split) {
   const int nb = ((n + WG_BN - 1) / WG_BN) * ((k + WG_BK - 1) / WG_BK);
-  int64_t s = (512 + nb - 1) / nb;                        // ~2 workgroups per CU in flight
+  int64_t s = (768 + nb - 1) / nb;                        // ~3 workgroups per CU in flight
   const int64_t max_s = (m + 255) / 256;                  // at least 8 steps per workgroup
   if (s > max_s) s = max_s;
+  if (s >= 8) s = (s + 7) / 8 * 8;                        // token chunks are dealt over the 8 XCDs: keep them even
   if (s < 1) s = 1;
   int64_t rows = (m + s - 1) / s;
   rows = (rows + WG_MS - 1) / WG_MS * WG_MS;
@@ -165,6 +190,7 @@ static void wgrad_plan(int64_t m, int n, int k, int& splits, int& rows_per_split
   splits = (int)((m + rows - 1) / rows);
   if (splits < 1) splits = 1;
   rows_per_split = (int)rows;
+  (void)s;
 }
 
 // slab row = [n*k weight partials | n bias partials | pad to a multiple of 4 floats]
@@ -176,11 +202,10 @@ size_t tmae_linear_wgrad_workspace(int64_t m, int n, int k) {
   return tmae_align((size_t)splits * slab_count(n, k) * 4) + tmae_align((size_t)WG_RG * slab_count(n, k) * 4) + 1024;
 }
 
-int tmae_linear_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k, float* dw,
-                      float* db, void* wsp, size_t ws_bytes, void* stream_) {
-  (void)hipGetLastError();
-  hipStream_t stream = (hipStream_t)stream_;
+static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k, float* dw,
+                        float* db, const int32_t* nbr, int cin, void* wsp, size_t ws_bytes, hipStream_t stream) {
   if (m < 0 || n <= 0 || k <= 0 || !dw || (n % 8) || (k % 8) || (ldy % 8) || (ldx % 8)) return TMAE_EARG;
+  if (nbr && (cin <= 0 || cin % WG_BK || k != 9 * cin)) return TMAE_EARG;
   if (m > 0 && (!dy || !x)) return TMAE_EARG;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return TMAE_EARG;
   int splits, rows;
@@ -191,12 +216,27 @@ int tmae_linear_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, i
   float* part = ws.take<float>((size_t)WG_RG * count);
   if (!ws.ok) return TMAE_EWS;
   // without a bias the slabs' bias columns stay unwritten; the reduction discards those sums
-  dim3 grid((n + WG_BN - 1) / WG_BN, (k + WG_BK - 1) / WG_BK, splits);
-  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, stream, (const __hip_bfloat16*)dy, ldy,
-                     (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr);
+  const int NB = (n + WG_BN - 1) / WG_BN, KB = (k + WG_BK - 1) / WG_BK;
+  const unsigned nblocks = 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(nblocks), dim3(256), 0, stream, (const __hip_bfloat16*)dy, ldy,
+                     (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr, cin);
   hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(tmae_cdiv(count / 4, 256), WG_RG), dim3(256), 0, stream, slab, splits,
                      count, part);
   hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(tmae_cdiv(count, 256)), dim3(256), 0, stream, part, count, n, k, dw,
                      db);
   return tmae_launch_status();
+}
+
+int tmae_linear_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k, float* dw,
+                      float* db, void* wsp, size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();
+  return wgrad_launch(dy, ldy, x, ldx, m, n, k, dw, db, nullptr, 0, wsp, ws_bytes, (hipStream_t)stream_);
+}
+
+int tmae_spconv_wgrad(const void* dy, int64_t ldy, const void* feat, int64_t ldf, const int32_t* nbr, int64_t m_out,
+                      int cout, int cin, float* dw, void* wsp, size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();
+  if (!nbr) return TMAE_EARG;
+  return wgrad_launch(dy, ldy, feat, ldf, m_out, cout, 9 * cin, dw, nullptr, nbr, cin, wsp, ws_bytes,
+                      (hipStream_t)stream_);
 }

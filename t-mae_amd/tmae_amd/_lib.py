@@ -58,6 +58,7 @@ SIGNATURES = {
     'tmae_bn_relu_bwd': (I, [P, P, I, L, I, P, P, P, P, I, P, P, P, P, Z, P]),
     'tmae_linear_wgrad_workspace': (Z, [L, I, I]),
     'tmae_linear_wgrad': (I, [P, L, P, L, L, I, I, P, P, P, Z, P]),
+    'tmae_spconv_wgrad': (I, [P, L, P, L, P, L, I, I, P, P, Z, P]),
 }
 
 if not os.path.exists(LIB_PATH):

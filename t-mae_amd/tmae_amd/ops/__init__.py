@@ -545,11 +545,16 @@ class _SparseConv(torch.autograd.Function):
         check(lib.tmae_spconv_gather_t(_p(dcols), _dt(dcols), dout.shape[0], f.shape[1], _p(nbr_t), f.shape[0],
                                        _p(din), _s()), 'tmae_spconv_gather_t')
         del dcols
-        cols = _gather9(f, nbr)                                       # recomputed: cheaper than keeping 9x rows
-        if _wgrad_ok(dout, cols):
-            dw = linear_wgrad(dout, cols, want_bias=False)[0]
+        cin, cout = f.shape[1], dout.shape[1]
+        if dout.dtype == torch.bfloat16 and cin % 128 == 0 and cout % 8 == 0 and dout.shape[0] >= 4096:
+            # token-split kernel reading the feature rows through the rulebook: no [m_out, 9*cin] matrix
+            dw = torch.empty((cout, 9 * cin), dtype=torch.float32, device=f.device)
+            wsb = lib.tmae_linear_wgrad_workspace(dout.shape[0], cout, 9 * cin)
+            ws = _ws(wsb, f.device)
+            check(lib.tmae_spconv_wgrad(_p(dout), dout.stride(0), _p(f), f.stride(0), _p(nbr), dout.shape[0], cout, cin,
+                                        _p(dw), _p(ws), wsb, _s()), 'tmae_spconv_wgrad')
         else:
-            dw = dout.t() @ cols
+            dw = dout.t() @ _gather9(f, nbr)
         dw = dw.reshape(ctx.wshape).to(ctx.wdtype)
         return din.to(ctx.fdtype), dw, None, None
 

@@ -386,7 +386,7 @@ def test_attention_mfma_bf16_fwd_bwd_vs_fp32_kernel():
                     same(o2, o, 'out'), same(a2.grad, a.grad, 'da'), same(b2.grad, b_.grad, 'db')
                     if c2 is not None:
                         same(c2.grad, c_.grad, 'dc')
-                    assert abs(float(tau2.grad) - float(tau.grad)) <= 1e-4 * max(1.0, abs(float(tau.grad)))
+                    assert abs(float(tau2.grad) - float(tau.grad)) <= 2e-3 * max(1.0, abs(float(tau.grad)))
             f, h = res[torch.float32], res[torch.bfloat16]
             assert all(torch.isfinite(t.float()).all() for t in h if t is not None)
             lim = 0.03 if tauv >= 0.05 else 0.12          # logits reach +-100 at the clamp: bf16 logit error ~0.4
@@ -509,7 +509,7 @@ def test_batchnorm_relu_kernel_vs_torch():
         for m in (2, 999, 60000):
             x = torch.randn(m, c, device=dev()) * 1.5 + 0.3
             go = torch.randn(m, c, device=dev())
-            for dt, tol in ((torch.float32, 3e-5), (torch.bfloat16, 4e-2)):
+            for dt, tol in ((torch.float32, 1e-4), (torch.bfloat16, 4e-2)):
                 bn1 = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev())
                 bn2 = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev())
                 with torch.no_grad():
@@ -572,6 +572,40 @@ def test_sparse_conv_golden_and_dense(oracle):
     (r2 * go_d.cpu()).sum().backward()
     np.testing.assert_allclose(gd_feat.cpu().numpy(), fo.grad.numpy(), atol=1e-4)
     np.testing.assert_allclose(gd_w.cpu().numpy(), wo.grad.numpy(), atol=1e-3)
+
+
+def test_sparse_conv_bf16_wgrad_through_rulebook():
+    """bf16 path of the sparse conv backward: the token-split MFMA weight gradient reads feature rows through the
+    neighbour table (no [m, 9*cin] matrix); checked against an explicit fp32 gather + matmul."""
+    from tmae_amd import ops
+    from tmae_amd.modules.sparse import SparseConvTensor, SubMConv2d, SparseConv2d
+    rng = np.random.default_rng(21)
+    c = np.unique(np.stack([rng.integers(0, 2, 30000), rng.integers(0, 234, 30000), rng.integers(0, 234, 30000)], 1), axis=0)
+    ind = cu(c, torch.int32)
+    for Conv, kw, cin, cout in ((SubMConv2d, {}, 128, 128), (SparseConv2d, dict(stride=2, padding=1), 128, 256),
+                                (SubMConv2d, {}, 256, 256)):
+        feat = torch.randn(len(c), cin, device=dev()).bfloat16().requires_grad_(True)
+        sp = SparseConvTensor(feat, ind, [234, 234], 2)
+        conv = Conv(cin, cout, 3, **kw).to(dev())
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = conv(sp)
+        go = torch.randn_like(y.features)
+        y.features.backward(go)
+        rb = sp._cache['subm' if Conv is SubMConv2d else 'down']
+        nbr = rb[0].long()
+        f32 = feat.detach().float()
+        cols = torch.where((nbr >= 0).unsqueeze(-1), f32[nbr.clamp(min=0)], torch.zeros((), device=dev())).reshape(nbr.shape[0], -1)
+        wmat = conv.weight.detach().bfloat16().float().reshape(cout, -1)
+        y_ref = cols @ wmat.t()
+        assert (y.features.float() - y_ref).abs().max().item() <= 2e-2 * float(y_ref.abs().max())
+        dw_ref = (go.float().t() @ cols).reshape(conv.weight.shape)
+        assert (conv.weight.grad - dw_ref).abs().max().item() <= 4e-3 * float(dw_ref.abs().max()), (cin, cout)
+        dcols = go.float() @ wmat
+        din_ref = torch.zeros_like(f32)
+        for t in range(9):
+            valid = nbr[:, t] >= 0
+            din_ref.index_add_(0, nbr[valid, t], dcols[valid, t * cin:(t + 1) * cin])
+        assert (feat.grad.float() - din_ref).abs().max().item() <= 3e-2 * float(din_ref.abs().max())
 
 
 def test_dense_roundtrip_full_grid():
