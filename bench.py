@@ -96,7 +96,10 @@ def kernel_roofline(model, batch, amp_dtype, iters=20):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    bytes_alg = m * d * es * (3 + 1 + 1 + 3) + m * H * 4 + bs * 468 * 468 * 4
+    # algorithmic bytes of the op: read q,k,v,dout (+ out on the fp32 path; the bf16 kernel rebuilds D from P.dP),
+    # write dq,dk,dv; + the lse rows and one pass over the row-index grid
+    units = 7 if code == 1 else 8
+    bytes_alg = m * d * es * units + m * H * 4 + bs * 468 * 468 * 4
     achieved = bytes_alg / (ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, 'profiles', 'round1_attn_bwd_pmc.json')      # rocprofv3 --pmc passes of --probe-only

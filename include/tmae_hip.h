@@ -258,6 +258,36 @@ int tmae_bn_relu_bwd(const void* dy, const void* x, int dtype, int64_t m, int c,
                      const float* gamma, const float* beta, int relu, void* dx, float* dgamma, float* dbeta,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* Split BatchNorm entry points with an explicit element count (used by the fused decoder head below): statistics
+ * of the m stored rows normalised by `count` >= m (the rows that are not stored are exact zeros), the two backward
+ * sums  sum(dz), sum(dz * xhat)  over the stored rows (dz = dy masked by the recomputed ReLU), and the backward apply
+ * dx = gamma * rstd * (dz - dbeta/count - xhat * dgamma/count) with caller-provided totals. */
+int tmae_bn_stats(const void* x, int dtype, int64_t m, int c, double count, float eps, float* mean, float* var,
+                  float* rstd, void* ws, size_t ws_bytes, void* stream);
+int tmae_bn_bwd_sums(const void* dy, const void* x, int dtype, int64_t m, int c, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, int relu, float* sum_dz, float* sum_dz_xhat, void* ws,
+                     size_t ws_bytes, void* stream);
+int tmae_bn_bwd_apply(const void* dy, const void* x, int dtype, int64_t m, int c, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, int relu, const float* dbeta,
+                      const float* dgamma, double count, void* dx, void* stream);
+
+/* Decoder head, SiamWCA_MAE.dense_conv (SiamWCA_MAE.py:231-253; modules :79-98): SparseConvTensor.dense() ->
+ * ConvTranspose2d(k = s, stride s, no bias) -> BatchNorm2d -> ReLU -> torch.cat(dim=1), without materialising the
+ * dense intermediates.  v [m, s*s*cout] = feat @ W (column order (dy, dx, cout)) holds the deconv output on the
+ * active input cells of the [batch, ys, xs] grid; every other output cell is exactly zero before the norm.
+ *   tmae_deblock_scatter: out[b, y, x, coff:coff+cout] (channels-last, row pitch ldc elements) =
+ *       relu(v[grid[b, y/s, x/s], (y%s, x%s), :] * rstd*gamma + beta - mean*rstd*gamma), v := 0 where grid < 0.
+ *   tmae_deblock_gather:  g [m, s*s*cout] = rows of the dense gradient dcat at the active cells (indices [m,3] b,y,x).
+ *   tmae_column_sums:     out[c] = sum over rows of x [rows, c] (c % 64 == 0, c <= 512), fixed-order. */
+int tmae_deblock_scatter(const void* v, int dtype, const int32_t* grid, int batch, int ys, int xs, int s, int cout,
+                         const float* mean, const float* rstd, const float* gamma, const float* beta, void* out,
+                         int ldc, int coff, void* stream);
+int tmae_deblock_gather(const void* dcat, int dtype, int ldc, int coff, const int32_t* indices, int64_t m, int ys,
+                        int xs, int s, int cout, void* g, void* stream);
+size_t tmae_column_sums_workspace(int64_t rows, int c);
+int tmae_column_sums(const void* x, int dtype, int64_t rows, int c, float* out, void* ws, size_t ws_bytes,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

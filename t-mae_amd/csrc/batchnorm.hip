@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 }
 
 // mean / biased variance / rstd per channel from the partials (double accumulation, fixed order)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblocks, int c, int64_t m,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblocks, int c, double m,
                                                          float eps, float* __restrict__ mean,
                                                          float* __restrict__ var, float* __restrict__ rstd) {
   __shared__ double red[16][17][2];
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
-    const double mu = s1 / (double)m;
-    double vr = s2 / (double)m - mu * mu;
+    const double mu = s1 / m;
+    double vr = s2 / m - mu * mu;
     if (vr < 0.0) vr = 0.0;
     mean[ch] = (float)mu;
     var[ch] = (float)vr;
@@ -158,11 +158,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int relu,
                                                           const float* __restrict__ dbeta,
-                                                          const float* __restrict__ dgamma, T* __restrict__ dx) {
+                                                          const float* __restrict__ dgamma, float invm,
+                                                          T* __restrict__ dx) {
   constexpr int C = VEC * 64;
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-  const float invm = 1.0f / (float)m;
   float mu[VEC], rs[VEC], g[VEC], bt[VEC], a[VEC], b[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
@@ -216,13 +216,13 @@ int tmae_bn_relu_fwd(const void* x_, int dtype, int64_t m, int c, const float* g
     const float* x = (const float*)x_;
     float* y = (float*)y_;
     BN_DISPATCH(float, bn_stats_kernel, x, m, part);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, m, eps, mean, var, rstd);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, (double)m, eps, mean, var, rstd);
     BN_DISPATCH(float, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y);
   } else {
     const __hip_bfloat16* x = (const __hip_bfloat16*)x_;
     __hip_bfloat16* y = (__hip_bfloat16*)y_;
     BN_DISPATCH(__hip_bfloat16, bn_stats_kernel, x, m, part);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, m, eps, mean, var, rstd);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, (double)m, eps, mean, var, rstd);
     BN_DISPATCH(__hip_bfloat16, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y);
   }
   return tmae_launch_status();
@@ -247,13 +247,83 @@ int tmae_bn_relu_bwd(const void* dy_, const void* x_, int dtype, int64_t m, int 
     float* dx = (float*)dx_;
     BN_DISPATCH(float, bn_bwd_reduce_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, dbeta, dgamma);
-    BN_DISPATCH(float, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, dx);
+    BN_DISPATCH(float, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, 1.0f / (float)m, dx);
   } else {
     const __hip_bfloat16 *dy = (const __hip_bfloat16*)dy_, *x = (const __hip_bfloat16*)x_;
     __hip_bfloat16* dx = (__hip_bfloat16*)dx_;
     BN_DISPATCH(__hip_bfloat16, bn_bwd_reduce_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, dbeta, dgamma);
-    BN_DISPATCH(__hip_bfloat16, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, dx);
+    BN_DISPATCH(__hip_bfloat16, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, 1.0f / (float)m, dx);
+  }
+  return tmae_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// split entry points (used by the fused sparse decoder head, deblock.hip): statistics with an explicit element
+// count (BatchNorm2d over a dense grid whose inactive cells are exact zeros: sum over the active rows / all cells),
+// partial backward sums, and the backward apply with given totals.
+// ------------------------------------------------------------------------------------------------
+static bool bn_args_ok(int64_t m, int c, int dtype) {
+  return m > 0 && (c == 64 || c == 128 || c == 256) && (dtype == TMAE_F32 || dtype == TMAE_BF16);
+}
+
+int tmae_bn_stats(const void* x_, int dtype, int64_t m, int c, double count, float eps, float* mean, float* var,
+                  float* rstd, void* wsp, size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!bn_args_ok(m, c, dtype) || !x_ || !mean || !var || !rstd || count < 1.0) return TMAE_EARG;
+  const int nb = bn_grid(m);
+  WsCarver ws(wsp, ws_bytes);
+  float* part = ws.take<float>((size_t)nb * 2 * c);
+  if (!ws.ok) return TMAE_EWS;
+  dim3 grid(nb), block(256);
+  if (dtype == TMAE_F32) { const float* x = (const float*)x_; BN_DISPATCH(float, bn_stats_kernel, x, m, part); }
+  else { const __hip_bfloat16* x = (const __hip_bfloat16*)x_; BN_DISPATCH(__hip_bfloat16, bn_stats_kernel, x, m, part); }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, count, eps, mean, var, rstd);
+  return tmae_launch_status();
+}
+
+int tmae_bn_bwd_sums(const void* dy_, const void* x_, int dtype, int64_t m, int c, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, int relu, float* sum_dz, float* sum_dz_xhat, void* wsp,
+                     size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!bn_args_ok(m, c, dtype) || !dy_ || !x_ || !mean || !rstd || !gamma || !beta || !sum_dz || !sum_dz_xhat)
+    return TMAE_EARG;
+  const int nb = bn_grid(m);
+  WsCarver ws(wsp, ws_bytes);
+  float* part = ws.take<float>((size_t)nb * 2 * c);
+  if (!ws.ok) return TMAE_EWS;
+  dim3 grid(nb), block(256);
+  if (dtype == TMAE_F32) {
+    const float *dy = (const float*)dy_, *x = (const float*)x_;
+    BN_DISPATCH(float, bn_bwd_reduce_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
+  } else {
+    const __hip_bfloat16 *dy = (const __hip_bfloat16*)dy_, *x = (const __hip_bfloat16*)x_;
+    BN_DISPATCH(__hip_bfloat16, bn_bwd_reduce_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, sum_dz, sum_dz_xhat);
+  return tmae_launch_status();
+}
+
+int tmae_bn_bwd_apply(const void* dy_, const void* x_, int dtype, int64_t m, int c, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, int relu, const float* dbeta,
+                      const float* dgamma, double count, void* dx_, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!bn_args_ok(m, c, dtype) || !dy_ || !x_ || !mean || !rstd || !gamma || !beta || !dbeta || !dgamma || !dx_ ||
+      count < 1.0)
+    return TMAE_EARG;
+  dim3 grid(bn_grid(m)), block(256);
+  const float invm = (float)(1.0 / count);
+  if (dtype == TMAE_F32) {
+    const float *dy = (const float*)dy_, *x = (const float*)x_;
+    float* dx = (float*)dx_;
+    BN_DISPATCH(float, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, invm, dx);
+  } else {
+    const __hip_bfloat16 *dy = (const __hip_bfloat16*)dy_, *x = (const __hip_bfloat16*)x_;
+    __hip_bfloat16* dx = (__hip_bfloat16*)dx_;
+    BN_DISPATCH(__hip_bfloat16, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, invm, dx);
   }
   return tmae_launch_status();
 }

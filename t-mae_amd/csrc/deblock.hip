@@ -1,0 +1,175 @@
+// A11, decoder head: ConvTranspose2d(k = s, stride s) + BatchNorm2d + ReLU of a SPARSE BEV tensor, written straight
+// into a channel slice of the dense channels-last concat buffer (SiamWCA_MAE.dense_conv, SiamWCA_MAE.py:231-253 with
+// the modules of :79-98).
+//
+// A k = s transposed conv maps every active input cell to its own s x s block of output cells and every other
+// output cell to exact zero, so the dense result is: rows v = feat @ W [m, s*s*cout] on the active cells, zero
+// elsewhere.  BatchNorm2d's batch statistics over ALL B*Y*X cells follow from the sums over the active rows (count =
+// all cells), every inactive cell becomes the per-channel constant relu(beta - mean*rstd*gamma), and the backward
+// needs the dense gradient only as (a) its rows at the active cells and (b) its per-channel column sums.  The dense
+// tensors are therefore touched once (one write forward, one read backward) instead of ~15 times.
+#include "common.h"
+
+// out[cell, coff + c] = relu(v[row(cell), sub(cell), c] * sc[c] + sh[c])   or   relu(sh[c]) on inactive cells
+template <class T>
+__global__ __launch_bounds__(256) void deblock_scatter_kernel(const T* __restrict__ v, const int32_t* __restrict__ grid,
+                                                             int batch, int ys, int xs, int s, int cout,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, T* __restrict__ out,
+                                                             int ldc, int coff) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int chunks = cout / VEC;
+  const int Y = ys * s, X = xs * s;
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)batch * Y * X * chunks) return;
+  const int ch = (int)(e % chunks);
+  const int64_t cell = e / chunks;
+  const int x = (int)(cell % X), y = (int)((cell / X) % Y), b = (int)(cell / ((int64_t)X * Y));
+  const int idx = grid[((int64_t)b * ys + y / s) * xs + x / s];
+  const int c0 = ch * VEC;
+  T tmp[VEC];
+  if (idx >= 0)
+    *reinterpret_cast<uint4*>(tmp) =
+        *reinterpret_cast<const uint4*>(v + ((int64_t)idx * s * s + (y % s) * s + (x % s)) * cout + c0);
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const float sc = rstd[c0 + k] * gamma[c0 + k];
+    const float sh = beta[c0 + k] - mean[c0 + k] * sc;
+    const float z = (idx >= 0 ? ld_f<T>(&tmp[k]) * sc : 0.f) + sh;
+    st_f<T>(&tmp[k], fmaxf(z, 0.f));
+  }
+  *reinterpret_cast<uint4*>(out + cell * ldc + coff + c0) = *reinterpret_cast<uint4*>(tmp);
+}
+
+// g[row, sub, c] = dcat[cell(row, sub), coff + c]
+template <class T>
+__global__ __launch_bounds__(256) void deblock_gather_kernel(const T* __restrict__ dcat, int ldc, int coff,
+                                                            const int32_t* __restrict__ indices, int64_t m, int ys,
+                                                            int xs, int s, int cout, T* __restrict__ g) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int chunks = cout / VEC;
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= m * s * s * chunks) return;
+  const int ch = (int)(e % chunks);
+  const int64_t rs = e / chunks;
+  const int sub = (int)(rs % (s * s));
+  const int64_t row = rs / (s * s);
+  const int b = indices[row * 3], yi = indices[row * 3 + 1], xi = indices[row * 3 + 2];
+  const int64_t cell = ((int64_t)b * ys * s + yi * s + sub / s) * (xs * s) + xi * s + sub % s;
+  *reinterpret_cast<uint4*>(g + rs * cout + ch * VEC) =
+      *reinterpret_cast<const uint4*>(dcat + cell * ldc + coff + ch * VEC);
+}
+
+// per-channel sums over all rows of a [rows, c] matrix (c <= 512, multiple of 64): partials + fixed-order finish
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t rows, float* __restrict__ part) {
+  constexpr int C = VEC * 64;
+  __shared__ float red[4][C];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+  float s[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s[i] = 0.f;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s[i] += ld_f<T>(x + r * C + lane * VEC + i);
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) red[w][lane * VEC + i] = s[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) part[(int64_t)blockIdx.x * C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nblocks, int c,
+                                                           float* __restrict__ out) {
+  __shared__ double red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double a = 0.0;
+  if (ch < c)
+    for (int k = rl; k < nblocks; k += 16) a += part[(int64_t)k * c + ch];
+  red[rl][cl] = a;
+  __syncthreads();
+  if (rl == 0 && ch < c) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][cl];
+    out[ch] = (float)t;
+  }
+}
+
+static int esz(int dtype) { return dtype == TMAE_F32 ? 4 : (dtype == TMAE_BF16 ? 2 : 0); }
+
+int tmae_deblock_scatter(const void* v, int dtype, const int32_t* grid, int batch, int ys, int xs, int s, int cout,
+                         const float* mean, const float* rstd, const float* gamma, const float* beta, void* out,
+                         int ldc, int coff, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  const int es = esz(dtype);
+  if (!es) return TMAE_EDTYPE;
+  if (!grid || !mean || !rstd || !gamma || !beta || !out || batch <= 0 || ys <= 0 || xs <= 0 || s <= 0 || cout <= 0 ||
+      (cout * es) % 16 || (ldc * es) % 16 || (coff * es) % 16)
+    return TMAE_EARG;
+  const int64_t total = (int64_t)batch * ys * s * xs * s * (cout * es / 16);
+  if (dtype == TMAE_F32)
+    hipLaunchKernelGGL(deblock_scatter_kernel<float>, dim3(tmae_cdiv(total, 256)), dim3(256), 0, stream, (const float*)v,
+                       grid, batch, ys, xs, s, cout, mean, rstd, gamma, beta, (float*)out, ldc, coff);
+  else
+    hipLaunchKernelGGL(deblock_scatter_kernel<__hip_bfloat16>, dim3(tmae_cdiv(total, 256)), dim3(256), 0, stream,
+                       (const __hip_bfloat16*)v, grid, batch, ys, xs, s, cout, mean, rstd, gamma, beta,
+                       (__hip_bfloat16*)out, ldc, coff);
+  return tmae_launch_status();
+}
+
+int tmae_deblock_gather(const void* dcat, int dtype, int ldc, int coff, const int32_t* indices, int64_t m, int ys,
+                        int xs, int s, int cout, void* g, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  const int es = esz(dtype);
+  if (!es) return TMAE_EDTYPE;
+  if (m < 0 || ys <= 0 || xs <= 0 || s <= 0 || cout <= 0 || (cout * es) % 16 || (ldc * es) % 16 || (coff * es) % 16)
+    return TMAE_EARG;
+  if (m == 0) return TMAE_OK;
+  if (!dcat || !indices || !g) return TMAE_EARG;
+  const int64_t total = m * s * s * (cout * es / 16);
+  if (dtype == TMAE_F32)
+    hipLaunchKernelGGL(deblock_gather_kernel<float>, dim3(tmae_cdiv(total, 256)), dim3(256), 0, stream,
+                       (const float*)dcat, ldc, coff, indices, m, ys, xs, s, cout, (float*)g);
+  else
+    hipLaunchKernelGGL(deblock_gather_kernel<__hip_bfloat16>, dim3(tmae_cdiv(total, 256)), dim3(256), 0, stream,
+                       (const __hip_bfloat16*)dcat, ldc, coff, indices, m, ys, xs, s, cout, (__hip_bfloat16*)g);
+  return tmae_launch_status();
+}
+
+static int colsum_grid(int64_t rows) {
+  int64_t g = (rows + 63) / 64;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+size_t tmae_column_sums_workspace(int64_t rows, int c) { return (size_t)colsum_grid(rows) * c * 4 + 256; }
+
+int tmae_column_sums(const void* x, int dtype, int64_t rows, int c, float* out, void* wsp, size_t ws_bytes,
+                     void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (rows <= 0 || c <= 0 || c % 64 || c > 512 || !x || !out) return TMAE_EARG;
+  if (dtype != TMAE_F32 && dtype != TMAE_BF16) return TMAE_EDTYPE;
+  const int nb = colsum_grid(rows);
+  WsCarver ws(wsp, ws_bytes);
+  float* part = ws.take<float>((size_t)nb * c);
+  if (!ws.ok) return TMAE_EWS;
+  dim3 grid(nb), block(256);
+#define CS(T, V) hipLaunchKernelGGL((colsum_kernel<T, V>), grid, block, 0, stream, (const T*)x, rows, part)
+#define CSD(T)                                                                                                    \
+  switch (c / 64) { case 1: CS(T, 1); break; case 2: CS(T, 2); break; case 3: CS(T, 3); break; case 4: CS(T, 4); break; \
+                    case 5: CS(T, 5); break; case 6: CS(T, 6); break; case 7: CS(T, 7); break; default: CS(T, 8); }
+  if (dtype == TMAE_F32) { CSD(float) } else { CSD(__hip_bfloat16) }
+#undef CSD
+#undef CS
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, out);
+  return tmae_launch_status();
+}

@@ -56,6 +56,13 @@ SIGNATURES = {
     'tmae_bn_workspace': (Z, [L, I]),
     'tmae_bn_relu_fwd': (I, [P, I, L, I, P, P, F, I, P, P, P, P, P, Z, P]),
     'tmae_bn_relu_bwd': (I, [P, P, I, L, I, P, P, P, P, I, P, P, P, P, Z, P]),
+    'tmae_bn_stats': (I, [P, I, L, I, D, F, P, P, P, P, Z, P]),
+    'tmae_bn_bwd_sums': (I, [P, P, I, L, I, P, P, P, P, I, P, P, P, Z, P]),
+    'tmae_bn_bwd_apply': (I, [P, P, I, L, I, P, P, P, P, I, P, P, D, P, P]),
+    'tmae_deblock_scatter': (I, [P, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P]),
+    'tmae_deblock_gather': (I, [P, I, I, I, P, L, I, I, I, I, P, P]),
+    'tmae_column_sums_workspace': (Z, [L, I]),
+    'tmae_column_sums': (I, [P, I, L, I, P, P, Z, P]),
     'tmae_linear_wgrad_workspace': (Z, [L, I, I]),
     'tmae_linear_wgrad': (I, [P, L, P, L, L, I, I, P, P, P, Z, P]),
     'tmae_spconv_wgrad': (I, [P, L, P, L, P, L, I, I, P, P, Z, P]),

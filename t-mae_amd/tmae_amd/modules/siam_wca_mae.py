@@ -88,12 +88,20 @@ class SiamWCA_MAE(nn.Module):
 
     # ------------------------------------------------------------------ decoder (SiamWCA_MAE.py:231-253)
     def dense_conv(self, feats, strides):
-        ups, out_strides = [], []
+        out_strides, sources = [], []
         for i, src in enumerate(self.model_cfg.FEATURES_SOURCE):
-            d = feats[src].dense()                                   # [B,C,Y,X], channels-last memory
-            ups.append(self.decoder_deblocks[i](d))
+            sp = feats[src]
+            blk = self.decoder_deblocks[i]
+            sources.append((sp.features, sp.grid, sp.indices, sp.spatial_shape, blk[0], blk[1]))
             out_strides.append(strides[src] // self.model_cfg.FUSE_LAYER[src].UPSAMPLE_STRIDE)
-        spatial = self.decoder_conv_out(torch.cat(ups, dim=1))
+        if ops.deblocks_fusable(sources, self.training):
+            # one write of the concat buffer instead of dense() + deconv + BN + ReLU + cat over dense tensors
+            cat = ops.deblocks_to_dense(sources, feats[self.model_cfg.FEATURES_SOURCE[0]].batch_size,
+                                        self.sparse_shape[0], self.sparse_shape[1]).permute(0, 3, 1, 2)
+        else:
+            cat = torch.cat([self.decoder_deblocks[i](feats[src].dense())
+                             for i, src in enumerate(self.model_cfg.FEATURES_SOURCE)], dim=1)
+        spatial = self.decoder_conv_out(cat)
         return spatial, out_strides[0]
 
     # ------------------------------------------------------------------ targets (SiamWCA_MAE.py:124-152)

@@ -593,6 +593,151 @@ def sparse_to_dense(feat, grid, indices, batch, ny, nx):
     return _ToDense.apply(feat, grid, indices, batch, ny, nx)
 
 
+
+class _DeblocksToDense(torch.autograd.Function):
+    """dense() -> ConvTranspose2d(k=s, stride s) -> BatchNorm2d (batch stats) -> ReLU -> cat(dim=1) for several
+    sparse sources at once, written straight into the channels-last concat buffer (csrc/deblock.hip).
+    args = (feat_i, weight_i [cin, cout, s, s], gamma_i, beta_i) per source."""
+
+    @staticmethod
+    def forward(ctx, metas, batch, ny, nx, eps, *args):
+        n_src = len(metas)
+        feats = args[0::4]
+        dev = feats[0].device
+        cdt = compute_dtype(feats[0])
+        couts = [args[4 * i + 1].shape[1] for i in range(n_src)]
+        ctot = sum(couts)
+        cat = torch.empty((batch, ny, nx, ctot), dtype=cdt, device=dev)
+        count = float(batch * ny * nx)
+        saved, stats = [], []
+        coff = 0
+        for i, (grid, indices, ys, xs, s) in enumerate(metas):
+            feat, w, gamma, beta = args[4 * i:4 * i + 4]
+            cin, cout = w.shape[0], w.shape[1]
+            assert ys * s == ny and xs * s == nx and w.shape[2] == s and w.shape[3] == s
+            x_c = feat.to(cdt).contiguous()
+            wmat = w.detach().to(cdt).permute(2, 3, 1, 0).reshape(s * s * cout, cin).contiguous()
+            v = torch.nn.functional.linear(x_c, wmat)                       # [m, s*s*cout], columns (dy, dx, cout)
+            m = v.shape[0]
+            mean = torch.empty((cout,), dtype=torch.float32, device=dev)
+            var, rstd = torch.empty_like(mean), torch.empty_like(mean)
+            g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+            rows = m * s * s
+            wsb = lib.tmae_bn_workspace(rows, cout)
+            ws = _ws(wsb, dev)
+            check(lib.tmae_bn_stats(_p(v), _dt(v), rows, cout, count, float(eps[i]), _p(mean), _p(var), _p(rstd),
+                                    _p(ws), wsb, _s()), 'tmae_bn_stats')
+            check(lib.tmae_deblock_scatter(_p(v), _dt(v), _p(grid), batch, ys, xs, s, cout, _p(mean), _p(rstd), _p(g32),
+                                           _p(b32), _p(cat), ctot, coff, _s()), 'tmae_deblock_scatter')
+            saved += [x_c, wmat, v, mean, rstd, g32, b32, grid, indices]
+            stats += [mean, var]
+            coff += cout
+        ctx.save_for_backward(*saved)
+        ctx.meta = (n_src, [(ys, xs, s) for (_, _, ys, xs, s) in metas], batch, ny, nx, couts, count,
+                    [(args[4 * i].dtype, args[4 * i + 1].dtype, args[4 * i + 2].dtype, args[4 * i + 3].dtype)
+                     for i in range(n_src)])
+        ctx.mark_non_differentiable(*stats)
+        return (cat, *stats)
+
+    @staticmethod
+    def backward(ctx, dcat, *_unused):
+        n_src, shapes, batch, ny, nx, couts, count, dts = ctx.meta
+        saved = ctx.saved_tensors
+        ctot = sum(couts)
+        dev = dcat.device
+        cdt = saved[2].dtype
+        dcat = dcat.to(cdt)
+        if not dcat.is_contiguous():
+            dcat = dcat.contiguous()
+        nrows = batch * ny * nx
+        s_all = torch.empty((ctot,), dtype=torch.float32, device=dev)
+        wsb = lib.tmae_column_sums_workspace(nrows, ctot)
+        ws = _ws(wsb, dev)
+        check(lib.tmae_column_sums(_p(dcat), _dt(dcat), nrows, ctot, _p(s_all), _p(ws), wsb, _s()), 'tmae_column_sums')
+        grads = []
+        coff = 0
+        for i in range(n_src):
+            x_c, wmat, v, mean, rstd, g32, b32, grid, indices = saved[9 * i:9 * i + 9]
+            ys, xs, s = shapes[i]
+            cout = couts[i]
+            m = v.shape[0]
+            rows = m * s * s
+            g = torch.empty_like(v)
+            check(lib.tmae_deblock_gather(_p(dcat), _dt(dcat), ctot, coff, _p(indices), m, ys, xs, s, cout, _p(g), _s()),
+                  'tmae_deblock_gather')
+            s_act = torch.empty((cout,), dtype=torch.float32, device=dev)
+            wsb = lib.tmae_column_sums_workspace(rows, cout)
+            ws = _ws(wsb, dev)
+            check(lib.tmae_column_sums(_p(g), _dt(g), rows, cout, _p(s_act), _p(ws), wsb, _s()), 'tmae_column_sums')
+            sum_dz = torch.empty((cout,), dtype=torch.float32, device=dev)
+            sum_dzx = torch.empty_like(sum_dz)
+            wsb = lib.tmae_bn_workspace(rows, cout)
+            ws = _ws(wsb, dev)
+            check(lib.tmae_bn_bwd_sums(_p(g), _p(v), _dt(v), rows, cout, _p(mean), _p(rstd), _p(g32), _p(b32), 1,
+                                       _p(sum_dz), _p(sum_dzx), _p(ws), wsb, _s()), 'tmae_bn_bwd_sums')
+            # inactive cells: z = beta - mean*rstd*gamma (constant per channel), xhat = -mean*rstd
+            xhat0 = -mean * rstd
+            live0 = ((b32 + xhat0 * g32) > 0).float()
+            rest = (s_all[coff:coff + cout] - s_act) * live0
+            dbeta = (sum_dz + rest).contiguous()
+            dgamma = (sum_dzx + rest * xhat0).contiguous()
+            dv = torch.empty_like(v)
+            check(lib.tmae_bn_bwd_apply(_p(g), _p(v), _dt(v), rows, cout, _p(mean), _p(rstd), _p(g32), _p(b32), 1,
+                                        _p(dbeta), _p(dgamma), count, _p(dv), _s()), 'tmae_bn_bwd_apply')
+            dfeat = (dv @ wmat) if ctx.needs_input_grad[5 + 4 * i] else None
+            dwmat = None
+            if ctx.needs_input_grad[5 + 4 * i + 1]:
+                if _wgrad_ok(dv, x_c):
+                    dwmat, _ = linear_wgrad(dv, x_c, want_bias=False)
+                else:
+                    dwmat = dv.float().t() @ x_c.float()
+                cin = x_c.shape[1]
+                dwmat = dwmat.view(s, s, cout, cin).permute(3, 2, 0, 1).to(dts[i][1])
+            grads += [None if dfeat is None else dfeat.to(dts[i][0]), dwmat, dgamma.to(dts[i][2]), dbeta.to(dts[i][3])]
+            coff += cout
+        return (None, None, None, None, None, *grads)
+
+
+def deblocks_to_dense(sources, batch, ny, nx):
+    """sources: list of (SparseConvTensor-like features [m,cin], grid, indices, (ys, xs), ConvTranspose2d, BatchNorm2d)
+    with kernel == stride and no bias.  Returns the channels-last concat [batch, ny, nx, sum(cout)] of
+    relu(bn(deconv(dense(source)))) -- SiamWCA_MAE.dense_conv (SiamWCA_MAE.py:231-250) -- and updates the running
+    statistics of the norms like torch does."""
+    metas, args, eps = [], [], []
+    for feat, grid, indices, (ys, xs), deconv, bn in sources:
+        s = int(deconv.stride[0])
+        metas.append((grid, indices, int(ys), int(xs), s))
+        args += [feat, deconv.weight, bn.weight, bn.bias]
+        eps.append(bn.eps)
+    out = _DeblocksToDense.apply(metas, batch, ny, nx, eps, *args)
+    cat, stats = out[0], out[1:]
+    n = float(batch * ny * nx)
+    with torch.no_grad():
+        for i, src in enumerate(sources):
+            bn = src[5]
+            if bn.track_running_stats:
+                mean, var = stats[2 * i], stats[2 * i + 1]
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var, alpha=mom * n / (n - 1))
+                bn.num_batches_tracked += 1
+    return cat
+
+
+def deblocks_fusable(sources, training):
+    for feat, grid, indices, shape, deconv, bn in sources:
+        if not (isinstance(deconv, torch.nn.ConvTranspose2d) and isinstance(bn, torch.nn.BatchNorm2d)):
+            return False
+        s = deconv.stride[0]
+        if (deconv.kernel_size != (s, s) or deconv.stride != (s, s) or deconv.bias is not None
+                or deconv.padding != (0, 0) or deconv.output_padding != (0, 0) or deconv.groups != 1):
+            return False
+        if not (training and bn.training and bn.affine and deconv.out_channels in (64, 128, 256) and feat.is_cuda
+                and feat.shape[0] > 0):
+            return False
+    return True
+
+
 class _DenseGather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dense, grid, indices):

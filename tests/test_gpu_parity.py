@@ -534,6 +534,54 @@ def test_batchnorm_relu_kernel_vs_torch():
 
 # ------------------------------------------------------------------------------------------ A9 / A11
 
+def test_fused_decoder_head_vs_torch_dense():
+    """A11: dense() -> ConvTranspose2d -> BatchNorm2d -> ReLU -> cat (SiamWCA_MAE.py:231-250) against the dense torch
+    modules, forward, all gradients and running statistics."""
+    from tmae_amd import ops
+    from tmae_amd.modules.sparse import SparseConvTensor
+    torch.manual_seed(5)
+    B, Y, X = 2, 24, 16
+    specs = [(1, 32, 128), (2, 48, 128), (4, 64, 64)]              # (stride, cin, cout)
+    for dt, tol in ((torch.float32, 2e-4), (torch.bfloat16, 6e-2)):
+        sources, dense_in, mods = [], [], []
+        for s, cin, cout in specs:
+            ys, xs = Y // s, X // s
+            occ = torch.rand(B, ys, xs, device=dev()) < 0.3
+            occ[0, 0, 0] = True
+            ind = occ.nonzero().int().contiguous()
+            feat = (torch.randn(ind.shape[0], cin, device=dev())).to(dt).requires_grad_(True)
+            sp = SparseConvTensor(feat, ind, [ys, xs], B)
+            deconv = torch.nn.ConvTranspose2d(cin, cout, s, stride=s, bias=False).to(dev())
+            bn = torch.nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01).to(dev())
+            with torch.no_grad():
+                bn.weight.normal_(1, 0.2), bn.bias.normal_(0, 0.3)
+            deconv2 = torch.nn.ConvTranspose2d(cin, cout, s, stride=s, bias=False).to(dev())
+            bn2 = torch.nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01).to(dev())
+            deconv2.load_state_dict(deconv.state_dict()), bn2.load_state_dict(bn.state_dict())
+            sources.append((sp.features, sp.grid, sp.indices, sp.spatial_shape, deconv, bn))
+            f2 = feat.detach().float().clone().requires_grad_(True)
+            d = torch.zeros(B, ys, xs, cin, device=dev())
+            d = d.index_put((ind[:, 0].long(), ind[:, 1].long(), ind[:, 2].long()), f2)
+            dense_in.append(f2)
+            mods.append((deconv2, bn2, d.permute(0, 3, 1, 2)))
+        assert ops.deblocks_fusable(sources, True)
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+            cat = ops.deblocks_to_dense(sources, B, Y, X)
+        ref = torch.cat([torch.relu(bn2(deconv2(d))) for deconv2, bn2, d in mods], dim=1).permute(0, 2, 3, 1)
+        assert cat.shape == ref.shape and cat.dtype == dt
+        assert (cat.float() - ref).abs().max().item() <= tol
+        go = torch.randn_like(ref)
+        cat.backward(go.to(dt))
+        ref.backward(go.to(dt).float())
+        for (feat, _, _, _, deconv, bn), f2, (deconv2, bn2, _) in zip(sources, dense_in, mods):
+            for a, b, name in ((feat.grad, f2.grad, 'feat'), (deconv.weight.grad, deconv2.weight.grad, 'w'),
+                               (bn.weight.grad, bn2.weight.grad, 'gamma'), (bn.bias.grad, bn2.bias.grad, 'beta')):
+                lim = tol * 3 * max(1.0, float(b.abs().max()))
+                assert (a.float() - b).abs().max().item() <= lim, (dt, name, (a.float() - b).abs().max().item(), lim)
+            assert (bn.running_mean - bn2.running_mean).abs().max().item() < 1e-4
+            assert (bn.running_var - bn2.running_var).abs().max().item() < 1e-3
+
+
 def test_sparse_conv_golden_and_dense(oracle):
     from tmae_amd.modules.sparse import SparseConvTensor, SubMConv2d, SparseConv2d
     g = golden('F9_sparse_conv')
