@@ -476,7 +476,10 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
       // pass 1 over the key tiles: logits, probabilities and dP; D_i = sum_j P_ij dP_ij is taken from THESE values
       // (not from dO . O with the bf16-rounded saved output), so that sum_j dS_ij = 0 holds to fp32 rounding --
       // the tau gradient sum_ij dS_ij s_ij is a difference of large terms and is biased otherwise
-      f32x4 sTk[NT], pTk[NT], dPk[NT];
+      // NT == 4: the tiles are recomputed in pass 2 (4 MFMAs + 4 exps per tile pair, far below the budget of this
+      // latency-bound kernel) instead of being held in 48 registers, which keeps two waves per SIMD resident.
+      constexpr bool RECOMP = NT >= 4;
+      f32x4 sTk[RECOMP ? 1 : NT], pTk[RECOMP ? 1 : NT], dPk[RECOMP ? 1 : NT];
       float dacc = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
@@ -486,14 +489,14 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
           f32x4 sT = mfma_s(kl[kt], qf[qt], z);
           sT = mfma_s(kf[kt], ql[qt], sT);
           sT = mfma_s(kf[kt], qf[qt], sT);
-          dPk[kt] = mfma_s(vr[kt], gf[qt], z);
-          sTk[kt] = sT;
+          const f32x4 dP = mfma_s(vr[kt], gf[qt], z);
+          if constexpr (!RECOMP) { sTk[kt] = sT; dPk[kt] = dP; }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool ok = qok && (kt * 16 + 4 * g + r < Tk);
             const float p = ok ? __expf(sT[r] - lse_i[qt]) : 0.f;
-            pTk[kt][r] = p;
-            dacc += p * dPk[kt][r];
+            if constexpr (!RECOMP) pTk[kt][r] = p;
+            dacc += p * dP[r];
           }
         }
       }
@@ -502,12 +505,27 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         if (kt < nk) {
+          f32x4 sT, dP, pT;
+          if constexpr (RECOMP) {
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            sT = mfma_s(kl[kt], qf[qt], z);
+            sT = mfma_s(kf[kt], ql[qt], sT);
+            sT = mfma_s(kf[kt], qf[qt], sT);
+            dP = mfma_s(vr[kt], gf[qt], z);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool ok = qok && (kt * 16 + 4 * g + r < Tk);
+              pT[r] = ok ? __expf(sT[r] - lse_i[qt]) : 0.f;
+            }
+          } else {
+            sT = sTk[kt]; dP = dPk[kt]; pT = pTk[kt];
+          }
           s16x4 dsT, pTb;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = pTk[kt][r];
-            const float ds = p * (dPk[kt][r] - dacc);
-            dtau_acc += (p > 0.f) ? ds * sTk[kt][r] : 0.f;
+            const float p = pT[r];
+            const float ds = p * (dP[r] - dacc);
+            dtau_acc += (p > 0.f) ? ds * sT[r] : 0.f;
             dsT[r] = f2bf(ds);
             pTb[r] = f2bf(p);
           }
