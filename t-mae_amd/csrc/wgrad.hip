@@ -10,6 +10,7 @@
 // Partial [N,K] blocks go to fp32 slabs (plain stores) and a second tiny kernel sums the slabs in a fixed order:
 // deterministic, no atomics.
 #include "common.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -39,7 +40,7 @@ __device__ __forceinline__ bf16x8 load_frag(const char* img, int cb, int lane) {
   return *reinterpret_cast<bf16x8*>(&v);
 }
 
-__global__ __launch_bounds__(256) void wgrad_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
                                                    const __hip_bfloat16* __restrict__ X, int64_t ldx, int64_t M,
                                                    int N, int K, int rows_per_split, float* __restrict__ slab,
                                                    int64_t count, bool has_bias, int NB, int KB, int S,
@@ -64,33 +65,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const __hip_bfloat16* __rest
   float* __restrict__ slab_w = slab + (int64_t)s * count;
   float* __restrict__ slab_b = slab_w + (int64_t)N * K;
 
-  uint4 ry[2], rx[2];
-  int xi[2] = {-1, -1};                 // gathered mode: feature-row ids of the NEXT slice, fetched one step early so
-  auto iload = [&](int step) {          // the row loads never wait on an index load (no dependent round trip)
+  // register staging, two slices deep: while slice st is contracted out of LDS, the loads of slices st+1 and st+2
+  // are in flight (32 KB per workgroup) -- one slice of prefetch left the kernel latency-bound at ~2.5 TB/s.
+  // Slice t uses register set t & 1; the main loop is unrolled by two so that every set index is a constant.
+  uint4 ry[2][2], rx[2][2];
+  int xi[2][2] = {{-1, -1}, {-1, -1}};  // gathered mode: feature-row ids, fetched one slice before their row loads so
+  auto iload = [&](int step, int P) {   // the row loads never wait on an index load (no dependent round trip)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int64_t m = m_begin + (int64_t)step * WG_MS + ((tid + 256 * i) >> 4);
-      xi[i] = (nbr && m < m_end) ? nbr[m * 9 + tap] : -1;
+      xi[P][i] = (nbr && m < m_end) ? nbr[m * 9 + tap] : -1;
     }
   };
-  auto gload = [&](int step) {
+  auto gload = [&](int step, int P) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
       const int64_t m = m_begin + (int64_t)step * WG_MS + row;
       const int cy = n0 + ch * 8, cx = k0 + ch * 8;
-      ry[i] = (m < m_end && cy < N) ? *reinterpret_cast<const uint4*>(dY + m * ldy + cy) : make_uint4(0, 0, 0, 0);
-      const int64_t xr = nbr ? (int64_t)xi[i] : m;
-      rx[i] = (m < m_end && cx < K && xr >= 0) ? *reinterpret_cast<const uint4*>(X + xr * ldx + c0 + ch * 8)
-                                              : make_uint4(0, 0, 0, 0);
+      ry[P][i] = (m < m_end && cy < N) ? *reinterpret_cast<const uint4*>(dY + m * ldy + cy) : make_uint4(0, 0, 0, 0);
+      const int64_t xr = nbr ? (int64_t)xi[P][i] : m;
+      rx[P][i] = (m < m_end && cx < K && xr >= 0) ? *reinterpret_cast<const uint4*>(X + xr * ldx + c0 + ch * 8)
+                                                 : make_uint4(0, 0, 0, 0);
     }
   };
-  auto lwrite = [&](int buf) {
+  auto lwrite = [&](int buf, int P) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
-      *reinterpret_cast<uint4*>(&lds[buf][0][tile_off(row, ch)]) = ry[i];
-      *reinterpret_cast<uint4*>(&lds[buf][1][tile_off(row, ch)]) = rx[i];
+      *reinterpret_cast<uint4*>(&lds[buf][0][tile_off(row, ch)]) = ry[P][i];
+      *reinterpret_cast<uint4*>(&lds[buf][1][tile_off(row, ch)]) = rx[P][i];
     }
   };
 
@@ -105,21 +109,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const __hip_bfloat16* __rest
   const bf16x8 ones = *reinterpret_cast<bf16x8*>(&ones_s);
 
   if (steps > 0) {
-    iload(0);
-    gload(0);
-    if (steps > 1) iload(1);
-    lwrite(0);
+    iload(0, 0);
+    if (steps > 1) iload(1, 1);
+    gload(0, 0);
+    if (steps > 1) gload(1, 1);
+    if (steps > 2) iload(2, 0);
+    lwrite(0, 0);
   }
   __syncthreads();
-  for (int st = 0; st < steps; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < steps) gload(st + 1);
-    if (st + 2 < steps) iload(st + 2);
+  auto step = [&](int st, int P) {      // P == st & 1, a literal at both call sites
+    if (st + 2 < steps) gload(st + 2, P);
+    if (st + 3 < steps) iload(st + 3, P ^ 1);
     bf16x8 fa[4], fb[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      fa[t] = load_frag(lds[buf][0], wn * 4 + t, lane);
-      fb[t] = load_frag(lds[buf][1], wk * 4 + t, lane);
+      fa[t] = load_frag(lds[P][0], wn * 4 + t, lane);
+      fb[t] = load_frag(lds[P][1], wk * 4 + t, lane);
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -129,8 +134,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const __hip_bfloat16* __rest
 #pragma unroll
       for (int a = 0; a < 4; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
     }
-    if (st + 1 < steps) lwrite(buf ^ 1);
+    if (st + 1 < steps) lwrite(P ^ 1, P ^ 1);
     __syncthreads();
+  };
+  for (int st = 0; st < steps; st += 2) {
+    step(st, 0);
+    if (st + 1 < steps) step(st + 1, 1);
   }
   // C layout of mfma_f32_16x16x*: lane holds rows 4*(lane>>4)+r, column lane&15
   const int g = lane >> 4, ci = lane & 15;
@@ -150,7 +159,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const __hip_bfloat16* __rest
   }
 }
 
-// Slab reduction, two levels, both in a fixed order (deterministic).  Level 1: block (x, y) sums the slabs
+// Slab reduction, two levels, both in a fixed order (deterministic).  (A single launch whose last-arriving block
+// finishes the sum needs a device-scope fence per block -- an L2 write-back on every XCD -- and measured 2-4x slower
+// than this kernel boundary.)  Level 1: block (x, y) sums the slabs
 // y, y+RG, y+2RG, ... for 1024 consecutive elements (float4 per thread) into part[y]; level 2 sums the RG parts.
 #define WG_RG 8
 __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restrict__ slab, int splits, int64_t count,
@@ -179,7 +190,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
 
 static void wgrad_plan(int64_t m, int n, int k, int& splits, int& rows_per_split) {
   const int nb = ((n + WG_BN - 1) / WG_BN) * ((k + WG_BK - 1) / WG_BK);
-  int64_t s = (768 + nb - 1) / nb;                        // ~3 workgroups per CU in flight
+  static const int target = [] { const char* e = getenv("TMAE_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+  int64_t s = (target + nb - 1) / nb;
   const int64_t max_s = (m + 255) / 256;                  // at least 8 steps per workgroup
   if (s > max_s) s = max_s;
   if (s >= 8) s = (s + 7) / 8 * 8;                        // token chunks are dealt over the 8 XCDs: keep them even
