@@ -21,3 +21,19 @@ print(f'wall {(t1 - t0) / 3e6:.1f} ms/step, GPU busy {busy / 3e6:.1f} ms/step, {
 print('| ms/step | % | launches/step | avg us | kernel |\n|---:|---:|---:|---:|---|')
 for n, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
     print(f'| {d / 3e6:.2f} | {100 * d / busy:.1f} | {c / 3:.1f} | {d / c / 1e3:.1f} | `{n}` |')
+
+# the roofline probe of bench.py (kernel_roofline): the launches of the stage-1 backward kernels after the last
+# voxelisation; the op = one launch of each tile class, its duration = the sum of the three averages
+probe = [r for r in rest[vk[-1]:] if 'win_attn_bwd_mfma_kernel<16' in r['Kernel_Name']]
+if probe:
+    pa = collections.defaultdict(lambda: [0, 0])
+    for r in probe:
+        n = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')
+        pa[n][0] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+        pa[n][1] += 1
+    print('\nroofline probe (bench.py kernel_roofline), per launch:')
+    tot = 0.0
+    for n, (d, c) in sorted(pa.items()):
+        print(f'- `{n}`: {c} launches, avg {d / c / 1e3:.1f} us')
+        tot += d / c / 1e3
+    print(f'- op (sum of the tile classes): {tot:.1f} us')
