@@ -159,6 +159,138 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 output tile, 8 waves (wave tile 128 x 64): used when n >= 256 and k >= 256 (the d = 256 stages and their
+// sparse convs).  With the 128 x 128 tile those shapes re-read every operand 2-18x through L2 and ran at ~2 TB/s of
+// algorithmic bytes; here each workgroup streams 32 KB per slice for four times the MFMA work.  One workgroup per CU
+// (238 registers, 64 KB LDS), two slices of loads in flight.  Each operand slice is kept as two [32][128] images so
+// the swizzle and the fragment reads are those of the small kernel.  The bias gradient is summed on the VALU from the
+// staged dY chunks (a thread always stages the same 8 columns), not with an extra MFMA: no accumulator registers.
+// ------------------------------------------------------------------------------------------------
+#define WG2_B 256
+__global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
+                                                         const __hip_bfloat16* __restrict__ X, int64_t ldx, int64_t M,
+                                                         int N, int K, int rows_per_split, float* __restrict__ slab,
+                                                         int64_t count, bool has_bias, int NB, int KB, int S,
+                                                         const int32_t* __restrict__ nbr, int cin) {
+  __shared__ __attribute__((aligned(16))) char lds[2][2][2][WG_MS * 256];     // [buffer][operand][column half]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w >> 2, wk = w & 3;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int per_s = NB * KB;
+  const int s = (j / per_s) * 8 + xcd;
+  if (s >= S) return;
+  const int blk = j % per_s;
+  const int n0 = (blk % NB) * WG2_B, kblk = blk / NB, k0 = kblk * WG2_B;
+  const int64_t m_begin = (int64_t)s * rows_per_split;
+  const int64_t m_end = min(M, m_begin + (int64_t)rows_per_split);
+  const int steps = m_end > m_begin ? (int)((m_end - m_begin + WG_MS - 1) / WG_MS) : 0;
+  const bool want_bias = has_bias && kblk == 0;                 // workgroup-uniform
+  float* __restrict__ slab_w = slab + (int64_t)s * count;
+  float* __restrict__ slab_b = slab_w + (int64_t)N * K;
+  // staging: thread owns 16-byte chunk ch (0..31) of rows r0 and r0 + 16 of both operands
+  const int r0 = tid >> 5, ch = tid & 31;
+  const int cy = n0 + ch * 8, cx = k0 + ch * 8;
+  const int tap = nbr ? cx / cin : 0, xcol = nbr ? cx % cin : cx;   // gathered X: column cx lies inside tap cx / cin
+  uint4 ry[2][2], rx[2][2];
+  int xi[2][2] = {{-1, -1}, {-1, -1}};
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto iload = [&](int step, int P) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t m = m_begin + (int64_t)step * WG_MS + r0 + 16 * i;
+      xi[P][i] = (nbr && m < m_end && cx < K) ? nbr[m * 9 + tap] : -1;
+    }
+  };
+  auto gload = [&](int step, int P) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t m = m_begin + (int64_t)step * WG_MS + r0 + 16 * i;
+      ry[P][i] = (m < m_end && cy < N) ? *reinterpret_cast<const uint4*>(dY + m * ldy + cy) : make_uint4(0, 0, 0, 0);
+      const int64_t xr = nbr ? (int64_t)xi[P][i] : m;
+      rx[P][i] = (m < m_end && cx < K && xr >= 0) ? *reinterpret_cast<const uint4*>(X + xr * ldx + xcol)
+                                                 : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lwrite = [&](int buf, int P) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = tile_off(r0 + 16 * i, ch & 15);
+      *reinterpret_cast<uint4*>(&lds[buf][0][ch >> 4][off]) = ry[P][i];
+      *reinterpret_cast<uint4*>(&lds[buf][1][ch >> 4][off]) = rx[P][i];
+      if (want_bias) {
+        const unsigned u[4] = {ry[P][i].x, ry[P][i].y, ry[P][i].z, ry[P][i].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bsum[2 * q] += __uint_as_float(u[q] << 16);
+          bsum[2 * q + 1] += __uint_as_float(u[q] & 0xFFFF0000u);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (steps > 0) {
+    iload(0, 0);
+    if (steps > 1) iload(1, 1);
+    gload(0, 0);
+    if (steps > 1) gload(1, 1);
+    if (steps > 2) iload(2, 0);
+    lwrite(0, 0);
+  }
+  __syncthreads();
+  auto step = [&](int st, int P) {
+    if (st + 2 < steps) gload(st + 2, P);
+    if (st + 3 < steps) iload(st + 3, P ^ 1);
+    bf16x8 fb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fb[t] = load_frag(lds[P][1][wk >> 1], (wk & 1) * 4 + t, lane);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const bf16x8 fa = load_frag(lds[P][0][wn], a, lane);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[b], acc[a][b], 0, 0, 0);
+    }
+    if (st + 1 < steps) lwrite(P ^ 1, P ^ 1);
+    __syncthreads();
+  };
+  for (int st = 0; st < steps; st += 2) {
+    step(st, 0);
+    if (st + 1 < steps) step(st + 1, 1);
+  }
+  const int g = lane >> 4, ci = lane & 15;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * 128 + a * 16 + 4 * g + r;
+      if (n >= N) continue;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int k = k0 + wk * 64 + b * 16 + ci;
+        if (k < K) slab_w[(int64_t)n * K + k] = acc[a][b][r];
+      }
+    }
+  }
+  if (want_bias) {                       // 16 threads (r0 = 0..15) hold partial sums of the same 8 columns
+    float* red = reinterpret_cast<float*>(&lds[0][0][0][0]);     // [16][256] floats = 16 KB, the loop is done with LDS
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[r0 * 256 + ch * 8 + q] = bsum[q];
+    __syncthreads();
+    if (tid < 256 && n0 + tid < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r * 256 + tid];
+      slab_b[n0 + tid] = t;
+    }
+  }
+}
+
 // Slab reduction, two levels, both in a fixed order (deterministic).  (A single launch whose last-arriving block
 // finishes the sum needs a device-scope fence per block -- an L2 write-back on every XCD -- and measured 2-4x slower
 // than this kernel boundary.)  Level 1: block (x, y) sums the slabs
@@ -188,13 +320,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
   else if (db && e < nk + n) db[e - nk] = acc;
 }
 
+// a single 256 x 256 output tile (n = k = 256) stays with the small kernel: there the big tile only doubles the slab
+// traffic (256 splits instead of 128) -- measured 5-15 % slower
+static bool wgrad_big_tile(int n, int k) {
+  return n >= WG2_B && k >= WG2_B && ((n + WG2_B - 1) / WG2_B) * ((k + WG2_B - 1) / WG2_B) >= 2;
+}
+
+// Token split.  A workgroup id is dealt to XCD id % 8 and all output tiles of one token chunk go to the same XCD
+// (they share dY / X through that L2), so chunks are handed out per XCD: as many as fit the XCD's resident
+// workgroups in ONE round (32 CUs x 2 for the 128-tile kernel, x 1 for the 256-tile kernel) -- a second, partly
+// filled round costs a whole extra pass (measured: 576 workgroups on 512 slots ran 1.8x longer than 504).
 static void wgrad_plan(int64_t m, int n, int k, int& splits, int& rows_per_split) {
-  const int nb = ((n + WG_BN - 1) / WG_BN) * ((k + WG_BK - 1) / WG_BK);
-  static const int target = [] { const char* e = getenv("TMAE_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
-  int64_t s = (target + nb - 1) / nb;
+  const bool big = wgrad_big_tile(n, k);
+  const int bt = big ? WG2_B : WG_BN;
+  const int nb = ((n + bt - 1) / bt) * ((k + bt - 1) / bt);
+  static const int slots = [] { const char* e = getenv("TMAE_WGRAD_SLOTS"); return e ? atoi(e) : 0; }();
+  const int per_xcd = slots > 0 ? slots : (big ? 32 : 64);
+  int64_t c = per_xcd / nb;
+  if (c < 1) c = 1;
+  int64_t s = 8 * c;
   const int64_t max_s = (m + 255) / 256;                  // at least 8 steps per workgroup
   if (s > max_s) s = max_s;
-  if (s >= 8) s = (s + 7) / 8 * 8;                        // token chunks are dealt over the 8 XCDs: keep them even
   if (s < 1) s = 1;
   int64_t rows = (m + s - 1) / s;
   rows = (rows + WG_MS - 1) / WG_MS * WG_MS;
@@ -202,7 +348,6 @@ static void wgrad_plan(int64_t m, int n, int k, int& splits, int& rows_per_split
   splits = (int)((m + rows - 1) / rows);
   if (splits < 1) splits = 1;
   rows_per_split = (int)rows;
-  (void)s;
 }
 
 // slab row = [n*k weight partials | n bias partials | pad to a multiple of 4 floats]
@@ -217,7 +362,7 @@ size_t tmae_linear_wgrad_workspace(int64_t m, int n, int k) {
 static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k, float* dw,
                         float* db, const int32_t* nbr, int cin, void* wsp, size_t ws_bytes, hipStream_t stream) {
   if (m < 0 || n <= 0 || k <= 0 || !dw || (n % 8) || (k % 8) || (ldy % 8) || (ldx % 8)) return TMAE_EARG;
-  if (nbr && (cin <= 0 || cin % WG_BK || k != 9 * cin)) return TMAE_EARG;
+  if (nbr && (cin <= 0 || cin % WG_BK || k != 9 * cin || (((uintptr_t)nbr) & 3))) return TMAE_EARG;
   if (m > 0 && (!dy || !x)) return TMAE_EARG;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return TMAE_EARG;
   int splits, rows;
@@ -228,10 +373,18 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
   float* part = ws.take<float>((size_t)WG_RG * count);
   if (!ws.ok) return TMAE_EWS;
   // without a bias the slabs' bias columns stay unwritten; the reduction discards those sums
-  const int NB = (n + WG_BN - 1) / WG_BN, KB = (k + WG_BK - 1) / WG_BK;
-  const unsigned nblocks = 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
-  hipLaunchKernelGGL(wgrad_kernel, dim3(nblocks), dim3(256), 0, stream, (const __hip_bfloat16*)dy, ldy,
-                     (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr, cin);
+  if (wgrad_big_tile(n, k)) {
+    const int NB = (n + WG2_B - 1) / WG2_B, KB = (k + WG2_B - 1) / WG2_B;
+    const unsigned nblocks = 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
+    hipLaunchKernelGGL(wgrad256_kernel, dim3(nblocks), dim3(512), 0, stream, (const __hip_bfloat16*)dy, ldy,
+                       (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr,
+                       cin);
+  } else {
+    const int NB = (n + WG_BN - 1) / WG_BN, KB = (k + WG_BK - 1) / WG_BK;
+    const unsigned nblocks = 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(nblocks), dim3(256), 0, stream, (const __hip_bfloat16*)dy, ldy,
+                       (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr, cin);
+  }
   hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(tmae_cdiv(count / 4, 256), WG_RG), dim3(256), 0, stream, slab, splits,
                      count, part);
   hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(tmae_cdiv(count, 256)), dim3(256), 0, stream, part, count, n, k, dw,

@@ -437,7 +437,7 @@ def test_linear_wgrad_kernel_vs_torch():
     from tmae_amd import ops
     torch.manual_seed(0)
     for (m, n, k) in ((4096, 128, 128), (50001, 256, 128), (37777, 48, 128), (20000, 256, 1152), (9000, 512, 256),
-                      (131072, 64, 64)):
+                      (131072, 64, 64), (30011, 256, 256), (12345, 256, 512), (8200, 2048, 256), (40000, 264, 328)):
         dy = (torch.randn(m, n, device=dev()) * 0.5).bfloat16()
         x = torch.randn(m, k, device=dev()).bfloat16()
         dw, db = ops.linear_wgrad(dy, x)
