@@ -56,6 +56,7 @@ class SiamWCA_MAE(nn.Module):
         self.decoder_pred = nn.Linear(in_channels, self.mask_cfg.NUM_PRD_POINTS * 3, bias=True)
         self.forward_ret_dict = {}
         self.num_point_features = in_channels
+        self.pair_encode = True        # both frames through the Siamese encoder as one token list (sparse_encode_pair)
 
     # ------------------------------------------------------------------ masking (SiamWCA_MAE.py:166-182)
     def mask_voxels(self, all_voxel_features, all_voxel_coords, batch_size, voxels_per_sample, noise=None):
@@ -80,6 +81,32 @@ class SiamWCA_MAE(nn.Module):
             feats[f'x_conv{i + 1}'] = x
             strides[f'x_conv{i + 1}'] = self.sparse_shape[0] // x.spatial_shape[0]
         return feats, strides
+
+    def sparse_encode_pair(self, feats_prev, coords_prev, feats_cur, coords_cur, batch_size):
+        """Both frames through the Siamese encoder as ONE token list (samples 0..B-1 = previous frame, B..2B-1 =
+        current frame): every kernel runs once on the larger list and every shared weight gets one gradient.
+        Attention and the sparse convs never mix samples, and BatchNorm keeps per-frame statistics (`groups`), so
+        the results are those of the reference's two calls (SiamWCA_MAE.py:262-263, :289)."""
+        B = batch_size
+        ind_p = coords_prev[:, [0, 2, 3]].int()
+        ind_c = coords_cur[:, [0, 2, 3]].int()
+        ind_c = ind_c + torch.tensor([B, 0, 0], dtype=torch.int32, device=ind_c.device)
+        cdt = ops.compute_dtype(feats_prev)
+        x = SparseConvTensor(torch.cat([feats_prev.to(cdt), feats_cur.to(cdt)], 0), torch.cat([ind_p, ind_c], 0),
+                             self.sparse_shape, 2 * B, groups=((ind_p.shape[0], B), (ind_c.shape[0], B)))
+        out_p, out_c, strides = {}, {}, {}
+        shift = torch.tensor([B, 0, 0], dtype=torch.int32, device=ind_c.device)
+        for i, blk in enumerate(self.sst_blocks):
+            x = blk(x)
+            key = f'x_conv{i + 1}'
+            m0 = x.groups[0][0]
+            ny, nx = x.spatial_shape
+            f_p, f_c = ops.split_rows(x.features, m0)
+            # previous frame: its rows come first, so the first B samples of the row-index grid are already its grid
+            out_p[key] = SparseConvTensor(f_p, x.indices[:m0], x.spatial_shape, B, grid=x.grid[:B * ny * nx])
+            out_c[key] = SparseConvTensor(f_c, x.indices[m0:] - shift, x.spatial_shape, B)
+            strides[key] = self.sparse_shape[0] // ny
+        return out_p, out_c, strides
 
     def sparse_cross_attn(self, feats, feats_prev, dtime=0):
         for i, blk in enumerate(self.wca_blocks):
@@ -123,13 +150,17 @@ class SiamWCA_MAE(nn.Module):
     # ------------------------------------------------------------------ forward (SiamWCA_MAE.py:255-322)
     def forward(self, batch_dict):
         bs = int(batch_dict['batch_size'])
-        feats_prev, strides_prev = self.sparse_encode(batch_dict['voxel_features_prev'],
-                                                      batch_dict['voxel_coords_prev'], bs, previous_sstblock=True)
         all_feats, all_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
         vis_feats, vis_coords, mask = self.mask_voxels(all_feats, all_coords, bs, batch_dict['voxels_per_sample'],
                                                       batch_dict.get('mae_noise', None))
         batch_dict['voxel_mae_mask'] = mask
-        feats, strides = self.sparse_encode(vis_feats, vis_coords, bs)
+        if self.pair_encode and batch_dict['voxel_coords_prev'].shape[0] > 1 and vis_coords.shape[0] > 1:
+            feats_prev, feats, strides = self.sparse_encode_pair(
+                batch_dict['voxel_features_prev'], batch_dict['voxel_coords_prev'], vis_feats, vis_coords, bs)
+        else:                                                       # the reference's two calls
+            feats_prev, _ = self.sparse_encode(batch_dict['voxel_features_prev'], batch_dict['voxel_coords_prev'], bs,
+                                               previous_sstblock=True)
+            feats, strides = self.sparse_encode(vis_feats, vis_coords, bs)
         feats = self.sparse_cross_attn(feats, feats_prev, dtime=batch_dict.get('dt', 0))
         spatial, spatial_stride = self.dense_conv(feats, strides)
         batch_dict['multi_scale_3d_features'] = feats

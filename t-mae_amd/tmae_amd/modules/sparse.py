@@ -11,7 +11,10 @@ from .. import ops
 class SparseConvTensor:
     """features [m,c]; indices [m,3] int32 (b,y,x), lexicographically ordered; spatial_shape (ny,nx)."""
 
-    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, cache=None):
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, cache=None, groups=None):
+        # groups: None, or ((rows, samples), ...) -- consecutive sample ranges that the reference runs as separate
+        # calls (the two frames of the Siamese encoder); BatchNorm keeps separate statistics per group
+        self.groups = groups
         self.features = features
         self.indices = indices.int().contiguous() if indices.dtype != torch.int32 else indices.contiguous()
         self.spatial_shape = [int(spatial_shape[0]), int(spatial_shape[1])]
@@ -27,7 +30,8 @@ class SparseConvTensor:
         return self._grid
 
     def replace_feature(self, new_features):
-        return SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self._grid, self._cache)
+        return SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self._grid, self._cache,
+                                self.groups)
 
     def dense_nhwc(self):
         ny, nx = self.spatial_shape
@@ -70,15 +74,26 @@ class SparseConvolution(SparseModule):
         rb = x._cache.get('down')
         if rb is None:
             out_grid, out_ind, n_out, (oy, ox) = ops.spconv_down_outputs(x.grid, x.batch_size, ny, nx)
-            m_out = int(n_out.item())                               # one host sync per strided conv (output count)
+            groups = None
+            if x.groups is None:
+                m_out = int(n_out.item())                           # one host sync per strided conv (output count)
+            else:                                                   # + the output rows of every sample group but the last
+                cells, counts = 0, [n_out.view(1).long()]
+                for _, nb in x.groups[:-1]:
+                    cells += nb * oy * ox
+                    counts.append((out_grid[:cells] >= 0).sum().view(1))
+                host = torch.cat(counts).cpu().tolist()             # still one sync
+                m_out = int(host[0])
+                ends = [int(v) for v in host[1:]] + [m_out]
+                groups = tuple((e - b, nb) for b, e, (_, nb) in zip([0] + ends[:-1], ends, x.groups))
             out_ind = out_ind[:m_out]
             nbr = ops.spconv_neighbors(out_ind, x.grid, x.batch_size, ny, nx, 2)
             nbr_t = ops.spconv_neighbors_t(x.indices, out_grid, x.batch_size, oy, ox, 2)
-            rb = (nbr, nbr_t, out_ind, out_grid, (oy, ox))
+            rb = (nbr, nbr_t, out_ind, out_grid, (oy, ox), groups)
             x._cache['down'] = rb
-        nbr, nbr_t, out_ind, out_grid, oshape = rb
+        nbr, nbr_t, out_ind, out_grid, oshape, groups = rb
         y = ops.sparse_conv(x.features, self.weight, nbr, nbr_t)
-        return SparseConvTensor(y, out_ind, oshape, x.batch_size, out_grid)
+        return SparseConvTensor(y, out_ind, oshape, x.batch_size, out_grid, groups=groups)
 
 
 class SubMConv2d(SparseConvolution):
@@ -108,8 +123,11 @@ class SparseSequential(SparseModule):
             if isinstance(m, SparseModule):
                 x = m(x)
             elif isinstance(m, nn.BatchNorm1d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
-                x = x.replace_feature(ops.batch_norm_relu(x.features, m, relu=True))     # fused BN + ReLU kernels
+                rows = None if x.groups is None else [g[0] for g in x.groups]
+                x = x.replace_feature(ops.batch_norm_relu(x.features, m, relu=True, groups=rows))   # fused BN + ReLU
                 i += 1
+            elif isinstance(m, nn.BatchNorm1d) and x.groups is not None:
+                x = x.replace_feature(ops.batch_norm_relu(x.features, m, relu=False, groups=[g[0] for g in x.groups]))
             else:
                 x = x.replace_feature(m(x.features))
             i += 1

@@ -148,20 +148,27 @@ def add_layer_norm(a, b, weight, bias, eps=1e-5):
 
 
 class _BatchNormReLU(torch.autograd.Function):
+    """`bounds` = row offsets [0, r1, ..., m]: every row range is normalised with its own batch statistics (the
+    Siamese encoder runs both frames as one token list; the reference normalises each frame's call separately)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, relu):
+    def forward(ctx, x, weight, bias, eps, relu, bounds):
         x = x.contiguous()
         m, c = x.shape
+        ng = len(bounds) - 1
         y = torch.empty_like(x)
-        mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+        mean = torch.empty((ng, c), dtype=torch.float32, device=x.device)
         var, rstd = torch.empty_like(mean), torch.empty_like(mean)
         g32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
-        wsb = lib.tmae_bn_workspace(m, c)
-        ws = _ws(wsb, x.device)
-        check(lib.tmae_bn_relu_fwd(_p(x), _dt(x), m, c, _p(g32), _p(b32), float(eps), 1 if relu else 0, _p(y), _p(mean),
-                                   _p(var), _p(rstd), _p(ws), wsb, _s()), 'tmae_bn_relu_fwd')
+        for g in range(ng):
+            r0, r1 = bounds[g], bounds[g + 1]
+            wsb = lib.tmae_bn_workspace(r1 - r0, c)
+            ws = _ws(wsb, x.device)
+            check(lib.tmae_bn_relu_fwd(_p(x[r0:r1]), _dt(x), r1 - r0, c, _p(g32), _p(b32), float(eps), 1 if relu else 0,
+                                       _p(y[r0:r1]), _p(mean[g]), _p(var[g]), _p(rstd[g]), _p(ws), wsb, _s()),
+                  'tmae_bn_relu_fwd')
         ctx.save_for_backward(x, mean, rstd, g32, b32)
-        ctx.relu = relu
+        ctx.relu, ctx.bounds = relu, bounds
         ctx.dtypes = (weight.dtype, bias.dtype)
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
@@ -171,32 +178,67 @@ class _BatchNormReLU(torch.autograd.Function):
         x, mean, rstd, g32, b32 = ctx.saved_tensors
         dy = dy.to(x.dtype).contiguous()
         m, c = x.shape
+        bounds = ctx.bounds
+        ng = len(bounds) - 1
         dx = torch.empty_like(x)
-        dg = torch.empty((c,), dtype=torch.float32, device=x.device)
+        dg = torch.empty((ng, c), dtype=torch.float32, device=x.device)
         db = torch.empty_like(dg)
-        wsb = lib.tmae_bn_workspace(m, c)
-        ws = _ws(wsb, x.device)
-        check(lib.tmae_bn_relu_bwd(_p(dy), _p(x), _dt(x), m, c, _p(mean), _p(rstd), _p(g32), _p(b32),
-                                   1 if ctx.relu else 0, _p(dx), _p(dg), _p(db), _p(ws), wsb, _s()), 'tmae_bn_relu_bwd')
-        return dx, dg.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None
+        for g in range(ng):
+            r0, r1 = bounds[g], bounds[g + 1]
+            wsb = lib.tmae_bn_workspace(r1 - r0, c)
+            ws = _ws(wsb, x.device)
+            check(lib.tmae_bn_relu_bwd(_p(dy[r0:r1]), _p(x[r0:r1]), _dt(x), r1 - r0, c, _p(mean[g]), _p(rstd[g]), _p(g32),
+                                       _p(b32), 1 if ctx.relu else 0, _p(dx[r0:r1]), _p(dg[g]), _p(db[g]), _p(ws), wsb,
+                                       _s()), 'tmae_bn_relu_bwd')
+        if ng > 1:
+            dg, db = dg.sum(0), db.sum(0)
+        else:
+            dg, db = dg[0], db[0]
+        return dx, dg.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None, None
 
 
-def batch_norm_relu(x, bn, relu=True):
+def batch_norm_relu(x, bn, relu=True, groups=None):
     """nn.BatchNorm1d `bn` (+ ReLU) over the rows of x [m,c]; fused HIP kernels in training mode for c in
-    {64,128,256}; updates bn's running statistics like torch does."""
-    if (x.is_cuda and x.dim() == 2 and bn.training and x.shape[1] in (64, 128, 256) and x.shape[0] > 1
+    {64,128,256}; updates bn's running statistics like torch does.  `groups` (row counts summing to m): each row
+    range is a separate BatchNorm call (own batch statistics, running statistics updated in order)."""
+    sizes = [int(x.shape[0])] if groups is None else [int(g) for g in groups]
+    assert sum(sizes) == x.shape[0]
+    if (x.is_cuda and x.dim() == 2 and bn.training and x.shape[1] in (64, 128, 256) and min(sizes) > 1
             and x.dtype in (torch.float32, torch.bfloat16)):
-        y, mean, var = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.eps, relu)
+        bounds = [0]
+        for g in sizes:
+            bounds.append(bounds[-1] + g)
+        y, mean, var = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.eps, relu, tuple(bounds))
         if bn.track_running_stats:
             with torch.no_grad():
-                m = x.shape[0]
-                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(var, alpha=mom * m / (m - 1))
-                bn.num_batches_tracked += 1
+                for g, m in enumerate(sizes):
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                    bn.running_mean.mul_(1 - mom).add_(mean[g], alpha=mom)
+                    bn.running_var.mul_(1 - mom).add_(var[g], alpha=mom * m / (m - 1))
+                    bn.num_batches_tracked += 1
         return y
-    y = bn(x)
+    if len(sizes) > 1:
+        ys = [bn(part) for part in torch.split(x, sizes)]
+        y = torch.cat(ys, 0)
+    else:
+        y = bn(x)
     return torch.relu(y) if relu else y
+
+
+class _SplitRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, m0):
+        ctx.m0 = m0
+        return x[:m0], x[m0:]
+
+    @staticmethod
+    def backward(ctx, d0, d1):
+        return torch.cat([d0, d1], 0), None           # one pass (narrow's own backward pads + adds twice)
+
+
+def split_rows(x, m0):
+    """x[:m0], x[m0:] as views; the backward is a single concatenation."""
+    return _SplitRows.apply(x, int(m0))
 
 
 # ----------------------------------------------------------------------------- voxelisation (A1)

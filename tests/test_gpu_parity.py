@@ -729,6 +729,30 @@ def test_e2e_golden_and_oracle(oracle, name, nst):
         assert (a - b).abs().max().item() <= 5e-3 * max(1.0, b.abs().max().item()), n
 
 
+def test_pair_encode_equals_two_encoder_calls(oracle):
+    """Running both frames through the Siamese encoder as one token list (SiamWCA_MAE.sparse_encode_pair, per-frame
+    BatchNorm groups) gives the results of the reference's two calls: loss, gradients, BatchNorm running statistics."""
+    g = golden('F10_e2e_3stage')
+    cfg = oracle.default_model_cfg(3)
+    P = oracle.init_params(cfg, seed=int(g['param_seed']), tau=float(g['tau']), pred_scale=float(g['pred_scale']))
+    bs = int(g['batch_size'])
+    res = []
+    for pair in (True, False):
+        model, _, _ = build_product_model(3, params=P, device=dev())
+        model.train()
+        model.backbone_3d.pair_encode = pair
+        loss, bd = _run_product(model, g['points'], g['points_prev'], g['noise'], bs)
+        res.append((float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None},
+                    {n: b.clone() for n, b in model.named_buffers() if 'running' in n or 'num_batches' in n}))
+    assert abs(res[0][0] - res[1][0]) < 2e-6
+    assert res[0][1].keys() == res[1][1].keys()
+    for n, a in res[0][1].items():
+        b = res[1][1][n]
+        assert (a - b).abs().max().item() <= 2e-4 * max(1.0, b.abs().max().item()), n
+    for n, a in res[0][2].items():
+        assert torch.allclose(a.float(), res[1][2][n].float(), rtol=1e-5, atol=1e-6), n
+
+
 def test_e2e_waymo_shape_config(oracle):
     """BASELINE configs[3] shape: 5 point features (VFE input width 11), z range [-2,4), 6 m pillars; same model.
     (Range +-74.88 -> grid 468: with the dataset yaml's +-75.2 the reference's own decoder cannot concatenate
