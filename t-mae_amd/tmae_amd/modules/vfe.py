@@ -65,7 +65,12 @@ class TemporalDynVFE(VFETemplate):
         layers = list(self.dvfe_mlps[0])
         for i, layer in enumerate(layers):
             if isinstance(layer, nn.Linear):
-                x = ops.linear(x, layer.weight, None)
+                w = layer.weight
+                if x.shape[1] % 8:           # 10 (11) point features: zero-pad the contraction to 16 so that the
+                    pad = 8 - x.shape[1] % 8  # weight gradient runs in the token-split kernel (k must be 8-aligned)
+                    x = torch.nn.functional.pad(x, (0, pad))
+                    w = torch.nn.functional.pad(w, (0, pad))
+                x = ops.linear(x, w, None)
             elif isinstance(layer, nn.BatchNorm1d):
                 x = ops.batch_norm_relu(x, layer, relu=True)         # the ReLU that follows is fused
         x_max, _ = ops.scatter_max(x, vox['inverse'], perm, offsets, m)

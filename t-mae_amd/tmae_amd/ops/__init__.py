@@ -42,6 +42,37 @@ def compute_dtype(t):
     return t.dtype if t.dtype in (torch.float32, torch.bfloat16) else torch.float32
 
 
+# ----------------------------------------------------------------------------- low-precision parameter copies
+
+def cast_param(p, dtype):
+    """p.to(dtype), served from the copy made by refresh_param_copies when that copy is still current (same storage,
+    same version counter): ~340 per-parameter cast launches per step become a handful of multi-tensor launches."""
+    if p.dtype == dtype:
+        return p
+    c = getattr(p, '_tmae_copy', None)
+    if c is not None and c[0] == p._version and c[1] == p.data_ptr() and c[2].dtype == dtype:
+        return c[2]
+    return p.detach().to(dtype)
+
+
+@torch.no_grad()
+def refresh_param_copies(params, dtype=torch.bfloat16):
+    """Re-cast every floating-point parameter to `dtype` with multi-tensor copies (call after optimizer.step())."""
+    ps = [p for p in params if p.is_cuda and p.is_floating_point() and p.dtype != dtype]
+    if not ps:
+        return
+    dst = []
+    for p in ps:
+        c = getattr(p, '_tmae_copy', None)
+        if c is None or c[2].dtype != dtype or c[2].shape != p.shape:
+            c = [0, 0, torch.empty_like(p, dtype=dtype)]
+            p._tmae_copy = c
+        dst.append(c[2])
+    torch._foreach_copy_(dst, ps)
+    for p in ps:
+        p._tmae_copy[0], p._tmae_copy[1] = p._version, p.data_ptr()
+
+
 # ----------------------------------------------------------------------------- token-list Linear
 
 def linear_wgrad(dy, x, want_bias=True):
@@ -73,8 +104,8 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         cdt = compute_dtype(x)
         x_c = x.to(cdt)
-        w_c = weight.to(cdt)
-        y = torch.nn.functional.linear(x_c, w_c, None if bias is None else bias.to(cdt))
+        w_c = cast_param(weight, cdt)
+        y = torch.nn.functional.linear(x_c, w_c, None if bias is None else cast_param(bias, cdt))
         ctx.save_for_backward(x_c, w_c)
         ctx.has_bias = bias is not None
         ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
@@ -571,7 +602,7 @@ class _SparseConv(torch.autograd.Function):
     def forward(ctx, feat, weight, nbr, nbr_t):
         cdt = compute_dtype(feat)
         f = feat.to(cdt).contiguous()
-        w = weight.to(cdt).reshape(weight.shape[0], -1)
+        w = cast_param(weight, cdt).reshape(weight.shape[0], -1)
         cols = _gather9(f, nbr)
         out = cols @ w.t()
         ctx.save_for_backward(f, w, nbr, nbr_t)

@@ -37,4 +37,7 @@ def train_one_step(model, optimizer, scheduler, batch_dict, it, model_func, amp_
     if not use_amp and grad_norm_clip:
         torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm_clip)
     optimizer.step()
+    if use_amp:
+        from .. import ops
+        ops.refresh_param_copies(optimizer.params if hasattr(optimizer, 'params') else model.parameters(), amp_dtype)
     return loss, tb_dict, disp_dict
