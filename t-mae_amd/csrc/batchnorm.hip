@@ -1,40 +1,61 @@
 // BatchNorm1d (training statistics) + ReLU over the rows of a token / point list [m, c], forward and backward
 // (spconv_utils.post_act_block: conv + BatchNorm1d(eps 1e-3) + ReLU, pcdet/utils/spconv_utils.py:37-56; the VFE's
-// Linear + BatchNorm1d + ReLU, model_utils/network_utils.py:25-40).  Pure HBM streaming: one wavefront per row,
-// c/64 contiguous channels per lane; column sums are accumulated per lane in registers, per workgroup in LDS, and
+// Linear + BatchNorm1d + ReLU, model_utils/network_utils.py:25-40).  Pure HBM streaming with 16-byte accesses,
+// several rows per wavefront; column sums are accumulated per lane in registers, per workgroup in LDS, and
 // finished in a fixed order (deterministic, no atomics); the final combination runs in double.
 #include "common.h"
 
-template <class T, int VEC>
-__device__ __forceinline__ void bn_load(const T* p, float* v) {
+// Row layout: 8 consecutive channels per lane (16-byte accesses in bf16), C/8 adjacent lanes per row, 512/C rows per
+// wavefront, two row groups per loop iteration.  VEC = C / 64 (1, 2 or 4) stays the template parameter of the dispatch.
+#define BN_LAYOUT                                                                   \
+  constexpr int C = VEC * 64, LPR = C / 8, RPW = 64 / LPR;                          \
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane / LPR, cl = lane % LPR; \
+  const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4; \
+  (void)w
+
+// workgroup partial of two per-channel sums held as s1[8], s2[8] per lane -> part[block][2][C]
+template <int C, int LPR>
+__device__ __forceinline__ void bn_block_partial(float* s1, float* s2, float (*red)[2][C], int w, int sub, int cl,
+                                                 float* __restrict__ part) {
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) v[i] = ld_f<T>(p + i);
+  for (int i = 0; i < 8; ++i) { s1[i] = cross_group_sum<LPR>(s1[i]); s2[i] = cross_group_sum<LPR>(s2[i]); }
+  if (sub == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[w][0][cl * 8 + i] = s1[i]; red[w][1][cl * 8 + i] = s2[i]; }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * C; e += 256) {
+    const int which = e / C, c = e % C;
+    part[(int64_t)blockIdx.x * 2 * C + e] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+  }
 }
 
 // partial column sums of x and x^2
 template <class T, int VEC>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t m,
                                                       float* __restrict__ part /*[grid][2][C]*/) {
-  constexpr int C = VEC * 64;
+  BN_LAYOUT;
   __shared__ float red[4][2][C];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
-  float s1[VEC], s2[VEC];
+  float s1[8], s2[8];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-  for (int64_t r = wave; r < m; r += nwaves) {
-    float v[VEC];
-    bn_load<T, VEC>(x + r * C + lane * VEC, v);
+  for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
+    float v[2][8];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { s1[i] += v[i]; s2[i] += v[i] * v[i]; }
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub;
+      if (r < m) load8<T>(x + r * C + cl * 8, v[u]);
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[u][i] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s1[i] += v[u][i]; s2[i] += v[u][i] * v[u][i]; }
   }
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) { red[w][0][lane * VEC + i] = s1[i]; red[w][1][lane * VEC + i] = s2[i]; }
-  __syncthreads();
-  for (int e = threadIdx.x; e < 2 * C; e += 256) {
-    const int which = e / C, c = e % C;
-    part[(int64_t)blockIdx.x * 2 * C + e] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
-  }
+  bn_block_partial<C, LPR>(s1, s2, red, w, sub, cl, part);
 }
 
 // mean / biased variance / rstd per channel from the partials (double accumulation, fixed order)
@@ -68,24 +89,32 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       int relu, T* __restrict__ y) {
-  constexpr int C = VEC * 64;
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-  float sc[VEC], sh[VEC];
+  BN_LAYOUT;
+  float sc[8], sh[8];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    const int ch = lane * VEC + i;
+  for (int i = 0; i < 8; ++i) {
+    const int ch = cl * 8 + i;
     sc[i] = rstd[ch] * gamma[ch];
     sh[i] = beta[ch] - mean[ch] * sc[i];
   }
-  for (int64_t r = wave; r < m; r += nwaves) {
-    float v[VEC];
-    bn_load<T, VEC>(x + r * C + lane * VEC, v);
+  for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
+    float v[2][8];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      float z = v[i] * sc[i] + sh[i];
-      if (relu) z = fmaxf(z, 0.f);
-      st_f<T>(y + r * C + lane * VEC + i, z);
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub;
+      if (r < m) load8<T>(x + r * C + cl * 8, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub;
+      if (r < m) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float z = v[u][i] * sc[i] + sh[i];
+          v[u][i] = relu ? fmaxf(z, 0.f) : z;
+        }
+        store8<T>(y + r * C + cl * 8, v[u]);
+      }
     }
   }
 }
@@ -98,36 +127,39 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int relu,
                                                            float* __restrict__ part) {
-  constexpr int C = VEC * 64;
+  BN_LAYOUT;
   __shared__ float red[4][2][C];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
-  float mu[VEC], rs[VEC], g[VEC], bt[VEC], s1[VEC], s2[VEC];
+  float mu[8], rs[8], g[8], bt[8], s1[8], s2[8];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    const int ch = lane * VEC + i;
+  for (int i = 0; i < 8; ++i) {
+    const int ch = cl * 8 + i;
     mu[i] = mean[ch]; rs[i] = rstd[ch]; g[i] = gamma[ch]; bt[i] = beta[ch];
     s1[i] = 0.f; s2[i] = 0.f;
   }
-  for (int64_t r = wave; r < m; r += nwaves) {
-    float v[VEC], d[VEC];
-    bn_load<T, VEC>(x + r * C + lane * VEC, v);
-    bn_load<T, VEC>(dy + r * C + lane * VEC, d);
+  for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
+    float v[2][8], d[2][8];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      const float xh = (v[i] - mu[i]) * rs[i];
-      const float dz = (relu && !(xh * g[i] + bt[i] > 0.f)) ? 0.f : d[i];
-      s1[i] += dz;
-      s2[i] += dz * xh;
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub;
+      if (r < m) {
+        load8<T>(x + r * C + cl * 8, v[u]);
+        load8<T>(dy + r * C + cl * 8, d[u]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[u][i] = 0.f; d[u][i] = 0.f; }
+      }
     }
-  }
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { red[w][0][lane * VEC + i] = s1[i]; red[w][1][lane * VEC + i] = s2[i]; }
-  __syncthreads();
-  for (int e = threadIdx.x; e < 2 * C; e += 256) {
-    const int which = e / C, c = e % C;
-    part[(int64_t)blockIdx.x * 2 * C + e] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (v[u][i] - mu[i]) * rs[i];
+        const float dz = (relu && !(xh * g[i] + bt[i] > 0.f)) ? 0.f : d[u][i];
+        s1[i] += dz;
+        s2[i] += dz * xh;
+      }
   }
+  bn_block_partial<C, LPR>(s1, s2, red, w, sub, cl, part);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int c,
@@ -160,32 +192,43 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                           const float* __restrict__ dbeta,
                                                           const float* __restrict__ dgamma, float invm,
                                                           T* __restrict__ dx) {
-  constexpr int C = VEC * 64;
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-  float mu[VEC], rs[VEC], g[VEC], bt[VEC], a[VEC], b[VEC];
+  BN_LAYOUT;
+  float mu[8], rs[8], g[8], bt[8], a[8], b[8];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    const int ch = lane * VEC + i;
+  for (int i = 0; i < 8; ++i) {
+    const int ch = cl * 8 + i;
     mu[i] = mean[ch]; rs[i] = rstd[ch]; g[i] = gamma[ch]; bt[i] = beta[ch];
     a[i] = dbeta[ch] * invm; b[i] = dgamma[ch] * invm;
   }
-  for (int64_t r = wave; r < m; r += nwaves) {
-    float v[VEC], d[VEC];
-    bn_load<T, VEC>(x + r * C + lane * VEC, v);
-    bn_load<T, VEC>(dy + r * C + lane * VEC, d);
+  for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
+    float v[2][8], d[2][8];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      const float xh = (v[i] - mu[i]) * rs[i];
-      const float dz = (relu && !(xh * g[i] + bt[i] > 0.f)) ? 0.f : d[i];
-      st_f<T>(dx + r * C + lane * VEC + i, g[i] * rs[i] * (dz - a[i] - xh * b[i]));
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub;
+      if (r < m) {
+        load8<T>(x + r * C + cl * 8, v[u]);
+        load8<T>(dy + r * C + cl * 8, d[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub;
+      if (r < m) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xh = (v[u][i] - mu[i]) * rs[i];
+          const float dz = (relu && !(xh * g[i] + bt[i] > 0.f)) ? 0.f : d[u][i];
+          d[u][i] = g[i] * rs[i] * (dz - a[i] - xh * b[i]);
+        }
+        store8<T>(dx + r * C + cl * 8, d[u]);
+      }
     }
   }
 }
 
 static int bn_grid(int64_t m) {
-  int64_t g = (m + 63) / 64;            // >= 16 rows per wave
-  if (g > 512) g = 512;
+  int64_t g = (m + 255) / 256;          // >= 64 rows per wave
+  if (g > 2048) g = 2048;
   if (g < 1) g = 1;
   return (int)g;
 }

@@ -72,6 +72,43 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- 8 consecutive elements per lane (one 16-byte access in bf16, two in fp32): the layout of the row-streaming
+// kernels (LayerNorm, BatchNorm).  A row of C channels is held by C/8 adjacent lanes, a wavefront holds 512/C rows.
+template <class T> __device__ __forceinline__ void load8(const T* p, float* v);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* v) {
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<__hip_bfloat16>(const __hip_bfloat16* p, float* v) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(w[q] << 16); v[2 * q + 1] = __uint_as_float(w[q] & 0xFFFF0000u); }
+}
+template <class T> __device__ __forceinline__ void store8(T* p, const float* v);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* v) {
+  reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+  reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store8<__hip_bfloat16>(__hip_bfloat16* p, const float* v) {
+  __hip_bfloat16 t[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = __float2bfloat16(v[i]);
+  *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(t);
+}
+// sum over the aligned group of G adjacent lanes (G a power of two <= 64)
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over the lanes that hold the same channels of different rows (stride G, G a power of two <= 64)
+template <int G> __device__ __forceinline__ float cross_group_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= G; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 // ---- device-wide exclusive scan of int32 (three small launches per level) ----------------------
 // out[i] = sum_{j<i} in[i];  *total (device, optional) = sum of all.  in != out.
 size_t tmae_scan_i32_workspace(int64_t n);

@@ -1,19 +1,12 @@
 // Fused residual-add + LayerNorm (post-norm encoder layers: sst_basic_block.py:77-84, wca_block.py:93-102)
-// forward and backward.  Pure HBM streaming: one wavefront per row, d/64 contiguous elements per lane, fp32
+// forward and backward.  Pure HBM streaming: 16-byte accesses, several rows per wavefront, fp32
 // statistics; the backward's gamma/beta column sums are accumulated per workgroup in registers/LDS and finished by
 // a fixed-order second pass (deterministic, no atomics).
 #include "common.h"
 
-template <class T, int VEC>
-__device__ __forceinline__ void load_vec(const T* p, float* v) {
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) v[i] = ld_f<T>(p + i);
-}
-template <class T, int VEC>
-__device__ __forceinline__ void store_vec(T* p, const float* v) {
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) st_f<T>(p + i, v[i]);
-}
+// Row layout: 8 consecutive channels per lane (16-byte accesses in bf16), D/8 adjacent lanes per row, 512/D rows per
+// wavefront, two row groups per loop iteration (all loads of both issued before any arithmetic).
+// VEC = D / 64 (2 or 4) is kept as the template parameter of the dispatch.
 
 // y = LN(a + b) * gamma + beta ; xsum (optional) = a + b in T ; mean/rstd per row (f32)
 template <class T, int VEC>
@@ -22,37 +15,54 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ a
                                                         const float* __restrict__ beta, float eps,
                                                         T* __restrict__ xsum, T* __restrict__ y,
                                                         float* __restrict__ mean, float* __restrict__ rstd) {
-  constexpr int D = VEC * 64;
-  const int lane = threadIdx.x & 63;
+  constexpr int D = VEC * 64, LPR = D / 8, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane / LPR, cl = lane % LPR;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-  float g[VEC], bt[VEC];
+  float g[8], bt[8];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { g[i] = gamma[lane * VEC + i]; bt[i] = beta[lane * VEC + i]; }
-  for (int64_t r = wave; r < m; r += nwaves) {
-    float v[VEC], w[VEC];
-    load_vec<T, VEC>(a + r * D + lane * VEC, v);
-    if (b) {
-      load_vec<T, VEC>(b + r * D + lane * VEC, w);
+  for (int i = 0; i < 8; ++i) { g[i] = gamma[cl * 8 + i]; bt[i] = beta[cl * 8 + i]; }
+  for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
+    float v[2][8], w[2][8];
+    bool ok[2];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) v[i] += w[i];
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub;
+      ok[u] = r < m;
+      if (ok[u]) {
+        load8<T>(a + r * D + cl * 8, v[u]);
+        if (b) load8<T>(b + r * D + cl * 8, w[u]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[u][i] = 0.f; w[u][i] = 0.f; }
+      }
     }
-    if (xsum) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) { T t; st_f<T>(&t, v[i]); v[i] = ld_f<T>(&t); }   // statistics of the STORED (rounded) sum
-      store_vec<T, VEC>(xsum + r * D + lane * VEC, v);
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub;
+      if (b) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[u][i] += w[u][i];
+      }
+      if (xsum) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { T t; st_f<T>(&t, v[u][i]); v[u][i] = ld_f<T>(&t); }   // statistics of the STORED (rounded) sum
+        if (ok[u]) store8<T>(xsum + r * D + cl * 8, v[u]);
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[u][i];
+      const float mu = group_sum<LPR>(s) * (1.0f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float dlt = v[u][i] - mu; q += dlt * dlt; }
+      const float rs = rsqrtf(group_sum<LPR>(q) * (1.0f / D) + eps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[u][i] = (v[u][i] - mu) * rs * g[i] + bt[i];
+      if (ok[u]) {
+        store8<T>(y + r * D + cl * 8, v[u]);
+        if (cl == 0) { mean[r] = mu; rstd[r] = rs; }
+      }
     }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) s += v[i];
-    const float mu = wave_sum(s) * (1.0f / D);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) { const float dlt = v[i] - mu; q += dlt * dlt; }
-    const float rs = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) v[i] = (v[i] - mu) * rs * g[i] + bt[i];
-    store_vec<T, VEC>(y + r * D + lane * VEC, v);
-    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
   }
 }
 
@@ -62,36 +72,57 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, T* __restrict__ dx,
                                                     float* __restrict__ part /*[grid][2][D]*/) {
-  constexpr int D = VEC * 64;
+  constexpr int D = VEC * 64, LPR = D / 8, RPW = 64 / LPR;
   __shared__ float red[4][2][D];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane / LPR, cl = lane % LPR;
   const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
-  float g[VEC], dg[VEC], db[VEC];
+  float g[8], dg[8], db[8];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { g[i] = gamma[lane * VEC + i]; dg[i] = 0.f; db[i] = 0.f; }
-  for (int64_t r = wave; r < m; r += nwaves) {
-    float v[VEC], d[VEC];
-    load_vec<T, VEC>(x + r * D + lane * VEC, v);
-    load_vec<T, VEC>(dy + r * D + lane * VEC, d);
-    const float mu = mean[r], rs = rstd[r];
-    float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < 8; ++i) { g[i] = gamma[cl * 8 + i]; dg[i] = 0.f; db[i] = 0.f; }
+  for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
+    float v[2][8], d[2][8], mu[2], rs[2];
+    bool ok[2];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      v[i] = (v[i] - mu) * rs;                 // xhat
-      dg[i] += d[i] * v[i];
-      db[i] += d[i];
-      d[i] *= g[i];
-      s1 += d[i];
-      s2 += d[i] * v[i];
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub;
+      ok[u] = r < m;
+      if (ok[u]) {
+        load8<T>(x + r * D + cl * 8, v[u]);
+        load8<T>(dy + r * D + cl * 8, d[u]);
+        mu[u] = mean[r];
+        rs[u] = rstd[r];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[u][i] = 0.f; d[u][i] = 0.f; }
+        mu[u] = 0.f;
+        rs[u] = 0.f;
+      }
     }
-    s1 = wave_sum(s1) * (1.0f / D);
-    s2 = wave_sum(s2) * (1.0f / D);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) d[i] = rs * (d[i] - s1 - v[i] * s2);
-    store_vec<T, VEC>(dx + r * D + lane * VEC, d);
+    for (int u = 0; u < 2; ++u) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[u][i] = (v[u][i] - mu[u]) * rs[u];                 // xhat
+        dg[i] += d[u][i] * v[u][i];
+        db[i] += d[u][i];
+        d[u][i] *= g[i];
+        s1 += d[u][i];
+        s2 += d[u][i] * v[u][i];
+      }
+      s1 = group_sum<LPR>(s1) * (1.0f / D);
+      s2 = group_sum<LPR>(s2) * (1.0f / D);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[u][i] = rs[u] * (d[u][i] - s1 - v[u][i] * s2);
+      if (ok[u]) store8<T>(dx + (r0 + u * RPW + sub) * D + cl * 8, d[u]);
+    }
   }
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) { red[w][0][lane * VEC + i] = dg[i]; red[w][1][lane * VEC + i] = db[i]; }
+  for (int i = 0; i < 8; ++i) { dg[i] = cross_group_sum<LPR>(dg[i]); db[i] = cross_group_sum<LPR>(db[i]); }
+  if (sub == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[w][0][cl * 8 + i] = dg[i]; red[w][1][cl * 8 + i] = db[i]; }
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < 2 * D; e += 256) {
     const int which = e / D, c = e % D;
@@ -119,8 +150,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 }
 
 static int ln_grid(int64_t m) {
-  int64_t g = (m + 31) / 32;            // >= 8 rows per wave
-  if (g > 512) g = 512;
+  int64_t g = (m + 127) / 128;          // >= 32 rows per wave
+  if (g > 2048) g = 2048;
   if (g < 1) g = 1;
   return (int)g;
 }
