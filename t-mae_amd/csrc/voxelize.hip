@@ -347,6 +347,75 @@ __global__ __launch_bounds__(256) void segmax_bwd_kernel(const T* __restrict__ d
   else st_f<T>(dx + e, 0.f);
 }
 
+// 16-byte variants (c a multiple of 8 with c/8 a power of two <= 64): c/8 adjacent lanes per voxel / point row, 8
+// channels per lane.  A voxel holds ~2-3 points, so one wavefront per voxel left most of the wave's width idle.
+template <class T, int LPV>
+__global__ __launch_bounds__(256) void segmax_fwd8_kernel(const T* __restrict__ x, int64_t m,
+                                                         const int32_t* __restrict__ perm,
+                                                         const int32_t* __restrict__ offsets, T* __restrict__ out,
+                                                         int32_t* __restrict__ argmax) {
+  constexpr int C = LPV * 8, VPW = 64 / LPV;
+  const int lane = threadIdx.x & 63, sub = lane / LPV, cl = lane % LPV;
+  const int64_t v = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * VPW + sub;
+  if (v >= m) return;
+  const int lo = offsets[v], hi = offsets[v + 1];
+  float best[8];
+  int arg[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; arg[i] = -1; }
+  for (int j = lo; j < hi; ++j) {
+    const int row = perm[j];
+    float val[8];
+    load8<T>(x + (int64_t)row * C + cl * 8, val);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (val[i] > best[i] || arg[i] < 0) { best[i] = val[i]; arg[i] = row; }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (arg[i] < 0) best[i] = 0.f;
+  store8<T>(out + v * C + cl * 8, best);
+  int4* ap = reinterpret_cast<int4*>(argmax + v * C + cl * 8);
+  ap[0] = make_int4(arg[0], arg[1], arg[2], arg[3]);
+  ap[1] = make_int4(arg[4], arg[5], arg[6], arg[7]);
+}
+
+template <class T, int LPV>
+__global__ __launch_bounds__(256) void segmax_bwd8_kernel(const T* __restrict__ dout, int64_t n,
+                                                         const int64_t* __restrict__ inv,
+                                                         const int32_t* __restrict__ argmax, T* __restrict__ dx) {
+  constexpr int C = LPV * 8;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t p = e / LPV;
+  if (p >= n) return;
+  const int cl = (int)(e % LPV);
+  const int64_t v = inv[p];
+  const int4* ap = reinterpret_cast<const int4*>(argmax + v * C + cl * 8);
+  const int4 a0 = ap[0], a1 = ap[1];
+  const int arg[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  float d[8];
+  load8<T>(dout + v * C + cl * 8, d);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (arg[i] != (int)p) d[i] = 0.f;
+  store8<T>(dx + p * C + cl * 8, d);
+}
+
+static bool segmax_vec_ok(int c, const void* a, const void* b) {
+  const int l = c / 8;
+  return c % 8 == 0 && (l == 8 || l == 16 || l == 32 || l == 64) && !(((uintptr_t)a | (uintptr_t)b) & 15);
+}
+
+#define SEGMAX8(KERNEL, T, GRID, ...)                                                                   \
+  do {                                                                                                  \
+    switch (c / 8) {                                                                                    \
+      case 8: hipLaunchKernelGGL((KERNEL<T, 8>), GRID, dim3(256), 0, stream, __VA_ARGS__); break;       \
+      case 16: hipLaunchKernelGGL((KERNEL<T, 16>), GRID, dim3(256), 0, stream, __VA_ARGS__); break;     \
+      case 32: hipLaunchKernelGGL((KERNEL<T, 32>), GRID, dim3(256), 0, stream, __VA_ARGS__); break;     \
+      default: hipLaunchKernelGGL((KERNEL<T, 64>), GRID, dim3(256), 0, stream, __VA_ARGS__); break;     \
+    }                                                                                                   \
+  } while (0)
+
 int tmae_segment_max_fwd(const void* x, int dtype, int64_t n, int64_t m, int c, const int32_t* perm,
                          const int32_t* offsets, void* out, int32_t* argmax, void* stream_) {
   (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
@@ -354,6 +423,15 @@ int tmae_segment_max_fwd(const void* x, int dtype, int64_t n, int64_t m, int c, 
   if (n < 0 || m < 0 || c <= 0) return TMAE_EARG;
   if (m == 0) return TMAE_OK;
   if (!x || !perm || !offsets || !out || !argmax) return TMAE_EARG;
+  if (segmax_vec_ok(c, x, out) && !((uintptr_t)argmax & 15) && (dtype == TMAE_F32 || dtype == TMAE_BF16)) {
+    const dim3 g8(tmae_cdiv(m, 4 * (512 / c)));
+    if (dtype == TMAE_F32)
+      SEGMAX8(segmax_fwd8_kernel, float, g8, (const float*)x, m, perm, offsets, (float*)out, argmax);
+    else
+      SEGMAX8(segmax_fwd8_kernel, __hip_bfloat16, g8, (const __hip_bfloat16*)x, m, perm, offsets,
+              (__hip_bfloat16*)out, argmax);
+    return tmae_launch_status();
+  }
   dim3 grid(tmae_cdiv(m, 4)), block(256);
   if (dtype == TMAE_F32)
     hipLaunchKernelGGL(segmax_fwd_kernel<float>, grid, block, 0, stream, (const float*)x, m, c, perm, offsets,
@@ -373,6 +451,15 @@ int tmae_segment_max_bwd(const void* dout, int dtype, int64_t n, int64_t m, int 
   if (n < 0 || m < 0 || c <= 0) return TMAE_EARG;
   if (n == 0) return TMAE_OK;
   if (!dout || !inverse || !argmax || !dx) return TMAE_EARG;
+  if (segmax_vec_ok(c, dout, dx) && !((uintptr_t)argmax & 15) && (dtype == TMAE_F32 || dtype == TMAE_BF16)) {
+    const dim3 g8(tmae_cdiv(n * (c / 8), 256));
+    if (dtype == TMAE_F32)
+      SEGMAX8(segmax_bwd8_kernel, float, g8, (const float*)dout, n, inverse, argmax, (float*)dx);
+    else
+      SEGMAX8(segmax_bwd8_kernel, __hip_bfloat16, g8, (const __hip_bfloat16*)dout, n, inverse, argmax,
+              (__hip_bfloat16*)dx);
+    return tmae_launch_status();
+  }
   dim3 grid(tmae_cdiv(n * c, 256)), block(256);
   if (dtype == TMAE_F32)
     hipLaunchKernelGGL(segmax_bwd_kernel<float>, grid, block, 0, stream, (const float*)dout, n, c, inverse, argmax,

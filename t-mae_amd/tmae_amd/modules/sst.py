@@ -86,15 +86,15 @@ class WindowAttention(nn.Module):
                                                   non_shared_tau=layer_cfg.get('non_shared_tau', False))
 
     def forward(self, x, plan, pos_table, window_shape, shift):
-        """q = k = x + pos, v = x (sst_basic_block.py:22-54), windows of `shift` read from plan.grid."""
+        """q = k = x + pos, v = x (sst_basic_block.py:22-54), windows of `shift` read from plan.grid.
+        Returns (attention output, x's alias for the residual branch): see ops.proj_fork."""
         a = self.self_attn
         d = a.embed_dim
-        xp = ops.add_pos_embed(x, plan.indices, pos_table, window_shape, shift)
-        qk = ops.linear(xp, a.in_proj_weight[:2 * d], a.in_proj_bias[:2 * d])
-        v = ops.linear(x, a.in_proj_weight[2 * d:], a.in_proj_bias[2 * d:])
+        qk, v, x_res = ops.proj_fork(x, a.in_proj_weight, a.in_proj_bias, ((0, 2 * d, True), (2 * d, 3 * d, False)),
+                                     pos=(plan.indices, pos_table, window_shape, shift), fork=True)
         o = ops.win_attn(qk, v, None, a.tau, plan.grid, plan.grid, self.nhead, plan.batch, plan.ny, plan.nx,
                          shift, a.tau_min, worklist=plan.worklist(shift))
-        return ops.linear(o, a.out_proj.weight, a.out_proj.bias)
+        return ops.linear(o, a.out_proj.weight, a.out_proj.bias), x_res
 
 
 class WindowCrossAttention(nn.Module):
@@ -113,12 +113,12 @@ class WindowCrossAttention(nn.Module):
         a = self.cross_attn
         d = a.embed_dim
         w, b = a.in_proj_weight, a.in_proj_bias
-        q = ops.linear(ops.add_pos_embed(x, plan.indices, pos_table, window_shape, shift), w[:d], b[:d])
-        k = ops.linear(ops.add_pos_embed(x_prv, plan_prv.indices, pos_table, window_shape, shift), w[d:2 * d],
-                       b[d:2 * d])
-        v = ops.linear(x_prv, w[2 * d:], b[2 * d:])
-        return ops.win_attn(q, k, v, a.tau, plan.grid, plan_prv.grid, self.nhead, plan.batch, plan.ny, plan.nx,
-                            shift, a.tau_min, worklist=plan.worklist(shift))
+        q, x_res = ops.proj_fork(x, w, b, ((0, d, True),), pos=(plan.indices, pos_table, window_shape, shift), fork=True)
+        k, v = ops.proj_fork(x_prv, w, b, ((d, 2 * d, True), (2 * d, 3 * d, False)),
+                             pos=(plan_prv.indices, pos_table, window_shape, shift))
+        o = ops.win_attn(q, k, v, a.tau, plan.grid, plan_prv.grid, self.nhead, plan.batch, plan.ny, plan.nx,
+                         shift, a.tau_min, worklist=plan.worklist(shift))
+        return o, x_res
 
 
 def _activation(name):
@@ -143,9 +143,10 @@ class _EncoderTail(nn.Module):
     def tail(self, src, attn):
         """src = LN1(src + attn); src = LN2(src + linear2(act(linear1(src)))) -- both adds fused into the norms."""
         src = ops.add_layer_norm(src, attn, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        h = self.activation(ops.linear(src, self.linear1.weight, self.linear1.bias))
-        src2 = ops.linear(h, self.linear2.weight, self.linear2.bias)
-        return ops.add_layer_norm(src, src2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        h_pre, src_res = ops.proj_fork(src, self.linear1.weight, self.linear1.bias,
+                                       ((0, self.linear1.out_features, False),), fork=True)
+        src2 = ops.linear(self.activation(h_pre), self.linear2.weight, self.linear2.bias)
+        return ops.add_layer_norm(src_res, src2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
 
 
 class EncoderLayer(_EncoderTail):
@@ -156,7 +157,8 @@ class EncoderLayer(_EncoderTail):
         self.win_attn = WindowAttention(d_model, nhead, dropout, layer_cfg)
 
     def forward(self, src, plan, pos_table, window_shape, shift):
-        return self.tail(src, self.win_attn(src, plan, pos_table, window_shape, shift))
+        attn, src_res = self.win_attn(src, plan, pos_table, window_shape, shift)
+        return self.tail(src_res, attn)
 
 
 class BasicShiftBlockV2(nn.Module):
@@ -182,11 +184,11 @@ class WCAEncoderLayer(_EncoderTail):
 
     def forward(self, src, plan, src_prv, plan_prv, pos_table, window_shape, shift, kept):
         a = self.win_attn.cross_attn
-        o = self.win_attn(src, plan, src_prv, plan_prv, pos_table, window_shape, shift)
+        o, src_res = self.win_attn(src, plan, src_prv, plan_prv, pos_table, window_shape, shift)
         # src[keep] += out_proj(attn): kept = query rows whose window also holds previous-frame tokens
         # (the out-proj bias must not reach the other rows)
         upd = ops.linear(o, a.out_proj.weight, a.out_proj.bias) * kept
-        return self.tail(src, upd)
+        return self.tail(src_res, upd)
 
 
 class BasicShiftBlock_WCA(nn.Module):

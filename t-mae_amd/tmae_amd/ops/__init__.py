@@ -127,6 +127,84 @@ class _Linear(torch.autograd.Function):
         return dx, dw.to(wdt), (db.to(bdt) if ctx.has_bias else None)
 
 
+class _ProjFork(torch.autograd.Function):
+    """Several Linear projections of ONE token list in one autograd node:
+        out_s = (x [+ pos]) W[r0:r1]^T + b[r0:r1]      for every segment s = (r0, r1, use_pos)
+    plus, with `fork`, x itself as a last output for the residual branch of the layer.  The backward folds every
+    contribution to dx -- also the gradient that arrives through the forked alias -- into accumulating GEMMs
+    (addmm, beta = 1), so autograd never runs a separate add over [m, d]; dW / db come back as one full-size tensor
+    (no slice-backward zero fills).  pos = (indices, table, wy, wx, do_shift) or None."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, segs, pos, fork):
+        cdt = compute_dtype(x)
+        x_c = x.to(cdt).contiguous()
+        w_c = cast_param(weight, cdt)
+        b_c = None if bias is None else cast_param(bias, cdt)
+        xp = None
+        if any(sg[2] for sg in segs):
+            indices, table, wy, wx, do_shift = pos
+            xp = torch.empty_like(x_c)
+            check(lib.tmae_add_pos_embed(_p(x_c), _dt(x_c), x_c.shape[0], x_c.shape[1], _p(indices), wy, wx,
+                                         1 if do_shift else 0, _p(table), _p(xp), _s()), 'tmae_add_pos_embed')
+        outs = []
+        for r0, r1, use_pos in segs:
+            outs.append(torch.nn.functional.linear(xp if use_pos else x_c, w_c[r0:r1],
+                                                   None if b_c is None else b_c[r0:r1]))
+        ctx.save_for_backward(x_c, xp, w_c)
+        ctx.segs, ctx.fork, ctx.has_bias = segs, fork, bias is not None
+        ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        ctx.set_materialize_grads(False)
+        if fork:
+            outs.append(x.view_as(x))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x_c, xp, w_c = ctx.saved_tensors
+        xdt, wdt, bdt = ctx.dtypes
+        segs = ctx.segs
+        dx = grads[-1] if ctx.fork else None
+        if dx is not None:
+            dx = dx.to(x_c.dtype)
+        rows = w_c.shape[0]
+        covered = sum(r1 - r0 for (r0, r1, _), g in zip(segs, grads) if g is not None) == rows
+        mk = torch.empty if covered else torch.zeros
+        dW = mk((rows, w_c.shape[1]), dtype=torch.float32, device=x_c.device) if ctx.needs_input_grad[1] else None
+        dB = mk((rows,), dtype=torch.float32, device=x_c.device) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        for (r0, r1, use_pos), dy in zip(segs, grads):
+            if dy is None:
+                continue
+            dy = dy.to(x_c.dtype)
+            if dy.stride(-1) != 1:
+                dy = dy.contiguous()
+            if ctx.needs_input_grad[0]:
+                dx = dy @ w_c[r0:r1] if dx is None else torch.addmm(dx, dy, w_c[r0:r1])
+            if dW is not None:
+                inp = xp if use_pos else x_c
+                if _wgrad_ok(dy, inp):
+                    dw, db = linear_wgrad(dy, inp, dB is not None)
+                else:
+                    dw = dy.float().t() @ inp.float()
+                    db = dy.float().sum(0) if dB is not None else None
+                dW[r0:r1] = dw
+                if dB is not None:
+                    dB[r0:r1] = db
+        return (None if dx is None else dx.to(xdt), None if dW is None else dW.to(wdt),
+                None if dB is None else dB.to(bdt), None, None, None)
+
+
+def proj_fork(x, weight, bias, segs, pos=None, fork=False):
+    """See _ProjFork.  Returns the projections (and x's alias last when fork) as a tuple."""
+    if not x.is_cuda or x.dim() != 2:
+        raise RuntimeError('proj_fork: 2-D GPU token lists only')
+    segs = tuple((int(a), int(b), bool(c)) for a, b, c in segs)
+    if pos is not None:
+        indices, table, window_shape, do_shift = pos
+        pos = (indices, table, int(window_shape[1]), int(window_shape[0]), bool(do_shift))
+    return _ProjFork.apply(x, weight, bias, segs, pos, bool(fork))
+
+
 def linear(x, weight, bias=None):
     """torch.nn.functional.linear with the token-split weight-gradient kernel (2-D inputs on the GPU)."""
     if x.is_cuda and x.dim() == 2:
