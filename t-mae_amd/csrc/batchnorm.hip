@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 static int bn_grid(int64_t m) {
   int64_t g = (m + 255) / 256;          // >= 64 rows per wave
-  if (g > 2048) g = 2048;
+  if (g > 1024) g = 1024;
   if (g < 1) g = 1;
   return (int)g;
 }

@@ -130,28 +130,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-// one workgroup per 16 columns: 16 column lanes x 16 row lanes walk the partial rows, then a fixed-order LDS tree
+// one workgroup per 8 columns: 8 column lanes x 32 row lanes walk the partial rows (4 independent accumulators per
+// thread), then a fixed-order LDS tree
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblocks, int d,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ float red[16][17];
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int e = blockIdx.x * 16 + cl;                 // column in [0, 2d)
-  float acc = 0.f;
-  if (e < 2 * d)
-    for (int b = rl; b < nblocks; b += 16) acc += part[(int64_t)b * 2 * d + e];
-  red[rl][cl] = acc;
+  __shared__ float red[32][9];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int e = blockIdx.x * 8 + cl;                  // column in [0, 2d)
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (e < 2 * d) {
+    const int64_t ld = 2 * (int64_t)d;
+    int b = rl;
+    for (; b + 96 < nblocks; b += 128) {
+      a0 += part[(int64_t)b * ld + e];
+      a1 += part[(int64_t)(b + 32) * ld + e];
+      a2 += part[(int64_t)(b + 64) * ld + e];
+      a3 += part[(int64_t)(b + 96) * ld + e];
+    }
+    for (; b < nblocks; b += 32) a0 += part[(int64_t)b * ld + e];
+  }
+  red[rl][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (rl == 0 && e < 2 * d) {
     float t = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t += red[r][cl];
+    for (int r = 0; r < 32; ++r) t += red[r][cl];
     if (e < d) dgamma[e] = t; else dbeta[e - d] = t;
   }
 }
 
 static int ln_grid(int64_t m) {
   int64_t g = (m + 127) / 128;          // >= 32 rows per wave
-  if (g > 2048) g = 2048;
+  if (g > 1024) g = 1024;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -197,7 +207,7 @@ int tmae_layernorm_bwd(const void* dy, const void* x, int dtype, int64_t m, int 
   else if (dtype == TMAE_BF16) { if (d == 128) BWD(__hip_bfloat16, 2); else BWD(__hip_bfloat16, 4); }
   else return TMAE_EDTYPE;
 #undef BWD
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(tmae_cdiv(2 * d, 16)), dim3(256), 0, stream, part, nb, d, dgamma,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(tmae_cdiv(2 * d, 8)), dim3(256), 0, stream, part, nb, d, dgamma,
                      dbeta);
   return tmae_launch_status();
 }

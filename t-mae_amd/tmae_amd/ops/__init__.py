@@ -179,7 +179,10 @@ class _ProjFork(torch.autograd.Function):
             if dy.stride(-1) != 1:
                 dy = dy.contiguous()
             if ctx.needs_input_grad[0]:
-                dx = dy @ w_c[r0:r1] if dx is None else torch.addmm(dx, dy, w_c[r0:r1])
+                # accumulate IN PLACE (torch.addmm would first memcpy dx into a new buffer).  The buffer that arrives
+                # through the alias is the dx of the layer's add+LayerNorm backward; its only other reader is the
+                # Linear on the norm's second input, a node created after this one, i.e. already executed.
+                dx = dy @ w_c[r0:r1] if dx is None else dx.addmm_(dy, w_c[r0:r1])
             if dW is not None:
                 inp = xp if use_pos else x_c
                 if _wgrad_ok(dy, inp):
