@@ -26,6 +26,20 @@ __device__ __forceinline__ short f2bf(float v) {
   return *reinterpret_cast<short*>(&b);
 }
 __device__ __forceinline__ float bf2f(short s) { return __uint_as_float(((unsigned)(unsigned short)s) << 16); }
+// 1/x in one instruction (1 ulp); an IEEE division costs ~10 VALU instructions and these kernels are VALU-bound
+#define MASKED_LOGIT (-30000.0f)   // finite: 0 * MASKED_LOGIT stays 0 in the tau gradient
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: four rotate-and-add steps on the
+// VALU (a __shfl_xor is a ds_bpermute through the LDS crossbar)
+__device__ __forceinline__ float row16_sum(float v) {
+#define TMAE_ROR(n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xF, 0xF, false))
+  v += TMAE_ROR(8);
+  v += TMAE_ROR(4);
+  v += TMAE_ROR(2);
+  v += TMAE_ROR(1);
+#undef TMAE_ROR
+  return v;
+}
 
 // Row fragment of a token: channels [FR*g, FR*g+FR) of head `hoff`, FR = 8 (dh 32) or 4 (dh 16), as floats.
 template <int FR>
@@ -58,7 +72,7 @@ __device__ __forceinline__ float normalize_frag(float* f, float scale) {
   ss += __shfl_xor(ss, 16, 64);
   ss += __shfl_xor(ss, 32, 64);
   const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-  const float inv = scale / nrm;
+  const float inv = scale * fast_rcp(nrm);
 #pragma unroll
   for (int j = 0; j < FR; ++j) f[j] *= inv;
   return nrm;                                   // max(|x|, eps) of the whole row
@@ -253,6 +267,17 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
     for (int ct = 0; ct < CT; ++ct)
       vf[kt][ct] = tr_read4(&vimg[w][(kt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3)]);
 
+  // key rows past Tk get a large negative logit through the MFMA's C operand (exp underflows to exactly 0): no
+  // per-element masking in the loops, and tiles kt >= nk need no special case
+  // (only where the 4*NT registers are free: the 64-token class would lose a resident wave and masks per element)
+  constexpr bool KB = NT <= 2;
+  f32x4 kbias[KB ? NT : 1];
+  if constexpr (KB) {
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kbias[kt][r] = (kt * 16 + 4 * g + r < Tk) ? 0.f : MASKED_LOGIT;
+  }
 #pragma unroll
   for (int qt = 0; qt < NT; ++qt) {
     if (qt < nq) {
@@ -261,7 +286,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
       float mx = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
-        st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (KB) st[kt] = kbias[kt]; else st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (kt < nk) {
           st[kt] = mfma_s(kl[kt], qf[qt], st[kt]);                   // S^T tile: rows = keys 4g+r, col = query i
           st[kt] = mfma_s(kf[kt], ql[qt], st[kt]);
@@ -269,7 +294,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (kt * 16 + 4 * g + r >= Tk) st[kt][r] = -INFINITY;
+          if constexpr (!KB) { if (kt * 16 + 4 * g + r >= Tk) st[kt][r] = MASKED_LOGIT; }
           mx = fmaxf(mx, st[kt][r]);
         }
       }
@@ -287,7 +312,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
         }
       l += __shfl_xor(l, 16, 64);
       l += __shfl_xor(l, 32, 64);
-      const float invl = 1.0f / l;
+      const float invl = fast_rcp(l);
       f32x4 o[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
@@ -406,7 +431,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
     }
     return;
   }
-  const float inv_tau = 1.0f / fmaxf(tau[0], tau_min);
+  const float tau_c = fmaxf(tau[0], tau_min), inv_tau = 1.0f / tau_c;
   if (w == 0) {
     if (tq >= 0) toks[0][__popcll(mq & ((1ull << lane) - 1ull))] = tq;
     if (tk >= 0) toks[1][__popcll(mk & ((1ull << lane) - 1ull))] = tk;
@@ -434,7 +459,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
       for (int j = 0; j < FR; ++j) { kf[t][j] = 0; kl[t][j] = 0; vr[t][j] = 0; }
     }
     *reinterpret_cast<frag_t*>(&kimg[w][slot * RB + FR * g * 2]) = kf[t];
-    lse_i[t] = 0.f;
+    lse_i[t] = INFINITY;
     if (t < nq) {
       const int tokq = slot < Tq ? toks[0][slot] : -1;
       load_row_frag<FR>(q, ldq, tokq, hoff, g, f);
@@ -446,7 +471,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
       load_row_frag<FR>(dout, lddo, tokq, hoff, g, gfl);
       gf[t] = pack_frag<FR>(gfl);                                        // exact: bf16 -> f32 -> bf16
       *reinterpret_cast<frag_t*>(&gimg[w][slot * RB + FR * g * 2]) = gf[t];
-      lse_i[t] = tokq >= 0 ? lse[(int64_t)tokq * nhead + head] : 0.f;
+      lse_i[t] = tokq >= 0 ? lse[(int64_t)tokq * nhead + head] : INFINITY;   // no query: p = exp(s - inf) = 0
     }
   }
   __syncthreads();
@@ -456,12 +481,19 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) { dKa[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dVa[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   float dtau_acc = 0.f;
+  constexpr bool KB = NT <= 2;             // MASKED_LOGIT on key rows past Tk through the C operand (see the forward)
+  f32x4 kbias[KB ? NT : 1];
+  if constexpr (KB) {
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kbias[kt][r] = (kt * 16 + 4 * g + r < Tk) ? 0.f : MASKED_LOGIT;
+  }
 
 #pragma unroll
   for (int qt = 0; qt < NT; ++qt) {
     if (qt < nq) {
       const int qslot = qt * 16 + i;
-      const bool qok = qslot < Tq;
       // transposed right-hand fragments of this query tile
       s16x4 trQ[CT], trG[CT];
 #pragma unroll
@@ -485,16 +517,16 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
       for (int kt = 0; kt < NT; ++kt) {
         if (kt < nk) {
           const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-          // swapped: rows = keys 4g+r of this tile, column = query i
-          f32x4 sT = mfma_s(kl[kt], qf[qt], z);
+          // swapped: rows = keys 4g+r of this tile, column = query i; masked keys / absent queries give p = 0
+          f32x4 sT = mfma_s(kl[kt], qf[qt], KB ? kbias[KB ? kt : 0] : z);
           sT = mfma_s(kf[kt], ql[qt], sT);
           sT = mfma_s(kf[kt], qf[qt], sT);
           const f32x4 dP = mfma_s(vr[kt], gf[qt], z);
           if constexpr (!RECOMP) { sTk[kt] = sT; dPk[kt] = dP; }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool ok = qok && (kt * 16 + 4 * g + r < Tk);
-            const float p = ok ? __expf(sT[r] - lse_i[qt]) : 0.f;
+            float p = __expf(sT[r] - lse_i[qt]);
+            if constexpr (!KB) { if (kt * 16 + 4 * g + r >= Tk) p = 0.f; }
             if constexpr (!RECOMP) pTk[kt][r] = p;
             dacc += p * dP[r];
           }
@@ -513,10 +545,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
             sT = mfma_s(kf[kt], qf[qt], sT);
             dP = mfma_s(vr[kt], gf[qt], z);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const bool ok = qok && (kt * 16 + 4 * g + r < Tk);
-              pT[r] = ok ? __expf(sT[r] - lse_i[qt]) : 0.f;
-            }
+            for (int r = 0; r < 4; ++r) pT[r] = (kt * 16 + 4 * g + r < Tk) ? __expf(sT[r] - lse_i[qt]) : 0.f;
           } else {
             sT = sTk[kt]; dP = dPk[kt]; pT = pTk[kt];
           }
@@ -525,7 +554,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
           for (int r = 0; r < 4; ++r) {
             const float p = pT[r];
             const float ds = p * (dP[r] - dacc);
-            dtau_acc += (p > 0.f) ? ds * sT[r] : 0.f;
+            dtau_acc += ds * sT[r];                        // p = 0 entries: 0 * finite
             dsT[r] = f2bf(ds);
             pTb[r] = f2bf(p);
           }
@@ -557,18 +586,15 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
         float qh[CT], dqh[CT], dot = 0.f;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-          qh[ct] = bf2f(*reinterpret_cast<const short*>(&qimg[w][qs * RB + (ct * 16 + i) * 2])) * (1.0f / inv_tau);
+          qh[ct] = bf2f(*reinterpret_cast<const short*>(&qimg[w][qs * RB + (ct * 16 + i) * 2])) * tau_c;
           dqh[ct] = dQa[ct][r] * inv_tau;
           dot += qh[ct] * dqh[ct];
         }
-        dot += __shfl_xor(dot, 1, 64);
-        dot += __shfl_xor(dot, 2, 64);
-        dot += __shfl_xor(dot, 4, 64);
-        dot += __shfl_xor(dot, 8, 64);
+        dot = row16_sum(dot);
         if (qs < Tq) {
           const float nrm = qnorm[w][qs];
           if (nrm <= 1e-12f) dot = 0.f;
-          const float inv = 1.0f / nrm;
+          const float inv = fast_rcp(nrm);
           __hip_bfloat16* p = dq + (int64_t)toks[0][qs] * lddq + hoff + i;
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) p[ct * 16] = __float2bfloat16((dqh[ct] - qh[ct] * dot) * inv);
@@ -591,14 +617,11 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
           kh[ct] = bf2f(*reinterpret_cast<const short*>(&kimg[w][ks * RB + (ct * 16 + i) * 2]));
           dot += kh[ct] * dKa[kt][ct][r];
         }
-        dot += __shfl_xor(dot, 1, 64);
-        dot += __shfl_xor(dot, 2, 64);
-        dot += __shfl_xor(dot, 4, 64);
-        dot += __shfl_xor(dot, 8, 64);
+        dot = row16_sum(dot);
         if (ks < Tk) {
           const float nrm = knorm[w][ks];
           if (nrm <= 1e-12f) dot = 0.f;
-          const float inv = 1.0f / nrm;
+          const float inv = fast_rcp(nrm);
           const int tokk = toks[1][ks];
           __hip_bfloat16* p1 = dk + (int64_t)tokk * lddk + hoff + i;
           __hip_bfloat16* p2 = dv + (int64_t)tokk * lddv + hoff + i;

@@ -128,7 +128,16 @@ class SiamWCA_MAE(nn.Module):
         else:
             cat = torch.cat([self.decoder_deblocks[i](feats[src].dense())
                              for i, src in enumerate(self.model_cfg.FEATURES_SOURCE)], dim=1)
-        spatial = self.decoder_conv_out(cat)
+        conv, bn = self.decoder_conv_out[0], self.decoder_conv_out[1]
+        y = conv(cat)
+        if (self.training and y.is_cuda and y.is_contiguous(memory_format=torch.channels_last)
+                and y.shape[1] in (64, 128, 256) and isinstance(self.decoder_conv_out[2], nn.ReLU)):
+            # BatchNorm2d + ReLU over a channels-last tensor = the row kernels over [B*Y*X, C]
+            b, c, ny, nx = y.shape
+            rows = ops.batch_norm_relu(y.permute(0, 2, 3, 1).reshape(b * ny * nx, c), bn, relu=True)
+            spatial = rows.view(b, ny, nx, c).permute(0, 3, 1, 2)
+        else:
+            spatial = self.decoder_conv_out[2](bn(y))
         return spatial, out_strides[0]
 
     # ------------------------------------------------------------------ targets (SiamWCA_MAE.py:124-152)

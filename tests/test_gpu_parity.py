@@ -386,7 +386,9 @@ def test_attention_mfma_bf16_fwd_bwd_vs_fp32_kernel():
                     same(o2, o, 'out'), same(a2.grad, a.grad, 'da'), same(b2.grad, b_.grad, 'db')
                     if c2 is not None:
                         same(c2.grad, c_.grad, 'dc')
-                    assert abs(float(tau2.grad) - float(tau.grad)) <= 2e-3 * max(1.0, abs(float(tau.grad)))
+                    # the tau gradient sums dS*S over every window: instantiations that mask differently (C-operand
+                    # bias for <= 32-token windows, per-element select for 64) differ in rounding, not in meaning
+                    assert abs(float(tau2.grad) - float(tau.grad)) <= 5e-3 * max(1.0, abs(float(tau.grad)))
             f, h = res[torch.float32], res[torch.bfloat16]
             assert all(torch.isfinite(t.float()).all() for t in h if t is not None)
             lim = 0.03 if tauv >= 0.05 else 0.12          # logits reach +-100 at the clamp: bf16 logit error ~0.4
