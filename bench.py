@@ -48,7 +48,48 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_roofline(model, batch, amp_dtype, iters=20):
+def _pmc(key):
+    f = os.path.join(ROOT, 'profiles', 'round1_pmc.json')       # rocprofv3 --pmc passes of --probe-only
+    if not os.path.exists(f):
+        return None
+    return json.load(open(f)).get(key, {}).get('traffic_bytes_per_op')
+
+
+def wgrad_roofline(model, batch, amp_dtype, iters=20):
+    """`roofline`: the dominant hand-written kernel of the step by GPU time (profiles/): the token-split weight
+    gradient of the d = 256 stages, wgrad256_kernel (csrc/wgrad.hip), on its most frequent heavy shape -- the
+    stage-2 FFN / in-projection  dW[512,256] = dY^T X  over the token list of both frames (bench batch).  The op = that
+    kernel + its two slab-reduction launches, timed with HIP events on the launch stream.  Algorithmic bytes: dY and
+    X read once, dW and db written once; the fp32 slabs are overhead and show up in `traffic`."""
+    from tmae_amd import ops
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        model(dict(batch))
+    m = int(model.backbone_3d.last_pair_tokens[1])            # stage-2 tokens, previous + current frame
+    n, k = 512, 256
+    dev = next(model.parameters()).device
+    dy = torch.randn(m, n, device=dev).bfloat16()
+    x = torch.randn(m, k, device=dev).bfloat16()
+    for _ in range(3):
+        ops.linear_wgrad(dy, x, True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.linear_wgrad(dy, x, True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    bytes_alg = m * (n + k) * 2 + (n * k + n) * 4
+    achieved = bytes_alg / (ms * 1e-3) / 1e9
+    return {'kernel': 'wgrad256_kernel (token-split weight gradient dW[512,256] = dY^T X of the stage-2 token list; the '
+                      'op = the kernel + its two slab-reduction launches)', 'bound': 'hbm',
+            'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': _pmc('wgrad'),
+            'traffic_source': 'profiles/round1_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
+            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k}
+
+
+def attention_roofline(model, batch, amp_dtype, iters=20):
     """Times the dominant hand-written kernel of the step -- the ragged window attention backward
     (`win_attn_bwd_mfma_kernel<16,{1,2,4}>`: one launch per tile class) on the stage-1 previous-frame tensors --
     through the C ABI with HIP events on torch's current stream (the stream the ABI launches on), nothing else in
@@ -101,14 +142,11 @@ def kernel_roofline(model, batch, amp_dtype, iters=20):
     units = 7 if code == 1 else 8
     bytes_alg = m * d * es * units + m * H * 4 + bs * 468 * 468 * 4
     achieved = bytes_alg / (ms * 1e-3) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'round1_attn_bwd_pmc.json')      # rocprofv3 --pmc passes of --probe-only
-    if os.path.exists(pmc) and code == 1:
-        traffic = json.load(open(pmc)).get('traffic_bytes_per_op')
+    traffic = _pmc('attention') if code == 1 else None
     return {'kernel': 'win_attn_bwd_mfma_kernel<16,NT> (stage-1 self-attention backward, previous frame; the op = its 3 '
                       'tile-class launches NT=1,2,4)', 'bound': 'hbm', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
-            'traffic_source': 'profiles/round1_attn_bwd_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
+            'traffic_source': 'profiles/round1_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': int(m)}
 
 
@@ -176,7 +214,8 @@ def main():
         return train_one_step(ddp, opt, sched, dict(batches[i % nb]), i, model_func, amp_dtype=amp)[0]
 
     if args.probe_only:
-        print(json.dumps({'roofline': kernel_roofline(model, dict(batches[0]), amp)}), flush=True)
+        print(json.dumps({'roofline': wgrad_roofline(model, dict(batches[0]), amp),
+                          'roofline_attention': attention_roofline(model, dict(batches[0]), amp)}), flush=True)
         return
 
     def log(msg):
@@ -220,7 +259,8 @@ def main():
                        'parallelism': f'dp{world}', 'grid': '468x468x1', 'final_loss': round(loss_val, 5)},
         }
         log(f'timed region done: {1e3 * elapsed / args.steps:.1f} ms/step; timing the dominant kernel ...')
-        line['roofline'] = kernel_roofline(model, dict(batches[0]), amp)
+        line['roofline'] = wgrad_roofline(model, dict(batches[0]), amp)
+        line['roofline_attention'] = attention_roofline(model, dict(batches[0]), amp)   # round-1 history: priced until the weight gradient overtook it
         if world == 1 and not args.no_cpu_baseline:
             log('timing the CPU oracle on one frame pair (cpu_baseline) ...')
             line['cpu_baseline'] = cpu_baseline(args.cpu_points)

@@ -7,7 +7,7 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 naive = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('naive_conv')]
 rest = rows[(max(naive) + 1) if naive else 0:]
 vk = [i for i, r in enumerate(rest) if 'vox_key_kernel' in r['Kernel_Name']]
-seg = rest[vk[-8]:vk[-2]]          # 3 timed steps (2 voxelisations each); the last 2 launches belong to the roofline probe
+seg = rest[vk[-10]:vk[-4]]         # 3 timed steps (2 voxelisations each); the last 4 launches belong to the two roofline probes
 t0, t1 = int(seg[0]['Start_Timestamp']), int(seg[-1]['End_Timestamp'])
 agg = collections.defaultdict(lambda: [0, 0])
 for r in seg:
@@ -22,18 +22,23 @@ print('| ms/step | % | launches/step | avg us | kernel |\n|---:|---:|---:|---:|-
 for n, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
     print(f'| {d / 3e6:.2f} | {100 * d / busy:.1f} | {c / 3:.1f} | {d / c / 1e3:.1f} | `{n}` |')
 
-# the roofline probe of bench.py (kernel_roofline): the launches of the stage-1 backward kernels after the last
-# voxelisation; the op = one launch of each tile class, its duration = the sum of the three averages
-probe = [r for r in rest[vk[-1]:] if 'win_attn_bwd_mfma_kernel<16' in r['Kernel_Name']]
-if probe:
+# the roofline probes of bench.py (wgrad_roofline, attention_roofline): the launches after the last voxelisation of
+# the training steps (+1: the probe's own forward pass voxelises both frames once more); an op = one launch of each
+# kernel of its group, its duration = the sum of the per-kernel averages
+tail = rest[vk[-4]:]
+for title, pats in (('wgrad256 op (kernel + 2 slab reductions)', ('wgrad256_kernel', 'wgrad_reduce1_kernel', 'wgrad_reduce2_kernel')),
+                    ('stage-1 attention backward op (3 tile classes)', ('win_attn_bwd_mfma_kernel<16',))):
+    probe = [r for r in tail if any(p in r['Kernel_Name'] for p in pats)]
+    if not probe:
+        continue
     pa = collections.defaultdict(lambda: [0, 0])
     for r in probe:
         n = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')
         pa[n][0] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
         pa[n][1] += 1
-    print('\nroofline probe (bench.py kernel_roofline), per launch:')
+    print(f'\nroofline probe, {title}, per launch:')
     tot = 0.0
     for n, (d, c) in sorted(pa.items()):
         print(f'- `{n}`: {c} launches, avg {d / c / 1e3:.1f} us')
         tot += d / c / 1e3
-    print(f'- op (sum of the tile classes): {tot:.1f} us')
+    print(f'- op: {tot:.1f} us')

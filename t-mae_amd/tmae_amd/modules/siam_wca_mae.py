@@ -56,6 +56,7 @@ class SiamWCA_MAE(nn.Module):
         self.decoder_pred = nn.Linear(in_channels, self.mask_cfg.NUM_PRD_POINTS * 3, bias=True)
         self.forward_ret_dict = {}
         self.num_point_features = in_channels
+        self.last_pair_tokens = []     # rows per stage of the last sparse_encode_pair call (both frames)
         self.pair_encode = True        # both frames through the Siamese encoder as one token list (sparse_encode_pair)
 
     # ------------------------------------------------------------------ masking (SiamWCA_MAE.py:166-182)
@@ -95,11 +96,13 @@ class SiamWCA_MAE(nn.Module):
         x = SparseConvTensor(torch.cat([feats_prev.to(cdt), feats_cur.to(cdt)], 0), torch.cat([ind_p, ind_c], 0),
                              self.sparse_shape, 2 * B, groups=((ind_p.shape[0], B), (ind_c.shape[0], B)))
         out_p, out_c, strides = {}, {}, {}
+        self.last_pair_tokens = []
         shift = torch.tensor([B, 0, 0], dtype=torch.int32, device=ind_c.device)
         for i, blk in enumerate(self.sst_blocks):
             x = blk(x)
             key = f'x_conv{i + 1}'
             m0 = x.groups[0][0]
+            self.last_pair_tokens.append(int(x.features.shape[0]))
             ny, nx = x.spatial_shape
             f_p, f_c = ops.split_rows(x.features, m0)
             # previous frame: its rows come first, so the first B samples of the row-index grid are already its grid
