@@ -358,7 +358,8 @@ def main():
          subm_pairs=np.array([len(p[0]) for p in pairs]), down_pairs=np.array([len(p[0]) for p in pairs2]))
 
     # ---- F10 / F11 end-to-end, 1-stage (config C1 reading) and 3-stage, small clouds
-    for tag, nst, npts, bs in (('F11_e2e_1stage', 1, 6000, 2), ('F10_e2e_3stage', 3, 5000, 2)):
+    # F12: ragged batch -- sample 1 has no current-frame points, sample 2 no previous-frame points
+    for tag, nst, npts, bs in (('F11_e2e_1stage', 1, 6000, 2), ('F10_e2e_3stage', 3, 5000, 2), ('F12_e2e_ragged', 3, 3000, 3)):
         print(tag)
         c1 = O.default_model_cfg(nst)
         Vn, Bn, _ = R.build_reference_model(nst, seed=0)
@@ -369,6 +370,8 @@ def main():
         assert not missing.unexpected_keys and all('running' in k or 'num_batches' in k for k in missing.missing_keys), missing
         Vn.train(), Bn.train()
         pts, pts_prev = O.synth_frame_pair(npts, bs, seed=21)
+        if tag == 'F12_e2e_ragged':
+            pts, pts_prev = pts[pts[:, 0] != 1], pts_prev[pts_prev[:, 0] != 2]
         bd = dict(points=torch.from_numpy(pts), points_prev=torch.from_numpy(pts_prev), batch_size=bs)
         bd = Vn(bd)
         vc = bd['voxel_coords'].numpy()

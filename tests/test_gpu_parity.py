@@ -691,7 +691,7 @@ def _run_product(model, pts, prv, noise, bs, amp=None):
     return ret['loss'], bd
 
 
-@pytest.mark.parametrize('name,nst', [('F11_e2e_1stage', 1), ('F10_e2e_3stage', 3)])
+@pytest.mark.parametrize('name,nst', [('F11_e2e_1stage', 1), ('F10_e2e_3stage', 3), ('F12_e2e_ragged', 3)])
 def test_e2e_golden_and_oracle(oracle, name, nst):
     """Whole step (VFE -> Siamese encoder -> masking -> WCA -> decoder -> Chamfer) in fp32 vs the reference's
     captured loss / mask / predictions / grad norms, and per-parameter gradients vs the CPU oracle."""

@@ -171,6 +171,11 @@ def test_f10_e2e_three_stage(oracle):
     _e2e(oracle, 'F10_e2e_3stage', 3)
 
 
+def test_e2e_ragged_batch_matches_reference(oracle):
+    """F12: batch of 3 where sample 1 has no current-frame points and sample 2 no previous-frame points."""
+    _e2e(oracle, 'F12_e2e_ragged', 3)
+
+
 def test_chamfer_zero_weights_and_groups(oracle):
     inv = np.array([2, 0, 2, 2, 1, 0])
     t = oracle.group_inner_inds(inv, 4, 4)
