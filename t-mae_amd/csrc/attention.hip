@@ -310,6 +310,36 @@ static inline void attn_dims(int ny, int nx, int& Wy, int& Wx) {
   Wx = (nx + WIN - 1) / WIN + 1;
 }
 
+// sum of the per-(window, head-group) tau partials, fixed order: thread t sums elements t, t+1024, ...; LDS tree
+__global__ __launch_bounds__(1024) void dtau_finish_kernel(const float* __restrict__ part, int64_t n,
+                                                          const float* __restrict__ tau, float tau_min,
+                                                          float* __restrict__ dtau) {
+  __shared__ float red[1024];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int64_t e = threadIdx.x;
+  for (; e + 3072 < n; e += 4096) { a0 += part[e]; a1 += part[e + 1024]; a2 += part[e + 2048]; a3 += part[e + 3072]; }
+  for (; e < n; e += 1024) a0 += part[e];
+  red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float t = tau[0];
+    dtau[0] = t >= tau_min ? -red[0] / t : 0.f;
+  }
+}
+
+int tmae_win_attn_dtau(const float* dtau_partial, int64_t n, const float* tau, float tau_min, float* dtau,
+                       void* stream_) {
+  (void)hipGetLastError();
+  if (n < 0 || !tau || !dtau || (n > 0 && !dtau_partial)) return TMAE_EARG;
+  hipLaunchKernelGGL(dtau_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream_, dtau_partial, n, tau, tau_min,
+                     dtau);
+  return tmae_launch_status();
+}
+
 int64_t tmae_win_attn_num_blocks(int batch, int ny, int nx, int nhead, int dh) {
   (void)dh;
   int Wy, Wx;

@@ -4,13 +4,17 @@
 // everything in registers; HBM traffic is the algorithmic minimum (each point read once).
 #include "common.h"
 
-__device__ __forceinline__ void wave_argmin(float& d, int& idx) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float od = __shfl_xor(d, o, 64);
-    const int oi = __shfl_xor(idx, o, 64);
-    if (od < d || (od == d && oi < idx)) { d = od; idx = oi; }
-  }
+// minimum over the wavefront, result in every lane: four DPP row rotations (VALU) + two cross-row exchanges
+__device__ __forceinline__ float wave_min_all(float v) {
+#define TMAE_ROR(n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xF, 0xF, false))
+  v = fminf(v, TMAE_ROR(8));
+  v = fminf(v, TMAE_ROR(4));
+  v = fminf(v, TMAE_ROR(2));
+  v = fminf(v, TMAE_ROR(1));
+#undef TMAE_ROR
+  v = fminf(v, __shfl_xor(v, 16, 64));
+  v = fminf(v, __shfl_xor(v, 32, 64));
+  return v;
 }
 
 __global__ __launch_bounds__(256) void chamfer_fwd_kernel(const float* __restrict__ pred,
@@ -32,14 +36,16 @@ __global__ __launch_bounds__(256) void chamfer_fwd_kernel(const float* __restric
   float best = INFINITY;
   int besti = 0;
   float cx_sum = 0.f;
-  for (int i = 0; i < np; ++i) {
-    const float ax = __shfl(px, i, 64), ay = __shfl(py, i, 64), az = __shfl(pz, i, 64);
+  for (int i = 0; i < np; ++i) {                         // i is wave-uniform: the broadcasts are v_readlane
+    const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), i));
+    const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), i));
+    const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), i));
     const float dx = ax - gx, dy = ay - gy, dz = az - gz;
-    float d = (lane < ng) ? (dx * dx + dy * dy + dz * dz) : INFINITY;
+    const float d = (lane < ng) ? (dx * dx + dy * dy + dz * dz) : INFINITY;
     if (d < best) { best = d; besti = i; }
-    int j = lane;
-    wave_argmin(d, j);
-    cx_sum += d;
+    const float dmin = wave_min_all(d);                  // exact (min of floats); ties -> the lowest gt index
+    const int j = __ffsll((unsigned long long)__ballot(d == dmin)) - 1;
+    cx_sum += dmin;
     if (lane == i) idx_x[v * np + i] = (int8_t)j;
   }
   if (lane < ng) idx_y[v * ng + lane] = (int8_t)besti;

@@ -36,6 +36,7 @@ SIGNATURES = {
     'tmae_win_attn_fwd': (I, [P, L, P, L, P, L, I, L, L, I, I, P, P, I, I, I, I, P, F, P, L, P, P, P]),
     'tmae_window_worklist_size': (Z, [I, I, I]),
     'tmae_window_worklist': (I, [P, P, I, I, I, I, P, P]),
+    'tmae_win_attn_dtau': (I, [P, L, P, F, P, P]),
     'tmae_win_attn_num_blocks': (L, [I, I, I, I, I]),
     'tmae_win_attn_bwd': (I, [P, L, P, L, P, L, P, L, P, L, P, I, L, L, I, I, P, P, I, I, I, I, P, F,
                               P, L, P, L, P, L, P, P, P]),

@@ -626,8 +626,10 @@ class _WinAttn(torch.autograd.Function):
                                     _p(tau32), float(tau_min), dq, lddq, dk, lddk, dv, lddv, _p(part), _p(worklist),
                                     _s()), 'tmae_win_attn_bwd')
         # d/d tau of logits = cos / max(tau, tau_min): -(1/tau_c) * sum dS*s, zero in the clamped branch
-        tau_c = tau32.clamp(min=tau_min)
-        dtau = (-(part.sum() / tau_c) * (tau32 >= tau_min).float()).reshape(tshape).to(tdtype)
+        dtau = torch.empty((1,), dtype=torch.float32, device=a.device)
+        psum = part.sum().reshape(1)                    # multi-block reduction; the finish kernel applies the clamp rule
+        check(lib.tmae_win_attn_dtau(_p(psum), 1, _p(tau32), float(tau_min), _p(dtau), _s()), 'tmae_win_attn_dtau')
+        dtau = dtau.reshape(tshape).to(tdtype)
         return da, db, dc, dtau, None, None, None, None, None, None, None, None, None
 
 
