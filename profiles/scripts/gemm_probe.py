@@ -36,3 +36,25 @@ for (M, K, N) in shapes:
         byts = 2 * (M * K + M * N + K * N)
         res.append(f'{name}: {ms*1e3:7.1f} us {flops/ms/1e9:6.1f} TF/s {byts/ms/1e6:6.0f} GB/s')
     print(f'M={M} K={K} N={N} | ' + ' | '.join(res), flush=True)
+
+# ---- our token GEMM on the eligible shapes
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 't-mae_amd'))
+from tmae_amd import ops
+print('token_gemm (csrc/token_gemm.hip)')
+for (M, K, N) in [(470000, 128, 256), (470000, 128, 128), (470000, 256, 128), (466000, 256, 512), (466000, 256, 256),
+                  (195000, 256, 512), (195000, 256, 256), (94000, 128, 256)]:
+    x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+    w = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(N, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        ops.token_gemm(x, w, b, force=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ops.token_gemm(x, w, b, force=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    byts = 2 * (M * K + M * N + K * N)
+    print(f'M={M} K={K} N={N} | ours: {ms*1e3:7.1f} us {2*M*K*N/ms/1e9:6.1f} TF/s {byts/ms/1e6:6.0f} GB/s', flush=True)

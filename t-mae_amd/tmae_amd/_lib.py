@@ -64,6 +64,7 @@ SIGNATURES = {
     'tmae_deblock_gather': (I, [P, I, I, I, P, L, I, I, I, I, P, P]),
     'tmae_column_sums_workspace': (Z, [L, I]),
     'tmae_column_sums': (I, [P, I, L, I, P, P, Z, P]),
+    'tmae_token_gemm': (I, [P, L, L, I, P, I, P, P, L, P]),
     'tmae_linear_wgrad_workspace': (Z, [L, I, I]),
     'tmae_linear_wgrad': (I, [P, L, P, L, L, I, I, P, P, P, Z, P]),
     'tmae_spconv_wgrad': (I, [P, L, P, L, P, L, I, I, P, P, Z, P]),

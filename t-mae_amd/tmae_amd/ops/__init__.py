@@ -42,6 +42,42 @@ def compute_dtype(t):
     return t.dtype if t.dtype in (torch.float32, torch.bfloat16) else torch.float32
 
 
+# ----------------------------------------------------------------------------- token-list GEMM
+
+_TOKEN_GEMM_MIN_ROWS = 8192
+
+
+def _tg_ok(x, k, n):
+    # shapes where the kernel beats the library (profiles/scripts/gemm_probe.py): k = 128 with n <= 256, k = 256 with n = 128
+    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[0] >= _TOKEN_GEMM_MIN_ROWS
+            and ((k == 128 and n in (64, 128, 192, 256)) or (k == 256 and n in (64, 128)))
+            and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
+
+
+def token_gemm(x, w, bias=None, force=False):
+    """y [m,n] = x [m,k] @ w[n,k]^T (+ bias) in bf16, fp32 accumulation: the x-stationary streaming kernel of
+    csrc/token_gemm.hip on the shapes where it is ahead of the library (force=True: whenever the kernel supports the
+    shape: k in {128,256}, n % 64 == 0), else the library."""
+    n, k = w.shape
+    ok = _tg_ok(x, k, n) or (force and x.dtype == torch.bfloat16 and k in (128, 256) and n % 64 == 0
+                             and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
+    if ok and w.dtype == torch.bfloat16 and w.is_contiguous() and (bias is None or bias.dtype == torch.bfloat16):
+        m = x.shape[0]
+        y = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
+        b = None if bias is None else bias.contiguous()
+        check(lib.tmae_token_gemm(_p(x), x.stride(0), m, k, _p(w), n, _p(b), _p(y), n, _s()), 'tmae_token_gemm')
+        return y
+    return torch.nn.functional.linear(x, w, bias)
+
+
+def token_gemm_dx(dy, w, force=False):
+    """dx [m,k] = dy [m,n] @ w[n,k]: the same kernel on w^T (contraction n in {128,256}, k % 64 == 0)."""
+    n, k = w.shape
+    if (force or _tg_ok(dy, n, k)) and w.dtype == torch.bfloat16:
+        return token_gemm(dy, w.t().contiguous(), None, force)
+    return dy @ w
+
+
 # ----------------------------------------------------------------------------- low-precision parameter copies
 
 def cast_param(p, dtype):
@@ -105,7 +141,7 @@ class _Linear(torch.autograd.Function):
         cdt = compute_dtype(x)
         x_c = x.to(cdt)
         w_c = cast_param(weight, cdt)
-        y = torch.nn.functional.linear(x_c, w_c, None if bias is None else cast_param(bias, cdt))
+        y = token_gemm(x_c, w_c, None if bias is None else cast_param(bias, cdt))
         ctx.save_for_backward(x_c, w_c)
         ctx.has_bias = bias is not None
         ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
@@ -118,7 +154,7 @@ class _Linear(torch.autograd.Function):
         dy = dy.to(x_c.dtype)
         if dy.stride(-1) != 1:
             dy = dy.contiguous()
-        dx = (dy @ w_c).to(xdt) if ctx.needs_input_grad[0] else None
+        dx = token_gemm_dx(dy, w_c).to(xdt) if ctx.needs_input_grad[0] else None
         if _wgrad_ok(dy, x_c):
             dw, db = linear_wgrad(dy, x_c, ctx.has_bias)
         else:
@@ -149,8 +185,7 @@ class _ProjFork(torch.autograd.Function):
                                          1 if do_shift else 0, _p(table), _p(xp), _s()), 'tmae_add_pos_embed')
         outs = []
         for r0, r1, use_pos in segs:
-            outs.append(torch.nn.functional.linear(xp if use_pos else x_c, w_c[r0:r1],
-                                                   None if b_c is None else b_c[r0:r1]))
+            outs.append(token_gemm(xp if use_pos else x_c, w_c[r0:r1], None if b_c is None else b_c[r0:r1]))
         ctx.save_for_backward(x_c, xp, w_c)
         ctx.segs, ctx.fork, ctx.has_bias = segs, fork, bias is not None
         ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
@@ -182,7 +217,7 @@ class _ProjFork(torch.autograd.Function):
                 # accumulate IN PLACE (torch.addmm would first memcpy dx into a new buffer).  The buffer that arrives
                 # through the alias is the dx of the layer's add+LayerNorm backward; its only other reader is the
                 # Linear on the norm's second input, a node created after this one, i.e. already executed.
-                dx = dy @ w_c[r0:r1] if dx is None else dx.addmm_(dy, w_c[r0:r1])
+                dx = token_gemm_dx(dy, w_c[r0:r1]) if dx is None else dx.addmm_(dy, w_c[r0:r1])
             if dW is not None:
                 inp = xp if use_pos else x_c
                 if _wgrad_ok(dy, inp):

@@ -473,6 +473,36 @@ def test_linear_wgrad_kernel_vs_torch():
     assert (g1[2] - b.grad).abs().max().item() <= 1e-2 * float(b.grad.abs().max())
 
 
+def test_token_gemm_kernel_vs_torch():
+    """x-stationary token GEMM (csrc/token_gemm.hip) vs fp32 matmul on the same bf16 inputs: forward with bias,
+    strided input (column slice of a packed buffer), ragged token counts, and the dX use on W^T."""
+    from tmae_amd import ops
+    torch.manual_seed(3)
+    for (m, k, n) in ((8192, 128, 128), (50001, 128, 256), (33333, 256, 512), (20000, 256, 768), (9999, 256, 64)):
+        x = torch.randn(m, k, device=dev()).bfloat16()
+        w = (torch.randn(n, k, device=dev()) * 0.1).bfloat16()
+        b = torch.randn(n, device=dev()).bfloat16()
+        y = ops.token_gemm(x, w, b, force=True)
+        ref = x.float() @ w.float().t() + b.float()
+        assert y.shape == (m, n) and y.dtype == torch.bfloat16
+        assert (y.float() - ref).abs().max().item() <= 2e-2 * max(1.0, float(ref.abs().max())), (m, k, n)
+        y0 = ops.token_gemm(x, w, None, force=True)
+        assert (y0.float() - x.float() @ w.float().t()).abs().max().item() <= 2e-2 * max(1.0, float(ref.abs().max()))
+        lib_y = F.linear(x, w, b)
+        assert (y.float() - lib_y.float()).abs().max().item() <= 4e-2 * max(1.0, float(ref.abs().max()))
+    big = torch.randn(30000, 384, device=dev()).bfloat16()
+    xs = big[:, 128:384]                                   # pitch 384, 256 columns
+    w = (torch.randn(128, 256, device=dev()) * 0.1).bfloat16()
+    y = ops.token_gemm(xs, w, None, force=True)
+    ref = xs.float() @ w.float().t()
+    assert (y.float() - ref).abs().max().item() <= 2e-2 * float(ref.abs().max())
+    dy = torch.randn(40000, 256, device=dev()).bfloat16()
+    w = (torch.randn(256, 512, device=dev()) * 0.1).bfloat16()     # [n, k]: dx = dy @ w -> [m, 512]
+    dx = ops.token_gemm_dx(dy, w, force=True)
+    ref = dy.float() @ w.float()
+    assert dx.shape == (40000, 512) and (dx.float() - ref).abs().max().item() <= 2e-2 * float(ref.abs().max())
+
+
 def test_add_layernorm_kernel_vs_torch():
     from tmae_amd import ops
     torch.manual_seed(1)
