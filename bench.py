@@ -42,6 +42,9 @@ def parse():
     ap.add_argument('--batch-per-gpu', type=int, default=8)        # OPTIMIZATION.BATCH_SIZE_PER_GPU
     ap.add_argument('--points', type=int, default=120000)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--shape', default='once', choices=['once', 'waymo'],
+                    help='once = BASELINE configs[1] (the metric); waymo = configs[3] shape: 5 point features, z in [-2,4), '
+                         '6 m pillars (use with --points 180000)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-points', type=int, default=120000)
     ap.add_argument('--probe-only', action='store_true', help='only time the roofline kernel (for PMC runs)')
@@ -191,8 +194,15 @@ def main():
     from tmae_amd.train import (SyntheticTemporalDataset, build_model_from_cfg, build_optimizer, build_scheduler,
                                 train_one_step, wrap_ddp)
     cfg = cfg_from_yaml_file(os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae_ssl.yaml'), EasyDict())
+    npf = 5
+    if args.shape == 'waymo':
+        cfg.DATA_CONFIG.POINT_CLOUD_RANGE = [-74.88, -74.88, -2.0, 74.88, 74.88, 4.0]
+        for p_ in cfg.DATA_CONFIG.DATA_PROCESSOR:
+            if p_.NAME == 'calculate_grid_size':
+                p_.VOXEL_SIZE = [0.32, 0.32, 6.0]
+        npf = 6
     ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=args.points,
-                                  batch_size=args.batch_per_gpu, rank=rank)
+                                  batch_size=args.batch_per_gpu, rank=rank, num_point_features=npf)
     torch.manual_seed(0)
     model = build_model_from_cfg(cfg, ds).to(dev)
     model.train()
@@ -253,10 +263,11 @@ def main():
             'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'configs[1]: ONCE-shape synthetic {args.points}-pt frame-pairs, full 3-stage SST '
+            'config': {'workload': f'configs[{1 if args.shape == "once" else 3}]: {"ONCE" if args.shape == "once" else "Waymo"}-shape synthetic {args.points}-pt frame-pairs, full 3-stage SST '
                                    f'encoder + temporal cross-attn + decoder + Chamfer, fwd+bwd+Adam one-cycle',
                        'batch_per_gpu': args.batch_per_gpu, 'global_batch': args.batch_per_gpu * world,
-                       'parallelism': f'dp{world}', 'grid': '468x468x1', 'final_loss': round(loss_val, 5)},
+                       'parallelism': f'dp{world}', 'grid': '468x468x1', 'final_loss': round(loss_val, 5),
+                       'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
         }
         log(f'timed region done: {1e3 * elapsed / args.steps:.1f} ms/step; timing the dominant kernel ...')
         line['roofline'] = wgrad_roofline(model, dict(batches[0]), amp)
