@@ -70,24 +70,50 @@ class Detector3DTemplate(nn.Module):
         raise NotImplementedError
 
     # ---- checkpoints (detector3d_template.py:398-451; train_utils.py:245-270)
+    def _load_state_dict(self, model_state_disk, *, strict=True):
+        """detector3d_template.py:365-396: keep entries whose name and shape match; sparse-conv weights saved in
+        another spconv layout are adapted first -- (..., c_in, c_out) -> (..., c_out, c_in) by a transpose, or the
+        spconv-1 kernel-major layout (k1, k2[, k3], c_in, c_out) -> (c_out, k1, k2[, k3], c_in)."""
+        from .sparse import SparseConvolution
+        state_dict = self.state_dict()
+        spconv_keys = {f'{n}.weight' for n, m in self.named_modules() if isinstance(m, SparseConvolution)}
+        update = {}
+        for key, val in model_state_disk.items():
+            if key in spconv_keys and key in state_dict and state_dict[key].shape != val.shape:
+                native = val.transpose(-1, -2)
+                if native.shape == state_dict[key].shape:
+                    val = native.contiguous()
+                else:
+                    implicit = val.permute(val.dim() - 1, *range(val.dim() - 1))
+                    if implicit.shape == state_dict[key].shape:
+                        val = implicit.contiguous()
+            if key in state_dict and state_dict[key].shape == val.shape:
+                update[key] = val
+        if strict:
+            self.load_state_dict(update)
+        else:
+            state_dict.update(update)
+            self.load_state_dict(state_dict)
+        return state_dict, update
+
     def load_params_from_file(self, filename, logger=None, to_cpu=False):
         if not os.path.isfile(filename):
             raise FileNotFoundError(filename)
         ckpt = torch.load(filename, map_location='cpu' if to_cpu else None, weights_only=False)
-        state = ckpt['model_state']
-        own = self.state_dict()
-        update = {k: v for k, v in state.items() if k in own and own[k].shape == v.shape}
-        own.update(update)
-        self.load_state_dict(own)
+        own, update = self._load_state_dict(ckpt['model_state'], strict=False)
         if logger is not None:
+            if ckpt.get('version', None) is not None:
+                logger.info('==> Checkpoint trained from version: %s' % ckpt['version'])
             for k in own:
                 if k not in update:
                     logger.info('Not updated weight %s: %s' % (k, str(own[k].shape)))
             logger.info('==> Done (loaded %d/%d)' % (len(update), len(own)))
 
     def load_params_with_optimizer(self, filename, to_cpu=False, optimizer=None, logger=None):
+        if not os.path.isfile(filename):
+            raise FileNotFoundError(filename)
         ckpt = torch.load(filename, map_location='cpu' if to_cpu else None, weights_only=False)
-        self.load_state_dict(ckpt['model_state'])
+        self._load_state_dict(ckpt['model_state'], strict=True)
         if optimizer is not None and ckpt.get('optimizer_state') is not None:
             optimizer.load_state_dict(ckpt['optimizer_state'])
         return ckpt.get('it', 0.0), ckpt.get('epoch', -1)

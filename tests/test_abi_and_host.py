@@ -111,3 +111,35 @@ def test_synthetic_dataset_shards_by_rank():
     assert np.array_equal(a['points'], a2['points']) and not np.array_equal(a['points'][:50], b['points'][:50])
     assert a['points'].dtype == np.float32 and a['points'].shape[1] == 5
     assert np.abs(a['points'][:, 1:3]).max() <= 74.88
+
+
+def test_checkpoint_roundtrip_and_spconv_layout_adaptation(tmp_path):
+    """Checkpoints use the reference's format {'model_state': state_dict, ...} (train_utils.py:263-270); sparse-conv
+    weights stored in the spconv-1 kernel-major layout are adapted on load (detector3d_template.py:365-396)."""
+    model, _, _ = build_product_model(3)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    conv_keys = [k for k in sd if ('sst_blocks' in k or 'wca_blocks' in k)
+                 and (k.endswith('conv_out.0.weight') or k.endswith('conv_down.0.weight'))]
+    assert conv_keys
+    legacy = dict(sd)
+    for k in conv_keys:                                   # (c_out, k1, k2, c_in) -> (k1, k2, c_in, c_out)
+        legacy[k] = sd[k].permute(1, 2, 3, 0).contiguous()
+    f = tmp_path / 'ckpt.pth'
+    torch.save({'model_state': legacy, 'epoch': 3, 'it': 17, 'version': 'pcdet+test'}, f)
+    fresh, _, _ = build_product_model(3)
+    for p in fresh.parameters():
+        torch.nn.init.zeros_(p)
+    fresh.load_params_from_file(str(f), to_cpu=True)
+    for k, v in fresh.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    fresh2, _, _ = build_product_model(3)
+    it, epoch = fresh2.load_params_with_optimizer(str(f), to_cpu=True)
+    assert (it, epoch) == (17, 3)
+    # an entry of the wrong shape is skipped by the lenient loader, as in the reference
+    bad = dict(sd)
+    bad['backbone_3d.decoder_pred.bias'] = torch.zeros(7)
+    torch.save({'model_state': bad}, f)
+    fresh3, _, _ = build_product_model(3)
+    before = fresh3.state_dict()['backbone_3d.decoder_pred.bias'].clone()
+    fresh3.load_params_from_file(str(f), to_cpu=True)
+    assert torch.equal(fresh3.state_dict()['backbone_3d.decoder_pred.bias'], before)
