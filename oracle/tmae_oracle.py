@@ -615,20 +615,20 @@ def to_dense(feat, indices, spatial_shape, batch_size):
     return out.view(batch_size, Y, X, -1).permute(0, 3, 1, 2)
 
 
-def dense_decoder(ms_feats, batch_size, p, prefix, cfg):
+def dense_decoder(ms_feats, batch_size, p, prefix, cfg, deblocks='decoder_deblocks', conv_out='decoder_conv_out'):
     """SiamWCA_MAE.dense_conv, SiamWCA_MAE.py:231-253 with modules :79-115:
     ConvTranspose2d(k=s) + BN2d(eps 1e-3) + ReLU per scale, cat, Conv3x3 + BN + ReLU."""
     ups = []
     for i, (feat, ind, shape) in enumerate(ms_feats):
         d = to_dense(feat, ind, shape, batch_size)
         s = cfg['fuse'][i]['stride']
-        y = F.conv_transpose2d(d, p[f'{prefix}decoder_deblocks.{i}.0.weight'], stride=s)
-        y = F.relu(batch_norm_train(y, p[f'{prefix}decoder_deblocks.{i}.1.weight'],
-                                    p[f'{prefix}decoder_deblocks.{i}.1.bias'], 1e-3))
+        y = F.conv_transpose2d(d, p[f'{prefix}{deblocks}.{i}.0.weight'], stride=s)
+        y = F.relu(batch_norm_train(y, p[f'{prefix}{deblocks}.{i}.1.weight'],
+                                    p[f'{prefix}{deblocks}.{i}.1.bias'], 1e-3))
         ups.append(y)
-    y = F.conv2d(torch.cat(ups, dim=1), p[prefix + 'decoder_conv_out.0.weight'], padding=1)
-    return F.relu(batch_norm_train(y, p[prefix + 'decoder_conv_out.1.weight'],
-                                   p[prefix + 'decoder_conv_out.1.bias'], 1e-3))
+    y = F.conv2d(torch.cat(ups, dim=1), p[prefix + conv_out + '.0.weight'], padding=1)
+    return F.relu(batch_norm_train(y, p[prefix + conv_out + '.1.weight'],
+                                   p[prefix + conv_out + '.1.bias'], 1e-3))
 
 
 def group_inner_inds(inverse, num_groups, K):
