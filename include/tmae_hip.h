@@ -299,6 +299,26 @@ int tmae_column_sums(const void* x, int dtype, int64_t rows, int c, float* out, 
 int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
                     int64_t ldy, void* stream);
 
+/* ---- fine-tune path (BASELINE configs[4]): CenterHead ------------------------------------------------------
+ * Target assignment of one head (CenterHead.assign_targets / assign_target_of_single_head, center_head.py:107-231;
+ * centernet_utils.gaussian_radius / draw_gaussian_to_heatmap, centernet_utils.py:9-74).  gt_boxes [batch, nbox, ncode]
+ * f32 rows (x, y, z, dx, dy, dz, heading, ..., class) with class 1..num_class_all (0 = padding row); cls_map
+ * [num_class_all + 1] i32 maps the global class id to the index inside this head or -1.  Outputs (ZEROED by the caller):
+ * heatmap [batch, num_class_head, H, W] f32, target_boxes [batch, nmax, ncode] f32, inds / mask [batch, nmax] i64.
+ * Slot k of a sample = rank of the box among the sample's boxes of this head (the reference's loop index). */
+int tmae_centerhead_targets(const float* gt_boxes, int batch, int nbox, int ncode, const int32_t* cls_map,
+                            int num_class_all, int num_class_head, int H, int W, float pcr_x, float pcr_y, float vs_x,
+                            float vs_y, float stride, int nmax, double overlap, int min_radius, float* heatmap,
+                            float* target_boxes, int64_t* inds, int64_t* mask, void* stream);
+/* CenterNet focal loss on logits (loss_utils.neg_loss_cornernet, loss_utils.py:273-309, applied to
+ * clamp(sigmoid(x), 1e-4, 1-1e-4), center_head.py:233-244).  out4 = {loss, num_pos, pos_sum, neg_sum} f32;
+ * backward: dlogits = grad_out * d loss / d logits (stats4 = out4 of the forward). */
+size_t tmae_focal_loss_workspace(int64_t n);
+int tmae_focal_loss_fwd(const void* logits, int dtype, const float* target, int64_t n, float* out4, void* ws,
+                        size_t ws_bytes, void* stream);
+int tmae_focal_loss_bwd(const void* logits, int dtype, const float* target, int64_t n, const float* stats4,
+                        const float* grad_out, void* dlogits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

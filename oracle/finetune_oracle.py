@@ -256,9 +256,11 @@ def finetune_loss(params, points, points_prev, gt_boxes, batch_size, cfg, captur
 
 
 # --------------------------------------------------------------------------- init / synthetic labels
-def init_finetune_params(cfg, seed=0, num_point_features=4, tau=None):
+def init_finetune_params(cfg, seed=0, num_point_features=4, tau=None, hm_scale=0.2):
     """State dict with the reference's names (CenterPoint of t_mae.yaml): vfe.*, backbone_3d.{sst_blocks,wca_blocks,
-    deblocks,conv_out}.*, backbone_2d.conv_layer.*, dense_head.{shared_conv,heads_list}.*"""
+    deblocks,conv_out}.*, backbone_2d.conv_layer.*, dense_head.{shared_conv,heads_list}.*.  `hm_scale` scales the last
+    heat-map conv (an untrained head with unit-scale logits gives a focal loss of several hundred whose gradient through
+    the seven BatchNorm layers below it is ill-conditioned: 1 % run-to-run in fp32)."""
     base = O.init_params(cfg, seed=seed, num_point_features=num_point_features, tau=tau)
     P = OrderedDict()
     for k, v in base.items():
@@ -295,6 +297,7 @@ def init_finetune_params(cfg, seed=0, num_point_features=4, tau=None):
             conv(f'{pre}{spec["num_conv"] - 1}', spec['out_channels'], sc, True)
             if name == 'hm':
                 P[f'{pre}{spec["num_conv"] - 1}.bias'].fill_(-2.19)
+                P[f'{pre}{spec["num_conv"] - 1}.weight'] *= hm_scale
     return P
 
 

@@ -161,7 +161,7 @@ def main():
         names = [k for k in P.keys()]
         ref_names = [pre + k for mod, pre in ((V, 'vfe.'), (B3, 'backbone_3d.'), (B2, 'backbone_2d.'), (H, 'dense_head.'))
                      for k in mod.state_dict().keys()]
-        save(tag, n_points=npts, batch_size=bs, param_seed=11, tau=np.float32(0.25), points=pts, points_prev=prv, gt_boxes=gtb,
+        save(tag, n_points=npts, batch_size=bs, param_seed=11, tau=np.float32(0.25), hm_scale=np.float32(0.2), points=pts, points_prev=prv, gt_boxes=gtb,
              loss=loss.detach().numpy(), hm_loss=np.float32(tb['hm_loss_head_0']), loc_loss=np.float32(tb['loc_loss_head_0']),
              grad_names=np.array(list(gn.keys())), grad_norms=np.array(list(gn.values())),
              state_names=np.array(ref_names), state_shapes=np.array([str(tuple(v.shape)) for mod in (V, B3, B2, H) for v in mod.state_dict().values()]),

@@ -64,6 +64,10 @@ SIGNATURES = {
     'tmae_deblock_gather': (I, [P, I, I, I, P, L, I, I, I, I, P, P]),
     'tmae_column_sums_workspace': (Z, [L, I]),
     'tmae_column_sums': (I, [P, I, L, I, P, P, Z, P]),
+    'tmae_centerhead_targets': (I, [P, I, I, I, P, I, I, I, I, F, F, F, F, F, I, D, I, P, P, P, P, P]),
+    'tmae_focal_loss_workspace': (Z, [L]),
+    'tmae_focal_loss_fwd': (I, [P, I, P, L, P, P, Z, P]),
+    'tmae_focal_loss_bwd': (I, [P, I, P, L, P, P, P, P]),
     'tmae_token_gemm': (I, [P, L, L, I, P, I, P, P, L, P]),
     'tmae_linear_wgrad_workspace': (Z, [L, I, I]),
     'tmae_linear_wgrad': (I, [P, L, P, L, L, I, I, P, P, P, Z, P]),

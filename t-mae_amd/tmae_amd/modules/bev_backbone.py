@@ -1,0 +1,46 @@
+"""SSTBEVBackbone (pcdet/models/backbones_2d/sst_bev_backbone.py:6-43): a stack of 3x3 Conv2d (+dilation) +
+BatchNorm2d(eps 1e-3, momentum 0.01) + ReLU with residual shortcuts.  The convolutions are MIOpen's (channels-last);
+the norm + ReLU run on the row kernels of csrc/batchnorm.hip over the [B*Y*X, C] view."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def conv_bn_relu_nhwc(seq, x):
+    """seq = Sequential(Conv2d, BatchNorm2d, ReLU) on a channels-last tensor; fused norm+ReLU in training."""
+    conv, bn = seq[0], seq[1]
+    y = conv(x)
+    if (bn.training and y.is_cuda and y.is_contiguous(memory_format=torch.channels_last)
+            and y.shape[1] in (64, 128, 256) and len(seq) == 3 and isinstance(seq[2], nn.ReLU)):
+        b, c, ny, nx = y.shape
+        rows = ops.batch_norm_relu(y.permute(0, 2, 3, 1).reshape(b * ny * nx, c), bn, relu=True)
+        return rows.view(b, ny, nx, c).permute(0, 3, 1, 2)
+    y = bn(y)
+    return seq[2](y) if len(seq) > 2 else y
+
+
+class SSTBEVBackbone(nn.Module):
+    def __init__(self, model_cfg, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        input_channels = model_cfg.NUM_FILTER
+        self.conv_shortcut = list(model_cfg.CONV_SHORTCUT)
+        layers = []
+        for kw in model_cfg.CONV_KWARGS:
+            kw = dict(kw)
+            layers.append(nn.Sequential(
+                nn.Conv2d(input_channels, **kw, bias=False),
+                nn.BatchNorm2d(kw['out_channels'], eps=1e-3, momentum=0.01),
+                nn.ReLU(inplace=True)))
+            input_channels = kw['out_channels']
+        self.conv_layer = nn.ModuleList(layers)
+        self.num_bev_features = input_channels
+
+    def forward(self, data_dict):
+        out = data_dict['spatial_features']
+        for i, conv in enumerate(self.conv_layer):
+            t = conv_bn_relu_nhwc(conv, out)
+            out = t + out if (t.shape == out.shape and i in self.conv_shortcut) else t
+        data_dict['spatial_features_2d'] = out
+        return data_dict

@@ -1,0 +1,151 @@
+"""CenterHead (pcdet/models/dense_heads/center_head.py:11-394), training path: shared conv, per-class-group separate
+heads, target assignment and losses.  Same constructor kwargs, forward contract (`data_dict -> data_dict`,
+`forward_ret_dict`, `get_loss() -> (loss, tb_dict)`) and state_dict names as the reference.  Targets are assigned on the
+device by one HIP launch per head (the reference loops over samples and boxes on the CPU) and the heat-map focal loss is
+one fused kernel; box decoding + NMS (evaluation) are the next row of SURVEY 8f."""
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.init import kaiming_normal_
+
+from .. import ops
+from .bev_backbone import conv_bn_relu_nhwc
+
+
+class SeparateHead(nn.Module):
+    """center_head.py:11-45."""
+
+    def __init__(self, input_channels, sep_head_dict, init_bias=-2.19, use_bias=False):
+        super().__init__()
+        self.sep_head_dict = sep_head_dict
+        for cur_name in self.sep_head_dict:
+            out_ch = self.sep_head_dict[cur_name]['out_channels']
+            num_conv = self.sep_head_dict[cur_name]['num_conv']
+            fc = []
+            for _ in range(num_conv - 1):
+                fc.append(nn.Sequential(
+                    nn.Conv2d(input_channels, input_channels, kernel_size=3, stride=1, padding=1, bias=use_bias),
+                    nn.BatchNorm2d(input_channels),
+                    nn.ReLU(inplace=True)))
+            fc.append(nn.Conv2d(input_channels, out_ch, kernel_size=3, stride=1, padding=1, bias=True))
+            fc = nn.Sequential(*fc)
+            if 'hm' in cur_name:
+                fc[-1].bias.data.fill_(init_bias)
+            else:
+                for m in fc.modules():
+                    if isinstance(m, nn.Conv2d):
+                        kaiming_normal_(m.weight.data)
+                        if hasattr(m, 'bias') and m.bias is not None:
+                            nn.init.constant_(m.bias, 0)
+            self.__setattr__(cur_name, fc)
+
+    def forward(self, x):
+        ret = {}
+        for cur_name in self.sep_head_dict:
+            fc = self.__getattr__(cur_name)
+            y = x
+            for layer in fc:
+                y = conv_bn_relu_nhwc(layer, y) if isinstance(layer, nn.Sequential) else layer(y)
+            ret[cur_name] = y
+        return ret
+
+
+def _reg_loss(pred, target, mask):
+    """loss_utils._reg_loss (loss_utils.py:321-352): per-code L1 sums over the assigned slots / number of objects."""
+    num = mask.float().sum()
+    m = mask.unsqueeze(2).expand_as(target).float() * (~torch.isnan(target)).float()
+    loss = torch.abs(pred * m - target * m).sum(dim=(0, 1))
+    return loss / torch.clamp_min(num, min=1.0)
+
+
+class CenterHead(nn.Module):
+    def __init__(self, model_cfg, input_channels, num_class, class_names, grid_size, point_cloud_range, voxel_size,
+                 predict_boxes_when_training=True, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.grid_size = grid_size
+        self.point_cloud_range = [float(v) for v in point_cloud_range]
+        self.voxel_size = [float(v) for v in voxel_size]
+        self.feature_map_stride = self.model_cfg.TARGET_ASSIGNER_CONFIG.get('FEATURE_MAP_STRIDE', None)
+        self.class_names = list(class_names)
+        self.class_names_each_head = []
+        for cur in self.model_cfg.CLASS_NAMES_EACH_HEAD:
+            self.class_names_each_head.append([x for x in cur if x in self.class_names])
+        total = sum(len(x) for x in self.class_names_each_head)
+        assert total == len(self.class_names), f'class_names_each_head={self.class_names_each_head}'
+        # global class id (1-based, 0 = padding) -> index inside the head, per head (center_head.py:195-206)
+        for hi, names in enumerate(self.class_names_each_head):
+            cmap = torch.full((len(self.class_names) + 1,), -1, dtype=torch.int32)
+            for gi, n in enumerate(self.class_names):
+                if n in names:
+                    cmap[gi + 1] = names.index(n)
+            self.register_buffer(f'_cls_map_{hi}', cmap, persistent=False)
+            self.register_buffer(f'_cls_id_{hi}', torch.tensor([self.class_names.index(n) for n in names]), persistent=False)
+        use_bias = self.model_cfg.get('USE_BIAS_BEFORE_NORM', False)
+        self.shared_conv = nn.Sequential(
+            nn.Conv2d(input_channels, self.model_cfg.SHARED_CONV_CHANNEL, 3, stride=1, padding=1, bias=use_bias),
+            nn.BatchNorm2d(self.model_cfg.SHARED_CONV_CHANNEL),
+            nn.ReLU(inplace=True))
+        self.heads_list = nn.ModuleList()
+        self.separate_head_cfg = self.model_cfg.SEPARATE_HEAD_CFG
+        for names in self.class_names_each_head:
+            hd = copy.deepcopy(dict(self.separate_head_cfg.HEAD_DICT))
+            hd = {k: dict(v) for k, v in hd.items()}
+            hd['hm'] = dict(out_channels=len(names), num_conv=self.model_cfg.NUM_HM_CONV)
+            self.heads_list.append(SeparateHead(self.model_cfg.SHARED_CONV_CHANNEL, hd, init_bias=-2.19, use_bias=use_bias))
+        self.with_iou = 'iou' in self.separate_head_cfg.HEAD_DICT
+        if self.with_iou:
+            raise NotImplementedError('IoU head (rotated-box IoU kernel): next row of SURVEY 8f')
+        self.predict_boxes_when_training = predict_boxes_when_training
+        self.forward_ret_dict = {}
+
+    def assign_targets(self, gt_boxes, feature_map_size=None, **kwargs):
+        """center_head.py:168-231.  gt_boxes [B, M, 8]; feature_map_size (H, W)."""
+        cfg = self.model_cfg.TARGET_ASSIGNER_CONFIG
+        ret = {'heatmaps': [], 'target_boxes': [], 'inds': [], 'masks': []}
+        for hi, names in enumerate(self.class_names_each_head):
+            heat, tb, inds, mask = ops.centerhead_targets(
+                gt_boxes, getattr(self, f'_cls_map_{hi}'), len(names), feature_map_size, self.point_cloud_range,
+                self.voxel_size, cfg.FEATURE_MAP_STRIDE, cfg.NUM_MAX_OBJS, cfg.GAUSSIAN_OVERLAP, cfg.MIN_RADIUS)
+            ret['heatmaps'].append(heat), ret['target_boxes'].append(tb), ret['inds'].append(inds), ret['masks'].append(mask)
+        return ret
+
+    def get_loss(self):
+        """center_head.py:237-262 (+ loss_utils FocalLossCenterNet / RegLossCenterNet)."""
+        pred_dicts = self.forward_ret_dict['pred_dicts']
+        target_dicts = self.forward_ret_dict['target_dicts']
+        w = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
+        tb_dict = {}
+        loss = 0
+        for idx, pd in enumerate(pred_dicts):
+            hm_loss = ops.focal_loss_centernet(pd['hm'], target_dicts['heatmaps'][idx]) * w['cls_weight']
+            pred_boxes = torch.cat([pd[n] for n in self.separate_head_cfg.HEAD_ORDER], dim=1).float()
+            B, C = pred_boxes.shape[0], pred_boxes.shape[1]
+            ind = target_dicts['inds'][idx]
+            feat = pred_boxes.permute(0, 2, 3, 1).reshape(B, -1, C)
+            pred = feat.gather(1, ind.unsqueeze(2).expand(B, ind.shape[1], C))
+            reg = _reg_loss(pred, target_dicts['target_boxes'][idx], target_dicts['masks'][idx])
+            loc_loss = (reg * reg.new_tensor(w['code_weights'])).sum() * w['loc_weight']
+            loss = loss + hm_loss + loc_loss
+            tb_dict['hm_loss_head_%d' % idx] = hm_loss.detach()        # tensors: no host sync (the reference calls .item())
+            tb_dict['loc_loss_head_%d' % idx] = loc_loss.detach()
+        return loss, tb_dict
+
+    def generate_predicted_boxes(self, batch_size, pred_dicts):
+        raise NotImplementedError('box decoding + NMS (evaluation path): next row of SURVEY 8f')
+
+    def forward(self, data_dict):
+        x2d = data_dict['spatial_features_2d']
+        x = conv_bn_relu_nhwc(self.shared_conv, x2d)
+        pred_dicts = [head(x) for head in self.heads_list]
+        if self.training:
+            self.forward_ret_dict['target_dicts'] = self.assign_targets(
+                data_dict['gt_boxes'], feature_map_size=x2d.size()[2:],
+                feature_map_stride=data_dict.get('spatial_features_2d_strides', None))
+        self.forward_ret_dict['pred_dicts'] = pred_dicts
+        if not self.training or self.predict_boxes_when_training:
+            data_dict['final_box_dicts'] = self.generate_predicted_boxes(data_dict['batch_size'], pred_dicts)
+        return data_dict

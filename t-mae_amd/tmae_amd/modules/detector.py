@@ -16,7 +16,7 @@ class Detector3DTemplate(nn.Module):
         self.model_cfg, self.num_class, self.dataset, self.logger = model_cfg, num_class, dataset, logger
         self.class_names = dataset.class_names
         self.register_buffer('global_step', torch.LongTensor(1).zero_())
-        self.module_topology = ['vfe', 'backbone_3d']        # the topology entries on the T-MAE path
+        self.module_topology = ['vfe', 'backbone_3d', 'backbone_2d', 'dense_head']   # the entries the T-MAE configs use
 
     @property
     def mode(self):
@@ -37,9 +37,9 @@ class Detector3DTemplate(nn.Module):
         for name in self.module_topology:
             module, info = getattr(self, 'build_%s' % name)(model_info_dict=info)
             self.add_module(name, module)
-        for unsupported in ('MAP_TO_BEV', 'PFE', 'BACKBONE_2D', 'DENSE_HEAD', 'POINT_HEAD', 'ROI_HEAD', 'IMG_BACKBONE'):
+        for unsupported in ('MAP_TO_BEV', 'PFE', 'POINT_HEAD', 'ROI_HEAD', 'IMG_BACKBONE'):
             if self.model_cfg.get(unsupported, None) is not None:
-                raise NotImplementedError(f'MODEL.{unsupported}: outside the T-MAE pre-training hot path (SURVEY 8f)')
+                raise NotImplementedError(f'MODEL.{unsupported}: not used by the T-MAE configs (SURVEY 8f)')
         return info['module_list']
 
     def build_vfe(self, model_info_dict):
@@ -64,6 +64,30 @@ class Detector3DTemplate(nn.Module):
             point_cloud_range=model_info_dict['point_cloud_range'])
         model_info_dict['module_list'].append(m)
         model_info_dict['num_point_features'] = m.num_point_features
+        return m, model_info_dict
+
+    def build_backbone_2d(self, model_info_dict):
+        from . import registry
+        if self.model_cfg.get('BACKBONE_2D', None) is None:
+            return None, model_info_dict
+        m = registry.BACKBONES_2D[self.model_cfg.BACKBONE_2D.NAME](
+            model_cfg=self.model_cfg.BACKBONE_2D, input_channels=model_info_dict.get('num_bev_features', None))
+        model_info_dict['module_list'].append(m)
+        model_info_dict['num_bev_features'] = m.num_bev_features
+        return m, model_info_dict
+
+    def build_dense_head(self, model_info_dict):
+        from . import registry
+        if self.model_cfg.get('DENSE_HEAD', None) is None:
+            return None, model_info_dict
+        m = registry.DENSE_HEADS[self.model_cfg.DENSE_HEAD.NAME](
+            model_cfg=self.model_cfg.DENSE_HEAD, input_channels=model_info_dict['num_bev_features'],
+            num_class=self.num_class if not self.model_cfg.DENSE_HEAD.CLASS_AGNOSTIC else 1,
+            class_names=self.class_names, grid_size=model_info_dict['grid_size'],
+            point_cloud_range=model_info_dict['point_cloud_range'],
+            predict_boxes_when_training=self.model_cfg.get('ROI_HEAD', False),
+            voxel_size=model_info_dict.get('voxel_size', False))
+        model_info_dict['module_list'].append(m)
         return m, model_info_dict
 
     def forward(self, **kwargs):
@@ -139,4 +163,25 @@ class TMAE(Detector3DTemplate):
         loss_rpn, tb_dict = self.backbone_3d.get_loss()
         # the reference calls loss.item() here (t_mae.py:31): a host sync per step; keep the tensor instead
         tb_dict = {'loss_rpn': loss_rpn.detach(), **tb_dict}
+        return loss_rpn, tb_dict, {}
+
+
+class CenterPoint(Detector3DTemplate):
+    """pcdet/models/detectors/centerpoint.py:4-50 (training path)."""
+
+    def __init__(self, model_cfg, num_class, dataset, logger=None):
+        super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset, logger=logger)
+        self.module_list = self.build_networks()
+
+    def forward(self, batch_dict):
+        for cur_module in self.module_list:
+            batch_dict = cur_module(batch_dict)
+        if self.training:
+            loss, tb_dict, disp_dict = self.get_training_loss()
+            return {'loss': loss}, tb_dict, disp_dict
+        raise NotImplementedError('evaluation (box decoding, NMS, recall): next row of SURVEY 8f')
+
+    def get_training_loss(self):
+        loss_rpn, tb_dict = self.dense_head.get_loss()
+        tb_dict = {'loss_rpn': loss_rpn.detach(), **tb_dict}      # the reference calls .item() here: a host sync
         return loss_rpn, tb_dict, {}

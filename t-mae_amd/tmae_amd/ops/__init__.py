@@ -995,3 +995,57 @@ def chamfer_distance(pred, gt, weights=None):
     if weights is None:
         weights = torch.ones(pred.shape[0], device=pred.device)
     return _Chamfer.apply(pred, gt, weights), None
+
+
+# ----------------------------------------------------------------------------- fine-tune path: CenterHead
+
+def centerhead_targets(gt_boxes, cls_map, num_class_head, fm_hw, pc_range, voxel_size, stride, nmax, overlap, min_radius):
+    """CenterHead.assign_targets for one head (center_head.py:107-231) on the device: gt_boxes [B, M, 8] f32
+    (class 1..n in the last column, zero rows = padding), cls_map [n+1] i32 (global class id -> index in the head or
+    -1).  Returns heatmap [B, C, H, W], target_boxes [B, nmax, 8], inds [B, nmax] i64, mask [B, nmax] i64."""
+    _need_cuda(gt_boxes)
+    g = gt_boxes.contiguous().float()
+    B, M, ncode = g.shape
+    H, W = int(fm_hw[0]), int(fm_hw[1])
+    dev = g.device
+    heat = torch.zeros((B, num_class_head, H, W), dtype=torch.float32, device=dev)
+    tb = torch.zeros((B, nmax, ncode), dtype=torch.float32, device=dev)
+    inds = torch.zeros((B, nmax), dtype=torch.int64, device=dev)
+    mask = torch.zeros((B, nmax), dtype=torch.int64, device=dev)
+    check(lib.tmae_centerhead_targets(_p(g), B, M, ncode, _p(cls_map), cls_map.numel() - 1, num_class_head, H, W,
+                                      float(pc_range[0]), float(pc_range[1]), float(voxel_size[0]), float(voxel_size[1]),
+                                      float(stride), int(nmax), float(overlap), int(min_radius), _p(heat), _p(tb), _p(inds),
+                                      _p(mask), _s()), 'tmae_centerhead_targets')
+    return heat, tb, inds, mask
+
+
+class _FocalLossCenterNet(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        x = logits.contiguous()
+        t = target.contiguous().float()
+        n = x.numel()
+        out = torch.empty((4,), dtype=torch.float32, device=x.device)
+        wsb = lib.tmae_focal_loss_workspace(n)
+        ws = _ws(wsb, x.device)
+        check(lib.tmae_focal_loss_fwd(_p(x), _dt(x), _p(t), n, _p(out), _p(ws), wsb, _s()), 'tmae_focal_loss_fwd')
+        ctx.save_for_backward(x, t, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t, out = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        g32 = g.reshape(1).float().contiguous()
+        check(lib.tmae_focal_loss_bwd(_p(x), _dt(x), _p(t), x.numel(), _p(out), _p(g32), _p(dx), _s()),
+              'tmae_focal_loss_bwd')
+        return dx, None
+
+
+def focal_loss_centernet(logits, target):
+    """FocalLossCenterNet()(clamp(sigmoid(logits), 1e-4, 1 - 1e-4), target) (center_head.py:233-244,
+    loss_utils.py:273-309) as one fused forward and one fused backward kernel."""
+    _need_cuda(logits)
+    if logits.dtype not in (torch.float32, torch.bfloat16):
+        logits = logits.float()
+    return _FocalLossCenterNet.apply(logits, target)

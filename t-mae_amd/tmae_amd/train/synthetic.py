@@ -32,13 +32,32 @@ class _PointFeatureEncoder:
         self.num_point_features = n   # ONCE: x, y, z, intensity, group_id = 5 (once_temporal_dataset.yaml); Waymo: 6
 
 
+def synth_gt_boxes(batch_size, n_boxes, seed, limit=74.0):
+    """Synthetic ONCE-style labels [B, n_boxes, 8]: x, y, z, dx, dy, dz, heading, class (1..5; zero rows = padding),
+    the layout of `gt_boxes` after collate (dataset.py:203-221)."""
+    rng = np.random.default_rng(seed)
+    sizes = np.array([[4.4, 1.9, 1.6], [11.0, 2.9, 3.4], [7.5, 2.6, 3.0], [0.8, 0.8, 1.75], [2.0, 0.8, 1.6]], np.float32)
+    out = np.zeros((batch_size, n_boxes, 8), np.float32)
+    for b in range(batch_size):
+        n = int(rng.integers(n_boxes // 2, n_boxes + 1))
+        cls = rng.integers(1, 6, n)
+        out[b, :n, 0] = rng.uniform(-limit, limit, n)
+        out[b, :n, 1] = rng.uniform(-limit, limit, n)
+        out[b, :n, 2] = rng.normal(-1.0, 0.4, n)
+        out[b, :n, 3:6] = sizes[cls - 1] * rng.uniform(0.85, 1.15, (n, 3)).astype(np.float32)
+        out[b, :n, 6] = rng.uniform(-np.pi, np.pi, n)
+        out[b, :n, 7] = cls
+    return out
+
+
 class SyntheticTemporalDataset:
     """Stands where ONCETemporalDataset stands for build_network: exposes class_names,
     point_feature_encoder.num_point_features, grid_size, point_cloud_range, voxel_size
     (detector3d_template.py:22,46-53) and yields collated batches."""
 
     def __init__(self, dataset_cfg, class_names, n_points=120000, batch_size=8, rank=0, length=1 << 30,
-                 num_point_features=5):
+                 num_point_features=5, n_boxes=0):
+        self.n_boxes = n_boxes                          # > 0: also yield synthetic `gt_boxes` (fine-tune path)
         self.class_names = class_names
         self.point_feature_encoder = _PointFeatureEncoder(num_point_features)
         self.point_cloud_range = np.array(dataset_cfg.POINT_CLOUD_RANGE, dtype=np.float32)
@@ -58,4 +77,8 @@ class SyntheticTemporalDataset:
         pts, prv = synth_frame_pair(self.n_points, self.batch_size, 1000 * self.rank + iteration,
                                     limit=float(self.point_cloud_range[3]),
                                     extra_features=self.point_feature_encoder.num_point_features - 5)
-        return {'points': pts, 'points_prev': prv, 'batch_size': self.batch_size}
+        out = {'points': pts, 'points_prev': prv, 'batch_size': self.batch_size}
+        if self.n_boxes > 0:
+            out['gt_boxes'] = synth_gt_boxes(self.batch_size, self.n_boxes, 7919 * self.rank + iteration,
+                                             limit=float(self.point_cloud_range[3]) - 1.0)
+        return out

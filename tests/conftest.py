@@ -31,6 +31,21 @@ def load_cfg(num_stages=3):
     return cfg
 
 
+def build_finetune_model(params=None, device='cpu', n_points=1000, batch_size=2):
+    """CenterPoint (t_mae.yaml: TemporalDynVFE + SiamWCA + SSTBEVBackbone + CenterHead) through the registry path."""
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    from pcdet.models import build_network
+    from tmae_amd.train import SyntheticTemporalDataset
+    cfg = cfg_from_yaml_file(os.path.join(os.path.dirname(CFG_YAML), 't_mae.yaml'), EasyDict())
+    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=n_points, batch_size=batch_size, n_boxes=20)
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
+    if params is not None:
+        res = model.load_state_dict(params, strict=False)
+        assert not res.unexpected_keys, res.unexpected_keys
+        assert all('running_' in k or 'num_batches' in k or k == 'global_step' for k in res.missing_keys), res.missing_keys
+    return model.to(device), cfg, ds
+
+
 def build_product_model(num_stages=3, params=None, device='cpu', n_points=1000, batch_size=2, partial=False,
                         waymo_shape=False):
     """TMAE through the pcdet registry path; `params` = oracle-style state dict (reference key names)."""
@@ -59,3 +74,9 @@ def build_product_model(num_stages=3, params=None, device='cpu', n_points=1000, 
 def oracle():
     import tmae_oracle
     return tmae_oracle
+
+
+@pytest.fixture(scope='session')
+def ft_oracle():
+    import finetune_oracle
+    return finetune_oracle

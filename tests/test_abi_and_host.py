@@ -64,8 +64,6 @@ def test_registry_and_state_dict_contract():
     assert {'TMAE', 'CenterPoint'} <= set(detectors.__all__)
     assert {'SiamWCA_MAE', 'SiamWCA'} <= set(backbones_3d.__all__)
     assert 'TemporalDynVFE' in vfe.__all__
-    with pytest.raises(NotImplementedError):
-        backbones_3d.__all__['SiamWCA']()
     model, cfg, ds = build_product_model(3)
     assert list(ds.grid_size) == [468, 468, 1]
     g = golden('F0_state_dict_contract')
@@ -143,3 +141,21 @@ def test_checkpoint_roundtrip_and_spconv_layout_adaptation(tmp_path):
     before = fresh3.state_dict()['backbone_3d.decoder_pred.bias'].clone()
     fresh3.load_params_from_file(str(f), to_cpu=True)
     assert torch.equal(fresh3.state_dict()['backbone_3d.decoder_pred.bias'], before)
+
+
+def test_finetune_registry_and_state_dict_contract():
+    """configs[4]: CenterPoint / SiamWCA / SSTBEVBackbone / CenterHead resolve through the registries and expose the
+    reference's state_dict (names and shapes captured from the reference modules in G3)."""
+    from conftest import build_finetune_model
+    from pcdet.models import backbones_2d, dense_heads, detectors, backbones_3d
+    assert 'CenterPoint' in detectors.__all__ and 'SiamWCA' in backbones_3d.__all__
+    assert 'SSTBEVBackbone' in backbones_2d.__all__ and 'CenterHead' in dense_heads.__all__
+    model, cfg, ds = build_finetune_model()
+    g = golden('G3_finetune_e2e_3stage')
+    ref = {str(n): str(s) for n, s in zip(g['state_names'], g['state_shapes'])}
+    mine = {k: str(tuple(v.shape)) for k, v in model.state_dict().items() if k != 'global_step'}
+    assert mine == ref
+    # pre-trained encoder weights load by name into the fine-tune model (README workflow: --pretrained_model)
+    pre, _, _ = build_product_model(3)
+    shared = [k for k in pre.state_dict() if k in model.state_dict() and ('sst_blocks' in k or 'wca_blocks' in k or k.startswith('vfe.'))]
+    assert len(shared) > 250

@@ -1,0 +1,60 @@
+"""CPU: the fine-tune oracle (oracle/finetune_oracle.py) against the golden vectors captured from the reference's
+CenterHead / SSTBEVBackbone / SiamWCA / loss_utils / centernet_utils (tests/golden/G*.npz, written by
+oracle/gen_golden_finetune.py)."""
+import numpy as np
+import torch
+
+from conftest import golden
+
+
+def _dense_heat(g):
+    hm = np.zeros(tuple(g['heat_shape']), np.float32)
+    ix = g['heat_nz_index']
+    hm[ix[:, 0], ix[:, 1], ix[:, 2], ix[:, 3]] = g['heat_nz_value']
+    return hm
+
+
+def test_g1_centerhead_targets(ft_oracle):
+    g = golden('G1_centerhead_targets')
+    cfg = ft_oracle.default_finetune_cfg(3)
+    t = ft_oracle.assign_targets(torch.from_numpy(g['gt_boxes']), (468, 468), cfg)
+    assert np.array_equal(t['heatmaps'][0].numpy(), _dense_heat(g))
+    assert np.array_equal(t['inds'][0].numpy(), g['inds']) and np.array_equal(t['masks'][0].numpy(), g['masks'])
+    assert np.array_equal(t['target_boxes'][0].numpy(), g['target_boxes'])
+    # the degenerate / clamped boxes of the fixture: dx = 0 is skipped, a centre outside the range lands in the last cell
+    assert t['masks'][0][1].sum() < (g['gt_boxes'][1, :, -1] > 0).sum()
+    assert int(t['inds'][0][0, 1]) % 468 == 467
+
+
+def test_g2_losses(ft_oracle):
+    g1, g2 = golden('G1_centerhead_targets'), golden('G2_centerhead_losses')
+    gen = torch.Generator().manual_seed(int(g2['pred_seed']))
+    pred_hm = (torch.rand(3, 5, 468, 468, generator=gen) * 0.98 + 0.01).requires_grad_(True)
+    pred_box = torch.randn(3, 8, 468, 468, generator=gen).requires_grad_(True)
+    heat = torch.from_numpy(_dense_heat(g1))
+    fl = ft_oracle.focal_loss_centernet(pred_hm, heat)
+    rl = ft_oracle.reg_loss_centernet(pred_box, torch.from_numpy(g1['masks']), torch.from_numpy(g1['inds']),
+                                      torch.from_numpy(g1['target_boxes']))
+    (fl + rl.sum()).backward()
+    assert abs(float(fl) - float(g2['focal'])) <= 1e-5 * abs(float(g2['focal']))
+    np.testing.assert_allclose(rl.detach().numpy(), g2['reg'], atol=1e-6)
+    np.testing.assert_allclose(pred_hm.grad.flatten()[torch.from_numpy(g2['grad_probe_index'])].numpy(), g2['grad_probe_hm'],
+                               atol=1e-7)
+    gb = pred_box.grad.flatten()
+    nz = gb.nonzero()[:, 0]
+    assert np.array_equal(nz.numpy(), g2['grad_box_nz_index'])
+    np.testing.assert_allclose(gb[nz].numpy(), g2['grad_box_nz'], atol=1e-8)
+
+
+def test_g3_finetune_e2e(ft_oracle):
+    g = golden('G3_finetune_e2e_3stage')
+    cfg = ft_oracle.default_finetune_cfg(3)
+    P = {k: v.requires_grad_(True) for k, v in ft_oracle.init_finetune_params(cfg, seed=int(g['param_seed']), tau=float(g['tau'])).items()}
+    cap = {}
+    loss = ft_oracle.finetune_loss(P, g['points'], g['points_prev'], g['gt_boxes'], int(g['batch_size']), cfg, cap)
+    loss.backward()
+    assert abs(float(loss) - float(g['loss'])) <= 2e-5 * max(1.0, abs(float(g['loss'])))
+    assert abs(float(cap['parts']['hm_loss_head_0']) - float(g['hm_loss'])) <= 2e-5 * max(1.0, float(g['hm_loss']))
+    assert abs(float(cap['parts']['loc_loss_head_0']) - float(g['loc_loss'])) <= 2e-5 * max(1.0, float(g['loc_loss']))
+    for n, gn in zip(g['grad_names'], g['grad_norms']):
+        assert abs(float(P[str(n)].grad.norm()) - gn) <= 3e-3 * max(1.0, gn), n
