@@ -42,6 +42,9 @@ def parse():
     ap.add_argument('--batch-per-gpu', type=int, default=8)        # OPTIMIZATION.BATCH_SIZE_PER_GPU
     ap.add_argument('--points', type=int, default=120000)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--task', default='pretrain', choices=['pretrain', 'finetune'],
+                    help='pretrain = the metric (t_mae_ssl.yaml); finetune = BASELINE configs[4]: CenterPoint head on the '
+                         'two-frame encoder (t_mae.yaml, synthetic labels; informational, batch 6 = its recipe)')
     ap.add_argument('--shape', default='once', choices=['once', 'waymo'],
                     help='once = BASELINE configs[1] (the metric); waymo = configs[3] shape: 5 point features, z in [-2,4), '
                          '6 m pillars (use with --points 180000)')
@@ -193,7 +196,8 @@ def main():
     from pcdet.models import model_fn_decorator
     from tmae_amd.train import (SyntheticTemporalDataset, build_model_from_cfg, build_optimizer, build_scheduler,
                                 train_one_step, wrap_ddp)
-    cfg = cfg_from_yaml_file(os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae_ssl.yaml'), EasyDict())
+    yaml_name = 't_mae_ssl.yaml' if args.task == 'pretrain' else 't_mae.yaml'
+    cfg = cfg_from_yaml_file(os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', yaml_name), EasyDict())
     npf = 5
     if args.shape == 'waymo':
         cfg.DATA_CONFIG.POINT_CLOUD_RANGE = [-74.88, -74.88, -2.0, 74.88, 74.88, 4.0]
@@ -202,7 +206,8 @@ def main():
                 p_.VOXEL_SIZE = [0.32, 0.32, 6.0]
         npf = 6
     ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=args.points,
-                                  batch_size=args.batch_per_gpu, rank=rank, num_point_features=npf)
+                                  batch_size=args.batch_per_gpu, rank=rank, num_point_features=npf,
+                                  n_boxes=40 if args.task == 'finetune' else 0)
     torch.manual_seed(0)
     model = build_model_from_cfg(cfg, ds).to(dev)
     model.train()
@@ -219,6 +224,8 @@ def main():
         b = ds.batch(i)
         batches.append({'points': torch.from_numpy(b['points']).to(dev), 'points_prev': torch.from_numpy(b['points_prev']).to(dev),
                         'batch_size': b['batch_size']})
+        if 'gt_boxes' in b:
+            batches[-1]['gt_boxes'] = torch.from_numpy(b['gt_boxes']).to(dev)
 
     def step(i):
         return train_one_step(ddp, opt, sched, dict(batches[i % nb]), i, model_func, amp_dtype=amp)[0]
@@ -259,7 +266,9 @@ def main():
     if rank == 0:
         pairs = args.batch_per_gpu * world * args.steps
         line = {
-            'metric': 'frame-pairs/sec T-MAE pretrain, 120k-pt ONCE scans', 'value': round(pairs / elapsed, 4),
+            'metric': ('frame-pairs/sec T-MAE pretrain, 120k-pt ONCE scans' if args.task == 'pretrain' else
+                       'frame-pairs/sec T-MAE fine-tune (CenterPoint head), 120k-pt ONCE scans'),
+            'value': round(pairs / elapsed, 4),
             'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',

@@ -74,7 +74,8 @@ def main():
     log_config_to_file(cfg, logger=logger)
     if not args.synthetic:
         raise NotImplementedError('the ONCE two-frame dataloader is outside this hot path (SURVEY 8f-2); use --synthetic')
-    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=args.synthetic_points, batch_size=bs, rank=rank)
+    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=args.synthetic_points, batch_size=bs, rank=rank,
+                                  n_boxes=40 if cfg.MODEL.get('DENSE_HEAD', None) is not None else 0)   # labels for the fine-tune config
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds, logger).cuda()
     opt = build_optimizer(model, cfg.OPTIMIZATION)
     start_epoch = it = 0
@@ -93,7 +94,7 @@ def main():
         for i in range(args.iters_per_epoch):
             batch = ds.batch(epoch * args.iters_per_epoch + i)
             loss, tb, _ = train_one_step(ddp, opt, sched, batch, it, model_func, amp_dtype=amp,
-                                         grad_norm_clip=cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+                                         grad_norm_clip=cfg.OPTIMIZATION.get('GRAD_NORM_CLIP', None))
             it += 1
             if rank == 0 and (i % 10 == 0 or i == args.iters_per_epoch - 1):
                 logger.info(f'epoch {epoch} it {i}/{args.iters_per_epoch} loss {float(loss):.5f} lr {opt.lr:.2e}')
