@@ -319,6 +319,16 @@ int tmae_focal_loss_fwd(const void* logits, int dtype, const float* target, int6
 int tmae_focal_loss_bwd(const void* logits, int dtype, const float* target, int64_t n, const float* stats4,
                         const float* grad_out, void* dlogits, void* stream);
 
+/* Rotated boxes (x, y, z, dx, dy, dz, heading), pcdet/ops/iou3d_nms (iou3d_nms_utils.py:31-99, iou3d_nms_kernel.cu).
+ * tmae_boxes_pairwise: out [na, nb] f32; mode 0 = BEV overlap area (boxes_overlap_bev_gpu), 1 = BEV IoU
+ * (boxes_iou_bev_gpu), 2 = 3-D IoU (boxes_iou3d_gpu).
+ * tmae_nms_bev: nms_gpu on boxes ALREADY sorted by descending score: keep [<= n] i64 = indices (into the sorted
+ * list) of the boxes that survive, in score order; num_keep [1] i32.  Greedy pass runs on the device. */
+int tmae_boxes_pairwise(const float* boxes_a, int na, const float* boxes_b, int nb, int mode, float* out, void* stream);
+size_t tmae_nms_bev_workspace(int n);
+int tmae_nms_bev(const float* boxes_sorted, int n, float thresh, int64_t* keep, int32_t* num_keep, void* ws,
+                 size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -316,3 +316,111 @@ def synth_gt_boxes(batch_size, n_boxes, seed, limit=74.0):
         out[b, :n, 6] = rng.uniform(-np.pi, np.pi, n)
         out[b, :n, 7] = cls
     return out
+
+
+# --------------------------------------------------------------------------- evaluation: decode + rotated NMS
+def decode_bbox_from_heatmap(heatmap, rot_cos, rot_sin, center, center_z, dim, pc_range, voxel_size, stride, K,
+                             score_thresh, post_center_limit_range):
+    """centernet_utils.decode_bbox_from_heatmap (centernet_utils.py:154-220, _topk :131-151): two-level top-K over the
+    class heat maps, gather the regression maps at the peaks, build (x, y, z, dx, dy, dz, heading), keep boxes inside
+    the centre range with score > thresh.  Inputs [B, c, H, W] tensors (heatmap already sigmoid, dim already exp)."""
+    B, C, H, W = heatmap.shape
+    ts, ti = torch.topk(heatmap.flatten(2, 3), K)
+    ti = ti % (H * W)
+    ys = torch.div(ti, W, rounding_mode='floor').float()
+    xs = (ti % W).int().float()
+    score, tind = torch.topk(ts.view(B, -1), K)
+    cls = torch.div(tind, K, rounding_mode='floor').int()
+    g1 = lambda t: t.view(B, -1, 1).gather(1, tind.unsqueeze(2)).view(B, K)
+    inds, ys, xs = g1(ti), g1(ys), g1(xs)
+
+    def tg(feat):
+        f = feat.permute(0, 2, 3, 1).contiguous().view(B, -1, feat.shape[1])
+        return f.gather(1, inds.unsqueeze(2).expand(B, K, feat.shape[1]))
+
+    c, rs, rc, cz, dm = tg(center), tg(rot_sin), tg(rot_cos), tg(center_z), tg(dim)
+    angle = torch.atan2(rs, rc)
+    x = (xs.view(B, K, 1) + c[:, :, 0:1]) * stride * voxel_size[0] + pc_range[0]
+    y = (ys.view(B, K, 1) + c[:, :, 1:2]) * stride * voxel_size[1] + pc_range[1]
+    boxes = torch.cat([x, y, cz, dm, angle], dim=-1)
+    lim = torch.as_tensor(post_center_limit_range, dtype=torch.float32)
+    mask = (boxes[..., :3] >= lim[:3]).all(2) & (boxes[..., :3] <= lim[3:]).all(2)
+    if score_thresh is not None:
+        mask &= score > score_thresh
+    return [dict(pred_boxes=boxes[k, mask[k]], pred_scores=score[k, mask[k]], pred_labels=cls[k, mask[k]]) for k in range(B)]
+
+
+def _rect_corners(b):
+    x, y, dx, dy, a = float(b[0]), float(b[1]), float(b[3]), float(b[4]), float(b[6])
+    c, s = math.cos(a), math.sin(a)
+    pts = [(-dx / 2, -dy / 2), (dx / 2, -dy / 2), (dx / 2, dy / 2), (-dx / 2, dy / 2)]      # counter-clockwise
+    return [(x + px * c - py * s, y + px * s + py * c) for px, py in pts]
+
+
+def _clip(poly, a, b):
+    """Sutherland-Hodgman: keep the part of `poly` on the left of the directed edge a -> b."""
+    out = []
+    n = len(poly)
+    for i in range(n):
+        p, q = poly[i], poly[(i + 1) % n]
+        sp = (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0])
+        sq = (b[0] - a[0]) * (q[1] - a[1]) - (b[1] - a[1]) * (q[0] - a[0])
+        if sp >= 0:
+            out.append(p)
+        if (sp >= 0) != (sq >= 0):
+            t = sp / (sp - sq)
+            out.append((p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1])))
+    return out
+
+
+def overlap_bev(box_a, box_b):
+    """Area of the intersection of two rotated BEV rectangles (x, y, z, dx, dy, dz, heading), float64.  Restates
+    what iou3d_nms `box_overlap` computes (iou3d_nms_kernel.cu:113-207: corner-in-box tests + edge intersections +
+    polygon area) by convex clipping.  PARITY UNPINNED: the reference's implementation is CUDA-only here
+    (iou3d_cpu.cpp includes cuda.h: unbuildable in this image) and ships no test vectors."""
+    poly = _rect_corners(box_a)
+    cb = _rect_corners(box_b)
+    for i in range(4):
+        if not poly:
+            return 0.0
+        poly = _clip(poly, cb[i], cb[(i + 1) % 4])
+    if len(poly) < 3:
+        return 0.0
+    area = 0.0
+    for i in range(len(poly)):
+        p, q = poly[i], poly[(i + 1) % len(poly)]
+        area += p[0] * q[1] - q[0] * p[1]
+    return abs(area) / 2
+
+
+def iou_bev(box_a, box_b):
+    """iou3d_nms `iou_bev` (iou3d_nms_kernel.cu:209-217): overlap / max(Sa + Sb - overlap, EPS=1e-8)."""
+    sa, sb = float(box_a[3]) * float(box_a[4]), float(box_b[3]) * float(box_b[4])
+    o = overlap_bev(box_a, box_b)
+    return o / max(sa + sb - o, 1e-8)
+
+
+def nms_bev(boxes, scores, thresh, pre_maxsize=None):
+    """iou3d_nms_utils.nms_gpu (iou3d_nms_utils.py:84-99) + nms_kernel / CPU suppression loop (iou3d_nms.cpp:104-150):
+    sort by score (descending), keep a box unless a kept higher-score box overlaps it with BEV IoU > thresh."""
+    boxes = np.asarray(boxes, np.float64)
+    order = np.argsort(-np.asarray(scores, np.float64), kind='stable')
+    if pre_maxsize is not None:
+        order = order[:pre_maxsize]
+    keep = []
+    for i in order:
+        if all(iou_bev(boxes[i], boxes[j]) <= thresh for j in keep):
+            keep.append(int(i))
+    return np.array(keep, np.int64)
+
+
+def iou3d(boxes_a, boxes_b):
+    """iou3d_nms_utils.boxes_iou3d_gpu (iou3d_nms_utils.py:48-81): BEV overlap x height overlap / union volume."""
+    A, Bn = np.asarray(boxes_a, np.float64), np.asarray(boxes_b, np.float64)
+    out = np.zeros((len(A), len(Bn)))
+    for i, a in enumerate(A):
+        for j, b in enumerate(Bn):
+            h = max(min(a[2] + a[5] / 2, b[2] + b[5] / 2) - max(a[2] - a[5] / 2, b[2] - b[5] / 2), 0.0)
+            o = overlap_bev(a, b) * h
+            out[i, j] = o / max(a[3] * a[4] * a[5] + b[3] * b[4] * b[5] - o, 1e-6)
+    return out

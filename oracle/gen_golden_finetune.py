@@ -130,6 +130,28 @@ def main():
          grad_box_nz=g_box_ref.flatten()[g_box_ref.flatten().nonzero()[:, 0]].numpy(),
          grad_box_nz_index=g_box_ref.flatten().nonzero()[:, 0].numpy())
 
+    # ---- G4: box decoding (pure torch in the reference: pinned) on random head outputs of a small map
+    gen = torch.Generator().manual_seed(77)
+    B, C, Hh, Ww, K = 2, 5, 96, 80, 60
+    hm = torch.rand(B, C, Hh, Ww, generator=gen) ** 6
+    center, cz = torch.rand(B, 2, Hh, Ww, generator=gen), torch.randn(B, 1, Hh, Ww, generator=gen) - 1
+    dim = torch.rand(B, 3, Hh, Ww, generator=gen) * 3 + 0.5
+    rc, rs = torch.randn(B, 1, Hh, Ww, generator=gen), torch.randn(B, 1, Hh, Ww, generator=gen)
+    pcr = np.array([-74.88, -74.88, -5.0, 74.88, 74.88, 3.0], dtype=np.float32)
+    lim = torch.tensor([-74.88, -74.88, -3.0, 74.88, -50.0, 3.0])            # a limit that actually removes boxes
+    ref_d = cu.decode_bbox_from_heatmap(heatmap=hm, rot_cos=rc, rot_sin=rs, center=center, center_z=cz, dim=dim, vel=None,
+                                        iou=torch.ones_like(hm[:, 0:1]), point_cloud_range=pcr, voxel_size=[0.32, 0.32, 8.0],
+                                        feature_map_stride=1, K=K, circle_nms=False, score_thresh=0.3,
+                                        post_center_limit_range=lim)
+    or_d = FO.decode_bbox_from_heatmap(hm, rc, rs, center, cz, dim, pcr, [0.32, 0.32, 8.0], 1, K, 0.3, lim)
+    arrs = {}
+    for k in range(B):
+        for key in ('pred_boxes', 'pred_scores', 'pred_labels'):
+            check(f'decode {key} {k}', or_d[k][key], ref_d[k][key], 0.0)
+            arrs[f'{key}_{k}'] = ref_d[k][key].numpy()
+        assert 0 < len(ref_d[k]['pred_scores']) < K
+    save('G4_decode', seed=77, shape=np.array([B, C, Hh, Ww, K]), score_thresh=np.float32(0.3), limit=lim.numpy(), **arrs)
+
     # ---- G3: end-to-end fine-tune step (VFE -> SiamWCA -> SSTBEVBackbone -> CenterHead loss), small clouds
     for tag, nst, npts, bs in (('G3_finetune_e2e_3stage', 3, 4000, 2),):
         print(tag)

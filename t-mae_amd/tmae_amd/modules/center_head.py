@@ -2,7 +2,7 @@
 heads, target assignment and losses.  Same constructor kwargs, forward contract (`data_dict -> data_dict`,
 `forward_ret_dict`, `get_loss() -> (loss, tb_dict)`) and state_dict names as the reference.  Targets are assigned on the
 device by one HIP launch per head (the reference loops over samples and boxes on the CPU) and the heat-map focal loss is
-one fused kernel; box decoding + NMS (evaluation) are the next row of SURVEY 8f."""
+one fused kernel; evaluation decodes the boxes with torch top-K / gathers and runs the rotated NMS of csrc/iou3d_nms.hip."""
 import copy
 
 import numpy as np
@@ -134,8 +134,63 @@ class CenterHead(nn.Module):
             tb_dict['loc_loss_head_%d' % idx] = loc_loss.detach()
         return loss, tb_dict
 
+    @staticmethod
+    def _decode(heatmap, rot_cos, rot_sin, center, center_z, dim, pc_range, voxel_size, stride, K, score_thresh, limit):
+        """centernet_utils.decode_bbox_from_heatmap / _topk (centernet_utils.py:131-220): two-level top-K over the class
+        maps, gather the regression maps at the peaks, boxes (x, y, z, dx, dy, dz, heading), centre-range + score mask."""
+        B, C, H, W = heatmap.shape
+        ts, ti = torch.topk(heatmap.flatten(2, 3), K)
+        ti = ti % (H * W)
+        ys = torch.div(ti, W, rounding_mode='floor').float()
+        xs = (ti % W).int().float()
+        score, tind = torch.topk(ts.view(B, -1), K)
+        cls = torch.div(tind, K, rounding_mode='floor').int()
+        inds = ti.view(B, -1).gather(1, tind)
+        ys, xs = ys.view(B, -1).gather(1, tind), xs.view(B, -1).gather(1, tind)
+
+        def tg(feat):
+            f = feat.permute(0, 2, 3, 1).reshape(B, -1, feat.shape[1])
+            return f.gather(1, inds.unsqueeze(2).expand(B, K, feat.shape[1]))
+
+        c, rs, rc, cz, dm = tg(center), tg(rot_sin), tg(rot_cos), tg(center_z), tg(dim)
+        angle = torch.atan2(rs, rc)
+        x = (xs.view(B, K, 1) + c[:, :, 0:1]) * stride * voxel_size[0] + pc_range[0]
+        y = (ys.view(B, K, 1) + c[:, :, 1:2]) * stride * voxel_size[1] + pc_range[1]
+        boxes = torch.cat([x, y, cz, dm, angle], dim=-1)
+        mask = (boxes[..., :3] >= limit[:3]).all(2) & (boxes[..., :3] <= limit[3:]).all(2)
+        if score_thresh is not None:
+            mask &= score > score_thresh
+        return [dict(pred_boxes=boxes[k, mask[k]], pred_scores=score[k, mask[k]], pred_labels=cls[k, mask[k]])
+                for k in range(B)]
+
     def generate_predicted_boxes(self, batch_size, pred_dicts):
-        raise NotImplementedError('box decoding + NMS (evaluation path): next row of SURVEY 8f')
+        """center_head.py:264-334: decode every head, class-agnostic rotated NMS (model_nms_utils.py:6-27)."""
+        pp = self.model_cfg.POST_PROCESSING
+        ret = [{'pred_boxes': [], 'pred_scores': [], 'pred_labels': []} for _ in range(batch_size)]
+        for idx, pd in enumerate(pred_dicts):
+            pd = {k: v.float() for k, v in pd.items()}
+            limit = pd['hm'].new_tensor(pp.POST_CENTER_LIMIT_RANGE)
+            dec = self._decode(pd['hm'].sigmoid(), pd['rot'][:, 0:1], pd['rot'][:, 1:2], pd['center'], pd['center_z'],
+                               pd['dim'].exp(), self.point_cloud_range, self.voxel_size, self.feature_map_stride,
+                               pp.MAX_OBJ_PER_SAMPLE, pp.SCORE_THRESH, limit)
+            if pp.NMS_CONFIG.NMS_TYPE != 'nms_gpu':
+                raise NotImplementedError(f'NMS_TYPE {pp.NMS_CONFIG.NMS_TYPE}: the T-MAE configs use nms_gpu')
+            for k, fd in enumerate(dec):
+                fd['pred_labels'] = getattr(self, f'_cls_id_{idx}')[fd['pred_labels'].long()]
+                scores, boxes = fd['pred_scores'], fd['pred_boxes']
+                sel = scores.new_zeros((0,), dtype=torch.long)
+                if scores.shape[0] > 0:
+                    top, indices = torch.topk(scores, k=min(pp.NMS_CONFIG.NMS_PRE_MAXSIZE, scores.shape[0]))
+                    keep, _ = ops.nms_gpu(boxes[indices][:, 0:7], top, pp.NMS_CONFIG.NMS_THRESH)
+                    sel = indices[keep[:pp.NMS_CONFIG.NMS_POST_MAXSIZE]]
+                ret[k]['pred_boxes'].append(boxes[sel])
+                ret[k]['pred_scores'].append(scores[sel])
+                ret[k]['pred_labels'].append(fd['pred_labels'][sel])
+        for k in range(batch_size):
+            ret[k]['pred_boxes'] = torch.cat(ret[k]['pred_boxes'], dim=0)
+            ret[k]['pred_scores'] = torch.cat(ret[k]['pred_scores'], dim=0)
+            ret[k]['pred_labels'] = torch.cat(ret[k]['pred_labels'], dim=0) + 1
+        return ret
 
     def forward(self, data_dict):
         x2d = data_dict['spatial_features_2d']

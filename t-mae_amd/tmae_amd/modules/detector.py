@@ -179,7 +179,34 @@ class CenterPoint(Detector3DTemplate):
         if self.training:
             loss, tb_dict, disp_dict = self.get_training_loss()
             return {'loss': loss}, tb_dict, disp_dict
-        raise NotImplementedError('evaluation (box decoding, NMS, recall): next row of SURVEY 8f')
+        return self.post_processing(batch_dict)
+
+    def post_processing(self, batch_dict):
+        """centerpoint.py:35-50 + Detector3DTemplate.generate_recall_record (detector3d_template.py:319-363)."""
+        from .. import ops
+        thresh_list = self.model_cfg.POST_PROCESSING.RECALL_THRESH_LIST
+        final = batch_dict['final_box_dicts']
+        recall = {}
+        for index in range(int(batch_dict['batch_size'])):
+            if 'gt_boxes' not in batch_dict:
+                continue
+            if not recall:
+                recall = {'gt_num': 0}
+                for t in thresh_list:
+                    recall['recall_roi_%s' % str(t)] = 0
+                    recall['recall_rcnn_%s' % str(t)] = 0
+            gt = batch_dict['gt_boxes'][index]
+            k = gt.shape[0] - 1
+            nz = (gt.abs().sum(1) != 0).nonzero()
+            gt = gt[:int(nz.max()) + 1] if nz.numel() else gt[:0]
+            if gt.shape[0] > 0:
+                boxes = final[index]['pred_boxes']
+                iou = ops.boxes_iou3d_gpu(boxes[:, 0:7], gt[:, 0:7]) if boxes.shape[0] > 0 else None
+                for t in thresh_list:
+                    if iou is not None:
+                        recall['recall_rcnn_%s' % str(t)] += int((iou.max(dim=0)[0] > t).sum())
+                recall['gt_num'] += gt.shape[0]
+        return final, recall
 
     def get_training_loss(self):
         loss_rpn, tb_dict = self.dense_head.get_loss()

@@ -1049,3 +1049,47 @@ def focal_loss_centernet(logits, target):
     if logits.dtype not in (torch.float32, torch.bfloat16):
         logits = logits.float()
     return _FocalLossCenterNet.apply(logits, target)
+
+
+# ----------------------------------------------------------------------------- rotated boxes: IoU / NMS (iou3d_nms)
+
+def _boxes_pairwise(a, b, mode):
+    _need_cuda(a)
+    a = a[:, :7].contiguous().float()
+    b = b[:, :7].contiguous().float()
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    check(lib.tmae_boxes_pairwise(_p(a), a.shape[0], _p(b), b.shape[0], mode, _p(out), _s()), 'tmae_boxes_pairwise')
+    return out
+
+
+def boxes_overlap_bev(boxes_a, boxes_b):
+    """iou3d_nms_utils.boxes_overlap_bev_gpu: BEV intersection areas [na, nb]."""
+    return _boxes_pairwise(boxes_a, boxes_b, 0)
+
+
+def boxes_iou_bev(boxes_a, boxes_b):
+    """iou3d_nms_utils.boxes_iou_bev (iou3d_nms_utils.py:31-45)."""
+    return _boxes_pairwise(boxes_a, boxes_b, 1)
+
+
+def boxes_iou3d_gpu(boxes_a, boxes_b):
+    """iou3d_nms_utils.boxes_iou3d_gpu (iou3d_nms_utils.py:48-81)."""
+    return _boxes_pairwise(boxes_a, boxes_b, 2)
+
+
+def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
+    """iou3d_nms_utils.nms_gpu (iou3d_nms_utils.py:84-99): indices of the kept boxes in descending score order.
+    The suppression pass runs on the device; the only host sync is reading the number of kept boxes."""
+    _need_cuda(boxes)
+    assert boxes.shape[1] == 7
+    order = scores.sort(0, descending=True)[1]
+    if pre_maxsize is not None:
+        order = order[:pre_maxsize]
+    b = boxes[order].contiguous().float()
+    n = b.shape[0]
+    keep = torch.empty((max(n, 1),), dtype=torch.int64, device=b.device)
+    num = torch.zeros((1,), dtype=torch.int32, device=b.device)
+    wsb = lib.tmae_nms_bev_workspace(n)
+    ws = _ws(wsb, b.device)
+    check(lib.tmae_nms_bev(_p(b), n, float(thresh), _p(keep), _p(num), _p(ws), wsb, _s()), 'tmae_nms_bev')
+    return order[keep[:int(num.item())]].contiguous(), None

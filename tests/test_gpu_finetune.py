@@ -130,3 +130,92 @@ def test_finetune_bf16_step_runs_and_is_close(ft_oracle):
     assert torch.isfinite(ret['loss'])
     assert abs(float(ret['loss']) - float(g['loss'])) <= 0.05 * abs(float(g['loss']))
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def _rand_boxes(rng, n, spread=20.0):
+    b = np.zeros((n, 7), np.float32)
+    b[:, 0:2] = rng.uniform(-spread, spread, (n, 2))
+    b[:, 2] = rng.normal(-1, 0.5, n)
+    b[:, 3:6] = rng.uniform(0.5, 6.0, (n, 3))
+    b[:, 6] = rng.uniform(-np.pi, np.pi, n)
+    return b
+
+
+def test_rotated_iou_and_nms_vs_oracle(ft_oracle):
+    """csrc/iou3d_nms.hip vs the float64 convex-clipping restatement: BEV overlap / IoU, 3-D IoU, edge cases
+    (identical, disjoint, contained, 45 degrees, touching), and the kept set + order of the rotated NMS."""
+    from tmae_amd import ops
+    rng = np.random.default_rng(5)
+    a, b = _rand_boxes(rng, 60), _rand_boxes(rng, 45)
+    special = np.array([[0, 0, 0, 4, 2, 1, 0.0], [0, 0, 0, 4, 2, 1, 0.0], [0, 0, 0, 2, 2, 1, np.pi / 4], [0, 0, 0, 2, 2, 1, 0.0],
+                        [0.5, 0.2, 0, 1, 0.5, 1, 0.3], [100, 100, 0, 4, 2, 1, 1.0], [4, 0, 0, 4, 2, 1, 0.0],
+                        [0, 0, 0.6, 4, 2, 1, 0.0]], np.float32)
+    a = np.concatenate([special, a])
+    b = np.concatenate([special, b])
+    ov = ops.boxes_overlap_bev(cu(a), cu(b)).cpu().numpy()
+    iou = ops.boxes_iou_bev(cu(a), cu(b)).cpu().numpy()
+    i3 = ops.boxes_iou3d_gpu(cu(a), cu(b)).cpu().numpy()
+    ref_ov = np.array([[ft_oracle.overlap_bev(x, y) for y in b] for x in a])
+    ref_iou = np.array([[ft_oracle.iou_bev(x, y) for y in b] for x in a])
+    assert np.abs(ov - ref_ov).max() <= 2e-4 * max(1.0, ref_ov.max())
+    assert np.abs(iou - ref_iou).max() <= 2e-5 + 1e-4
+    assert np.abs(i3 - ft_oracle.iou3d(a, b)).max() <= 2e-4
+    assert abs(iou[0, 1] - 1.0) < 1e-5 and iou[0, 5] == 0.0 and abs(ov[2, 3] - 8 * (np.sqrt(2) - 1)) < 1e-4
+    assert abs(ov[0, 4] - 0.5) < 1e-5                                  # contained box: its own area
+    # NMS: clustered boxes so that many suppressions happen; no IoU sits within 1e-3 of the threshold
+    n = 700
+    centers = rng.uniform(-30, 30, (40, 2))
+    bx = _rand_boxes(rng, n)
+    bx[:, 0:2] = centers[rng.integers(0, 40, n)] + rng.normal(0, 0.8, (n, 2))
+    sc = rng.random(n).astype(np.float32)
+    full = np.array([[ft_oracle.iou_bev(x, y) for y in bx[:200]] for x in bx[:200]])
+    assert (np.abs(full - 0.5) < 1e-3).sum() == 0
+    keep, _ = ops.nms_gpu(cu(bx), cu(sc), 0.5)
+    ref_keep = ft_oracle.nms_bev(bx, sc, 0.5)
+    assert np.array_equal(keep.cpu().numpy(), ref_keep)
+    keep2, _ = ops.nms_gpu(cu(bx), cu(sc), 0.5, pre_maxsize=100)
+    assert np.array_equal(keep2.cpu().numpy(), ft_oracle.nms_bev(bx, sc, 0.5, pre_maxsize=100))
+    k0, _ = ops.nms_gpu(torch.zeros((0, 7), device=dev()), torch.zeros((0,), device=dev()), 0.5)
+    assert k0.numel() == 0
+
+
+def test_decode_golden_and_eval_forward(ft_oracle):
+    """Box decoding vs the reference's decode_bbox_from_heatmap (G4, bit-exact selection) and the whole evaluation
+    forward of CenterPoint (decode + rotated NMS + recall record) on the fine-tune model."""
+    from tmae_amd.modules.center_head import CenterHead
+    g = golden('G4_decode')
+    B, C, Hh, Ww, K = (int(v) for v in g['shape'])
+    gen = torch.Generator().manual_seed(int(g['seed']))
+    hm = torch.rand(B, C, Hh, Ww, generator=gen) ** 6
+    center, cz = torch.rand(B, 2, Hh, Ww, generator=gen), torch.randn(B, 1, Hh, Ww, generator=gen) - 1
+    dim = torch.rand(B, 3, Hh, Ww, generator=gen) * 3 + 0.5
+    rc, rs = torch.randn(B, 1, Hh, Ww, generator=gen), torch.randn(B, 1, Hh, Ww, generator=gen)
+    d = lambda t: t.to(dev())
+    out = CenterHead._decode(d(hm), d(rc), d(rs), d(center), d(cz), d(dim), [-74.88, -74.88, -5.0], [0.32, 0.32, 8.0], 1, K,
+                             float(g['score_thresh']), d(torch.from_numpy(g['limit'])))
+    for k in range(B):
+        assert np.array_equal(out[k]['pred_labels'].cpu().numpy(), g[f'pred_labels_{k}'])
+        np.testing.assert_allclose(out[k]['pred_scores'].cpu().numpy(), g[f'pred_scores_{k}'], atol=1e-7)
+        np.testing.assert_allclose(out[k]['pred_boxes'].cpu().numpy(), g[f'pred_boxes_{k}'], atol=2e-5)
+    # evaluation forward of the detector
+    g3 = golden('G3_finetune_e2e_3stage')
+    cfg = ft_oracle.default_finetune_cfg(3)
+    P = ft_oracle.init_finetune_params(cfg, seed=int(g3['param_seed']), tau=float(g3['tau']))
+    P['dense_head.heads_list.0.hm.1.bias'] = P['dense_head.heads_list.0.hm.1.bias'] + 2.0      # some scores above 0.1
+    model, _, _ = build_finetune_model(params=P, device=dev())
+    model.eval()
+    bd = {'points': cu(g3['points']), 'points_prev': cu(g3['points_prev']), 'batch_size': int(g3['batch_size']),
+          'gt_boxes': cu(g3['gt_boxes'])}
+    with torch.no_grad():
+        preds, recall = model(bd)
+    assert len(preds) == int(g3['batch_size']) and recall['gt_num'] > 0
+    for p in preds:
+        n = p['pred_boxes'].shape[0]
+        assert p['pred_boxes'].shape == (n, 7) and p['pred_scores'].shape == (n,) and n <= 500
+        assert n == 0 or (int(p['pred_labels'].min()) >= 1 and int(p['pred_labels'].max()) <= 5)
+        if n > 1:                                            # survivors of the NMS do not overlap above the threshold
+            from tmae_amd import ops
+            iou = ops.boxes_iou_bev(p['pred_boxes'], p['pred_boxes'])
+            iou.fill_diagonal_(0)
+            assert float(iou.max()) <= 0.5 + 1e-4
+            assert bool((p['pred_scores'][:-1] >= p['pred_scores'][1:]).all())

@@ -58,3 +58,31 @@ def test_g3_finetune_e2e(ft_oracle):
     assert abs(float(cap['parts']['loc_loss_head_0']) - float(g['loc_loss'])) <= 2e-5 * max(1.0, float(g['loc_loss']))
     for n, gn in zip(g['grad_names'], g['grad_norms']):
         assert abs(float(P[str(n)].grad.norm()) - gn) <= 3e-3 * max(1.0, gn), n
+
+
+def test_g4_decode(ft_oracle):
+    g = golden('G4_decode')
+    B, C, Hh, Ww, K = (int(v) for v in g['shape'])
+    gen = torch.Generator().manual_seed(int(g['seed']))
+    hm = torch.rand(B, C, Hh, Ww, generator=gen) ** 6
+    center, cz = torch.rand(B, 2, Hh, Ww, generator=gen), torch.randn(B, 1, Hh, Ww, generator=gen) - 1
+    dim = torch.rand(B, 3, Hh, Ww, generator=gen) * 3 + 0.5
+    rc, rs = torch.randn(B, 1, Hh, Ww, generator=gen), torch.randn(B, 1, Hh, Ww, generator=gen)
+    out = ft_oracle.decode_bbox_from_heatmap(hm, rc, rs, center, cz, dim, [-74.88, -74.88, -5.0], [0.32, 0.32, 8.0], 1, K,
+                                             float(g['score_thresh']), g['limit'])
+    for k in range(B):
+        assert np.array_equal(out[k]['pred_boxes'].numpy(), g[f'pred_boxes_{k}'])
+        assert np.array_equal(out[k]['pred_scores'].numpy(), g[f'pred_scores_{k}'])
+        assert np.array_equal(out[k]['pred_labels'].numpy(), g[f'pred_labels_{k}'])
+
+
+def test_rotated_iou_known_answers(ft_oracle):
+    """The rotated-IoU restatement is unpinned against the reference (CUDA-only there): closed-form cases."""
+    a = [0, 0, 0, 4, 2, 1, 0.0]
+    assert ft_oracle.iou_bev(a, a) == 1.0 and ft_oracle.iou_bev(a, [10, 0, 0, 4, 2, 1, 0.3]) == 0.0
+    assert abs(ft_oracle.overlap_bev([0, 0, 0, 2, 2, 1, np.pi / 4], [0, 0, 0, 2, 2, 1, 0]) - 8 * (np.sqrt(2) - 1)) < 1e-12
+    assert abs(ft_oracle.overlap_bev(a, [1, 0, 0, 4, 2, 1, 0]) - 6.0) < 1e-12
+    assert abs(ft_oracle.overlap_bev(a, [0, 0, 0, 4, 2, 1, np.pi / 2]) - 4.0) < 1e-12
+    assert abs(ft_oracle.iou3d([a], [[0, 0, 0.5, 4, 2, 1, 0]])[0, 0] - 1 / 3) < 1e-12
+    keep = ft_oracle.nms_bev(np.array([a, [0.2, 0, 0, 4, 2, 1, 0.0], [10, 0, 0, 4, 2, 1, 0.0]]), [0.5, 0.9, 0.1], 0.5)
+    assert keep.tolist() == [1, 2]
