@@ -9,17 +9,19 @@
 // W streams through LDS in chunks of 64 output columns (double buffered; W is at most a few hundred KB and stays in
 // L2), each chunk is contracted against the resident x fragments with v_mfma_f32_16x16x32_bf16 in the swapped
 // orientation (rows = output columns n, columns = tokens): a lane then holds 4 consecutive n of one token, i.e. one
-// 8-byte store per tile, bias added in fp32 before the rounding.
+// 8-byte piece per tile; the W rows of a chunk are permuted in LDS so that the four tiles give a lane 16 CONSECUTIVE
+// columns (two 16-byte stores; four lanes cover a 128-byte line of y), bias added in fp32 before the rounding.
 //
-// Measured (MI355X, m = 470 k): 4.3 TB/s at k = n = 128, 3.8 at k = 256 / n = 128, 3.4 at k = 128 / n = 256 -- 10-25 %
-// faster than hipBLASLt there; for n >= 256 at k = 256 the library wins (the y stores of a chunk are not overlapped
-// with the next chunk's MFMAs: a wave waits for its stores before it may reuse their registers), so the Python side
-// routes only the shapes where this kernel is ahead (ops.token_gemm).
+// Measured (MI355X, m = 470 k): 5.0 TB/s at k = n = 128, 4.5 at k = 128 / n = 256, 4.2 at k = 256 / n = 128, 3.5 at
+// k = 256 / n = 512 -- ahead of hipBLASLt (3.0-3.4 TB/s) on every shape it supports.  The store width decides: with
+// one 8-byte store per tile (32-byte segments per row) the same kernel ran at 2.9 TB/s, the partial-line requests
+// saturate the L2 request rate long before its bandwidth.
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned bf16_bits(float v) {
   return (unsigned)__builtin_bit_cast(unsigned short, __float2bfloat16(v));
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
                                                            const __hip_bfloat16* __restrict__ W,
                                                            const __hip_bfloat16* __restrict__ bias,
                                                            __hip_bfloat16* __restrict__ y, int64_t ldy, int64_t m,
-                                                           int N) {
+                                                           int N, unsigned ybytes) {
   constexpr int KS = K / 32;             // MFMA k-steps
   constexpr int PITCH = K * 2 + 16;      // bytes per W row in LDS: the +16 spreads the 16 rows of a tile over all banks
   constexpr int CPR = K / 8;             // 16-byte chunks per W row
@@ -64,93 +66,110 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
 #define TG_WSTORE(buf)                                                                                \
   _Pragma("unroll") for (int j = 0; j < WL; ++j) {                                                    \
     const int c_ = tid + NTH * j, row_ = c_ / CPR, ch_ = c_ % CPR;                                    \
-    *reinterpret_cast<u32x4*>(&wl[buf][row_ * PITCH + ch_ * 16]) = wr[j];                             \
+    *reinterpret_cast<u32x4*>(&wl[buf][(16 * ((row_ >> 2) & 3) + 4 * (row_ >> 4) + (row_ & 3)) * PITCH + ch_ * 16]) = wr[j]; \
   }
   const int nch = N / TG_NCH;
   // Ordering inside a chunk: the loads of the NEXT chunk (W, bias) are issued before the MFMAs and CONSUMED (LDS
   // write / unpack) right after them, before this chunk's y stores are issued.  On gfx9 loads and stores share
-  // vmcnt and may complete out of order, so a wait on a load while stores are pending is a wait for the stores too:
-  // with the stores issued last, they drain during the next chunk's MFMAs instead of stalling this one (measured:
-  // the naive order ran at one memory round trip per chunk).
-  f32x4 bcur[4], bnext[4];
-#define TG_BLOAD(chunk, dst)                                                                                \
-  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                        \
-    const uint2 u_ = bias ? *reinterpret_cast<const uint2*>(bias + (chunk) * TG_NCH + nt * 16 + 4 * g)      \
-                          : make_uint2(0u, 0u);                                                             \
-    dst[nt] = f32x4{__uint_as_float(u_.x << 16), __uint_as_float(u_.x & 0xFFFF0000u),                       \
-                    __uint_as_float(u_.y << 16), __uint_as_float(u_.y & 0xFFFF0000u)};                      \
+  // vmcnt, and the compiler makes a wave wait for a store before any of its source registers is overwritten, so:
+  //  * the stores are buffer stores whose only VGPR sources are the packed data and a per-lane offset that never
+  //    changes (the chunk offset travels in an SGPR): no address temporaries to recycle;
+  //  * the chunk loop is unrolled by two with two sets of data registers, and a set is kept formally alive (empty
+  //    asm) until the MFMAs of the following chunk are done: its stores drain under those MFMAs instead of
+  //    stalling the wave at the top of the loop (measured before: one memory round trip per chunk).
+  uint2 bcur[4], bnext[4];                           // packed bf16 bias of the lane's 4 columns per tile (zeros if none)
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)ybytes, 0x00020000);
+  int voff[TT];                                       // byte offset of (row, 16g) in y; >= ybytes drops the store
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int64_t row = tok0 + tt * 16 + i;
+    voff[tt] = row < m ? (int)((row * ldy + 16 * g) * 2) : (int)ybytes;
   }
+  u32x4 oA[2][TT], oB[2][TT];                         // [half of the lane's 16 columns][token tile]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) { oA[h][tt] = u32x4{0u, 0u, 0u, 0u}; oB[h][tt] = u32x4{0u, 0u, 0u, 0u}; }
   TG_WLOAD(0)
-  TG_BLOAD(0, bcur)
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) bcur[nt] = *reinterpret_cast<const uint2*>(bias + 16 * g + 4 * nt);
   TG_WSTORE(0)
   __syncthreads();
-  for (int c = 0; c < nch; ++c) {
-    const int buf = c & 1;
-    const bool more = c + 1 < nch;
-    uint2 braw[4];
-    if (more) {
-      TG_WLOAD(c + 1)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        braw[nt] = bias ? *reinterpret_cast<const uint2*>(bias + (c + 1) * TG_NCH + nt * 16 + 4 * g) : make_uint2(0u, 0u);
-    }
-    f32x4 acc[4][TT];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) acc[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&wl[buf][(nt * 16 + i) * PITCH + (ks * 4 + g) * 16]));
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-          acc[nt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xf[tt][ks], acc[nt][tt], 0, 0, 0);
-      }
-    }
-    if (more) {                          // consume the prefetched loads BEFORE any store of this chunk is issued
-      TG_WSTORE(buf ^ 1)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        bnext[nt] = f32x4{__uint_as_float(braw[nt].x << 16), __uint_as_float(braw[nt].x & 0xFFFF0000u),
-                          __uint_as_float(braw[nt].y << 16), __uint_as_float(braw[nt].y & 0xFFFF0000u)};
-    }
-    // C layout: rows (= output columns) 4g + r, column (= token) i
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n0 = c * TG_NCH + nt * 16 + 4 * g;
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        const int64_t row = tok0 + tt * 16 + i;
-        if (row < m) {
-          const f32x4 v = acc[nt][tt] + bcur[nt];
-          uint2 o;
-          o.x = bf16_bits(v[0]) | (bf16_bits(v[1]) << 16);
-          o.y = bf16_bits(v[2]) | (bf16_bits(v[3]) << 16);
-          *reinterpret_cast<uint2*>(y + row * ldy + n0) = o;
-        }
-      }
-    }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) bcur[nt] = bnext[nt];
-    __syncthreads();
+
+#define TG_KEEP(o)                                                                                          \
+  _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                             \
+    _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
+      asm volatile("" ::"v"(o[h][tt].x), "v"(o[h][tt].y), "v"(o[h][tt].z), "v"(o[h][tt].w));
+
+#define TG_CHUNK(c, buf, ocur, oprev)                                                                       \
+  {                                                                                                         \
+    const bool more = (c) + 1 < nch;                                                                        \
+    if (more) {                                                                                             \
+      TG_WLOAD((c) + 1)                                                                                     \
+      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                      \
+        bnext[nt] = *reinterpret_cast<const uint2*>(bias + ((c) + 1) * TG_NCH + 16 * g + 4 * nt);           \
+    }                                                                                                       \
+    f32x4 acc[4][TT];                                                                                       \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                        \
+      _Pragma("unroll") for (int tt = 0; tt < TT; ++tt) acc[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};            \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                     \
+      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                    \
+        const bf16x8 a_ = __builtin_bit_cast(                                                               \
+            bf16x8, *reinterpret_cast<const u32x4*>(&wl[buf][(nt * 16 + i) * PITCH + (ks * 4 + g) * 16]));   \
+        _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                   \
+          acc[nt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, xf[tt][ks], acc[nt][tt], 0, 0, 0);      \
+      }                                                                                                     \
+    }                                                                                                       \
+    TG_KEEP(oprev) /* the previous chunk's store data stayed untouched while its stores drained */          \
+    if (more) {    /* consume the prefetched loads BEFORE any store of this chunk is issued */               \
+      TG_WSTORE((buf) ^ 1)                                                                                  \
+    }                                                                                                       \
+    /* C layout: rows 4g + r of tile t = output columns 16g + 4t + r (W rows are permuted in LDS), column = token i: */ \
+    /* a lane holds 16 consecutive columns of one token = two 16-byte stores, 4 lanes cover a 128-byte line */        \
+    _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
+      _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                       \
+        unsigned w_[4];                                                                                     \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                     \
+          const int nt = 2 * h + q;                                                                         \
+          const f32x4 v_ = acc[nt][tt] + f32x4{__uint_as_float(bcur[nt].x << 16), __uint_as_float(bcur[nt].x & 0xFFFF0000u), \
+                                               __uint_as_float(bcur[nt].y << 16), __uint_as_float(bcur[nt].y & 0xFFFF0000u)}; \
+          w_[2 * q] = bf16_bits(v_[0]) | (bf16_bits(v_[1]) << 16);                                           \
+          w_[2 * q + 1] = bf16_bits(v_[2]) | (bf16_bits(v_[3]) << 16);                                       \
+        }                                                                                                   \
+        ocur[h][tt] = u32x4{w_[0], w_[1], w_[2], w_[3]};                                                    \
+      }                                                                                                     \
+    /* take over the prefetched bias BEFORE the stores are issued (a wait on a load after them waits for them) */ \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) bcur[nt] = bnext[nt];                                  \
+    asm volatile("" ::"v"(bcur[0].x), "v"(bcur[1].x), "v"(bcur[2].x), "v"(bcur[3].x), "v"(bcur[0].y), "v"(bcur[1].y), "v"(bcur[2].y), "v"(bcur[3].y)); \
+    _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
+      _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                         \
+        __builtin_amdgcn_raw_buffer_store_b128(ocur[h][tt], yrsrc, voff[tt] + h * 16, (c) * (TG_NCH * 2), 0); \
+    __syncthreads();                                                                                        \
   }
+
+  for (int c = 0; c < nch; c += 2) {
+    TG_CHUNK(c, 0, oA, oB)
+    if (c + 1 < nch) TG_CHUNK(c + 1, 1, oB, oA)
+  }
+#undef TG_CHUNK
+#undef TG_KEEP
 }
 
 int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
                     int64_t ldy, void* stream_) {
   (void)hipGetLastError();
   hipStream_t stream = (hipStream_t)stream_;
-  if (m < 0 || (k != 128 && k != 256) || n <= 0 || (n % TG_NCH) || ldx < k || ldy < n || (ldx % 8) || (ldy % 4))
+  if (m < 0 || (k != 128 && k != 256) || n <= 0 || (n % TG_NCH) || ldx < k || ldy < n || (ldx % 8) || (ldy % 8))
     return TMAE_EARG;
   if (m == 0) return TMAE_OK;
-  if (!x || !w || !y) return TMAE_EARG;
-  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 7) || (bias && ((uintptr_t)bias & 7))) return TMAE_EARG;
+  if (!x || !w || !y || !bias) return TMAE_EARG;          // no bias: pass a zero vector (keeps the kernel branch-free)
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 7)) return TMAE_EARG;
+  const int64_t ybytes = ((m - 1) * ldy + n) * 2;                 // buffer stores address y with 32-bit byte offsets
+  if (ybytes >= (int64_t)1 << 31) return TMAE_EARG;
 #define TG_LAUNCH(KK, TT, NW)                                                                                       \
   hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW>), dim3(tmae_cdiv(m, NW * TT * 16)), dim3(64 * NW), 0, stream,    \
                      (const __hip_bfloat16*)x, ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias,          \
-                     (__hip_bfloat16*)y, ldy, m, n)
+                     (__hip_bfloat16*)y, ldy, m, n, (unsigned)ybytes)
   // 4 waves x 32 tokens per workgroup; 8 waves x 16 tokens (twice the resident waves) measured no better
   if (k == 128) TG_LAUNCH(128, 2, 4); else TG_LAUNCH(256, 2, 4);
 #undef TG_LAUNCH

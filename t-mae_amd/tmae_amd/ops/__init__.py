@@ -48,9 +48,9 @@ _TOKEN_GEMM_MIN_ROWS = 8192
 
 
 def _tg_ok(x, k, n):
-    # shapes where the kernel beats the library (profiles/scripts/gemm_probe.py): k = 128 with n <= 256, k = 256 with n = 128
-    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[0] >= _TOKEN_GEMM_MIN_ROWS
-            and ((k == 128 and n in (64, 128, 192, 256)) or (k == 256 and n in (64, 128)))
+    # every shape the kernel supports: it is ahead of the library on all of them (profiles/scripts/gemm_probe.py)
+    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[0] >= _TOKEN_GEMM_MIN_ROWS and k in (128, 256)
+            and n % 64 == 0 and x.shape[0] * n * 2 < 2 ** 31
             and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
 
 
@@ -64,7 +64,7 @@ def token_gemm(x, w, bias=None, force=False):
     if ok and w.dtype == torch.bfloat16 and w.is_contiguous() and (bias is None or bias.dtype == torch.bfloat16):
         m = x.shape[0]
         y = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
-        b = None if bias is None else bias.contiguous()
+        b = torch.zeros((n,), dtype=torch.bfloat16, device=x.device) if bias is None else bias.contiguous()
         check(lib.tmae_token_gemm(_p(x), x.stride(0), m, k, _p(w), n, _p(b), _p(y), n, _s()), 'tmae_token_gemm')
         return y
     return torch.nn.functional.linear(x, w, bias)
