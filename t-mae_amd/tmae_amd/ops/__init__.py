@@ -731,7 +731,7 @@ class _SparseConv(torch.autograd.Function):
     def backward(ctx, dout):
         f, w, nbr, nbr_t = ctx.saved_tensors
         dout = dout.to(f.dtype).contiguous()
-        dcols = dout @ w                                              # [m_out, 9*cin]
+        dcols = token_gemm_dx(dout, w)                                # [m_out, 9*cin]: streaming kernel when it fits
         din = torch.empty_like(f)
         check(lib.tmae_spconv_gather_t(_p(dcols), _dt(dcols), dout.shape[0], f.shape[1], _p(nbr_t), f.shape[0],
                                        _p(din), _s()), 'tmae_spconv_gather_t')
@@ -808,7 +808,7 @@ class _DeblocksToDense(torch.autograd.Function):
             assert ys * s == ny and xs * s == nx and w.shape[2] == s and w.shape[3] == s
             x_c = feat.to(cdt).contiguous()
             wmat = w.detach().to(cdt).permute(2, 3, 1, 0).reshape(s * s * cout, cin).contiguous()
-            v = torch.nn.functional.linear(x_c, wmat)                       # [m, s*s*cout], columns (dy, dx, cout)
+            v = token_gemm(x_c, wmat)                                       # [m, s*s*cout], columns (dy, dx, cout)
             m = v.shape[0]
             mean = torch.empty((cout,), dtype=torch.float32, device=dev)
             var, rstd = torch.empty_like(mean), torch.empty_like(mean)
@@ -875,7 +875,7 @@ class _DeblocksToDense(torch.autograd.Function):
             dv = torch.empty_like(v)
             check(lib.tmae_bn_bwd_apply(_p(g), _p(v), _dt(v), rows, cout, _p(mean), _p(rstd), _p(g32), _p(b32), 1,
                                         _p(dbeta), _p(dgamma), count, _p(dv), _s()), 'tmae_bn_bwd_apply')
-            dfeat = (dv @ wmat) if ctx.needs_input_grad[5 + 4 * i] else None
+            dfeat = token_gemm_dx(dv, wmat) if ctx.needs_input_grad[5 + 4 * i] else None
             dwmat = None
             if ctx.needs_input_grad[5 + 4 * i + 1]:
                 if _wgrad_ok(dv, x_c):
