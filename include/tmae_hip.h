@@ -294,7 +294,7 @@ int tmae_column_sums(const void* x, int dtype, int64_t rows, int c, float* out, 
 
 /* Token-list Linear in bf16 (fp32 accumulate):  y[m,n] = x[m,k] . w[n,k]^T (+ bias[n]) -- the in-/out-projections
  * and FFN layers of EncoderLayer (sst_basic_block.py:45-83, F.linear) and, on w^T, their input gradients.
- * k in {128, 256}, n a multiple of 64; ldx / ldy = row pitches in elements (column slices of packed buffers are
+ * k in {128, 256, 512}, n a multiple of 64; ldx / ldy = row pitches in elements (column slices of packed buffers are
  * fine); all pointers 16-byte aligned (y, bias: 8); bias [n] bf16 is required (zeros for none); y must span
  * < 2^31 bytes.  x is read once, y written once. */
 int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,

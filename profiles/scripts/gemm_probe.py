@@ -42,7 +42,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 from tmae_amd import ops
 print('token_gemm (csrc/token_gemm.hip)')
 for (M, K, N) in [(470000, 128, 256), (470000, 128, 128), (470000, 256, 128), (466000, 256, 512), (466000, 256, 256),
-                  (195000, 256, 512), (195000, 256, 256), (94000, 128, 256)]:
+                  (195000, 256, 512), (195000, 256, 256), (94000, 128, 256), (466000, 512, 256), (195000, 512, 256),
+                  (466000, 256, 2304)]:
     x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
     w = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
     b = torch.randn(N, device=dev, dtype=torch.bfloat16)

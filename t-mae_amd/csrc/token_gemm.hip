@@ -28,9 +28,9 @@ __device__ __forceinline__ unsigned bf16_bits(float v) {
 }
 
 #define TG_TOK 128   // tokens per workgroup
-#define TG_NCH 64    // output columns per W chunk
+#define TG_NCH (NTC * 16)   // output columns per W chunk (NTC 16-column tiles: 4, or 2 for K = 512)
 
-template <int K, int TT, int NW>
+template <int K, int TT, int NW, int NTC>
 __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bfloat16* __restrict__ x, int64_t ldx,
                                                            const __hip_bfloat16* __restrict__ W,
                                                            const __hip_bfloat16* __restrict__ bias,
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
 #define TG_WSTORE(buf)                                                                                \
   _Pragma("unroll") for (int j = 0; j < WL; ++j) {                                                    \
     const int c_ = tid + NTH * j, row_ = c_ / CPR, ch_ = c_ % CPR;                                    \
-    *reinterpret_cast<u32x4*>(&wl[buf][(16 * ((row_ >> 2) & 3) + 4 * (row_ >> 4) + (row_ & 3)) * PITCH + ch_ * 16]) = wr[j]; \
+    *reinterpret_cast<u32x4*>(&wl[buf][(16 * ((row_ >> 2) % NTC) + 4 * (row_ / (4 * NTC)) + (row_ & 3)) * PITCH + ch_ * 16]) = wr[j]; \
   }
   const int nch = N / TG_NCH;
   // Ordering inside a chunk: the loads of the NEXT chunk (W, bias) are issued before the MFMAs and CONSUMED (LDS
@@ -77,27 +77,27 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
   //  * the chunk loop is unrolled by two with two sets of data registers, and a set is kept formally alive (empty
   //    asm) until the MFMAs of the following chunk are done: its stores drain under those MFMAs instead of
   //    stalling the wave at the top of the loop (measured before: one memory round trip per chunk).
-  uint2 bcur[4], bnext[4];                           // packed bf16 bias of the lane's 4 columns per tile (zeros if none)
+  uint2 bcur[NTC], bnext[NTC];                           // packed bf16 bias of the lane's 4 columns per tile (zeros if none)
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)ybytes, 0x00020000);
   int voff[TT];                                       // byte offset of (row, 16g) in y; >= ybytes drops the store
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     const int64_t row = tok0 + tt * 16 + i;
-    voff[tt] = row < m ? (int)((row * ldy + 16 * g) * 2) : (int)ybytes;
+    voff[tt] = row < m ? (int)((row * ldy + 4 * NTC * g) * 2) : (int)ybytes;
   }
-  u32x4 oA[2][TT], oB[2][TT];                         // [half of the lane's 16 columns][token tile]
+  u32x4 oA[NTC / 2][TT], oB[NTC / 2][TT];             // [16-byte piece of the lane's 4*NTC columns][token tile]
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < NTC / 2; ++h)
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) { oA[h][tt] = u32x4{0u, 0u, 0u, 0u}; oB[h][tt] = u32x4{0u, 0u, 0u, 0u}; }
   TG_WLOAD(0)
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) bcur[nt] = *reinterpret_cast<const uint2*>(bias + 16 * g + 4 * nt);
+  for (int nt = 0; nt < NTC; ++nt) bcur[nt] = *reinterpret_cast<const uint2*>(bias + 4 * NTC * g + 4 * nt);
   TG_WSTORE(0)
   __syncthreads();
 
 #define TG_KEEP(o)                                                                                          \
-  _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                             \
+  _Pragma("unroll") for (int h = 0; h < NTC / 2; ++h)                                                       \
     _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
       asm volatile("" ::"v"(o[h][tt].x), "v"(o[h][tt].y), "v"(o[h][tt].z), "v"(o[h][tt].w));
 
@@ -106,14 +106,14 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
     const bool more = (c) + 1 < nch;                                                                        \
     if (more) {                                                                                             \
       TG_WLOAD((c) + 1)                                                                                     \
-      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                      \
-        bnext[nt] = *reinterpret_cast<const uint2*>(bias + ((c) + 1) * TG_NCH + 16 * g + 4 * nt);           \
+      _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt)                                                    \
+        bnext[nt] = *reinterpret_cast<const uint2*>(bias + ((c) + 1) * TG_NCH + 4 * NTC * g + 4 * nt);      \
     }                                                                                                       \
-    f32x4 acc[4][TT];                                                                                       \
-    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                        \
+    f32x4 acc[NTC][TT];                                                                                     \
+    _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt)                                                      \
       _Pragma("unroll") for (int tt = 0; tt < TT; ++tt) acc[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};            \
     _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                     \
-      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                    \
+      _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt) {                                                  \
         const bf16x8 a_ = __builtin_bit_cast(                                                               \
             bf16x8, *reinterpret_cast<const u32x4*>(&wl[buf][(nt * 16 + i) * PITCH + (ks * 4 + g) * 16]));   \
         _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                   \
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
     /* C layout: rows 4g + r of tile t = output columns 16g + 4t + r (W rows are permuted in LDS), column = token i: */ \
     /* a lane holds 16 consecutive columns of one token = two 16-byte stores, 4 lanes cover a 128-byte line */        \
     _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
-      _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                       \
+      _Pragma("unroll") for (int h = 0; h < NTC / 2; ++h) {                                                 \
         unsigned w_[4];                                                                                     \
         _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                     \
           const int nt = 2 * h + q;                                                                         \
@@ -139,10 +139,10 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
         ocur[h][tt] = u32x4{w_[0], w_[1], w_[2], w_[3]};                                                    \
       }                                                                                                     \
     /* take over the prefetched bias BEFORE the stores are issued (a wait on a load after them waits for them) */ \
-    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) bcur[nt] = bnext[nt];                                  \
-    asm volatile("" ::"v"(bcur[0].x), "v"(bcur[1].x), "v"(bcur[2].x), "v"(bcur[3].x), "v"(bcur[0].y), "v"(bcur[1].y), "v"(bcur[2].y), "v"(bcur[3].y)); \
+    _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt) bcur[nt] = bnext[nt];                                \
+    _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt) asm volatile("" ::"v"(bcur[nt].x), "v"(bcur[nt].y));   \
     _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
-      _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                         \
+      _Pragma("unroll") for (int h = 0; h < NTC / 2; ++h)                                                   \
         __builtin_amdgcn_raw_buffer_store_b128(ocur[h][tt], yrsrc, voff[tt] + h * 16, (c) * (TG_NCH * 2), 0); \
     __syncthreads();                                                                                        \
   }
@@ -159,19 +159,21 @@ int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w,
                     int64_t ldy, void* stream_) {
   (void)hipGetLastError();
   hipStream_t stream = (hipStream_t)stream_;
-  if (m < 0 || (k != 128 && k != 256) || n <= 0 || (n % TG_NCH) || ldx < k || ldy < n || (ldx % 8) || (ldy % 8))
+  if (m < 0 || (k != 128 && k != 256 && k != 512) || n <= 0 || (n % 64) || ldx < k || ldy < n || (ldx % 8) || (ldy % 8))
     return TMAE_EARG;
   if (m == 0) return TMAE_OK;
   if (!x || !w || !y || !bias) return TMAE_EARG;          // no bias: pass a zero vector (keeps the kernel branch-free)
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 7)) return TMAE_EARG;
   const int64_t ybytes = ((m - 1) * ldy + n) * 2;                 // buffer stores address y with 32-bit byte offsets
   if (ybytes >= (int64_t)1 << 31) return TMAE_EARG;
-#define TG_LAUNCH(KK, TT, NW)                                                                                       \
-  hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW>), dim3(tmae_cdiv(m, NW * TT * 16)), dim3(64 * NW), 0, stream,    \
+#define TG_LAUNCH(KK, TT, NW, NTC)                                                                                  \
+  hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW, NTC>), dim3(tmae_cdiv(m, NW * TT * 16)), dim3(64 * NW), 0, stream, \
                      (const __hip_bfloat16*)x, ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias,          \
                      (__hip_bfloat16*)y, ldy, m, n, (unsigned)ybytes)
-  // 4 waves x 32 tokens per workgroup; 8 waves x 16 tokens (twice the resident waves) measured no better
-  if (k == 128) TG_LAUNCH(128, 2, 4); else TG_LAUNCH(256, 2, 4);
+  // 4 waves x 32 tokens, 64-column chunks; contraction 512: 16 tokens per wave (64 x registers) and 32-column chunks
+  if (k == 128) TG_LAUNCH(128, 2, 4, 4);
+  else if (k == 256) TG_LAUNCH(256, 2, 4, 4);
+  else TG_LAUNCH(512, 1, 4, 2);
 #undef TG_LAUNCH
   return tmae_launch_status();
 }

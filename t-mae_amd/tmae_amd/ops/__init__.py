@@ -48,7 +48,8 @@ _TOKEN_GEMM_MIN_ROWS = 8192
 
 
 def _tg_ok(x, k, n):
-    # every shape the kernel supports: it is ahead of the library on all of them (profiles/scripts/gemm_probe.py)
+    # contraction 128 / 256: ahead of the library on every shape (profiles/scripts/gemm_probe.py).  Contraction 512 is
+    # supported by the kernel (16 tokens per wave: LDS-bound) but 10-15 % behind hipBLASLt: left to the library.
     return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[0] >= _TOKEN_GEMM_MIN_ROWS and k in (128, 256)
             and n % 64 == 0 and x.shape[0] * n * 2 < 2 ** 31
             and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
@@ -57,9 +58,9 @@ def _tg_ok(x, k, n):
 def token_gemm(x, w, bias=None, force=False):
     """y [m,n] = x [m,k] @ w[n,k]^T (+ bias) in bf16, fp32 accumulation: the x-stationary streaming kernel of
     csrc/token_gemm.hip on the shapes where it is ahead of the library (force=True: whenever the kernel supports the
-    shape: k in {128,256}, n % 64 == 0), else the library."""
+    shape: k in {128,256,512}, n % 64 == 0), else the library."""
     n, k = w.shape
-    ok = _tg_ok(x, k, n) or (force and x.dtype == torch.bfloat16 and k in (128, 256) and n % 64 == 0
+    ok = _tg_ok(x, k, n) or (force and x.dtype == torch.bfloat16 and k in (128, 256, 512) and n % 64 == 0
                              and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
     if ok and w.dtype == torch.bfloat16 and w.is_contiguous() and (bias is None or bias.dtype == torch.bfloat16):
         m = x.shape[0]

@@ -478,7 +478,8 @@ def test_token_gemm_kernel_vs_torch():
     strided input (column slice of a packed buffer), ragged token counts, and the dX use on W^T."""
     from tmae_amd import ops
     torch.manual_seed(3)
-    for (m, k, n) in ((8192, 128, 128), (50001, 128, 256), (33333, 256, 512), (20000, 256, 768), (9999, 256, 64)):
+    for (m, k, n) in ((8192, 128, 128), (50001, 128, 256), (33333, 256, 512), (20000, 256, 768), (9999, 256, 64),
+                      (30001, 512, 256), (12000, 512, 64), (9000, 256, 2304)):
         x = torch.randn(m, k, device=dev()).bfloat16()
         w = (torch.randn(n, k, device=dev()) * 0.1).bfloat16()
         b = torch.randn(n, device=dev()).bfloat16()
