@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
 // finishes the sum needs a device-scope fence per block -- an L2 write-back on every XCD -- and measured 2-4x slower
 // than this kernel boundary.)  Level 1: block (x, y) sums the slabs
 // y, y+RG, y+2RG, ... for 1024 consecutive elements (float4 per thread) into part[y]; level 2 sums the RG parts.
-#define WG_RG 32
+#define WG_RG 16
 __global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restrict__ slab, int splits, int64_t count,
                                                            float* __restrict__ part) {
   const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
