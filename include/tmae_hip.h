@@ -330,6 +330,17 @@ size_t tmae_nms_bev_workspace(int n);
 int tmae_nms_bev(const float* boxes_sorted, int n, float thresh, int64_t* keep, int32_t* num_keep, void* ws,
                  size_t ws_bytes, void* stream);
 
+/* ---- data path in front of the step (ONCETemporalDataset.__getitem__ / prepare_data, once_temporal_dataset.py:139-330)
+ * One frame of one sample: drop ego-vehicle returns (|x| and |y| < ego_radius), apply the previous->current alignment
+ * (r1t1 = [R1 row-major 9 | t1 3] float64 or NULL; m2 = first three rows of the inverse current pose, 12 float64, or
+ * NULL -- once_utils.convert_prv_frame_to_cur), world flip / rotation (cos, sin of the fp32 angle) / scaling
+ * (data_augmentor.py:55-142), keep x, y inside [min, max] (common_utils.mask_points_by_range), write the kept rows in
+ * input order as (batch_idx, x, y, z, features...) into out [<= n, row + 1]; count [1] i32 = kept rows. */
+size_t tmae_frame_prepare_workspace(int64_t n);
+int tmae_frame_prepare(const float* points, int row, int64_t n, const double* r1t1, const double* m2, float ego_radius,
+                       int flip_x, int flip_y, float cosa, float sina, float scale, float xmin, float ymin, float xmax,
+                       float ymax, int batch_idx, float* out, int32_t* count, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,6 +71,8 @@ SIGNATURES = {
     'tmae_boxes_pairwise': (I, [P, I, P, I, I, P, P]),
     'tmae_nms_bev_workspace': (Z, [I]),
     'tmae_nms_bev': (I, [P, I, F, P, P, P, Z, P]),
+    'tmae_frame_prepare_workspace': (Z, [L]),
+    'tmae_frame_prepare': (I, [P, I, L, P, P, F, I, I, F, F, F, F, F, F, F, I, P, P, P, Z, P]),
     'tmae_token_gemm': (I, [P, L, L, I, P, I, P, P, L, P]),
     'tmae_linear_wgrad_workspace': (Z, [L, I, I]),
     'tmae_linear_wgrad': (I, [P, L, P, L, L, I, I, P, P, P, Z, P]),

@@ -1094,3 +1094,30 @@ def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
     ws = _ws(wsb, b.device)
     check(lib.tmae_nms_bev(_p(b), n, float(thresh), _p(keep), _p(num), _p(ws), wsb, _s()), 'tmae_nms_bev')
     return order[keep[:int(num.item())]].contiguous(), None
+
+
+# ----------------------------------------------------------------------------- data path (frame preparation)
+
+def frame_prepare(points, r1t1, m2, ego_radius, flip_x, flip_y, cosa, sina, scale, pc_range, batch_idx):
+    """One frame of one sample through tmae_frame_prepare: returns (rows [n, row+1] worst case, count [1] i32 on the
+    device); the caller slices after its one sync.  r1t1 / m2: float64 host arrays of 12 or None."""
+    import ctypes as C
+    _need_cuda(points)
+    pts = points.contiguous().float()
+    n, row = pts.shape
+    out = torch.empty((n, row + 1), dtype=torch.float32, device=pts.device)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=pts.device)
+    wsb = lib.tmae_frame_prepare_workspace(n)
+    ws = _ws(wsb, pts.device)
+
+    def dptr(a):
+        if a is None:
+            return None, None
+        arr = (C.c_double * 12)(*[float(v) for v in a])
+        return arr, C.cast(arr, C.c_void_p)
+    k1, p1 = dptr(r1t1)
+    k2, p2 = dptr(m2)
+    check(lib.tmae_frame_prepare(_p(pts), row, n, p1, p2, float(ego_radius), int(bool(flip_x)), int(bool(flip_y)), float(cosa),
+                                 float(sina), float(scale), float(pc_range[0]), float(pc_range[1]), float(pc_range[3]),
+                                 float(pc_range[4]), int(batch_idx), _p(out), _p(cnt), _p(ws), wsb, _s()), 'tmae_frame_prepare')
+    return out, cnt

@@ -80,3 +80,9 @@ def oracle():
 def ft_oracle():
     import finetune_oracle
     return finetune_oracle
+
+
+@pytest.fixture(scope='session')
+def dp_oracle():
+    import datapath_oracle
+    return datapath_oracle
