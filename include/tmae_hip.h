@@ -299,6 +299,11 @@ int tmae_column_sums(const void* x, int dtype, int64_t rows, int c, float* out, 
  * < 2^31 bytes.  x is read once, y written once. */
 int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
                     int64_t ldy, void* stream);
+/* Same GEMM with the backward of the exact (erf) GELU fused into the epilogue: y = (x . w^T + bias) * gelu'(aux),
+ * aux [m,n] bf16 with y's pitch = the pre-activation saved by the forward (the FFN of EncoderLayer,
+ * sst_basic_block.py:81: linear2(gelu(linear1(src))): dX of linear2 and GeluBackward in one pass). */
+int tmae_token_gemm_dgelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias,
+                          const void* aux, void* y, int64_t ldy, void* stream);
 
 /* ---- fine-tune path (BASELINE configs[4]): CenterHead ------------------------------------------------------
  * Target assignment of one head (CenterHead.assign_targets / assign_target_of_single_head, center_head.py:107-231;

@@ -27,15 +27,28 @@ __device__ __forceinline__ unsigned bf16_bits(float v) {
   return (unsigned)__builtin_bit_cast(unsigned short, __float2bfloat16(v));
 }
 
+// d/dx of the exact (erf) GELU: Phi(x) + x phi(x).  erf through Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far
+// below the bf16 rounding of the result), which shares its exponential with the density: one exp, one rcp, a few FMAs
+// -- the library erff costs ~40 live registers per value in this fully unrolled epilogue.
+__device__ __forceinline__ float dgelu(float x) {
+  const float e = __expf(-0.5f * x * x);                          // = exp(-u^2), u = x / sqrt(2)
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * 0.70710678f * fabsf(x));
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;
+  const float cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  return cdf + x * e * 0.39894228040143267794f;
+}
+
 #define TG_TOK 128   // tokens per workgroup
 #define TG_NCH (NTC * 16)   // output columns per W chunk (NTC 16-column tiles: 4, or 2 for K = 512)
 
-template <int K, int TT, int NW, int NTC>
+template <int K, int TT, int NW, int NTC, int EPI>
 __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bfloat16* __restrict__ x, int64_t ldx,
                                                            const __hip_bfloat16* __restrict__ W,
                                                            const __hip_bfloat16* __restrict__ bias,
                                                            __hip_bfloat16* __restrict__ y, int64_t ldy, int64_t m,
-                                                           int N, unsigned ybytes) {
+                                                           int N, unsigned ybytes,
+                                                           const __hip_bfloat16* __restrict__ aux) {
   constexpr int KS = K / 32;             // MFMA k-steps
   constexpr int PITCH = K * 2 + 16;      // bytes per W row in LDS: the +16 spreads the 16 rows of a tile over all banks
   constexpr int CPR = K / 8;             // 16-byte chunks per W row
@@ -79,6 +92,10 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
   //    stalling the wave at the top of the loop (measured before: one memory round trip per chunk).
   uint2 bcur[NTC], bnext[NTC];                           // packed bf16 bias of the lane's 4 columns per tile (zeros if none)
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)ybytes, 0x00020000);
+  // EPI == 2 (DGELU): y = (x . W^T) * gelu'(aux), aux [m, N] bf16 with y's pitch (the pre-activation saved by the
+  // forward): the lane's 16-byte pieces of the NEXT chunk are fetched right after this chunk's were consumed.
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 2 ? aux : y), 0, (int)ybytes, 0x00020000);
+  u32x4 auxr[NTC / 2][TT];
   int voff[TT];                                       // byte offset of (row, 16g) in y; >= ybytes drops the store
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
@@ -93,6 +110,12 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
   TG_WLOAD(0)
 #pragma unroll
   for (int nt = 0; nt < NTC; ++nt) bcur[nt] = *reinterpret_cast<const uint2*>(bias + 4 * NTC * g + 4 * nt);
+  if constexpr (EPI == 2) {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+      for (int h = 0; h < NTC / 2; ++h) auxr[h][tt] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff[tt] + h * 16, 0, 0);
+  }
   TG_WSTORE(0)
   __syncthreads();
 
@@ -131,13 +154,25 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
         unsigned w_[4];                                                                                     \
         _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                     \
           const int nt = 2 * h + q;                                                                         \
-          const f32x4 v_ = acc[nt][tt] + f32x4{__uint_as_float(bcur[nt].x << 16), __uint_as_float(bcur[nt].x & 0xFFFF0000u), \
-                                               __uint_as_float(bcur[nt].y << 16), __uint_as_float(bcur[nt].y & 0xFFFF0000u)}; \
+          f32x4 v_ = acc[nt][tt] + f32x4{__uint_as_float(bcur[nt].x << 16), __uint_as_float(bcur[nt].x & 0xFFFF0000u), \
+                                         __uint_as_float(bcur[nt].y << 16), __uint_as_float(bcur[nt].y & 0xFFFF0000u)}; \
+          if constexpr (EPI == 2) {                                                                         \
+            const unsigned a0_ = auxr[h][tt][2 * q], a1_ = auxr[h][tt][2 * q + 1];                          \
+            v_[0] *= dgelu(__uint_as_float(a0_ << 16)); v_[1] *= dgelu(__uint_as_float(a0_ & 0xFFFF0000u));   \
+            v_[2] *= dgelu(__uint_as_float(a1_ << 16)); v_[3] *= dgelu(__uint_as_float(a1_ & 0xFFFF0000u));   \
+          }                                                                                                 \
           w_[2 * q] = bf16_bits(v_[0]) | (bf16_bits(v_[1]) << 16);                                           \
           w_[2 * q + 1] = bf16_bits(v_[2]) | (bf16_bits(v_[3]) << 16);                                       \
         }                                                                                                   \
         ocur[h][tt] = u32x4{w_[0], w_[1], w_[2], w_[3]};                                                    \
       }                                                                                                     \
+    if constexpr (EPI == 2) {                                                                               \
+      if (more) {                                                                                           \
+        _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                   \
+          _Pragma("unroll") for (int h = 0; h < NTC / 2; ++h)                                               \
+            auxr[h][tt] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff[tt] + h * 16, ((c) + 1) * (TG_NCH * 2), 0); \
+      }                                                                                                     \
+    }                                                                                                       \
     /* take over the prefetched bias BEFORE the stores are issued (a wait on a load after them waits for them) */ \
     _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt) bcur[nt] = bnext[nt];                                \
     _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt) asm volatile("" ::"v"(bcur[nt].x), "v"(bcur[nt].y));   \
@@ -155,9 +190,8 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
 #undef TG_KEEP
 }
 
-int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
-                    int64_t ldy, void* stream_) {
-  (void)hipGetLastError();
+static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
+                             int64_t ldy, const void* aux, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || (k != 128 && k != 256 && k != 512) || n <= 0 || (n % 64) || ldx < k || ldy < n || (ldx % 8) || (ldy % 8))
     return TMAE_EARG;
@@ -167,13 +201,33 @@ int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w,
   const int64_t ybytes = ((m - 1) * ldy + n) * 2;                 // buffer stores address y with 32-bit byte offsets
   if (ybytes >= (int64_t)1 << 31) return TMAE_EARG;
 #define TG_LAUNCH(KK, TT, NW, NTC)                                                                                  \
-  hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW, NTC>), dim3(tmae_cdiv(m, NW * TT * 16)), dim3(64 * NW), 0, stream, \
-                     (const __hip_bfloat16*)x, ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias,          \
-                     (__hip_bfloat16*)y, ldy, m, n, (unsigned)ybytes)
+  do {                                                                                                              \
+    if (aux)                                                                                                        \
+      hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW, NTC, 2>), dim3(tmae_cdiv(m, NW * TT * 16)), dim3(64 * NW), 0, \
+                         stream, (const __hip_bfloat16*)x, ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, \
+                         (__hip_bfloat16*)y, ldy, m, n, (unsigned)ybytes, (const __hip_bfloat16*)aux);               \
+    else                                                                                                            \
+      hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW, NTC, 0>), dim3(tmae_cdiv(m, NW * TT * 16)), dim3(64 * NW), 0, \
+                         stream, (const __hip_bfloat16*)x, ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, \
+                         (__hip_bfloat16*)y, ldy, m, n, (unsigned)ybytes, (const __hip_bfloat16*)nullptr);           \
+  } while (0)
   // 4 waves x 32 tokens, 64-column chunks; contraction 512: 16 tokens per wave (64 x registers) and 32-column chunks
   if (k == 128) TG_LAUNCH(128, 2, 4, 4);
   else if (k == 256) TG_LAUNCH(256, 2, 4, 4);
   else TG_LAUNCH(512, 1, 4, 2);
 #undef TG_LAUNCH
   return tmae_launch_status();
+}
+
+int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
+                    int64_t ldy, void* stream_) {
+  (void)hipGetLastError();
+  return token_gemm_launch(x, ldx, m, k, w, n, bias, y, ldy, nullptr, stream_);
+}
+
+int tmae_token_gemm_dgelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias,
+                          const void* aux, void* y, int64_t ldy, void* stream_) {
+  (void)hipGetLastError();
+  if (!aux || ((uintptr_t)aux & 15)) return TMAE_EARG;
+  return token_gemm_launch(x, ldx, m, k, w, n, bias, y, ldy, aux, stream_);
 }

@@ -145,7 +145,10 @@ class _EncoderTail(nn.Module):
         src = ops.add_layer_norm(src, attn, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         h_pre, src_res = ops.proj_fork(src, self.linear1.weight, self.linear1.bias,
                                        ((0, self.linear1.out_features, False),), fork=True)
-        src2 = ops.linear(self.activation(h_pre), self.linear2.weight, self.linear2.bias)
+        if self.activation is F.gelu:
+            src2 = ops.gelu_linear(h_pre, self.linear2.weight, self.linear2.bias)     # GELU backward fused into the dX GEMM
+        else:
+            src2 = ops.linear(self.activation(h_pre), self.linear2.weight, self.linear2.bias)
         return ops.add_layer_norm(src_res, src2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
 
 

@@ -244,6 +244,58 @@ def proj_fork(x, weight, bias, segs, pos=None, fork=False):
     return _ProjFork.apply(x, weight, bias, segs, pos, bool(fork))
 
 
+class _GeluLinear(torch.autograd.Function):
+    """y = gelu(h_pre) W^T + b, the second half of the encoder FFN (exact erf GELU, sst_basic_block.py:81).
+    Backward: dW / db from the token-split kernel on h = gelu(h_pre); d h_pre = (dy W) * gelu'(h_pre) in ONE pass
+    (tmae_token_gemm_dgelu: the GEMM's epilogue reads h_pre) instead of a GEMM plus an elementwise GeluBackward."""
+
+    @staticmethod
+    def forward(ctx, h_pre, weight, bias):
+        cdt = compute_dtype(h_pre)
+        hp = h_pre.to(cdt).contiguous()
+        h = torch.nn.functional.gelu(hp)
+        w_c = cast_param(weight, cdt)
+        y = token_gemm(h, w_c, None if bias is None else cast_param(bias, cdt))
+        ctx.save_for_backward(hp, h, w_c)
+        ctx.has_bias = bias is not None
+        ctx.dtypes = (h_pre.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        hp, h, w_c = ctx.saved_tensors
+        xdt, wdt, bdt = ctx.dtypes
+        dy = dy.to(hp.dtype)
+        if dy.stride(-1) != 1:
+            dy = dy.contiguous()
+        dhp = None
+        if ctx.needs_input_grad[0]:
+            n, k = w_c.shape                                     # [d, dff]
+            if _tg_ok(dy, n, k) and w_c.dtype == torch.bfloat16 and hp.dtype == torch.bfloat16:
+                m = dy.shape[0]
+                dhp = torch.empty((m, k), dtype=torch.bfloat16, device=dy.device)
+                zb = torch.zeros((k,), dtype=torch.bfloat16, device=dy.device)
+                wt = w_c.t().contiguous()
+                check(lib.tmae_token_gemm_dgelu(_p(dy), dy.stride(0), m, n, _p(wt), k, _p(zb), _p(hp), _p(dhp), k, _s()),
+                      'tmae_token_gemm_dgelu')
+            else:
+                dhp = torch.ops.aten.gelu_backward(dy @ w_c, hp)
+            dhp = dhp.to(xdt)
+        if _wgrad_ok(dy, h):
+            dw, db = linear_wgrad(dy, h, ctx.has_bias)
+        else:
+            dw = dy.float().t() @ h.float()
+            db = dy.float().sum(0) if ctx.has_bias else None
+        return dhp, dw.to(wdt), (db.to(bdt) if ctx.has_bias else None)
+
+
+def gelu_linear(h_pre, weight, bias=None):
+    """linear(gelu(h_pre), weight, bias) with the GELU backward fused into the input-gradient GEMM (GPU, 2-D)."""
+    if h_pre.is_cuda and h_pre.dim() == 2:
+        return _GeluLinear.apply(h_pre, weight, bias)
+    return torch.nn.functional.linear(torch.nn.functional.gelu(h_pre), weight, bias)
+
+
 def linear(x, weight, bias=None):
     """torch.nn.functional.linear with the token-split weight-gradient kernel (2-D inputs on the GPU)."""
     if x.is_cuda and x.dim() == 2:

@@ -504,6 +504,32 @@ def test_token_gemm_kernel_vs_torch():
     assert dx.shape == (40000, 512) and (dx.float() - ref).abs().max().item() <= 2e-2 * float(ref.abs().max())
 
 
+def test_gelu_linear_fused_backward_vs_torch():
+    """ops.gelu_linear: forward = F.linear(F.gelu(x)); backward with the GELU derivative fused into the dX GEMM
+    (tmae_token_gemm_dgelu) vs torch autograd in bf16, for both FFN shapes (d = 128 / dff = 256, d = 256 / dff = 512)."""
+    from tmae_amd import ops
+    torch.manual_seed(4)
+    for (m, dff, d) in ((30001, 256, 128), (20000, 512, 256)):
+        hp = (torch.randn(m, dff, device=dev()) * 1.5).bfloat16().requires_grad_(True)
+        w = (torch.randn(d, dff, device=dev()) * 0.05).requires_grad_(True)
+        b = torch.randn(d, device=dev(), requires_grad=True)
+        go = torch.randn(m, d, device=dev()).bfloat16()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = ops.gelu_linear(hp, w, b)
+        y.backward(go)
+        g1 = (hp.grad.clone(), w.grad.clone(), b.grad.clone())
+        hp.grad = w.grad = b.grad = None
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y2 = F.linear(F.gelu(hp), w, b)
+        y2.backward(go)
+        assert (y.float() - y2.float()).abs().max().item() <= 4e-2 * max(1.0, float(y2.float().abs().max()))
+        ref = hp.grad.float()
+        assert (g1[0].float() - ref).abs().max().item() <= 2e-2 * max(1.0, float(ref.abs().max())), (m, dff, d)
+        assert ((g1[0].float() - ref).norm() / ref.norm()).item() < 6e-3
+        assert (g1[1] - w.grad).abs().max().item() <= 1e-2 * float(w.grad.abs().max())
+        assert (g1[2] - b.grad).abs().max().item() <= 1e-2 * float(b.grad.abs().max())
+
+
 def test_add_layernorm_kernel_vs_torch():
     from tmae_amd import ops
     torch.manual_seed(1)
