@@ -25,6 +25,9 @@ __device__ __forceinline__ short f2bf(float v) {
   __hip_bfloat16 b = __float2bfloat16(v);
   return *reinterpret_cast<short*>(&b);
 }
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  return (unsigned)(unsigned short)f2bf(a) | ((unsigned)(unsigned short)f2bf(b) << 16);
+}
 __device__ __forceinline__ float bf2f(short s) { return __uint_as_float(((unsigned)(unsigned short)s) << 16); }
 // 1/x in one instruction (1 ulp); an IEEE division costs ~10 VALU instructions and these kernels are VALU-bound
 #define MASKED_LOGIT (-30000.0f)   // finite: 0 * MASKED_LOGIT stays 0 in the tau gradient
@@ -99,6 +102,36 @@ __device__ __forceinline__ void split_frag(const float* f, typename Frag<FR * 4>
     const short h = f2bf(f[j]);
     hi[j] = h;
     lo[j] = f2bf(f[j] - bf2f(h));
+  }
+}
+
+
+// Row images whose transposed reads feed the SWAPPED products (rows = channels, columns = tokens): tile ct, position
+// 4a + b of an image row holds channel (DH/4) a + 4 ct + b, so that the lane group a = lane>>4 ends up with DH/4
+// CONSECUTIVE channels of its token (one 16-byte store for dh 32, 8 bytes for dh 16) instead of one 2-byte store per
+// (row, tile).  A lane owns the channels (DH/4) g .. of a row: for dh 32 they go to two 8-byte places, dh 16: identity.
+template <int DH>
+__device__ __forceinline__ void store_img_frag(char* row_base, int g, const typename Frag<DH>::T& f) {
+  if constexpr (DH == 32) {
+    s16x4 lo = {f[0], f[1], f[2], f[3]}, hi = {f[4], f[5], f[6], f[7]};
+    *reinterpret_cast<s16x4*>(row_base + 8 * g) = lo;            // tile 0, positions 4g .. 4g+3
+    *reinterpret_cast<s16x4*>(row_base + 32 + 8 * g) = hi;       // tile 1, positions 4g .. 4g+3
+  } else {
+    *reinterpret_cast<s16x4*>(row_base + 8 * g) = f;
+  }
+}
+
+// FR consecutive channels of one token row as one 16-byte (FR 8) / 8-byte (FR 4) store
+template <int FR>
+__device__ __forceinline__ void store_row_frag(__hip_bfloat16* p, const float* f) {
+  if constexpr (FR == 8) {
+    uint4 u;
+    u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]); u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
+    *reinterpret_cast<uint4*>(p) = u;
+  } else {
+    uint2 u;
+    u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]);
+    *reinterpret_cast<uint2*>(p) = u;
   }
 }
 
@@ -243,14 +276,14 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
       normalize_frag<FR>(f, 1.0f);
       split_frag<FR>(f, kf[t], kl[t]);
       load_row_frag<FR>(v, ldv, tokk, hoff, g, f);
-      *reinterpret_cast<frag_t*>(&vimg[w][slot * RB + FR * g * 2]) = pack_frag<FR>(f);
+      store_img_frag<DH>(&vimg[w][slot * RB], g, pack_frag<FR>(f));
     } else {
 #pragma unroll
       for (int j = 0; j < FR; ++j) { kf[t][j] = 0; kl[t][j] = 0; }
       frag_t z;
 #pragma unroll
       for (int j = 0; j < FR; ++j) z[j] = 0;
-      *reinterpret_cast<frag_t*>(&vimg[w][slot * RB + FR * g * 2]) = z;     // P is 0 there, but 0 * garbage = NaN
+      store_img_frag<DH>(&vimg[w][slot * RB], g, z);                        // P is 0 there, but 0 * garbage = NaN
     }
     if (t < nq) {
       load_row_frag<FR>(q, ldq, slot < Tq ? toks[0][slot] : -1, hoff, g, f);
@@ -259,7 +292,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
     }
   }
   __syncthreads();
-  // V fragments (B operand of P.V): [key tile][channel tile], 4 keys x 1 channel per lane
+  // V fragments (A operand of O^T = V^T.P^T): [key tile][channel tile], 4 keys x 1 (permuted) channel per lane
   s16x4 vf[NT][CT];
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt)
@@ -313,24 +346,24 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
       l += __shfl_xor(l, 16, 64);
       l += __shfl_xor(l, 32, 64);
       const float invl = fast_rcp(l);
+      // O^T = V^T . P^T (swapped: rows = channels, column = query i): the V fragments serve as the A operand, the
+      // probabilities stay where the S^T accumulators left them
       f32x4 o[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
-          if (kt < nk) o[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pf[kt], vf[kt][ct], o[ct], 0, 0, 0);
+          if (kt < nk) o[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[kt][ct], pf[kt], o[ct], 0, 0, 0);
       }
-      // O tile: rows = queries 4g+r, col = channel i
+      // lane (g, i): query i, channels (DH/4) g + 4 ct + r -- DH/4 consecutive channels: one wide store
+      if (qslot < Tq) {
+        float of[FR];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qs = qt * 16 + 4 * g + r;
-        const float il = __shfl(invl, 4 * g + r, 64);
-        if (qs < Tq) {
-          __hip_bfloat16* op = out + (int64_t)toks[0][qs] * ldo + hoff + i;
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) op[ct * 16] = __float2bfloat16(o[ct][r] * il);
-        }
+          for (int r = 0; r < 4; ++r) of[4 * ct + r] = o[ct][r] * invl;
+        store_row_frag<FR>(out + (int64_t)toks[0][qslot] * ldo + hoff + FR * g, of);
       }
       if (g == 0 && qslot < Tq) lse[(int64_t)toks[0][qslot] * nhead + head] = mx + __logf(l);
     }
@@ -378,13 +411,18 @@ int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward (bf16): P is recomputed from the saved log-sum-exp with the query on the lane column (what dQ-hat =
-// dS.K-hat needs as its A operand); dV = P^T.dO and dK-hat = dS^T.Q-hat need the key on the lane column, which a
-// 16x16 bf16 tile written with one 8-byte store per lane and read back with ds_read_b64_tr_b16 provides.
-// The right-hand factors (K-hat, Q-hat/tau, dO) are row-major LDS images read with the same transposing read.
+// backward (bf16): P is recomputed from the saved log-sum-exp with the query on the lane column; dV = P^T.dO and
+// dK-hat = dS^T.Q-hat need the key on the lane column, which a 16x16 bf16 tile written with one 8-byte store per lane
+// and read back with ds_read_b64_tr_b16 provides.  All three gradient products are taken TRANSPOSED (rows = channels,
+// column = token) with the row-major LDS images (K-hat, Q-hat/tau, dO; channel-permuted, see store_img_frag) as the A
+// operand: a lane ends up with DH/4 consecutive channels of ONE token -- the same channels as its own row fragment --
+// so the normalisation Jacobian reads q-hat / k-hat from registers and every gradient row leaves in 16-byte
+// (dh 32) / 8-byte (dh 16) stores.  (With rows = tokens each lane wrote 2 bytes per (row, tile): the L2 request
+// rate of those stores was 16 % of the stage-1 kernel.)
+// NT = 4 is compiled for two waves per SIMD (the LDS images allow no more): 233 registers, no scratch.
 // ------------------------------------------------------------------------------------------------
 template <int DH, int NT>
-__global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
+__global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel(
     const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
     const __hip_bfloat16* __restrict__ v, int64_t ldv, const __hip_bfloat16* __restrict__ outp, int64_t ldo,
     const __hip_bfloat16* __restrict__ dout, int64_t lddo, const float* __restrict__ lse, int nhead,
@@ -458,19 +496,19 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
 #pragma unroll
       for (int j = 0; j < FR; ++j) { kf[t][j] = 0; kl[t][j] = 0; vr[t][j] = 0; }
     }
-    *reinterpret_cast<frag_t*>(&kimg[w][slot * RB + FR * g * 2]) = kf[t];
+    store_img_frag<DH>(&kimg[w][slot * RB], g, kf[t]);
     lse_i[t] = INFINITY;
     if (t < nq) {
       const int tokq = slot < Tq ? toks[0][slot] : -1;
       load_row_frag<FR>(q, ldq, tokq, hoff, g, f);
       const float nrm = normalize_frag<FR>(f, inv_tau);
       split_frag<FR>(f, qf[t], ql[t]);
-      *reinterpret_cast<frag_t*>(&qimg[w][slot * RB + FR * g * 2]) = qf[t];
+      store_img_frag<DH>(&qimg[w][slot * RB], g, qf[t]);
       if (g == 0) qnorm[w][slot] = nrm;
       float gfl[FR];
       load_row_frag<FR>(dout, lddo, tokq, hoff, g, gfl);
       gf[t] = pack_frag<FR>(gfl);                                        // exact: bf16 -> f32 -> bf16
-      *reinterpret_cast<frag_t*>(&gimg[w][slot * RB + FR * g * 2]) = gf[t];
+      store_img_frag<DH>(&gimg[w][slot * RB], g, gf[t]);
       lse_i[t] = tokq >= 0 ? lse[(int64_t)tokq * nhead + head] : INFINITY;   // no query: p = exp(s - inf) = 0
     }
   }
@@ -561,7 +599,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
             const s16x4 trK = tr_read4(&kimg[w][(kt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3)]);
-            dQa[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsT, trK, dQa[ct], 0, 0, 0);
+            dQa[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(trK, dsT, dQa[ct], 0, 0, 0);   // dQ-hat^T
           }
           // the key-on-lane factors for dV / dK-hat: P and dS of this tile transposed through a 16x16 LDS tile
           // (one 8-byte store + one hardware-transposing read each) instead of recomputing exp() per element
@@ -574,63 +612,67 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
-            dVa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pU, trG[ct], dVa[kt][ct], 0, 0, 0);
-            dKa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dsU, trQ[ct], dKa[kt][ct], 0, 0, 0);
+            dVa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(trG[ct], pU, dVa[kt][ct], 0, 0, 0);    // dV^T
+            dKa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(trQ[ct], dsU, dKa[kt][ct], 0, 0, 0);   // dK-hat^T
           }
         }
       }
-      // dq = (dq-hat - q-hat (q-hat . dq-hat)) / |q| ; accumulators: rows = queries 4g+r, column = channel ct*16+i
+      // dq = (dq-hat - q-hat (q-hat . dq-hat)) / |q|.  The products are taken transposed (rows = channels) over the
+      // permuted images, so lane (g, i) holds channels FR g + 4 ct + r of query qt*16+i: the SAME channels as its own
+      // row fragment qf[qt] -- q-hat comes from registers, the dot product needs two shuffles, one wide store per lane
+      {
+        float dqh[FR], qh[FR], dot = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qs = qt * 16 + 4 * g + r;
-        float qh[CT], dqh[CT], dot = 0.f;
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          qh[ct] = bf2f(*reinterpret_cast<const short*>(&qimg[w][qs * RB + (ct * 16 + i) * 2])) * tau_c;
-          dqh[ct] = dQa[ct][r] * inv_tau;
-          dot += qh[ct] * dqh[ct];
-        }
-        dot = row16_sum(dot);
-        if (qs < Tq) {
-          const float nrm = qnorm[w][qs];
+          for (int r = 0; r < 4; ++r) {
+            qh[4 * ct + r] = bf2f(qf[qt][4 * ct + r]) * tau_c;
+            dqh[4 * ct + r] = dQa[ct][r] * inv_tau;
+            dot += qh[4 * ct + r] * dqh[4 * ct + r];
+          }
+        dot += __shfl_xor(dot, 16, 64);
+        dot += __shfl_xor(dot, 32, 64);
+        if (qslot < Tq) {
+          const float nrm = qnorm[w][qslot];
           if (nrm <= 1e-12f) dot = 0.f;
           const float inv = fast_rcp(nrm);
-          __hip_bfloat16* p = dq + (int64_t)toks[0][qs] * lddq + hoff + i;
+          float o[FR];
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) p[ct * 16] = __float2bfloat16((dqh[ct] - qh[ct] * dot) * inv);
+          for (int j = 0; j < FR; ++j) o[j] = (dqh[j] - qh[j] * dot) * inv;
+          store_row_frag<FR>(dq + (int64_t)toks[0][qslot] * lddq + hoff + FR * g, o);
         }
       }
     }
   }
   dtau_acc = wave_sum(dtau_acc);
   if (lane == 0) *dtp = dtau_acc;
-  // ---- dk, dv: rows = keys 4g+r of tile kt, column = channel ct*16+i
+  // ---- dk, dv (transposed accumulators): lane (g, i) holds channels FR g + 4 ct + r of key kt*16+i
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt) {
     if (kt < nk) {
+      const int ks = kt * 16 + i;
+      float kh[FR], dkh[FR], dvv[FR], dot = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ks = kt * 16 + 4 * g + r;
-        float kh[CT], dot = 0.f;
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          kh[ct] = bf2f(*reinterpret_cast<const short*>(&kimg[w][ks * RB + (ct * 16 + i) * 2]));
-          dot += kh[ct] * dKa[kt][ct][r];
+        for (int r = 0; r < 4; ++r) {
+          kh[4 * ct + r] = bf2f(kf[kt][4 * ct + r]);
+          dkh[4 * ct + r] = dKa[kt][ct][r];
+          dvv[4 * ct + r] = dVa[kt][ct][r];
+          dot += kh[4 * ct + r] * dkh[4 * ct + r];
         }
-        dot = row16_sum(dot);
-        if (ks < Tk) {
-          const float nrm = knorm[w][ks];
-          if (nrm <= 1e-12f) dot = 0.f;
-          const float inv = fast_rcp(nrm);
-          const int tokk = toks[1][ks];
-          __hip_bfloat16* p1 = dk + (int64_t)tokk * lddk + hoff + i;
-          __hip_bfloat16* p2 = dv + (int64_t)tokk * lddv + hoff + i;
+      dot += __shfl_xor(dot, 16, 64);
+      dot += __shfl_xor(dot, 32, 64);
+      if (ks < Tk) {
+        const float nrm = knorm[w][ks];
+        if (nrm <= 1e-12f) dot = 0.f;
+        const float inv = fast_rcp(nrm);
+        const int tokk = toks[1][ks];
+        float o[FR];
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            p1[ct * 16] = __float2bfloat16((dKa[kt][ct][r] - kh[ct] * dot) * inv);
-            p2[ct * 16] = __float2bfloat16(dVa[kt][ct][r]);
-          }
-        }
+        for (int j = 0; j < FR; ++j) o[j] = (dkh[j] - kh[j] * dot) * inv;
+        store_row_frag<FR>(dk + (int64_t)tokk * lddk + hoff + FR * g, o);
+        store_row_frag<FR>(dv + (int64_t)tokk * lddv + hoff + FR * g, dvv);
       }
     }
   }
