@@ -4,7 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 't-mae_amd'))
 from tmae_amd import ops
 
-shapes = [(376000, 256, 128), (376000, 128, 128), (376000, 128, 256), (113000, 256, 128), (113000, 128, 128),
+shapes = [(466000, 512, 256), (466000, 256, 256), (466000, 256, 512), (466000, 768, 256), (752000, 256, 128), (752000, 128, 128), (376000, 256, 128), (376000, 128, 128), (376000, 128, 256), (113000, 256, 128), (113000, 128, 128),
           (150000, 512, 256), (150000, 256, 256), (150000, 256, 512), (150000, 512, 512), (60000, 512, 256), (60000, 256, 256),
           (50000, 512, 256), (50000, 256, 256), (376000, 128, 64), (376000, 64, 16), (376000, 2048, 256)]
 dev = 'cuda:0'

@@ -16,6 +16,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define WG_BN 128   // output rows (n) per workgroup
 #define WG_BK 128   // output cols (k) per workgroup
@@ -40,6 +41,7 @@ __device__ __forceinline__ bf16x8 load_frag(const char* img, int cb, int lane) {
   return *reinterpret_cast<bf16x8*>(&v);
 }
 
+template <bool G>          // G: X rows are gathered through nbr (sparse-conv rulebook)
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
                                                    const __hip_bfloat16* __restrict__ X, int64_t ldx, int64_t M,
                                                    int N, int K, int rows_per_split, float* __restrict__ slab,
@@ -61,40 +63,61 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
   const int steps = m_end > m_begin ? (int)((m_end - m_begin + WG_MS - 1) / WG_MS) : 0;
   const bool want_bias = has_bias && kblk == 0 && wk == 0;     // wave-uniform
   // gathered X (sparse conv): column block k0 lies inside tap k0 / cin; row m reads feature row nbr[m, tap]
-  const int tap = nbr ? k0 / cin : 0, c0 = nbr ? k0 % cin : k0;
+  const int tap = G ? k0 / cin : 0, c0 = G ? k0 % cin : k0;
   float* __restrict__ slab_w = slab + (int64_t)s * count;
   float* __restrict__ slab_b = slab_w + (int64_t)N * K;
 
   // register staging, two slices deep: while slice st is contracted out of LDS, the loads of slices st+1 and st+2
   // are in flight (32 KB per workgroup) -- one slice of prefetch left the kernel latency-bound at ~2.5 TB/s.
   // Slice t uses register set t & 1; the main loop is unrolled by two so that every set index is a constant.
-  uint4 ry[2][2], rx[2][2];
-  int xi[2][2] = {{-1, -1}, {-1, -1}};  // gathered mode: feature-row ids, fetched one slice before their row loads so
-  auto iload = [&](int step, int P) {   // the row loads never wait on an index load (no dependent round trip)
+  // EVERY global load is unconditional (clamped address) and its predicate is applied when the registers are written
+  // to LDS: a load under a branch makes the compiler wait for it (s_waitcnt vmcnt(0)) before the next one is issued,
+  // which serialised the four loads of a slice and left nothing in flight behind the MFMAs.
+  // Addresses are a workgroup-uniform base (SGPRs) + a 32-bit byte offset: no 64-bit multiplies, no address VGPR pairs.
+  u32x4 ry[2][2], rx[2][2];
+  bool oky[2][2], okx[2][2];
+  int xi[2][2] = {{0, 0}, {0, 0}};     // gathered mode: feature-row ids, fetched one slice before their row loads so
+                                       // the row loads never wait on an index load (no dependent round trip)
+  const int rows_here = (int)(m_end - m_begin);
+  const char* __restrict__ baseY = reinterpret_cast<const char*>(dY + m_begin * ldy);
+  const char* __restrict__ baseX = reinterpret_cast<const char*>(G ? X : X + m_begin * ldx);
+  const int32_t* __restrict__ baseI = G ? nbr + m_begin * 9 + tap : nullptr;
+  const unsigned pitchY = (unsigned)ldy * 2u, pitchX = (unsigned)ldx * 2u;
+  auto iload = [&](int step, int P) {
+    if constexpr (G) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t m = m_begin + (int64_t)step * WG_MS + ((tid + 256 * i) >> 4);
-      xi[P][i] = (nbr && m < m_end) ? nbr[m * 9 + tap] : -1;
+      for (int i = 0; i < 2; ++i) {
+        const int r = step * WG_MS + ((tid + 256 * i) >> 4);
+        xi[P][i] = baseI[(unsigned)min(r, rows_here - 1) * 9u];
+      }
     }
   };
   auto gload = [&](int step, int P) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
-      const int64_t m = m_begin + (int64_t)step * WG_MS + row;
+      const int r = step * WG_MS + row, rc = min(r, rows_here - 1);
       const int cy = n0 + ch * 8, cx = k0 + ch * 8;
-      ry[P][i] = (m < m_end && cy < N) ? *reinterpret_cast<const uint4*>(dY + m * ldy + cy) : make_uint4(0, 0, 0, 0);
-      const int64_t xr = nbr ? (int64_t)xi[P][i] : m;
-      rx[P][i] = (m < m_end && cx < K && xr >= 0) ? *reinterpret_cast<const uint4*>(X + xr * ldx + c0 + ch * 8)
-                                                 : make_uint4(0, 0, 0, 0);
+      oky[P][i] = r < rows_here && cy < N;
+      ry[P][i] = *reinterpret_cast<const u32x4*>(baseY + ((unsigned)rc * pitchY + (unsigned)(cy < N ? cy : 0) * 2u));
+      const unsigned xc = (unsigned)(cx < K ? c0 + ch * 8 : 0) * 2u;
+      if constexpr (G) {
+        const int xr = xi[P][i];
+        okx[P][i] = r < rows_here && cx < K && xr >= 0;
+        rx[P][i] = *reinterpret_cast<const u32x4*>(baseX + ((int64_t)max(xr, 0) * pitchX + xc));
+      } else {
+        okx[P][i] = r < rows_here && cx < K;
+        rx[P][i] = *reinterpret_cast<const u32x4*>(baseX + ((unsigned)rc * pitchX + xc));
+      }
     }
   };
   auto lwrite = [&](int buf, int P) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
-      *reinterpret_cast<uint4*>(&lds[buf][0][tile_off(row, ch)]) = ry[P][i];
-      *reinterpret_cast<uint4*>(&lds[buf][1][tile_off(row, ch)]) = rx[P][i];
+      *reinterpret_cast<u32x4*>(&lds[buf][0][tile_off(row, ch)]) = oky[P][i] ? ry[P][i] : z;
+      *reinterpret_cast<u32x4*>(&lds[buf][1][tile_off(row, ch)]) = okx[P][i] ? rx[P][i] : z;
     }
   };
 
@@ -110,16 +133,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
 
   if (steps > 0) {
     iload(0, 0);
-    if (steps > 1) iload(1, 1);
+    iload(1, 1);
     gload(0, 0);
-    if (steps > 1) gload(1, 1);
-    if (steps > 2) iload(2, 0);
+    gload(1, 1);
+    iload(2, 0);
     lwrite(0, 0);
   }
   __syncthreads();
   auto step = [&](int st, int P) {      // P == st & 1, a literal at both call sites
-    if (st + 2 < steps) gload(st + 2, P);
-    if (st + 3 < steps) iload(st + 3, P ^ 1);
+    // no branches around the loads / LDS writes (slices past the end read clamped rows and stage zeros): the
+    // compiler's wait-count bookkeeping turns conservative (vmcnt(0)) at every control-flow join
+    iload(st + 3, P ^ 1);     // index loads first: vmcnt retires in order, and the next step's row
+    gload(st + 2, P);         // loads must be able to wait for the ids without draining these
+    __builtin_amdgcn_sched_barrier(0);   // keep the loads up here and their consumers below the MFMAs: left alone, the
+                                         // scheduler sinks the loads and hoists the waits to shorten live ranges
     bf16x8 fa[4], fb[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -134,7 +161,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
 #pragma unroll
       for (int a = 0; a < 4; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
     }
-    if (st + 1 < steps) lwrite(P ^ 1, P ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    lwrite(P ^ 1, P ^ 1);
     __syncthreads();
   };
   for (int st = 0; st < steps; st += 2) {
@@ -168,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
 // staged dY chunks (a thread always stages the same 8 columns), not with an extra MFMA: no accumulator registers.
 // ------------------------------------------------------------------------------------------------
 #define WG2_B 256
+template <bool G>
 __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
                                                          const __hip_bfloat16* __restrict__ X, int64_t ldx, int64_t M,
                                                          int N, int K, int rows_per_split, float* __restrict__ slab,
@@ -190,39 +219,53 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
   // staging: thread owns 16-byte chunk ch (0..31) of rows r0 and r0 + 16 of both operands
   const int r0 = tid >> 5, ch = tid & 31;
   const int cy = n0 + ch * 8, cx = k0 + ch * 8;
-  const int tap = nbr ? cx / cin : 0, xcol = nbr ? cx % cin : cx;   // gathered X: column cx lies inside tap cx / cin
-  uint4 ry[2][2], rx[2][2];
-  int xi[2][2] = {{-1, -1}, {-1, -1}};
+  const int tap = G ? cx / cin : 0, xcol = G ? cx % cin : cx;   // gathered X: column cx lies inside tap cx / cin
+  // unconditional loads from clamped addresses, predicates applied at the LDS write (see wgrad_kernel)
+  u32x4 ry[2][2], rx[2][2];
+  bool oky[2][2], okx[2][2];
+  int xi[2][2] = {{0, 0}, {0, 0}};
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int rows_here = (int)(m_end - m_begin);
+  const unsigned pitchY = (unsigned)ldy * 2u, pitchX = (unsigned)ldx * 2u;
+  const char* __restrict__ baseY = reinterpret_cast<const char*>(dY + m_begin * ldy) + (cy < N ? cy : 0) * 2;
+  const char* __restrict__ baseX = reinterpret_cast<const char*>(G ? X : X + m_begin * ldx) + (cx < K ? xcol : 0) * 2;
+  const int32_t* __restrict__ baseI = G ? nbr + m_begin * 9 + (cx < K ? tap : 0) : nullptr;
+  const bool coly = cy < N, colx = cx < K;
   auto iload = [&](int step, int P) {
+    if constexpr (G) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t m = m_begin + (int64_t)step * WG_MS + r0 + 16 * i;
-      xi[P][i] = (nbr && m < m_end && cx < K) ? nbr[m * 9 + tap] : -1;
+      for (int i = 0; i < 2; ++i) xi[P][i] = baseI[(unsigned)min(step * WG_MS + r0 + 16 * i, rows_here - 1) * 9u];
     }
   };
   auto gload = [&](int step, int P) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int64_t m = m_begin + (int64_t)step * WG_MS + r0 + 16 * i;
-      ry[P][i] = (m < m_end && cy < N) ? *reinterpret_cast<const uint4*>(dY + m * ldy + cy) : make_uint4(0, 0, 0, 0);
-      const int64_t xr = nbr ? (int64_t)xi[P][i] : m;
-      rx[P][i] = (m < m_end && cx < K && xr >= 0) ? *reinterpret_cast<const uint4*>(X + xr * ldx + xcol)
-                                                 : make_uint4(0, 0, 0, 0);
+      const int r = step * WG_MS + r0 + 16 * i, rc = min(r, rows_here - 1);
+      oky[P][i] = r < rows_here && coly;
+      ry[P][i] = *reinterpret_cast<const u32x4*>(baseY + (unsigned)rc * pitchY);
+      if constexpr (G) {
+        const int xr = xi[P][i];
+        okx[P][i] = r < rows_here && colx && xr >= 0;
+        rx[P][i] = *reinterpret_cast<const u32x4*>(baseX + (int64_t)max(xr, 0) * pitchX);
+      } else {
+        okx[P][i] = r < rows_here && colx;
+        rx[P][i] = *reinterpret_cast<const u32x4*>(baseX + (unsigned)rc * pitchX);
+      }
     }
   };
   auto lwrite = [&](int buf, int P) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int off = tile_off(r0 + 16 * i, ch & 15);
-      *reinterpret_cast<uint4*>(&lds[buf][0][ch >> 4][off]) = ry[P][i];
-      *reinterpret_cast<uint4*>(&lds[buf][1][ch >> 4][off]) = rx[P][i];
+      const u32x4 vy = oky[P][i] ? ry[P][i] : z;
+      *reinterpret_cast<u32x4*>(&lds[buf][0][ch >> 4][off]) = vy;
+      *reinterpret_cast<u32x4*>(&lds[buf][1][ch >> 4][off]) = okx[P][i] ? rx[P][i] : z;
       if (want_bias) {
-        const unsigned u[4] = {ry[P][i].x, ry[P][i].y, ry[P][i].z, ry[P][i].w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          bsum[2 * q] += __uint_as_float(u[q] << 16);
-          bsum[2 * q + 1] += __uint_as_float(u[q] & 0xFFFF0000u);
+          bsum[2 * q] += __uint_as_float(vy[q] << 16);
+          bsum[2 * q + 1] += __uint_as_float(vy[q] & 0xFFFF0000u);
         }
       }
     }
@@ -236,16 +279,20 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
 
   if (steps > 0) {
     iload(0, 0);
-    if (steps > 1) iload(1, 1);
+    iload(1, 1);
     gload(0, 0);
-    if (steps > 1) gload(1, 1);
-    if (steps > 2) iload(2, 0);
+    gload(1, 1);
+    iload(2, 0);
     lwrite(0, 0);
   }
   __syncthreads();
   auto step = [&](int st, int P) {
-    if (st + 2 < steps) gload(st + 2, P);
-    if (st + 3 < steps) iload(st + 3, P ^ 1);
+    // no branches around the loads / LDS writes (slices past the end read clamped rows and stage zeros): the
+    // compiler's wait-count bookkeeping turns conservative (vmcnt(0)) at every control-flow join
+    iload(st + 3, P ^ 1);     // index loads first: vmcnt retires in order, and the next step's row
+    gload(st + 2, P);         // loads must be able to wait for the ids without draining these
+    __builtin_amdgcn_sched_barrier(0);   // keep the loads up here and their consumers below the MFMAs: left alone, the
+                                         // scheduler sinks the loads and hoists the waits to shorten live ranges
     bf16x8 fb[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) fb[t] = load_frag(lds[P][1][wk >> 1], (wk & 1) * 4 + t, lane);
@@ -255,7 +302,8 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[b], acc[a][b], 0, 0, 0);
     }
-    if (st + 1 < steps) lwrite(P ^ 1, P ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    lwrite(P ^ 1, P ^ 1);
     __syncthreads();
   };
   for (int st = 0; st < steps; st += 2) {
@@ -368,6 +416,8 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
   int splits, rows;
   wgrad_plan(m, n, k, splits, rows);
   const int64_t count = slab_count(n, k);
+  // the kernels address a workgroup's rows with 32-bit byte offsets from its first row
+  if ((int64_t)rows * (ldy > ldx ? ldy : ldx) * 2 >= (int64_t)1 << 31 || (nbr && (int64_t)rows * 36 >= (int64_t)1 << 31)) return TMAE_EARG;
   WsCarver ws(wsp, ws_bytes);
   float* slab = ws.take<float>((size_t)splits * count);
   float* part = ws.take<float>((size_t)WG_RG * count);
@@ -376,14 +426,23 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
   if (wgrad_big_tile(n, k)) {
     const int NB = (n + WG2_B - 1) / WG2_B, KB = (k + WG2_B - 1) / WG2_B;
     const unsigned nblocks = 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
-    hipLaunchKernelGGL(wgrad256_kernel, dim3(nblocks), dim3(512), 0, stream, (const __hip_bfloat16*)dy, ldy,
-                       (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr,
-                       cin);
+    if (nbr)
+      hipLaunchKernelGGL(wgrad256_kernel<true>, dim3(nblocks), dim3(512), 0, stream, (const __hip_bfloat16*)dy, ldy,
+                         (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr,
+                         cin);
+    else
+      hipLaunchKernelGGL(wgrad256_kernel<false>, dim3(nblocks), dim3(512), 0, stream, (const __hip_bfloat16*)dy, ldy,
+                         (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr,
+                         cin);
   } else {
     const int NB = (n + WG_BN - 1) / WG_BN, KB = (k + WG_BK - 1) / WG_BK;
     const unsigned nblocks = 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
-    hipLaunchKernelGGL(wgrad_kernel, dim3(nblocks), dim3(256), 0, stream, (const __hip_bfloat16*)dy, ldy,
-                       (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr, cin);
+    if (nbr)
+      hipLaunchKernelGGL(wgrad_kernel<true>, dim3(nblocks), dim3(256), 0, stream, (const __hip_bfloat16*)dy, ldy,
+                         (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr, cin);
+    else
+      hipLaunchKernelGGL(wgrad_kernel<false>, dim3(nblocks), dim3(256), 0, stream, (const __hip_bfloat16*)dy, ldy,
+                         (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr, cin);
   }
   hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(tmae_cdiv(count / 4, 256), WG_RG), dim3(256), 0, stream, slab, splits,
                      count, part);
