@@ -17,6 +17,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ s16x4 tr_read4(const char* lds_ptr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_ptr);
@@ -44,25 +46,29 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// Row fragment of a token: channels [FR*g, FR*g+FR) of head `hoff`, FR = 8 (dh 32) or 4 (dh 16), as floats.
+// Row fragment of a token: channels [FR*g, FR*g+FR) of head `hoff`, FR = 8 (dh 32) or 4 (dh 16).
+// The load is UNCONDITIONAL (an absent token, tok < 0, reads row 0) and the zeroing happens at unpack time: a load under
+// `if (tok >= 0)` makes the compiler wait for it (s_waitcnt vmcnt(0)) before the next one can be issued, which turned the
+// K, V, Q, dO rows of a window into four back-to-back memory round trips.  All raw loads of a workgroup are issued
+// first, then unpacked.
+template <int FR> struct RawFrag;
+template <> struct RawFrag<8> { typedef u32x4 T; };
+template <> struct RawFrag<4> { typedef u32x2 T; };
+
 template <int FR>
-__device__ __forceinline__ void load_row_frag(const __hip_bfloat16* base, int64_t ld, int tok, int hoff, int g,
-                                              float* f) {
-  if (tok < 0) {
+__device__ __forceinline__ typename RawFrag<FR>::T load_row_raw(const __hip_bfloat16* base, int64_t ld, int tok, int hoff,
+                                                                int g) {
+  const __hip_bfloat16* p = base + (int64_t)(tok < 0 ? 0 : tok) * ld + hoff + FR * g;
+  return *reinterpret_cast<const typename RawFrag<FR>::T*>(p);
+}
+
+template <int FR>
+__device__ __forceinline__ void unpack_row(const typename RawFrag<FR>::T& u, int tok, float* f) {
 #pragma unroll
-    for (int j = 0; j < FR; ++j) f[j] = 0.f;
-    return;
-  }
-  const __hip_bfloat16* p = base + (int64_t)tok * ld + hoff + FR * g;
-  if constexpr (FR == 8) {
-    const uint4 u = *reinterpret_cast<const uint4*>(p);
-    const unsigned w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(w[j] << 16); f[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u); }
-  } else {
-    const uint2 u = *reinterpret_cast<const uint2*>(p);
-    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xFFFF0000u);
-    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xFFFF0000u);
+  for (int j = 0; j < FR / 2; ++j) {
+    const unsigned w = tok < 0 ? 0u : u[j];
+    f[2 * j] = __uint_as_float(w << 16);
+    f[2 * j + 1] = __uint_as_float(w & 0xFFFF0000u);
   }
 }
 
@@ -266,16 +272,27 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
   const float inv_tau = 1.0f / fmaxf(tau[0], tau_min);
   // ---- all global row loads are issued here, one dependent round after the token ids
   frag_t kf[NT], kl[NT], qf[NT], ql[NT];
+  typedef typename RawFrag<FR>::T raw_t;
+  raw_t rk[NT], rv[NT], rq[NT];
+  int tokk_[NT], tokq_[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {                    // no branches here: every load of the wave is in flight at once
+    const int slot = t * 16 + i;
+    tokk_[t] = slot < Tk ? toks[1][slot] : -1;
+    tokq_[t] = slot < Tq ? toks[0][slot] : -1;
+    rk[t] = load_row_raw<FR>(k, ldk, tokk_[t], hoff, g);
+    rv[t] = load_row_raw<FR>(v, ldv, tokk_[t], hoff, g);
+    rq[t] = load_row_raw<FR>(q, ldq, tokq_[t], hoff, g);
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int slot = t * 16 + i;
     float f[FR];
     if (t < nk) {                                   // wave-uniform
-      const int tokk = slot < Tk ? toks[1][slot] : -1;
-      load_row_frag<FR>(k, ldk, tokk, hoff, g, f);
+      unpack_row<FR>(rk[t], tokk_[t], f);
       normalize_frag<FR>(f, 1.0f);
       split_frag<FR>(f, kf[t], kl[t]);
-      load_row_frag<FR>(v, ldv, tokk, hoff, g, f);
+      unpack_row<FR>(rv[t], tokk_[t], f);
       store_img_frag<DH>(&vimg[w][slot * RB], g, pack_frag<FR>(f));
     } else {
 #pragma unroll
@@ -286,7 +303,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
       store_img_frag<DH>(&vimg[w][slot * RB], g, z);                        // P is 0 there, but 0 * garbage = NaN
     }
     if (t < nq) {
-      load_row_frag<FR>(q, ldq, slot < Tq ? toks[0][slot] : -1, hoff, g, f);
+      unpack_row<FR>(rq[t], tokq_[t], f);
       normalize_frag<FR>(f, inv_tau);
       split_frag<FR>(f, qf[t], ql[t]);
     }
@@ -480,36 +497,47 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
   //      row-major LDS images are written from the same 16-byte fragments: lane (g,i) owns chunk g of row tile*16+i.
   frag_t kf[NT], kl[NT], vr[NT], qf[NT], ql[NT], gf[NT];
   float lse_i[NT];
+  typedef typename RawFrag<FR>::T raw_t;
+  raw_t rk[NT], rv[NT], rq[NT], rg[NT];
+  int tokk_[NT], tokq_[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {                     // no branches here: every load of the wave is in flight at once
+    const int slot = t * 16 + i;
+    tokk_[t] = slot < Tk ? toks[1][slot] : -1;
+    tokq_[t] = slot < Tq ? toks[0][slot] : -1;
+    rk[t] = load_row_raw<FR>(k, ldk, tokk_[t], hoff, g);
+    rv[t] = load_row_raw<FR>(v, ldv, tokk_[t], hoff, g);
+    rq[t] = load_row_raw<FR>(q, ldq, tokq_[t], hoff, g);
+    rg[t] = load_row_raw<FR>(dout, lddo, tokq_[t], hoff, g);
+    lse_i[t] = lse[(int64_t)(tokq_[t] < 0 ? 0 : tokq_[t]) * nhead + head];
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int slot = t * 16 + i;
     float f[FR];
     if (t < nk) {                                    // wave-uniform
-      const int tokk = slot < Tk ? toks[1][slot] : -1;
-      load_row_frag<FR>(k, ldk, tokk, hoff, g, f);
+      unpack_row<FR>(rk[t], tokk_[t], f);
       const float nrm = normalize_frag<FR>(f, 1.0f);
       split_frag<FR>(f, kf[t], kl[t]);
       if (g == 0) knorm[w][slot] = nrm;
-      load_row_frag<FR>(v, ldv, tokk, hoff, g, f);
+      unpack_row<FR>(rv[t], tokk_[t], f);
       vr[t] = pack_frag<FR>(f);
     } else {
 #pragma unroll
       for (int j = 0; j < FR; ++j) { kf[t][j] = 0; kl[t][j] = 0; vr[t][j] = 0; }
     }
     store_img_frag<DH>(&kimg[w][slot * RB], g, kf[t]);
-    lse_i[t] = INFINITY;
+    if (tokq_[t] < 0 || t >= nq) lse_i[t] = INFINITY;                      // no query: p = exp(s - inf) = 0
     if (t < nq) {
-      const int tokq = slot < Tq ? toks[0][slot] : -1;
-      load_row_frag<FR>(q, ldq, tokq, hoff, g, f);
+      unpack_row<FR>(rq[t], tokq_[t], f);
       const float nrm = normalize_frag<FR>(f, inv_tau);
       split_frag<FR>(f, qf[t], ql[t]);
       store_img_frag<DH>(&qimg[w][slot * RB], g, qf[t]);
       if (g == 0) qnorm[w][slot] = nrm;
       float gfl[FR];
-      load_row_frag<FR>(dout, lddo, tokq, hoff, g, gfl);
+      unpack_row<FR>(rg[t], tokq_[t], gfl);
       gf[t] = pack_frag<FR>(gfl);                                        // exact: bf16 -> f32 -> bf16
       store_img_frag<DH>(&gimg[w][slot * RB], g, gf[t]);
-      lse_i[t] = tokq >= 0 ? lse[(int64_t)tokq * nhead + head] : INFINITY;   // no query: p = exp(s - inf) = 0
     }
   }
   __syncthreads();
