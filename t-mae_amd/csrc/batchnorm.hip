@@ -43,12 +43,12 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
     float v[2][8];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
+      // unconditional load of a clamped row, masked afterwards: a load under `if (r < m)` is waited for
+      // (s_waitcnt vmcnt(0)) before the next one is issued, i.e. the two rows of an iteration never overlap
       const int64_t r = r0 + u * RPW + sub;
-      if (r < m) load8<T>(x + r * C + cl * 8, v[u]);
-      else {
+      load8<T>(x + (r < m ? r : m - 1) * C + cl * 8, v[u]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[u][i] = 0.f;
-      }
+      for (int i = 0; i < 8; ++i) v[u][i] = r < m ? v[u][i] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int64_t r = r0 + u * RPW + sub;
-      if (r < m) load8<T>(x + r * C + cl * 8, v[u]);
+      load8<T>(x + (r < m ? r : m - 1) * C + cl * 8, v[u]);      // unconditional (clamped): both rows in flight
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -140,14 +140,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     float v[2][8], d[2][8];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int64_t r = r0 + u * RPW + sub;
-      if (r < m) {
-        load8<T>(x + r * C + cl * 8, v[u]);
-        load8<T>(dy + r * C + cl * 8, d[u]);
-      } else {
+      const int64_t r = r0 + u * RPW + sub, rc = r < m ? r : m - 1;
+      load8<T>(x + rc * C + cl * 8, v[u]);                        // unconditional (clamped), masked below
+      load8<T>(dy + rc * C + cl * 8, d[u]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { v[u][i] = 0.f; d[u][i] = 0.f; }
-      }
+      for (int i = 0; i < 8; ++i) d[u][i] = r < m ? d[u][i] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -204,11 +201,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     float v[2][8], d[2][8];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int64_t r = r0 + u * RPW + sub;
-      if (r < m) {
-        load8<T>(x + r * C + cl * 8, v[u]);
-        load8<T>(dy + r * C + cl * 8, d[u]);
-      }
+      const int64_t r = r0 + u * RPW + sub, rc = r < m ? r : m - 1;
+      load8<T>(x + rc * C + cl * 8, v[u]);                        // unconditional (clamped): four loads in flight
+      load8<T>(dy + rc * C + cl * 8, d[u]);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {

@@ -21,20 +21,18 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ a
   float g[8], bt[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { g[i] = gamma[cl * 8 + i]; bt[i] = beta[cl * 8 + i]; }
+  const T* __restrict__ bsrc = b ? b : a;           // no second summand: read (and ignore) a again, branch-free
   for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
     float v[2][8], w[2][8];
     bool ok[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int64_t r = r0 + u * RPW + sub;
+      // unconditional loads of a clamped row (rows past m are computed and dropped): a load under `if (r < m)` is
+      // waited for before the next one is issued, so the four loads of an iteration would never overlap
+      const int64_t r = r0 + u * RPW + sub, rc = r < m ? r : m - 1;
       ok[u] = r < m;
-      if (ok[u]) {
-        load8<T>(a + r * D + cl * 8, v[u]);
-        if (b) load8<T>(b + r * D + cl * 8, w[u]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { v[u][i] = 0.f; w[u][i] = 0.f; }
-      }
+      load8<T>(a + rc * D + cl * 8, v[u]);
+      load8<T>(bsrc + rc * D + cl * 8, w[u]);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -84,19 +82,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     bool ok[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int64_t r = r0 + u * RPW + sub;
+      const int64_t r = r0 + u * RPW + sub, rc = r < m ? r : m - 1;
       ok[u] = r < m;
-      if (ok[u]) {
-        load8<T>(x + r * D + cl * 8, v[u]);
-        load8<T>(dy + r * D + cl * 8, d[u]);
-        mu[u] = mean[r];
-        rs[u] = rstd[r];
-      } else {
+      load8<T>(x + rc * D + cl * 8, v[u]);                        // unconditional (clamped), dy masked below
+      load8<T>(dy + rc * D + cl * 8, d[u]);
+      mu[u] = mean[rc];
+      rs[u] = rstd[rc];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { v[u][i] = 0.f; d[u][i] = 0.f; }
-        mu[u] = 0.f;
-        rs[u] = 0.f;
-      }
+      for (int i = 0; i < 8; ++i) d[u][i] = ok[u] ? d[u][i] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {

@@ -153,14 +153,21 @@ __global__ __launch_bounds__(256) void gather9_t_kernel(const T* __restrict__ dc
   float acc[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+  // all nine rulebook entries, then all nine rows, unconditionally (an absent tap reads row 0 and is masked): a load
+  // under `if (o >= 0)` is waited for before the next one is issued -- nine dependent round trips per thread
+  int o[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) o[t] = nbr_t[i * 9 + t];
+  uint4 raw[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+    raw[t] = *reinterpret_cast<const uint4*>(dcols + ((int64_t)(o[t] < 0 ? 0 : o[t]) * 9 + t) * c + c0);
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    const int o = nbr_t[i * 9 + t];
-    if (o < 0) continue;
     T tmp[VEC];
-    *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(dcols + ((int64_t)o * 9 + t) * c + c0);
+    *reinterpret_cast<uint4*>(tmp) = raw[t];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] += ld_f<T>(&tmp[k]);
+    for (int k = 0; k < VEC; ++k) acc[k] += o[t] < 0 ? 0.f : ld_f<T>(&tmp[k]);
   }
   T outv[VEC];
 #pragma unroll
