@@ -61,16 +61,66 @@ def _pmc(key):
     return json.load(open(f)).get(key, {}).get('traffic_bytes_per_op')
 
 
+_STAGE2_TOKENS = []
+
+
+def _stage2_tokens(model, batch):
+    """Stage-2 token count (previous + current frame) of `batch`: one no-grad forward pass, once per process."""
+    if not _STAGE2_TOKENS:
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+            model(dict(batch))
+        _STAGE2_TOKENS.append(int(model.backbone_3d.last_pair_tokens[1]))
+    return _STAGE2_TOKENS[0]
+
+
+def token_gemm_roofline(model, batch, amp_dtype, iters=20):
+    """`roofline`: the dominant kernel of the step by GPU time (profiles/round1_f_kernel_stats.md): the x-stationary
+    token GEMM token_gemm_kernel<256,2,4,4,0> (csrc/token_gemm.hip), on its heaviest frequent shape -- the stage-2
+    FFN / q,k in-projection  Y[m,512] = X[m,256] W^T + b  over the token list of both frames (bench batch).  One launch
+    per op, timed with HIP events on the launch stream.  Algorithmic bytes: X read once, Y written once, W and b read
+    once.  The probe runs on m rounded down to whole 128-token workgroups minus one, so that its
+    launches have a grid of their own and the PMC summary can tell them from the forward pass that measures m."""
+    from tmae_amd._lib import lib, check
+    m = (_stage2_tokens(model, batch) // 128 - 1) * 128
+    n, k = 512, 256
+    dev = next(model.parameters()).device
+    x = torch.randn(m, k, device=dev).bfloat16()
+    w = (torch.randn(n, k, device=dev) * 0.05).bfloat16()
+    b = torch.randn(n, device=dev).bfloat16()
+    y = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        check(lib.tmae_token_gemm(x.data_ptr(), k, m, k, w.data_ptr(), n, b.data_ptr(), y.data_ptr(), n, st),
+              'tmae_token_gemm')
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    bytes_alg = m * (n + k) * 2 + (n * k + n) * 2
+    achieved = bytes_alg / (ms * 1e-3) / 1e9
+    return {'kernel': 'token_gemm_kernel<256,2,4,4,0> (x-stationary token GEMM Y[m,512] = X[m,256] W^T + b of the stage-2 '
+                      'token list; one launch per op)', 'bound': 'hbm', 'achieved': round(achieved, 2),
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
+            'traffic': _pmc('token_gemm'),
+            'traffic_source': 'profiles/round1_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
+            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k}
+
+
 def wgrad_roofline(model, batch, amp_dtype, iters=20):
-    """`roofline`: the dominant hand-written kernel of the step by GPU time (profiles/): the token-split weight
+    """`roofline_wgrad` (the step's dominant kernel until its loads were made branch-free): the token-split weight
     gradient of the d = 256 stages, wgrad256_kernel (csrc/wgrad.hip), on its most frequent heavy shape -- the
     stage-2 FFN / in-projection  dW[512,256] = dY^T X  over the token list of both frames (bench batch).  The op = that
     kernel + its two slab-reduction launches, timed with HIP events on the launch stream.  Algorithmic bytes: dY and
     X read once, dW and db written once; the fp32 slabs are overhead and show up in `traffic`."""
     from tmae_amd import ops
-    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
-        model(dict(batch))
-    m = int(model.backbone_3d.last_pair_tokens[1])            # stage-2 tokens, previous + current frame
+    m = _stage2_tokens(model, batch)
     n, k = 512, 256
     dev = next(model.parameters()).device
     dy = torch.randn(m, n, device=dev).bfloat16()
@@ -231,7 +281,8 @@ def main():
         return train_one_step(ddp, opt, sched, dict(batches[i % nb]), i, model_func, amp_dtype=amp)[0]
 
     if args.probe_only:
-        print(json.dumps({'roofline': wgrad_roofline(model, dict(batches[0]), amp),
+        print(json.dumps({'roofline': token_gemm_roofline(model, dict(batches[0]), amp),
+                          'roofline_wgrad': wgrad_roofline(model, dict(batches[0]), amp),
                           'roofline_attention': attention_roofline(model, dict(batches[0]), amp)}), flush=True)
         return
 
@@ -279,8 +330,10 @@ def main():
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
         }
         log(f'timed region done: {1e3 * elapsed / args.steps:.1f} ms/step; timing the dominant kernel ...')
-        line['roofline'] = wgrad_roofline(model, dict(batches[0]), amp)
-        line['roofline_attention'] = attention_roofline(model, dict(batches[0]), amp)   # round-1 history: priced until the weight gradient overtook it
+        line['roofline'] = token_gemm_roofline(model, dict(batches[0]), amp)
+        # round-1 history: the two kernels that led the profile before this one, still priced the same way
+        line['roofline_wgrad'] = wgrad_roofline(model, dict(batches[0]), amp)
+        line['roofline_attention'] = attention_roofline(model, dict(batches[0]), amp)
         if world == 1 and not args.no_cpu_baseline:
             log('timing the CPU oracle on one frame pair (cpu_baseline) ...')
             line['cpu_baseline'] = cpu_baseline(args.cpu_points)

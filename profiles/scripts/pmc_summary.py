@@ -9,21 +9,33 @@
 Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in KB;
 FETCH_SIZE reports half of the bytes of wide coalesced reads on gfx950 and is doubled; WRITE_SIZE is exact.
 An op = one launch of every kernel of its group (wgrad: the kernel + two slab reductions; attention: the three
-tile-class launches NT = 1, 2, 4 of the stage-1 backward); bytes per op = sum of the per-launch averages.
+tile-class launches NT = 1, 2, 4 of the stage-1 backward; token GEMM: its one launch); bytes per op = sum of the per-launch averages.
 The training step itself is not run by --probe-only, so every launch of these kernels belongs to a probe."""
 import collections, csv, glob, json, sys
 
 out_dir = sys.argv[1]
-groups = {'wgrad': ('wgrad256_kernel', 'wgrad_reduce1_kernel', 'wgrad_reduce2_kernel'),
+groups = {'token_gemm': ('token_gemm_kernel<256, 2, 4, 4, 0>',),
+          'wgrad': ('wgrad256_kernel', 'wgrad_reduce1_kernel', 'wgrad_reduce2_kernel'),
           'attention': ('win_attn_bwd_mfma_kernel<16',)}
+# the token GEMM also runs in the forward pass that measures the token count: its probe launches use a grid of their own
+# (bench.py token_gemm_roofline) -- the most frequent grid of that kernel -- and only those are counted
+MODE_GRID = ('token_gemm_kernel<256, 2, 4, 4, 0>',)
 raw = {}
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     f = glob.glob(f'{out_dir}/pmc_{c}/**/*counter_collection.csv', recursive=True)[0]
     agg = collections.defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(f)):
-        if r['Counter_Name'] != c:
+    rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == c]
+    for r in rows:
+        r['_name'] = r['Kernel_Name'].split('(')[0].replace('void ', '')
+    mode = {}
+    for k in MODE_GRID:
+        grids = collections.Counter(r['Grid_Size'] for r in rows if r['_name'] == k)
+        if grids:
+            mode[k] = grids.most_common(1)[0][0]
+    for r in rows:
+        name = r['_name']
+        if name in mode and r['Grid_Size'] != mode[name]:
             continue
-        name = r['Kernel_Name'].split('(')[0].replace('void ', '')
         agg[name][0] += float(r['Counter_Value'])
         agg[name][1] += 1
     raw[c] = {k: v[0] / v[1] for k, v in agg.items()}

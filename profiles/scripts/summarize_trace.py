@@ -22,15 +22,23 @@ print('| ms/step | % | launches/step | avg us | kernel |\n|---:|---:|---:|---:|-
 for n, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
     print(f'| {d / 3e6:.2f} | {100 * d / busy:.1f} | {c / 3:.1f} | {d / c / 1e3:.1f} | `{n}` |')
 
-# the roofline probes of bench.py (wgrad_roofline, attention_roofline): the launches after the last voxelisation of
+# the roofline probes of bench.py (token_gemm_roofline, wgrad_roofline, attention_roofline): the launches after the last voxelisation of
 # the training steps (+1: the probe's own forward pass voxelises both frames once more); an op = one launch of each
 # kernel of its group, its duration = the sum of the per-kernel averages
 tail = rest[vk[-4]:]
-for title, pats in (('wgrad256 op (kernel + 2 slab reductions)', ('wgrad256_kernel', 'wgrad_reduce1_kernel', 'wgrad_reduce2_kernel')),
+def grid_of(r):
+    return r.get('Grid_Size_X', r.get('Grid_Size', ''))
+
+
+for title, pats in (('token GEMM op (one launch)', ('token_gemm_kernel<256, 2, 4, 4, 0>',)),
+                    ('wgrad256 op (kernel + 2 slab reductions)', ('wgrad256_kernel', 'wgrad_reduce1_kernel', 'wgrad_reduce2_kernel')),
                     ('stage-1 attention backward op (3 tile classes)', ('win_attn_bwd_mfma_kernel<16',))):
     probe = [r for r in tail if any(p in r['Kernel_Name'] for p in pats)]
     if not probe:
         continue
+    if 'token_gemm' in pats[0]:      # the probe's forward pass launches this kernel too: keep the probe's own grid (the mode)
+        g = collections.Counter(grid_of(r) for r in probe).most_common(1)[0][0]
+        probe = [r for r in probe if grid_of(r) == g]
     pa = collections.defaultdict(lambda: [0, 0])
     for r in probe:
         n = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')

@@ -40,9 +40,10 @@ __device__ __forceinline__ float dgelu(float x) {
 }
 
 #define TG_TOK 128   // tokens per workgroup
+#define TG_NT 2      // cache policy of the y stores: nt (written once, streamed; measured 7 % faster than the default)
 #define TG_NCH (NTC * 16)   // output columns per W chunk (NTC 16-column tiles: 4, or 2 for K = 512)
 
-template <int K, int TT, int NW, int NTC, int EPI>
+template <int K, int TT, int NW, int NTC, int EPI, int NCHT>
 __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bfloat16* __restrict__ x, int64_t ldx,
                                                            const __hip_bfloat16* __restrict__ W,
                                                            const __hip_bfloat16* __restrict__ bias,
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
   constexpr int NTH = 64 * NW;           // threads per workgroup
   constexpr int WL = TG_NCH * CPR / NTH; // chunks per thread per W chunk
   __shared__ __attribute__((aligned(16))) char wl[2][TG_NCH * PITCH];
+  __shared__ __attribute__((aligned(16))) char bl[2][TG_NCH * 2];       // the chunk's bias values travel with its W rows
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15;
   const int64_t tok0 = (int64_t)blockIdx.x * (NW * TT * 16) + w * (TT * 16);
 
@@ -70,27 +72,32 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
       xf[tt][ks] = __builtin_bit_cast(bf16x8, u);
     }
   }
-  u32x4 wr[WL];
+  u32x4 wr[WL], br;
 #define TG_WLOAD(chunk)                                                                               \
   _Pragma("unroll") for (int j = 0; j < WL; ++j) {                                                    \
     const int c_ = tid + NTH * j, row_ = c_ / CPR, ch_ = c_ % CPR;                                    \
     wr[j] = *reinterpret_cast<const u32x4*>(W + (int64_t)((chunk) * TG_NCH + row_) * K + ch_ * 8);     \
-  }
+  }                                                                                                   \
+  br = *reinterpret_cast<const u32x4*>(bias + (chunk) * TG_NCH + (tid & (TG_NCH / 8 - 1)) * 8);
 #define TG_WSTORE(buf)                                                                                \
   _Pragma("unroll") for (int j = 0; j < WL; ++j) {                                                    \
     const int c_ = tid + NTH * j, row_ = c_ / CPR, ch_ = c_ % CPR;                                    \
     *reinterpret_cast<u32x4*>(&wl[buf][(16 * ((row_ >> 2) % NTC) + 4 * (row_ / (4 * NTC)) + (row_ & 3)) * PITCH + ch_ * 16]) = wr[j]; \
-  }
-  const int nch = N / TG_NCH;
-  // Ordering inside a chunk: the loads of the NEXT chunk (W, bias) are issued before the MFMAs and CONSUMED (LDS
-  // write / unpack) right after them, before this chunk's y stores are issued.  On gfx9 loads and stores share
-  // vmcnt, and the compiler makes a wave wait for a store before any of its source registers is overwritten, so:
+  }                                                                                                   \
+  *reinterpret_cast<u32x4*>(&bl[buf][(tid & (TG_NCH / 8 - 1)) * 16]) = br;   /* every thread (same data): under `if (tid < 8)` the compiler sinks the LOAD into the branch and follows it with vmcnt(0) */
+  const int nch = NCHT ? NCHT : N / TG_NCH;     // NCHT > 0: the chunk loop is fully unrolled (straight-line code)
+  // Ordering inside a chunk.  On gfx9 loads and stores share vmcnt and retire in order, so a wait for a load also
+  // waits for every store issued BEFORE it.  The loads of chunk c+2 (W, bias) are therefore issued at the end of
+  // chunk c, right BEFORE chunk c's y stores: when chunk c+1 needs them (LDS write after its MFMAs) the wait is
+  // vmcnt(#stores of chunk c) -- the stores keep draining for two chunks instead of having to reach L2 within one
+  // MFMA phase (measured before: ~4 us per chunk per workgroup, the store round trip, for 0.4 us of MFMA work).
+  // No branches around the loads / LDS writes (the last chunks re-load a clamped chunk index): the compiler's
+  // wait-count bookkeeping turns conservative (vmcnt(0)) at control-flow joins.  Also:
   //  * the stores are buffer stores whose only VGPR sources are the packed data and a per-lane offset that never
   //    changes (the chunk offset travels in an SGPR): no address temporaries to recycle;
   //  * the chunk loop is unrolled by two with two sets of data registers, and a set is kept formally alive (empty
   //    asm) until the MFMAs of the following chunk are done: its stores drain under those MFMAs instead of
   //    stalling the wave at the top of the loop (measured before: one memory round trip per chunk).
-  uint2 bcur[NTC], bnext[NTC];                           // packed bf16 bias of the lane's 4 columns per tile (zeros if none)
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)ybytes, 0x00020000);
   // EPI == 2 (DGELU): y = (x . W^T) * gelu'(aux), aux [m, N] bf16 with y's pitch (the pre-activation saved by the
   // forward): the lane's 16-byte pieces of the NEXT chunk are fetched right after this chunk's were consumed.
@@ -108,8 +115,6 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) { oA[h][tt] = u32x4{0u, 0u, 0u, 0u}; oB[h][tt] = u32x4{0u, 0u, 0u, 0u}; }
   TG_WLOAD(0)
-#pragma unroll
-  for (int nt = 0; nt < NTC; ++nt) bcur[nt] = *reinterpret_cast<const uint2*>(bias + 4 * NTC * g + 4 * nt);
   if constexpr (EPI == 2) {
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt)
@@ -117,6 +122,18 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
       for (int h = 0; h < NTC / 2; ++h) auxr[h][tt] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff[tt] + h * 16, 0, 0);
   }
   TG_WSTORE(0)
+  {
+    const int c1_ = nch > 1 ? 1 : 0;
+    TG_WLOAD(c1_)
+    // the compiler merges the wait-count state of the loop entry with that of the back edge and waits for the more
+    // conservative one: give the entry the same shape -- the loads followed by TT * NTC / 2 stores (out of range:
+    // dropped by the buffer bounds check) -- or every first chunk of the unrolled pair drains the previous stores
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+      for (int h = 0; h < NTC / 2; ++h)
+        __builtin_amdgcn_raw_buffer_store_b128(oB[h][tt], yrsrc, (int)ybytes, 0, 0);
+  }
   __syncthreads();
 
 #define TG_KEEP(o)                                                                                          \
@@ -127,12 +144,11 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
 #define TG_CHUNK(c, buf, ocur, oprev)                                                                       \
   {                                                                                                         \
     const bool more = (c) + 1 < nch;                                                                        \
-    if (more) {                                                                                             \
-      TG_WLOAD((c) + 1)                                                                                     \
-      _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt)                                                    \
-        bnext[nt] = *reinterpret_cast<const uint2*>(bias + ((c) + 1) * TG_NCH + 4 * NTC * g + 4 * nt);      \
-    }                                                                                                       \
+    const int c2_ = (c) + 2 < nch ? (c) + 2 : nch - 1;                                                      \
     f32x4 acc[NTC][TT];                                                                                     \
+    uint2 bcur[NTC];           /* packed bf16 bias of the lane's 4 columns per tile (zeros if none) */     \
+    _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt)                                                      \
+      bcur[nt] = *reinterpret_cast<const uint2*>(&bl[buf][(4 * NTC * g + 4 * nt) * 2]);                     \
     _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt)                                                      \
       _Pragma("unroll") for (int tt = 0; tt < TT; ++tt) acc[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};            \
     _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                     \
@@ -144,9 +160,8 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
       }                                                                                                     \
     }                                                                                                       \
     TG_KEEP(oprev) /* the previous chunk's store data stayed untouched while its stores drained */          \
-    if (more) {    /* consume the prefetched loads BEFORE any store of this chunk is issued */               \
-      TG_WSTORE((buf) ^ 1)                                                                                  \
-    }                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    TG_WSTORE((buf) ^ 1) /* chunk c+1 (loaded before the previous chunk's stores) -> the other buffer */     \
     /* C layout: rows 4g + r of tile t = output columns 16g + 4t + r (W rows are permuted in LDS), column = token i: */ \
     /* a lane holds 16 consecutive columns of one token = two 16-byte stores, 4 lanes cover a 128-byte line */        \
     _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
@@ -173,18 +188,29 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
             auxr[h][tt] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff[tt] + h * 16, ((c) + 1) * (TG_NCH * 2), 0); \
       }                                                                                                     \
     }                                                                                                       \
-    /* take over the prefetched bias BEFORE the stores are issued (a wait on a load after them waits for them) */ \
-    _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt) bcur[nt] = bnext[nt];                                \
-    _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt) asm volatile("" ::"v"(bcur[nt].x), "v"(bcur[nt].y));   \
+    /* issue the loads of chunk c+2 BEFORE this chunk's stores */                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    TG_WLOAD(c2_)                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
     _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
       _Pragma("unroll") for (int h = 0; h < NTC / 2; ++h)                                                   \
-        __builtin_amdgcn_raw_buffer_store_b128(ocur[h][tt], yrsrc, voff[tt] + h * 16, (c) * (TG_NCH * 2), 0); \
+        __builtin_amdgcn_raw_buffer_store_b128(ocur[h][tt], yrsrc, voff[tt] + h * 16, (c) * (TG_NCH * 2), NCHT ? TG_NT : 0); \
     __syncthreads();                                                                                        \
   }
 
-  for (int c = 0; c < nch; c += 2) {
-    TG_CHUNK(c, 0, oA, oB)
-    if (c + 1 < nch) TG_CHUNK(c + 1, 1, oB, oA)
+  if constexpr (NCHT > 0) {
+    // the frequent widths (N = 128, 256, 512): no loop, so the compiler's wait counts are exact -- across a back edge it
+    // merges the states of loop entry and latch conservatively and every other chunk drains the stores before it
+#pragma unroll
+    for (int c = 0; c < NCHT; c += 2) {
+      TG_CHUNK(c, 0, oA, oB)
+      if (c + 1 < NCHT) TG_CHUNK(c + 1, 1, oB, oA)
+    }
+  } else {
+    for (int c = 0; c < nch; c += 2) {
+      TG_CHUNK(c, 0, oA, oB)
+      if (c + 1 < nch) TG_CHUNK(c + 1, 1, oB, oA)
+    }
   }
 #undef TG_CHUNK
 #undef TG_KEEP
@@ -200,21 +226,26 @@ static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 7)) return TMAE_EARG;
   const int64_t ybytes = ((m - 1) * ldy + n) * 2;                 // buffer stores address y with 32-bit byte offsets
   if (ybytes >= (int64_t)1 << 31) return TMAE_EARG;
-#define TG_LAUNCH(KK, TT, NW, NTC)                                                                                  \
+#define TG_LAUNCH(KK, TT, NW, NTC, NCHT)                                                                            \
   do {                                                                                                              \
     if (aux)                                                                                                        \
-      hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW, NTC, 2>), dim3(tmae_cdiv(m, NW * TT * 16)), dim3(64 * NW), 0, \
+      hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW, NTC, 2, NCHT>), dim3(tmae_cdiv(m, NW * TT * 16)), dim3(64 * NW), 0, \
                          stream, (const __hip_bfloat16*)x, ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, \
                          (__hip_bfloat16*)y, ldy, m, n, (unsigned)ybytes, (const __hip_bfloat16*)aux);               \
     else                                                                                                            \
-      hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW, NTC, 0>), dim3(tmae_cdiv(m, NW * TT * 16)), dim3(64 * NW), 0, \
+      hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW, NTC, 0, NCHT>), dim3(tmae_cdiv(m, NW * TT * 16)), dim3(64 * NW), 0, \
                          stream, (const __hip_bfloat16*)x, ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, \
                          (__hip_bfloat16*)y, ldy, m, n, (unsigned)ybytes, (const __hip_bfloat16*)nullptr);           \
   } while (0)
   // 4 waves x 32 tokens, 64-column chunks; contraction 512: 16 tokens per wave (64 x registers) and 32-column chunks
-  if (k == 128) TG_LAUNCH(128, 2, 4, 4);
-  else if (k == 256) TG_LAUNCH(256, 2, 4, 4);
-  else TG_LAUNCH(512, 1, 4, 2);
+  // (the frequent widths run the fully unrolled chunk loop)
+  if (k == 128) {
+    if (n == 128) TG_LAUNCH(128, 2, 4, 4, 2); else if (n == 256) TG_LAUNCH(128, 2, 4, 4, 4); else TG_LAUNCH(128, 2, 4, 4, 0);
+  } else if (k == 256) {
+    if (n == 256) TG_LAUNCH(256, 2, 4, 4, 4); else if (n == 512) TG_LAUNCH(256, 2, 4, 4, 8); else TG_LAUNCH(256, 2, 4, 4, 0);
+  } else {
+    TG_LAUNCH(512, 1, 4, 2, 0);
+  }
 #undef TG_LAUNCH
   return tmae_launch_status();
 }
