@@ -14,12 +14,12 @@ The training step itself is not run by --probe-only, so every launch of these ke
 import collections, csv, glob, json, sys
 
 out_dir = sys.argv[1]
-groups = {'token_gemm': ('token_gemm_kernel<256, 2, 4, 4, 0>',),
+groups = {'token_gemm': ('token_gemm_kernel<256, 2, 4, 4, 0, 8>',),
           'wgrad': ('wgrad256_kernel', 'wgrad_reduce1_kernel', 'wgrad_reduce2_kernel'),
           'attention': ('win_attn_bwd_mfma_kernel<16',)}
 # the token GEMM also runs in the forward pass that measures the token count: its probe launches use a grid of their own
 # (bench.py token_gemm_roofline) -- the most frequent grid of that kernel -- and only those are counted
-MODE_GRID = ('token_gemm_kernel<256, 2, 4, 4, 0>',)
+MODE_GRID = ('token_gemm_kernel<256, 2, 4, 4, 0, 8>',)
 raw = {}
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     f = glob.glob(f'{out_dir}/pmc_{c}/**/*counter_collection.csv', recursive=True)[0]

@@ -30,7 +30,7 @@ def grid_of(r):
     return r.get('Grid_Size_X', r.get('Grid_Size', ''))
 
 
-for title, pats in (('token GEMM op (one launch)', ('token_gemm_kernel<256, 2, 4, 4, 0>',)),
+for title, pats in (('token GEMM op (one launch)', ('token_gemm_kernel<256, 2, 4, 4, 0, 8>',)),
                     ('wgrad256 op (kernel + 2 slab reductions)', ('wgrad256_kernel', 'wgrad_reduce1_kernel', 'wgrad_reduce2_kernel')),
                     ('stage-1 attention backward op (3 tile classes)', ('win_attn_bwd_mfma_kernel<16',))):
     probe = [r for r in tail if any(p in r['Kernel_Name'] for p in pats)]

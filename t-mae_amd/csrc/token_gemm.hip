@@ -12,10 +12,14 @@
 // 8-byte piece per tile; the W rows of a chunk are permuted in LDS so that the four tiles give a lane 16 CONSECUTIVE
 // columns (two 16-byte stores; four lanes cover a 128-byte line of y), bias added in fp32 before the rounding.
 //
-// Measured (MI355X, m = 470 k): 5.0 TB/s at k = n = 128, 4.5 at k = 128 / n = 256, 4.2 at k = 256 / n = 128, 3.5 at
-// k = 256 / n = 512 -- ahead of hipBLASLt (3.0-3.4 TB/s) on every shape it supports.  The store width decides: with
-// one 8-byte store per tile (32-byte segments per row) the same kernel ran at 2.9 TB/s, the partial-line requests
-// saturate the L2 request rate long before its bandwidth.
+// Measured (MI355X, m = 470 k): 5.4 TB/s at k = n = 128, 5.3 at k = 128 / n = 256, 4.1 at k = n = 256, 3.1 at
+// k = 256 / n = 512 -- ahead of hipBLASLt (3.0-3.4 TB/s) on every shape it supports; a trivial copy kernel with the
+// same 1 : 2 read : write mix moves the n = 512 traffic at 5.8 TB/s, which is the practical ceiling.
+// What the ablations of the n = 512 case say (each term removed alone, 250 us total): x loads 100 us, stores 70 us,
+// MFMAs 40 us, W loads 30 us, LDS reads 12 us -- nearly additive, i.e. the phases of a workgroup do not overlap, and
+// the x loads of a starting workgroup queue behind the other workgroups' stores (without stores they cost 30 us).
+// The store width also decides: with one 8-byte store per tile (32-byte segments per row) the kernel ran at
+// 2.9 TB/s, the partial-line requests saturate the L2 request rate long before its bandwidth.
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
