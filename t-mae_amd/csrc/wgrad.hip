@@ -2,8 +2,9 @@
 //
 // Why a kernel of our own: on this path M is 1e5..4e5 tokens while N,K <= 512, so the output is a few tiles and
 // the library GEMM runs on a handful of workgroups (measured 15-130 TFLOP/s, 0.25-0.7 TB/s; profiles/).  The work
-// is one streaming pass over dY and X, so the bound is HBM.  Here the token axis is split over ~1k workgroups; each
-// streams its 32-row slices of dY and X through LDS once (16-byte coalesced loads, double buffered) and contracts
+// is one streaming pass over dY and X, so the bound is HBM.  Here the token axis is split over one resident round of
+// workgroups; each streams its 32-row slices of dY and X through LDS once (16-byte coalesced loads, two slices in flight
+// in registers, double-buffered LDS) and contracts
 // them on the matrix cores.  The contraction index (token m) is the ROW index of both operands, i.e. both MFMA
 // operands are needed "transposed"; gfx950's ds_read_b64_tr_b16 delivers exactly that from a row-major LDS image
 // (XOR-swizzled so the transposed reads are bank-conflict free), so no transposed copy is ever materialised.
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
 // 256 x 256 output tile, 8 waves (wave tile 128 x 64): used when n >= 256 and k >= 256 (the d = 256 stages and their
 // sparse convs).  With the 128 x 128 tile those shapes re-read every operand 2-18x through L2 and ran at ~2 TB/s of
 // algorithmic bytes; here each workgroup streams 32 KB per slice for four times the MFMA work.  One workgroup per CU
-// (238 registers, 64 KB LDS), two slices of loads in flight.  Each operand slice is kept as two [32][128] images so
+// (236-244 registers, 64 KB LDS), two slices of loads in flight.  Each operand slice is kept as two [32][128] images so
 // the swizzle and the fragment reads are those of the small kernel.  The bias gradient is summed on the VALU from the
 // staged dY chunks (a thread always stages the same 8 columns), not with an extra MFMA: no accumulator registers.
 // ------------------------------------------------------------------------------------------------
