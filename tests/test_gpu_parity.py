@@ -448,6 +448,16 @@ def test_linear_wgrad_kernel_vs_torch():
         scale = float(ref_w.abs().max())
         assert (dw - ref_w).abs().max().item() <= 2e-3 * scale, (m, n, k)
         assert (db - ref_b).abs().max().item() <= 2e-3 * float(ref_b.abs().max()) + 1e-3, (m, n, k)
+    # token counts around the 32-row slice and the two-slice prefetch depth (clamped loads past the end, 1-3 slices per
+    # workgroup), both tile sizes, partial output tiles
+    for (m, n, k) in ((1, 128, 128), (31, 256, 256), (33, 512, 256), (64, 128, 256), (95, 512, 512), (257, 264, 328),
+                      (300, 768, 256)):
+        dy = torch.randn(m, n, device=dev()).bfloat16()
+        x = torch.randn(m, k, device=dev()).bfloat16()
+        dw, db = ops.linear_wgrad(dy, x)
+        ref_w = dy.float().t() @ x.float()
+        assert (dw - ref_w).abs().max().item() <= 2e-3 * max(1.0, float(ref_w.abs().max())), (m, n, k)
+        assert (db - dy.float().sum(0)).abs().max().item() <= 2e-3 * max(1.0, float(dy.float().sum(0).abs().max())), (m, n, k)
     # strided views (columns of a packed buffer), as the attention projections produce them
     big = torch.randn(30000, 384, device=dev()).bfloat16()
     dy, x = big[:, 128:384], big[:, :128]
