@@ -74,14 +74,15 @@ def _stage2_tokens(model, batch):
 
 
 def token_gemm_roofline(model, batch, amp_dtype, iters=20):
-    """`roofline`: the dominant kernel of the step by GPU time (profiles/round1_f_kernel_stats.md): the x-stationary
-    token GEMM token_gemm_kernel<256,2,4,4,0,8> (csrc/token_gemm.hip), on its heaviest frequent shape -- the stage-2
-    FFN / q,k in-projection  Y[m,512] = X[m,256] W^T + b  over the token list of both frames (bench batch).  One launch
-    per op, timed with HIP events on the launch stream.  Algorithmic bytes: X read once, Y written once, W and b read
-    once.  The probe runs on m rounded down to whole 128-token workgroups minus one, so that its
-    launches have a grid of their own and the PMC summary can tell them from the forward pass that measures m."""
+    """`roofline`: the dominant hand-written kernel family of the step by GPU time (profiles/round1_g_kernel_stats.md):
+    the token GEMM of csrc/token_gemm.hip, here its W-resident persistent kernel token_gemm_res_kernel<256,4> on its
+    heaviest frequent shape -- the stage-2 FFN / q,k in-projection  Y[m,512] = X[m,256] W^T + b  over the token list of
+    both frames (bench batch).  One launch per op, timed with HIP events on the launch stream.  Algorithmic bytes: X read
+    once, Y written once, W and b read once.  The probe's launches are the last 23 launches of that
+    kernel in the process (3 warm-up + 20 timed): that is how the profile summaries tell them from the forward pass
+    that measures m."""
     from tmae_amd._lib import lib, check
-    m = (_stage2_tokens(model, batch) // 128 - 1) * 128
+    m = _stage2_tokens(model, batch)
     n, k = 512, 256
     dev = next(model.parameters()).device
     x = torch.randn(m, k, device=dev).bfloat16()
@@ -105,7 +106,7 @@ def token_gemm_roofline(model, batch, amp_dtype, iters=20):
     ms = e0.elapsed_time(e1) / iters
     bytes_alg = m * (n + k) * 2 + (n * k + n) * 2
     achieved = bytes_alg / (ms * 1e-3) / 1e9
-    return {'kernel': 'token_gemm_kernel<256,2,4,4,0,8> (x-stationary token GEMM Y[m,512] = X[m,256] W^T + b of the stage-2 '
+    return {'kernel': 'token_gemm_res_kernel<256,4> (W-resident persistent token GEMM Y[m,512] = X[m,256] W^T + b of the stage-2 '
                       'token list; one launch per op)', 'bound': 'hbm', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
             'traffic': _pmc('token_gemm'),

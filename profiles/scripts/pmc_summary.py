@@ -14,12 +14,12 @@ The training step itself is not run by --probe-only, so every launch of these ke
 import collections, csv, glob, json, sys
 
 out_dir = sys.argv[1]
-groups = {'token_gemm': ('token_gemm_kernel<256, 2, 4, 4, 0, 8>',),
+groups = {'token_gemm': ('token_gemm_res_kernel<256, 4>',),
           'wgrad': ('wgrad256_kernel', 'wgrad_reduce1_kernel', 'wgrad_reduce2_kernel'),
           'attention': ('win_attn_bwd_mfma_kernel<16',)}
-# the token GEMM also runs in the forward pass that measures the token count: its probe launches use a grid of their own
-# (bench.py token_gemm_roofline) -- the most frequent grid of that kernel -- and only those are counted
-MODE_GRID = ('token_gemm_kernel<256, 2, 4, 4, 0, 8>',)
+# the token GEMM also runs in the forward pass that measures the token count (same grid: the kernel is persistent, one
+# workgroup per CU): the probe's 3 warm-up + 20 timed launches are the LAST 23 dispatches of that kernel in the process
+LAST_N = {'token_gemm_res_kernel<256, 4>': 23}
 raw = {}
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     f = glob.glob(f'{out_dir}/pmc_{c}/**/*counter_collection.csv', recursive=True)[0]
@@ -27,14 +27,13 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == c]
     for r in rows:
         r['_name'] = r['Kernel_Name'].split('(')[0].replace('void ', '')
-    mode = {}
-    for k in MODE_GRID:
-        grids = collections.Counter(r['Grid_Size'] for r in rows if r['_name'] == k)
-        if grids:
-            mode[k] = grids.most_common(1)[0][0]
+    keep = {}
+    for k, nlast in LAST_N.items():
+        ids = sorted(int(r['Dispatch_Id']) for r in rows if r['_name'] == k)
+        keep[k] = set(ids[-nlast:])
     for r in rows:
         name = r['_name']
-        if name in mode and r['Grid_Size'] != mode[name]:
+        if name in keep and int(r['Dispatch_Id']) not in keep[name]:
             continue
         agg[name][0] += float(r['Counter_Value'])
         agg[name][1] += 1

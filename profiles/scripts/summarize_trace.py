@@ -30,15 +30,14 @@ def grid_of(r):
     return r.get('Grid_Size_X', r.get('Grid_Size', ''))
 
 
-for title, pats in (('token GEMM op (one launch)', ('token_gemm_kernel<256, 2, 4, 4, 0, 8>',)),
+for title, pats in (('token GEMM op (one launch)', ('token_gemm_res_kernel<256, 4>',)),
                     ('wgrad256 op (kernel + 2 slab reductions)', ('wgrad256_kernel', 'wgrad_reduce1_kernel', 'wgrad_reduce2_kernel')),
                     ('stage-1 attention backward op (3 tile classes)', ('win_attn_bwd_mfma_kernel<16',))):
     probe = [r for r in tail if any(p in r['Kernel_Name'] for p in pats)]
     if not probe:
         continue
-    if 'token_gemm' in pats[0]:      # the probe's forward pass launches this kernel too: keep the probe's own grid (the mode)
-        g = collections.Counter(grid_of(r) for r in probe).most_common(1)[0][0]
-        probe = [r for r in probe if grid_of(r) == g]
+    if 'token_gemm' in pats[0]:      # the probe's forward pass launches this kernel too: the probe = its last 23 launches
+        probe = probe[-23:]
     pa = collections.defaultdict(lambda: [0, 0])
     for r in probe:
         n = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')

@@ -220,6 +220,148 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
 #undef TG_KEEP
 }
 
+// ------------------------------------------------------------------------------------------------
+// W-resident variant (contraction K, 64 * NCH output columns per workgroup): one workgroup per CU keeps its whole W
+// slice in LDS (256 x 256 bf16 = 132 KB with the row padding) and walks over 256-token tiles (32 tokens per
+// wavefront, 8 wavefronts).  After the prologue there is no barrier and no W traffic: a wavefront issues the x loads of
+// its NEXT tile, contracts the current one chunk by chunk out of LDS, stores, and only then takes over the prefetched
+// fragments -- the only loads it ever waits for are older than every store in flight (vmcnt retires in order), so
+// neither the HBM latency of x (which the chunk-streaming kernel above exposes at every workgroup start, queued behind
+// the other workgroups' stores) nor the stores ever stall it.  N > 64 * NCH: column groups; the workgroups of the
+// column groups of one token range get ids of the same residue mod 8, i.e. the same XCD: x comes from HBM once and
+// from that L2 for the other groups.
+// ------------------------------------------------------------------------------------------------
+template <int K, int NCH>
+__global__ __launch_bounds__(512, 2) void token_gemm_res_kernel(const __hip_bfloat16* __restrict__ x, int64_t ldx,
+                                                               const __hip_bfloat16* __restrict__ W,
+                                                               const __hip_bfloat16* __restrict__ bias,
+                                                               __hip_bfloat16* __restrict__ y, int64_t ldy, int64_t m,
+                                                               int ncg, unsigned ybytes) {
+  constexpr int KS = K / 32, PITCH = K * 2 + 16, CPR = K / 8, NTC = 4, TT = 2, NG = 64 * NCH;
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  char* wl = lds_raw;                                  // [NG][PITCH], rows permuted per 64-row chunk (see above)
+  char* bl = lds_raw + NG * PITCH;                     // [NG] bf16
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int cg = j % ncg, tg = (j / ncg) * 8 + xcd, ntg = gridDim.x / ncg;
+  const int64_t ntiles = (m + 255) / 256;
+  // ---- prologue: the W slice (rows cg*NG ..) and its bias into LDS
+  {
+    constexpr int PER = NG * CPR / 512;                // 16-byte pieces per thread
+    const __hip_bfloat16* Ws = W + (int64_t)cg * NG * K;
+#pragma unroll
+    for (int b0 = 0; b0 < PER; b0 += 8) {
+      u32x4 r[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c_ = tid + 512 * (b0 + q), row_ = c_ / CPR, ch_ = c_ % CPR;
+        r[q] = *reinterpret_cast<const u32x4*>(Ws + (int64_t)row_ * K + ch_ * 8);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c_ = tid + 512 * (b0 + q), row_ = c_ / CPR, ch_ = c_ % CPR, rr = row_ & 63;
+        const int prow = (row_ & ~63) + 16 * ((rr >> 2) % NTC) + 4 * (rr / (4 * NTC)) + (rr & 3);
+        *reinterpret_cast<u32x4*>(&wl[prow * PITCH + ch_ * 16]) = r[q];
+      }
+    }
+    if (tid < NG / 8) *reinterpret_cast<u32x4*>(&bl[tid * 16]) = *reinterpret_cast<const u32x4*>(bias + cg * NG + tid * 8);
+  }
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)ybytes, 0x00020000);
+  auto xload = [&](int64_t tile, bf16x8 (&xf)[TT][KS]) {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      int64_t row = tile * 256 + w * 32 + tt * 16 + i;
+      row = row < m ? row : m - 1;                     // unconditional (clamped) loads; rows >= m are never stored
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        xf[tt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(x + row * ldx + ks * 32 + g * 8));
+    }
+  };
+  bf16x8 xf[TT][KS], xn[TT][KS];
+  int64_t tile = tg;
+  if (tile < ntiles) xload(tile, xf);
+  __syncthreads();                                     // W slice visible; the only barrier of the kernel
+  // two alternating sets of store-data registers, kept formally alive over the whole tile loop: a set is rewritten two
+  // chunks after its stores were issued, and the compiler cannot recycle it for temporaries in between (either would
+  // make the wave wait for those stores: it protects the sources of a store in flight)
+  u32x4 oS[2][NTC / 2][TT];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int h = 0; h < NTC / 2; ++h)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) oS[c][h][tt] = u32x4{0u, 0u, 0u, 0u};
+
+#define TGR_CHUNK(c, ocur)                                                                                  \
+  {                                                                                                         \
+    f32x4 acc[NTC][TT];                                                                                     \
+    uint2 bcur[NTC];                                                                                        \
+    _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt) {                                                    \
+      bcur[nt] = *reinterpret_cast<const uint2*>(&bl[((c) * 64 + 4 * NTC * g + 4 * nt) * 2]);               \
+      _Pragma("unroll") for (int tt = 0; tt < TT; ++tt) acc[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};            \
+    }                                                                                                       \
+    /* W fragments one k-step ahead of the MFMAs that use them (LDS latency behind 8 MFMAs) */              \
+    u32x4 af[2][NTC];                                                                                       \
+    _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt)                                                      \
+      af[0][nt] = *reinterpret_cast<const u32x4*>(&wl[((c) * 64 + nt * 16 + i) * PITCH + g * 16]);          \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                     \
+      if (ks + 1 < KS) {                                                                                    \
+        _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt)                                                  \
+          af[(ks + 1) & 1][nt] =                                                                            \
+              *reinterpret_cast<const u32x4*>(&wl[((c) * 64 + nt * 16 + i) * PITCH + ((ks + 1) * 4 + g) * 16]); \
+      }                                                                                                     \
+      _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt)                                                    \
+        _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                   \
+          acc[nt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[ks & 1][nt]), \
+                                                                xf[tt][ks], acc[nt][tt], 0, 0, 0);          \
+    }                                                                                                       \
+    _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
+      _Pragma("unroll") for (int h = 0; h < NTC / 2; ++h) {                                                 \
+        unsigned w_[4];                                                                                     \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                     \
+          const int nt = 2 * h + q;                                                                         \
+          const f32x4 v_ = acc[nt][tt] + f32x4{__uint_as_float(bcur[nt].x << 16), __uint_as_float(bcur[nt].x & 0xFFFF0000u), \
+                                               __uint_as_float(bcur[nt].y << 16), __uint_as_float(bcur[nt].y & 0xFFFF0000u)}; \
+          w_[2 * q] = bf16_bits(v_[0]) | (bf16_bits(v_[1]) << 16);                                           \
+          w_[2 * q + 1] = bf16_bits(v_[2]) | (bf16_bits(v_[3]) << 16);                                       \
+        }                                                                                                   \
+        ocur[h][tt] = u32x4{w_[0], w_[1], w_[2], w_[3]};                                                    \
+      }                                                                                                     \
+    _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
+      _Pragma("unroll") for (int h = 0; h < NTC / 2; ++h)                                                   \
+        __builtin_amdgcn_raw_buffer_store_b128(ocur[h][tt], yrsrc, voff[tt] + h * 16, (cg * NG + (c) * 64) * 2, TG_NT); \
+  }
+
+  for (; tile < ntiles; tile += ntg) {
+    const int64_t nxt = tile + ntg < ntiles ? tile + ntg : tile;     // past the end: re-load this tile (never used)
+    xload(nxt, xn);
+    __builtin_amdgcn_sched_barrier(0);
+    int voff[TT];                                       // byte offset of (row, 16g) in y; >= ybytes drops the store
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int64_t row = tile * 256 + w * 32 + tt * 16 + i;
+      voff[tt] = row < m ? (int)((row * ldy + 4 * NTC * g) * 2) : (int)ybytes;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      TGR_CHUNK(c, oS[c & 1])
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int h = 0; h < NTC / 2; ++h)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+          asm volatile("" ::"v"(oS[c][h][tt].x), "v"(oS[c][h][tt].y), "v"(oS[c][h][tt].z), "v"(oS[c][h][tt].w));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) xf[tt][ks] = xn[tt][ks];
+  }
+#undef TGR_CHUNK
+}
+
 static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
                              int64_t ldy, const void* aux, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -242,6 +384,21 @@ static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const
                          (__hip_bfloat16*)y, ldy, m, n, (unsigned)ybytes, (const __hip_bfloat16*)nullptr);           \
   } while (0)
   // 4 waves x 32 tokens, 64-column chunks; contraction 512: 16 tokens per wave (64 x registers) and 32-column chunks
+  // W-resident persistent kernel: contraction 256, 256-column groups, when there is at least one 256-token tile per CU
+  static const int res_off = [] { const char* e = getenv("TMAE_TG_RES"); return e && atoi(e) == 0; }();
+  if (!aux && !res_off && k == 256 && (n == 256 || n == 512) && m >= 256 * 256) {
+    const int ncg = n / 256;
+    const int lds = 256 * (256 * 2 + 16) + 256 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)token_gemm_res_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((token_gemm_res_kernel<256, 4>), dim3(256), dim3(512), lds, stream, (const __hip_bfloat16*)x, ldx,
+                       (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, (__hip_bfloat16*)y, ldy, m, ncg,
+                       (unsigned)ybytes);
+    return tmae_launch_status();
+  }
   // (the frequent widths run the fully unrolled chunk loop)
   if (k == 128) {
     if (n == 128) TG_LAUNCH(128, 2, 4, 4, 2); else if (n == 256) TG_LAUNCH(128, 2, 4, 4, 4); else TG_LAUNCH(128, 2, 4, 4, 0);

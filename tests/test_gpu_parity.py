@@ -488,8 +488,10 @@ def test_token_gemm_kernel_vs_torch():
     strided input (column slice of a packed buffer), ragged token counts, and the dX use on W^T."""
     from tmae_amd import ops
     torch.manual_seed(3)
+    # (>= 65536 tokens with contraction 256 and 256 / 512 columns: the W-resident persistent kernel)
     for (m, k, n) in ((8192, 128, 128), (50001, 128, 256), (33333, 256, 512), (20000, 256, 768), (9999, 256, 64),
-                      (30001, 512, 256), (12000, 512, 64), (9000, 256, 2304)):
+                      (30001, 512, 256), (12000, 512, 64), (9000, 256, 2304), (70001, 256, 512), (150003, 256, 256),
+                      (65536, 256, 512)):
         x = torch.randn(m, k, device=dev()).bfloat16()
         w = (torch.randn(n, k, device=dev()) * 0.1).bfloat16()
         b = torch.randn(n, device=dev()).bfloat16()
@@ -504,6 +506,12 @@ def test_token_gemm_kernel_vs_torch():
     big = torch.randn(30000, 384, device=dev()).bfloat16()
     xs = big[:, 128:384]                                   # pitch 384, 256 columns
     w = (torch.randn(128, 256, device=dev()) * 0.1).bfloat16()
+    y = ops.token_gemm(xs, w, None, force=True)
+    ref = xs.float() @ w.float().t()
+    assert (y.float() - ref).abs().max().item() <= 2e-2 * float(ref.abs().max())
+    big = torch.randn(80001, 384, device=dev()).bfloat16()   # the same through the W-resident kernel
+    xs = big[:, 128:384]
+    w = (torch.randn(256, 256, device=dev()) * 0.1).bfloat16()
     y = ops.token_gemm(xs, w, None, force=True)
     ref = xs.float() @ w.float().t()
     assert (y.float() - ref).abs().max().item() <= 2e-2 * float(ref.abs().max())
