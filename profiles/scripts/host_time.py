@@ -19,9 +19,11 @@ for i in range(3):
 torch.cuda.synchronize()
 # wall per step with full sync vs host enqueue time
 for rep in range(3):
+    c0 = time.process_time(); th0 = time.thread_time()
     t0 = time.perf_counter()
     train_one_step(model, opt, sched, dict(batch), 3, fn, amp_dtype=torch.bfloat16)
     t1 = time.perf_counter()
+    print(f'cpu time: process {1e3*(time.process_time()-c0):.1f} ms, main thread {1e3*(time.thread_time()-th0):.1f} ms')
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f'host enqueue {1e3*(t1-t0):.1f} ms, +wait {1e3*(t2-t1):.1f} ms, total {1e3*(t2-t0):.1f} ms')
@@ -29,4 +31,4 @@ import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 train_one_step(model, opt, sched, dict(batch), 3, fn, amp_dtype=torch.bfloat16)
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(35)
+pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
