@@ -10,7 +10,14 @@ from .. import _lib
 from .._lib import lib, check
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _s():
+    """HIP stream of torch's current stream on the current device (the raw-handle query is ~20x cheaper than building
+    a torch.cuda.Stream object; ~250 calls per step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
