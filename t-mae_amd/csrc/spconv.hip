@@ -6,6 +6,7 @@
 // conv over the gathered [m_out, 9*cin] matrix (output-stationary: no atomics, deterministic), and the
 // data gradient uses the transposed neighbour table, again without atomics.
 #include "common.h"
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void down_flag_kernel(const int32_t* __restrict__ grid_in, int batch, int ny,
                                                        int nx, int oy, int ox, int32_t* __restrict__ flag) {
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(256) void gather9_kernel(const char* __restrict__ f
   const int r = nbr[ot];
   uint4 val = make_uint4(0, 0, 0, 0);
   if (r >= 0) val = *reinterpret_cast<const uint4*>(feat + (int64_t)r * row_bytes + (int64_t)ch * VEC_BYTES);
-  *reinterpret_cast<uint4*>(cols + e * VEC_BYTES) = val;
+  // the im2col matrix (~1 GB) is written once and read once by the GEMM: streamed past the caches (nt)
+  __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, val), reinterpret_cast<u32x4_t*>(cols + e * VEC_BYTES));
 }
 
 template <class T, int VEC>

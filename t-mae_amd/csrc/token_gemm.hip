@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
       _Pragma("unroll") for (int h = 0; h < NTC / 2; ++h)                                                   \
-        __builtin_amdgcn_raw_buffer_store_b128(ocur[h][tt], yrsrc, voff[tt] + h * 16, (c) * (TG_NCH * 2), NCHT ? TG_NT : 0); \
+        __builtin_amdgcn_raw_buffer_store_b128(ocur[h][tt], yrsrc, voff[tt] + h * 16, (c) * (TG_NCH * 2), (NCHT || K == 256) ? TG_NT : 0); \
     __syncthreads();                                                                                        \
   }
 
