@@ -96,6 +96,21 @@ template <> __device__ __forceinline__ void store8<__hip_bfloat16>(__hip_bfloat1
   for (int i = 0; i < 8; ++i) t[i] = __float2bfloat16(v[i]);
   *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(t);
 }
+// the same with the nt (streaming) cache policy: for tensors that are written now and read much later (saved for the
+// backward pass), so that they do not push the next kernel's inputs out of L2 / the Infinity Cache
+typedef unsigned tmae_u32x4 __attribute__((ext_vector_type(4)));
+typedef float tmae_f32x4 __attribute__((ext_vector_type(4)));
+template <class T> __device__ __forceinline__ void store8_nt(T* p, const float* v);
+template <> __device__ __forceinline__ void store8_nt<float>(float* p, const float* v) {
+  __builtin_nontemporal_store(tmae_f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<tmae_f32x4*>(p));
+  __builtin_nontemporal_store(tmae_f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<tmae_f32x4*>(p) + 1);
+}
+template <> __device__ __forceinline__ void store8_nt<__hip_bfloat16>(__hip_bfloat16* p, const float* v) {
+  __hip_bfloat16 t[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = __float2bfloat16(v[i]);
+  __builtin_nontemporal_store(*reinterpret_cast<const tmae_u32x4*>(t), reinterpret_cast<tmae_u32x4*>(p));
+}
 // sum over the aligned group of G adjacent lanes (G a power of two <= 64)
 template <int G> __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ a
       if (xsum) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { T t; st_f<T>(&t, v[u][i]); v[u][i] = ld_f<T>(&t); }   // statistics of the STORED (rounded) sum
-        if (ok[u]) store8<T>(xsum + r * D + cl * 8, v[u]);
+        if (ok[u]) store8_nt<T>(xsum + r * D + cl * 8, v[u]);       // saved for the backward pass only
       }
       float s = 0.f;
 #pragma unroll
