@@ -132,14 +132,23 @@ def refresh_param_copies(params, dtype=torch.bfloat16):
 
 # ----------------------------------------------------------------------------- token-list Linear
 
-def linear_wgrad(dy, x, want_bias=True):
+def linear_wgrad(dy, x, want_bias=True, out_w=None, out_b=None):
     """dW [n,k] f32 = dy^T @ x, db [n] f32 = column sums of dy; dy [m,n], x [m,k] bf16 (row-major, last dim
-    contiguous).  One streaming pass, token axis split over the chip (csrc/wgrad.hip)."""
+    contiguous).  One streaming pass, token axis split over the chip (csrc/wgrad.hip).  out_w / out_b: contiguous f32
+    destinations (e.g. a row slice of a packed gradient) written in place of fresh tensors."""
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(1) == 1 and x.stride(1) == 1
     m, n = dy.shape
     k = x.shape[1]
-    dw = torch.empty((n, k), dtype=torch.float32, device=dy.device)
-    db = torch.empty((n,), dtype=torch.float32, device=dy.device) if want_bias else None
+    if out_w is not None:
+        assert out_w.shape == (n, k) and out_w.dtype == torch.float32 and out_w.is_contiguous()
+        dw = out_w
+    else:
+        dw = torch.empty((n, k), dtype=torch.float32, device=dy.device)
+    if want_bias and out_b is not None:
+        assert out_b.shape == (n,) and out_b.dtype == torch.float32 and out_b.is_contiguous()
+        db = out_b
+    else:
+        db = torch.empty((n,), dtype=torch.float32, device=dy.device) if want_bias else None
     wsb = lib.tmae_linear_wgrad_workspace(m, n, k)
     ws = _ws(wsb, dy.device)
     check(lib.tmae_linear_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), m, n, k, _p(dw), _p(db), _p(ws), wsb, _s()),
@@ -241,14 +250,12 @@ class _ProjFork(torch.autograd.Function):
                 dx = token_gemm_dx(dy, w_c[r0:r1]) if dx is None else dx.addmm_(dy, w_c[r0:r1])
             if dW is not None:
                 inp = xp if use_pos else x_c
-                if _wgrad_ok(dy, inp):
-                    dw, db = linear_wgrad(dy, inp, dB is not None)
+                if _wgrad_ok(dy, inp):          # straight into the rows of the packed gradient: no slice copies
+                    linear_wgrad(dy, inp, dB is not None, out_w=dW[r0:r1], out_b=None if dB is None else dB[r0:r1])
                 else:
-                    dw = dy.float().t() @ inp.float()
-                    db = dy.float().sum(0) if dB is not None else None
-                dW[r0:r1] = dw
-                if dB is not None:
-                    dB[r0:r1] = db
+                    dW[r0:r1] = dy.float().t() @ inp.float()
+                    if dB is not None:
+                        dB[r0:r1] = dy.float().sum(0)
         return (None if dx is None else dx.to(xdt), None if dW is None else dW.to(wdt),
                 None if dB is None else dB.to(bdt), None, None, None)
 
