@@ -149,8 +149,10 @@ class TMAE(Detector3DTemplate):
         self.module_list = self.build_networks()
 
     def forward(self, batch_dict):
-        for cur_module in self.module_list:
-            batch_dict = cur_module(batch_dict)
+        from .. import ops
+        with ops.defer_bn_updates():            # running statistics: one multi-tensor update per forward pass
+            for cur_module in self.module_list:
+                batch_dict = cur_module(batch_dict)
         if self.training:
             loss, tb_dict, disp_dict = self.get_training_loss()
             return {'loss': loss}, tb_dict, disp_dict
@@ -174,8 +176,10 @@ class CenterPoint(Detector3DTemplate):
         self.module_list = self.build_networks()
 
     def forward(self, batch_dict):
-        for cur_module in self.module_list:
-            batch_dict = cur_module(batch_dict)
+        from .. import ops
+        with ops.defer_bn_updates():            # running statistics: one multi-tensor update per forward pass
+            for cur_module in self.module_list:
+                batch_dict = cur_module(batch_dict)
         if self.training:
             loss, tb_dict, disp_dict = self.get_training_loss()
             return {'loss': loss}, tb_dict, disp_dict

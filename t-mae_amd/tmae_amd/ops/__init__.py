@@ -99,6 +99,61 @@ def token_gemm_dx(dy, w, force=False):
     return dy @ w
 
 
+# ----------------------------------------------------------------------------- BatchNorm running statistics
+
+_BN_PENDING = None          # None: update immediately; a list: inside defer_bn_updates()
+
+
+def _bn_running_update(bn, mean, var, count):
+    """running = (1 - mom) * running + mom * batch statistic (unbiased variance), num_batches_tracked += 1 -- torch's
+    BatchNorm update.  Inside `defer_bn_updates()` the update is queued and applied at the exit in multi-tensor
+    launches (the step has ~26 such updates x 5 tiny launches each)."""
+    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+    if _BN_PENDING is not None and bn.momentum is not None:
+        _BN_PENDING.append((bn, mean, var, float(mom), float(count)))
+        return
+    with torch.no_grad():
+        bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+        bn.running_var.mul_(1 - mom).add_(var, alpha=mom * count / (count - 1))
+        bn.num_batches_tracked += 1
+
+
+class defer_bn_updates:
+    """Context manager: BatchNorm running-statistics updates made inside are applied at the exit, in order, with
+    torch._foreach kernels (one round per repeated use of a module, so the sequential semantics are kept)."""
+
+    def __enter__(self):
+        global _BN_PENDING
+        self.prev = _BN_PENDING
+        if _BN_PENDING is None:
+            _BN_PENDING = []
+        return self
+
+    def __exit__(self, *exc):
+        global _BN_PENDING
+        if self.prev is not None:            # nested: the outermost context flushes
+            return False
+        pending, _BN_PENDING = _BN_PENDING, None
+        with torch.no_grad():
+            while pending:
+                seen, now, later = set(), [], []
+                for item in pending:
+                    (later if id(item[0]) in seen else now).append(item)
+                    seen.add(id(item[0]))
+                bufs, stats, keep, scale, nbt = [], [], [], [], []
+                for bn, mean, var, mom, count in now:
+                    bufs += [bn.running_mean, bn.running_var]
+                    stats += [mean, var]
+                    keep += [1.0 - mom, 1.0 - mom]
+                    scale += [mom, mom * count / (count - 1.0)]
+                    nbt.append(bn.num_batches_tracked)
+                torch._foreach_mul_(bufs, keep)
+                torch._foreach_add_(bufs, torch._foreach_mul(stats, scale))
+                torch._foreach_add_(nbt, 1)
+                pending = later
+        return False
+
+
 # ----------------------------------------------------------------------------- low-precision parameter copies
 
 def cast_param(p, dtype):
@@ -437,12 +492,8 @@ def batch_norm_relu(x, bn, relu=True, groups=None):
             bounds.append(bounds[-1] + g)
         y, mean, var = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.eps, relu, tuple(bounds))
         if bn.track_running_stats:
-            with torch.no_grad():
-                for g, m in enumerate(sizes):
-                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                    bn.running_mean.mul_(1 - mom).add_(mean[g], alpha=mom)
-                    bn.running_var.mul_(1 - mom).add_(var[g], alpha=mom * m / (m - 1))
-                    bn.num_batches_tracked += 1
+            for g, m in enumerate(sizes):
+                _bn_running_update(bn, mean[g], var[g], m)
         return y
     if len(sizes) > 1:
         ys = [bn(part) for part in torch.split(x, sizes)]
@@ -983,15 +1034,10 @@ def deblocks_to_dense(sources, batch, ny, nx):
     out = _DeblocksToDense.apply(metas, batch, ny, nx, eps, *args)
     cat, stats = out[0], out[1:]
     n = float(batch * ny * nx)
-    with torch.no_grad():
-        for i, src in enumerate(sources):
-            bn = src[5]
-            if bn.track_running_stats:
-                mean, var = stats[2 * i], stats[2 * i + 1]
-                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(var, alpha=mom * n / (n - 1))
-                bn.num_batches_tracked += 1
+    for i, src in enumerate(sources):
+        bn = src[5]
+        if bn.track_running_stats:
+            _bn_running_update(bn, stats[2 * i].detach(), stats[2 * i + 1].detach(), n)
     return cat
 
 
