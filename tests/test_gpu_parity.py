@@ -607,6 +607,23 @@ def test_batchnorm_relu_kernel_vs_torch():
                 assert (bn1.running_mean - bn2.running_mean).abs().max().item() < 1e-4
                 assert (bn1.running_var - bn2.running_var).abs().max().item() < 1e-3
                 assert int(bn1.num_batches_tracked) == 1
+    # running statistics queued inside defer_bn_updates() (what the detectors' forward does) = the immediate updates:
+    # a module used three times (two row groups, then once more), another one once
+    bn_a = [torch.nn.BatchNorm1d(128, eps=1e-3, momentum=0.01).to(dev()) for _ in range(2)]
+    bn_b = [torch.nn.BatchNorm1d(64, eps=1e-3, momentum=0.01).to(dev()) for _ in range(2)]
+    xa, xb = torch.randn(5000, 128, device=dev()) * 2 + 1, torch.randn(700, 64, device=dev())
+    def run(i):
+        ops.batch_norm_relu(xa, bn_a[i], relu=True, groups=[3000, 2000])
+        ops.batch_norm_relu(xb, bn_b[i], relu=False)
+        ops.batch_norm_relu(xa * 0.5, bn_a[i], relu=True)
+    run(0)
+    with ops.defer_bn_updates():
+        run(1)
+        assert int(bn_a[1].num_batches_tracked) == 0          # still queued
+    for u, v in ((bn_a[0], bn_a[1]), (bn_b[0], bn_b[1])):
+        assert torch.allclose(u.running_mean, v.running_mean, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(u.running_var, v.running_var, rtol=1e-6, atol=1e-7)
+        assert int(u.num_batches_tracked) == int(v.num_batches_tracked) > 0
 
 
 # ------------------------------------------------------------------------------------------ A9 / A11
