@@ -118,7 +118,7 @@ def wgrad_roofline(model, batch, amp_dtype, iters=20):
     """`roofline_wgrad` (the step's dominant kernel until its loads were made branch-free): the token-split weight
     gradient of the d = 256 stages, wgrad256_kernel (csrc/wgrad.hip), on its most frequent heavy shape -- the
     stage-2 FFN / in-projection  dW[512,256] = dY^T X  over the token list of both frames (bench batch).  The op = that
-    kernel + its two slab-reduction launches, timed with HIP events on the launch stream.  Algorithmic bytes: dY and
+    kernel + its slab-reduction launch, timed with HIP events on the launch stream.  Algorithmic bytes: dY and
     X read once, dW and db written once; the fp32 slabs are overhead and show up in `traffic`."""
     from tmae_amd import ops
     m = _stage2_tokens(model, batch)
@@ -139,7 +139,7 @@ def wgrad_roofline(model, batch, amp_dtype, iters=20):
     bytes_alg = m * (n + k) * 2 + (n * k + n) * 4
     achieved = bytes_alg / (ms * 1e-3) / 1e9
     return {'kernel': 'wgrad256_kernel (token-split weight gradient dW[512,256] = dY^T X of the stage-2 token list; the '
-                      'op = the kernel + its two slab-reduction launches)', 'bound': 'hbm',
+                      'op = the kernel + its slab-reduction launch)', 'bound': 'hbm',
             'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': _pmc('wgrad'),
             'traffic_source': 'profiles/round1_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',

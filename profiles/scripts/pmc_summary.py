@@ -15,7 +15,7 @@ import collections, csv, glob, json, sys
 
 out_dir = sys.argv[1]
 groups = {'token_gemm': ('token_gemm_res_kernel<256, 4>',),
-          'wgrad': ('wgrad256_kernel', 'wgrad_reduce1_kernel', 'wgrad_reduce2_kernel'),
+          'wgrad': ('wgrad256_kernel', 'wgrad_reduce_kernel'),
           'attention': ('win_attn_bwd_mfma_kernel<16',)}
 # the token GEMM also runs in the forward pass that measures the token count (same grid: the kernel is persistent, one
 # workgroup per CU): the probe's 3 warm-up + 20 timed launches are the LAST 23 dispatches of that kernel in the process

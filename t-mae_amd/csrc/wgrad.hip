@@ -8,7 +8,7 @@
 // them on the matrix cores.  The contraction index (token m) is the ROW index of both operands, i.e. both MFMA
 // operands are needed "transposed"; gfx950's ds_read_b64_tr_b16 delivers exactly that from a row-major LDS image
 // (XOR-swizzled so the transposed reads are bank-conflict free), so no transposed copy is ever materialised.
-// Partial [N,K] blocks go to fp32 slabs (plain stores) and a second tiny kernel sums the slabs in a fixed order:
+// Partial [N,K] blocks go to fp32 slabs (plain stores) and a second small kernel sums the slabs in a fixed order:
 // deterministic, no atomics.
 #include "common.h"
 #include <cstdlib>
@@ -340,33 +340,40 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
   }
 }
 
-// Slab reduction, two levels, both in a fixed order (deterministic).  (A single launch whose last-arriving block
-// finishes the sum needs a device-scope fence per block -- an L2 write-back on every XCD -- and measured 2-4x slower
-// than this kernel boundary.)  Level 1: block (x, y) sums the slabs
-// y, y+RG, y+2RG, ... for 1024 consecutive elements (float4 per thread) into part[y]; level 2 sums the RG parts.
+// Slab reduction, two levels in ONE launch, both in a fixed order (deterministic): a 1024-thread workgroup owns 64
+// float4 of the output; wavefront y sums the slabs y, y+RG, y+2RG, ... for them (one float4 per lane and slab, all
+// loads independent), the 16 partial sums meet in LDS and wavefront 0 adds them in the order y = 0..15 and writes dW /
+// db.  (Two launches with the partials in global memory cost a second ~5 us dispatch per weight gradient, 112 per
+// step; a last-arriving-block finish across workgroups needs a device-scope fence per block and measured 2-4x slower.)
 #define WG_RG 16
-__global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restrict__ slab, int splits, int64_t count,
-                                                           float* __restrict__ part) {
-  const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (e >= count) return;
+__global__ __launch_bounds__(64 * WG_RG) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits,
+                                                                 int64_t count, int n, int k, float* __restrict__ dw,
+                                                                 float* __restrict__ db) {
+  __shared__ float4 red[WG_RG][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t e = ((int64_t)blockIdx.x * 64 + lane) * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = blockIdx.y; s < splits; s += WG_RG) {
-    const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)s * count + e);
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  if (e < count) {
+    for (int s = w; s < splits; s += WG_RG) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)s * count + e);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
   }
-  *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * count + e) = acc;
-}
-
-__global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restrict__ part, int64_t count, int n, int k,
-                                                           float* __restrict__ dw, float* __restrict__ db) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= count) return;
-  float acc = 0.f;
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && e < count) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int y = 0; y < WG_RG; ++y) acc += part[(int64_t)y * count + e];
-  const int64_t nk = (int64_t)n * k;
-  if (e < nk) dw[e] = acc;
-  else if (db && e < nk + n) db[e - nk] = acc;
+    for (int y = 0; y < WG_RG; ++y) { const float4 v = red[y][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+    const int64_t nk = (int64_t)n * k;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t idx = e + j;
+      if (idx < nk) dw[idx] = tv[j];
+      else if (db && idx < nk + n) db[idx - nk] = tv[j];
+    }
+  }
 }
 
 // a single 256 x 256 output tile (n = k = 256) stays with the small kernel: there the big tile only doubles the slab
@@ -405,7 +412,7 @@ static int64_t slab_count(int n, int k) { return (((int64_t)n * k + n) + 3) / 4 
 size_t tmae_linear_wgrad_workspace(int64_t m, int n, int k) {
   int splits, rows;
   wgrad_plan(m, n, k, splits, rows);
-  return tmae_align((size_t)splits * slab_count(n, k) * 4) + tmae_align((size_t)WG_RG * slab_count(n, k) * 4) + 1024;
+  return tmae_align((size_t)splits * slab_count(n, k) * 4) + 1024;
 }
 
 static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k, float* dw,
@@ -421,7 +428,6 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
   if ((int64_t)rows * (ldy > ldx ? ldy : ldx) * 2 >= (int64_t)1 << 31 || (nbr && (int64_t)rows * 36 >= (int64_t)1 << 31)) return TMAE_EARG;
   WsCarver ws(wsp, ws_bytes);
   float* slab = ws.take<float>((size_t)splits * count);
-  float* part = ws.take<float>((size_t)WG_RG * count);
   if (!ws.ok) return TMAE_EWS;
   // without a bias the slabs' bias columns stay unwritten; the reduction discards those sums
   if (wgrad_big_tile(n, k)) {
@@ -445,10 +451,8 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
       hipLaunchKernelGGL(wgrad_kernel<false>, dim3(nblocks), dim3(256), 0, stream, (const __hip_bfloat16*)dy, ldy,
                          (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr, cin);
   }
-  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(tmae_cdiv(count / 4, 256), WG_RG), dim3(256), 0, stream, slab, splits,
-                     count, part);
-  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(tmae_cdiv(count, 256)), dim3(256), 0, stream, part, count, n, k, dw,
-                     db);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tmae_cdiv(count / 4, 64)), dim3(64 * WG_RG), 0, stream, slab, splits,
+                     count, n, k, dw, db);
   return tmae_launch_status();
 }
 
