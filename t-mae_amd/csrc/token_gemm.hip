@@ -45,7 +45,6 @@ __device__ __forceinline__ float dgelu(float x) {
   return cdf + x * e * 0.39894228040143267794f;
 }
 
-#define TG_TOK 128   // tokens per workgroup
 #define TG_NT 2      // cache policy of the y stores: nt (written once, streamed; measured 7 % faster than the default)
 #define TG_NCH (NTC * 16)   // output columns per W chunk (NTC 16-column tiles: 4, or 2 for K = 512)
 
