@@ -1,8 +1,9 @@
 """Benchmark of the T-MAE pre-training hot path on MI355X (contract: see the task statement / DESIGN.md).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          # starts N rank processes itself (before any GPU call)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # or under an external launcher (WORLD_SIZE set)
 
 A "step" = one full pre-training iteration (VFE -> Siamese SST encoder -> masking -> WCA -> dense decoder ->
 Chamfer -> backward -> Adam one-cycle) over one batch of synthetic 120k-point ONCE-shape frame pairs, inputs
@@ -207,32 +208,200 @@ def attention_roofline(model, batch, amp_dtype, iters=20):
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': int(m)}
 
 
-def cpu_baseline(n_points):
-    """The oracle (oracle/tmae_oracle.py, a CPU restatement pinned against the reference) timed on this box's
-    host cores: forward + backward of ONE frame pair, fp32, all cores."""
-    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-    import tmae_oracle as O
+def _host_cores():
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))          # the 1-GPU box's CPU share is 16 cores
-    torch.set_num_threads(cores)
-    cfg = O.default_model_cfg(3)
-    P = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=0).items()}
+    return max(1, min(cores, 16))          # the 1-GPU box's CPU share is 16 cores
+
+
+def _oracle_case(O, n_points, stages, iters, pred_scale=1.0):
+    """Warm-up + `iters` timed forward+backward passes of the oracle on ONE synthetic frame pair (seed 0)."""
+    cfg = O.default_model_cfg(stages)
+    P = {k: v.requires_grad_(True) for k, v in O.init_params(cfg, seed=0, pred_scale=pred_scale).items()}
     pts, prv = O.synth_frame_pair(n_points, 1, seed=0)
     vox = O.voxelize(pts, cfg['point_cloud_range'], cfg['voxel_size'], cfg['grid_size'])
     noise = np.random.default_rng(0).random(vox['voxel_coords'].shape[0]).astype(np.float32)
-    t0 = time.perf_counter()
-    loss = O.forward_loss(P, pts, prv, noise, 1, cfg)
-    loss.backward()
-    dt = time.perf_counter() - t0
-    return {'value': round(1.0 / dt, 5), 'unit': 'frame-pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': f'1 frame pair of {n_points} pts/frame, forward+backward (no optimizer), fp32, {dt:.1f} s'}
+    times, loss = [], None
+    for i in range(iters + 1):
+        for p in P.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        loss = O.forward_loss(P, pts, prv, noise, 1, cfg)
+        loss.backward()
+        if i > 0:                           # iteration 0 = warm-up (allocator, thread pool, first-touch)
+            times.append(time.perf_counter() - t0)
+    return times, float(loss), (cfg, pts, prv, noise)
+
+
+def cpu_baseline(n_points, iters=3):
+    """The oracle (oracle/tmae_oracle.py, a CPU restatement pinned against the reference) timed on this box's
+    host cores: forward + backward of ONE frame pair, fp32, all cores -- 1 warm-up + `iters` timed iterations at
+    C2 (120 k points, full model; the metric's configuration) and at C1 (8 k points, one SST stage)."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import tmae_oracle as O
+    cores = _host_cores()
+    torch.set_num_threads(cores)
+    t2, loss2, case2 = _oracle_case(O, n_points, 3, iters)
+    t1, _, _ = _oracle_case(O, 8000, 1, iters)
+    med2, med1 = float(np.median(t2)), float(np.median(t1))
+    try:
+        model = [ln.split(':', 1)[1].strip() for ln in open('/proc/cpuinfo') if ln.startswith('model name')][0]
+    except Exception:
+        model = 'unknown'
+    out = {'value': round(1.0 / med2, 5), 'unit': 'frame-pairs/s', 'cores': cores, 'kind': 'port',
+           'sample': f'C2: 1 frame pair of {n_points} pts/frame, full 3-stage model, forward+backward (no optimizer), '
+                     f'fp32; 1 warm-up + {iters} timed iterations, median {med2:.2f} s '
+                     f'(all: {", ".join(f"{t:.2f}" for t in t2)})',
+           'c1': {'value': round(1.0 / med1, 5), 'unit': 'frame-pairs/s',
+                  'sample': f'C1: 1 frame pair of 8000 pts/frame, one SST stage; 1 warm-up + {iters} timed iterations, '
+                            f'median {med1:.2f} s'},
+           'cpu_model': model}
+    return out, (O, loss2, case2)
+
+
+def chamfer_parity(O, loss_default_cpu, case, dev):
+    """BASELINE.md section 3's "Chamfer |delta| vs CPU path": the GPU product in fp32 and in bf16 autocast on the SAME
+    120 k-point frame pair, weights and masking noise that the cpu_baseline leg fed the oracle (default head), and on
+    the conditioned head (decoder_pred x 0.1, the fixtures' choice: with the default head an untrained model's loss
+    moves by ~2e-3 between thread counts of the CPU path ITSELF, measured here as `oracle_thread_spread`)."""
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    from pcdet.models import build_network
+    from tmae_amd.train import SyntheticTemporalDataset
+    cfg_o, pts, prv, noise = case
+    ycfg = cfg_from_yaml_file(os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae_ssl.yaml'), EasyDict())
+    ds = SyntheticTemporalDataset(ycfg.DATA_CONFIG, ycfg.CLASS_NAMES, n_points=1000, batch_size=1)
+    bd0 = {'points': torch.from_numpy(pts).to(dev), 'points_prev': torch.from_numpy(prv).to(dev), 'batch_size': 1,
+           'mae_noise': torch.from_numpy(noise).to(dev)}
+
+    def gpu_losses(P):
+        model = build_network(ycfg.MODEL, len(ycfg.CLASS_NAMES), ds)
+        res = model.load_state_dict(P, strict=False)
+        assert not res.unexpected_keys
+        model.to(dev).train()
+        out = []
+        for amp in (False, True):
+            with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+                ret, _, _ = model(dict(bd0))
+            out.append(float(ret['loss']))
+        return out
+
+    def cpu_loss(P, threads):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            return float(O.forward_loss(P, pts, prv, noise, 1, cfg_o))
+
+    cores = _host_cores()
+    P1 = O.init_params(cfg_o, seed=0)
+    g32, g16 = gpu_losses(P1)
+    spread = abs(cpu_loss(P1, 1) - loss_default_cpu)
+    Pc = O.init_params(cfg_o, seed=0, pred_scale=0.1)
+    lc = cpu_loss(Pc, cores)
+    c32, c16 = gpu_losses(Pc)
+    torch.set_num_threads(cores)
+    return {'config': f'1 frame pair of {pts.shape[0]} + {prv.shape[0]} in-range points (seed 0), 3 stages, same weights '
+                      f'and masking noise on both sides; forward loss',
+            'default_head': {'cpu_loss': round(loss_default_cpu, 6), 'gpu_fp32': round(g32, 6), 'gpu_bf16': round(g16, 6),
+                             'chamfer_abs_err_fp32': round(abs(g32 - loss_default_cpu), 7),
+                             'chamfer_abs_err_bf16': round(abs(g16 - loss_default_cpu), 7),
+                             'oracle_thread_spread': round(spread, 7),
+                             'note': f'oracle_thread_spread = |CPU loss at 1 thread - at {cores} threads|'},
+            'conditioned_head': {'cpu_loss': round(lc, 6), 'gpu_fp32': round(c32, 6), 'gpu_bf16': round(c16, 6),
+                                 'chamfer_abs_err_fp32': round(abs(c32 - lc), 7),
+                                 'chamfer_abs_err_bf16': round(abs(c16 - lc), 7), 'pred_scale': 0.1}}
+
+
+def step_flops(model, batch, amp):
+    """Algorithmic FLOPs of ONE training step on `batch` from SURVEY.md 8(d)'s formulas, evaluated on the batch's REAL
+    token / window / kernel-pair counts (one extra no-grad forward pass collects the index sets): forward, and 3x that
+    for forward + backward."""
+    from tmae_amd import ops
+    bb = model.backbone_3d
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp is not None):
+        bd = dict(batch)
+        model(bd)
+    B = int(bd['batch_size'])
+    drop = {0: dict(max_tokens=16, drop_range=(0, 16)), 1: dict(max_tokens=32, drop_range=(16, 32)),
+            2: dict(max_tokens=64, drop_range=(32, 100000))}
+
+    def win_counts(ind, grid, other, ny, nx, shift, nb):
+        wb = ops.window_bucket(ind, grid, other, nb, ny, nx, [8, 8, 1], shift, drop)
+        return wb['batch_win_inds']
+
+    enc = wca = 0.0
+    cfgs = [c.ENCODER for c in bb.model_cfg.SST_BLOCK_LIST]
+    d_prev = bb.sst_blocks[0].encoder_blocks[0].encoder_list[0].linear1.in_features
+    detail = []
+    for si, (e, (ind_p, ind_c, shape)) in enumerate(zip(cfgs, bb.last_stage_indices)):
+        d, dff, nblk = e.D_MODEL, e.DIM_FEEDFORWARD, e.NUM_BLOCKS
+        ny, nx = shape
+        nwin = B * 64 * 64 * 4 + 64
+        stage = {}
+        for tag, ind in (('prev', ind_p), ('cur', ind_c)):
+            M = ind.shape[0]
+            grid = ops.index_grid(ind, B, ny, nx)
+            t2 = []
+            for shift in (False, True):
+                cnt = torch.bincount(win_counts(ind, grid, None, ny, nx, shift, B), minlength=1).double()
+                t2.append(float((cnt * cnt).sum()))
+            layers = 2 * nblk                                           # alternating shift 0 / shift 1
+            f = layers * M * 2 * (4 * d * d + 2 * d * dff) + nblk * sum(4 * t * d for t in t2)
+            p_subm = float((ops.spconv_neighbors(ind, grid, B, ny, nx, 1) >= 0).sum())
+            f += 2 * p_subm * d * d
+            if e.STRIDE > 1:
+                ind_in = bb.last_stage_indices[si - 1][0 if tag == 'prev' else 1]
+                iy, ix = bb.last_stage_indices[si - 1][2]
+                gin = ops.index_grid(ind_in, B, iy, ix)
+                p_down = float((ops.spconv_neighbors(ind, gin, B, iy, ix, 2) >= 0).sum())
+                f += 2 * p_down * d_prev * d
+            enc += f
+            stage[tag + '_tokens'] = int(M)
+        # window cross-attention: queries = current tokens, keys = previous-frame tokens of the same window
+        gp, gc = ops.index_grid(ind_p, B, ny, nx), ops.index_grid(ind_c, B, ny, nx)
+        m_c = ind_c.shape[0]
+        w = 2 * (m_c * 2 * (2 * d * d + 2 * d * dff))
+        for shift in (False, True):
+            wq = win_counts(ind_c, gc, None, ny, nx, shift, B)
+            wk = win_counts(ind_p, gp, None, ny, nx, shift, B)
+            n = int(max(int(wq.max()), int(wk.max()))) + 1
+            cq, ck = torch.bincount(wq, minlength=n).double(), torch.bincount(wk, minlength=n).double()
+            kept_prev = float(ck[cq > 0].sum())
+            w += kept_prev * 2 * (2 * d * d) + float((cq * ck).sum()) * 4 * d
+        w += 2 * float((ops.spconv_neighbors(ind_c, gc, B, ny, nx, 1) >= 0).sum()) * d * d
+        wca += w
+        d_prev = d
+        detail.append(stage)
+    dense = B * 229.8e9
+    n_pts = bd['points'].shape[0] + bd['points_prev'].shape[0] if 'points' in bd else 0
+    vfe = 2.0 * n_pts * 8832
+    M_all = bd['voxel_coords'].shape[0]
+    head = 2.0 * M_all * 128 * 48 + 8.0 * M_all * 16 * 64
+    fwd = enc + wca + dense + vfe + head
+    return {'forward': fwd, 'step': 3.0 * fwd, 'encoder': enc, 'wca': wca, 'dense_decoder': dense, 'vfe': vfe,
+            'head_chamfer': head, 'stages': detail}
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes through torch.distributed.run BEFORE this
+    process touches the GPU (nothing here has made a HIP call yet), relay their output and exit with their code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(_self_launch(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -305,12 +474,20 @@ def main():
     for i in range(args.steps):
         loss = step(args.warmup + i)
     torch.cuda.synchronize()
+    t_own = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    # per-rank time of the rank's own K steps (before the closing barrier): the skew between ranks
+    own = torch.tensor([t_own], device=dev, dtype=torch.float64)
+    per_rank = [own.clone() for _ in range(world)]
+    ranks_seen = 1
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_gather(per_rank, own)
+        ranks_seen = dist.get_world_size()
+    per_rank = [float(v.item()) for v in per_rank]
     elapsed = float(t.item())
     loss_val = float(loss.detach())
     assert np.isfinite(loss_val), 'non-finite loss in the timed region'
@@ -329,15 +506,34 @@ def main():
                        'batch_per_gpu': args.batch_per_gpu, 'global_batch': args.batch_per_gpu * world,
                        'parallelism': f'dp{world}', 'grid': '468x468x1', 'final_loss': round(loss_val, 5),
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
+            'ranks': ranks_seen, 'collective_backend': 'nccl (RCCL)' if world > 1 else None,
+            'rank_ms_per_step': {'min': round(1e3 * min(per_rank) / args.steps, 3),
+                                 'max': round(1e3 * max(per_rank) / args.steps, 3)},
         }
+        if args.task == 'pretrain':
+            fl = step_flops(model, dict(batches[0]), amp)
+            tfs = fl['step'] * world / (elapsed / args.steps) / 1e12
+            line['roofline_step'] = {
+                'bound': 'mfma', 'achieved': round(tfs / world, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(tfs / world / MFMA_BF16_PEAK_TFLOPS, 5), 'per': 'GPU',
+                'flops_per_step_per_gpu': fl['step'], 'forward_flops': fl['forward'],
+                'breakdown_forward': {k: fl[k] for k in ('encoder', 'wca', 'dense_decoder', 'vfe', 'head_chamfer')},
+                'stage_tokens': fl['stages'],
+                'note': 'algorithmic FLOPs of SURVEY.md 8(d) on the real token / window / kernel-pair counts of batch 0 '
+                        '(forward x 3 for forward + backward) / measured step time / dense bf16 MFMA peak'}
         log(f'timed region done: {1e3 * elapsed / args.steps:.1f} ms/step; timing the dominant kernel ...')
         line['roofline'] = token_gemm_roofline(model, dict(batches[0]), amp)
         # round-1 history: the two kernels that led the profile before this one, still priced the same way
         line['roofline_wgrad'] = wgrad_roofline(model, dict(batches[0]), amp)
         line['roofline_attention'] = attention_roofline(model, dict(batches[0]), amp)
         if world == 1 and not args.no_cpu_baseline:
-            log('timing the CPU oracle on one frame pair (cpu_baseline) ...')
-            line['cpu_baseline'] = cpu_baseline(args.cpu_points)
+            log('timing the CPU oracle (cpu_baseline: warm-up + 3 iterations at C2 and C1) ...')
+            line['cpu_baseline'], (O, loss_cpu, case) = cpu_baseline(args.cpu_points)
+            if args.task == 'pretrain' and args.shape == 'once':
+                log('Chamfer |delta| of the GPU path (fp32, bf16) vs the CPU path on the same 120k-point pair ...')
+                line['parity'] = chamfer_parity(O, loss_cpu, case, dev)
+                line['chamfer_abs_err_fp32'] = line['parity']['default_head']['chamfer_abs_err_fp32']
+                line['chamfer_abs_err_bf16'] = line['parity']['default_head']['chamfer_abs_err_bf16']
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

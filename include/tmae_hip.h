@@ -79,6 +79,15 @@ int tmae_vfe_point_features(const float* points, int row, const int64_t* point_c
                             float rmin_x, float rmin_y, float rmin_z, float vs_x, float vs_y, float vs_z,
                             float* voxel_mean, float* feats, void* stream);
 
+/* The same point features for the bf16 (autocast) path, which must not round absolute coordinates (up to 75 m) to
+ * 8 mantissa bits before the first Linear (temporal_dyn_vfe.py:110-112 under AMP keeps 11): feats_hl [n,32] bf16 =
+ * [hi(16) | lo(16)] with hi + lo = the fp32 feature to ~2^-17 relative, columns >= F+6 of each half zero. */
+int tmae_vfe_point_features_bf16x2(const float* points, int row, const int64_t* point_coords_i64,
+                                   const int64_t* inverse_i64, const int32_t* perm, const int32_t* offsets,
+                                   int64_t n, int64_t m,
+                                   float rmin_x, float rmin_y, float rmin_z, float vs_x, float vs_y, float vs_z,
+                                   float* voxel_mean, void* feats_hl, void* stream);
+
 /* torch_scatter.scatter_max (temporal_dyn_vfe.py:113): out[v,c] = max over the voxel's points,
  * argmax[v,c] = first point (ascending id) attaining it.  x [n,c]; backward routes the
  * gradient to the argmax rows (dx fully written, no pre-zeroing needed). */

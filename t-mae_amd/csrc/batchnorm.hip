@@ -30,15 +30,23 @@ __device__ __forceinline__ void bn_block_partial(float* s1, float* s2, float (*r
   }
 }
 
-// partial column sums of x and x^2
+// partial column sums of (x - p) and (x - p)^2, p = a per-channel pivot (row 0 of x when `use_pivot`, else 0).
+// Shifting by a sample of the data keeps E[(x-p)^2] - E[x-p]^2 free of the cancellation that the raw moments suffer
+// when |mean| >> std (dense BEV maps whose inactive region is one constant per channel); torch uses Welford there.
+// Block 0 also writes the pivot behind the partials: part[grid*2*C + c].
 template <class T, int VEC>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t m,
-                                                      float* __restrict__ part /*[grid][2][C]*/) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t m, int use_pivot,
+                                                      float* __restrict__ part /*[grid][2][C] + [C]*/) {
   BN_LAYOUT;
   __shared__ float red[4][2][C];
-  float s1[8], s2[8];
+  float s1[8], s2[8], pv[8];
+  load8<T>(x + cl * 8, pv);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+  for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; pv[i] = use_pivot ? pv[i] : 0.f; }
+  if (blockIdx.x == 0 && w == 0 && sub == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[(int64_t)gridDim.x * 2 * C + cl * 8 + i] = pv[i];
+  }
   for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
     float v[2][8];
 #pragma unroll
@@ -48,7 +56,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
       const int64_t r = r0 + u * RPW + sub;
       load8<T>(x + (r < m ? r : m - 1) * C + cl * 8, v[u]);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[u][i] = r < m ? v[u][i] : 0.f;
+      for (int i = 0; i < 8; ++i) v[u][i] = r < m ? v[u][i] - pv[i] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -75,8 +83,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
-    const double mu = s1 / m;
-    double vr = s2 / m - mu * mu;
+    const double d = s1 / m;                                   // mean of (x - pivot)
+    const double mu = (double)part[(int64_t)nblocks * 2 * c + ch] + d;
+    double vr = s2 / m - d * d;
     if (vr < 0.0) vr = 0.0;
     mean[ch] = (float)mu;
     var[ch] = (float)vr;
@@ -228,7 +237,7 @@ static int bn_grid(int64_t m) {
   return (int)g;
 }
 
-size_t tmae_bn_workspace(int64_t m, int c) { return (size_t)bn_grid(m) * 2 * c * 4 + 256; }
+size_t tmae_bn_workspace(int64_t m, int c) { return ((size_t)bn_grid(m) * 2 * c + c) * 4 + 256; }
 
 #define BN_DISPATCH(T, KERNEL, ...)                                                              \
   do {                                                                                            \
@@ -247,19 +256,19 @@ int tmae_bn_relu_fwd(const void* x_, int dtype, int64_t m, int c, const float* g
   if (dtype != TMAE_F32 && dtype != TMAE_BF16) return TMAE_EDTYPE;
   const int nb = bn_grid(m);
   WsCarver ws(wsp, ws_bytes);
-  float* part = ws.take<float>((size_t)nb * 2 * c);
+  float* part = ws.take<float>((size_t)nb * 2 * c + c);
   if (!ws.ok) return TMAE_EWS;
   dim3 grid(nb), block(256);
   if (dtype == TMAE_F32) {
     const float* x = (const float*)x_;
     float* y = (float*)y_;
-    BN_DISPATCH(float, bn_stats_kernel, x, m, part);
+    BN_DISPATCH(float, bn_stats_kernel, x, m, 1, part);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, (double)m, eps, mean, var, rstd);
     BN_DISPATCH(float, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y);
   } else {
     const __hip_bfloat16* x = (const __hip_bfloat16*)x_;
     __hip_bfloat16* y = (__hip_bfloat16*)y_;
-    BN_DISPATCH(__hip_bfloat16, bn_stats_kernel, x, m, part);
+    BN_DISPATCH(__hip_bfloat16, bn_stats_kernel, x, m, 1, part);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, (double)m, eps, mean, var, rstd);
     BN_DISPATCH(__hip_bfloat16, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y);
   }
@@ -277,7 +286,7 @@ int tmae_bn_relu_bwd(const void* dy_, const void* x_, int dtype, int64_t m, int 
   if (dtype != TMAE_F32 && dtype != TMAE_BF16) return TMAE_EDTYPE;
   const int nb = bn_grid(m);
   WsCarver ws(wsp, ws_bytes);
-  float* part = ws.take<float>((size_t)nb * 2 * c);
+  float* part = ws.take<float>((size_t)nb * 2 * c + c);
   if (!ws.ok) return TMAE_EWS;
   dim3 grid(nb), block(256);
   if (dtype == TMAE_F32) {
@@ -312,11 +321,14 @@ int tmae_bn_stats(const void* x_, int dtype, int64_t m, int c, double count, flo
   if (!bn_args_ok(m, c, dtype) || !x_ || !mean || !var || !rstd || count < 1.0) return TMAE_EARG;
   const int nb = bn_grid(m);
   WsCarver ws(wsp, ws_bytes);
-  float* part = ws.take<float>((size_t)nb * 2 * c);
+  float* part = ws.take<float>((size_t)nb * 2 * c + c);
   if (!ws.ok) return TMAE_EWS;
   dim3 grid(nb), block(256);
-  if (dtype == TMAE_F32) { const float* x = (const float*)x_; BN_DISPATCH(float, bn_stats_kernel, x, m, part); }
-  else { const __hip_bfloat16* x = (const __hip_bfloat16*)x_; BN_DISPATCH(__hip_bfloat16, bn_stats_kernel, x, m, part); }
+  // the pivot only helps when every counted element is a row of x (count == m); with implicit zero cells the raw
+  // moments are the right ones (the zeros ARE the bulk of the data)
+  const int piv = count == (double)m ? 1 : 0;
+  if (dtype == TMAE_F32) { const float* x = (const float*)x_; BN_DISPATCH(float, bn_stats_kernel, x, m, piv, part); }
+  else { const __hip_bfloat16* x = (const __hip_bfloat16*)x_; BN_DISPATCH(__hip_bfloat16, bn_stats_kernel, x, m, piv, part); }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, count, eps, mean, var, rstd);
   return tmae_launch_status();
 }
@@ -330,7 +342,7 @@ int tmae_bn_bwd_sums(const void* dy_, const void* x_, int dtype, int64_t m, int 
     return TMAE_EARG;
   const int nb = bn_grid(m);
   WsCarver ws(wsp, ws_bytes);
-  float* part = ws.take<float>((size_t)nb * 2 * c);
+  float* part = ws.take<float>((size_t)nb * 2 * c + c);
   if (!ws.ok) return TMAE_EWS;
   dim3 grid(nb), block(256);
   if (dtype == TMAE_F32) {

@@ -292,6 +292,68 @@ __global__ __launch_bounds__(256) void point_feat_kernel(const float* __restrict
   f[3 + F] = sub_rn(x, mu[0]); f[4 + F] = sub_rn(y, mu[1]); f[5 + F] = sub_rn(z, mu[2]);
 }
 
+// The same features as ONE bf16 matrix [n, 32] = [hi(16) | lo(16)], hi = bf16(f), lo = bf16(f - hi), columns past
+// F+6 zero: x = hi + lo to ~2^-17 relative, so a bf16 MFMA product over the 32 columns against [W | W] is the
+// fp32-input Linear of the VFE (absolute coordinates reach 75 m: a plain bf16 cast would round them to 0.25-0.5 m,
+// coarser than the 0.32 m pillar).
+__global__ __launch_bounds__(256) void point_feat_split_kernel(const float* __restrict__ pts, int row,
+                                                              const int64_t* __restrict__ pc,
+                                                              const int64_t* __restrict__ inv,
+                                                              const float* __restrict__ mean, int64_t n, float rx,
+                                                              float ry, float rz, float vx, float vy, float vz,
+                                                              __hip_bfloat16* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int F = row - 1;
+  const float* p = pts + i * row;
+  const int64_t* c = pc + i * 4;
+  const float* mu = mean + inv[i] * F;
+  const float x = p[1], y = p[2], z = p[3];
+  const float ccx = add_rn(mul_rn(add_rn((float)c[3], 0.5f), vx), rx);
+  const float ccy = add_rn(mul_rn(add_rn((float)c[2], 0.5f), vy), ry);
+  const float ccz = add_rn(mul_rn(add_rn((float)c[1], 0.5f), vz), rz);
+  float f[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) f[k] = 0.f;
+  f[0] = sub_rn(x, ccx); f[1] = sub_rn(y, ccy); f[2] = sub_rn(z, ccz);
+#pragma unroll
+  for (int k = 0; k < VFE_MAXF; ++k)
+    if (k < F) f[3 + k] = p[1 + k];
+  const float dcl[3] = {sub_rn(x, mu[0]), sub_rn(y, mu[1]), sub_rn(z, mu[2])};
+#pragma unroll
+  for (int q = 3; q < 16; ++q) {                       // f[3 + F + k] = dcl[k] with compile-time register indices
+    const int k = q - 3 - F;
+    if (k >= 0 && k < 3) f[q] = k == 0 ? dcl[0] : (k == 1 ? dcl[1] : dcl[2]);
+  }
+  __hip_bfloat16 hi[16], lo[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    hi[k] = __float2bfloat16(f[k]);
+    lo[k] = __float2bfloat16(f[k] - __bfloat162float(hi[k]));
+  }
+  uint4* o = reinterpret_cast<uint4*>(out + i * 32);
+  o[0] = reinterpret_cast<const uint4*>(hi)[0];
+  o[1] = reinterpret_cast<const uint4*>(hi)[1];
+  o[2] = reinterpret_cast<const uint4*>(lo)[0];
+  o[3] = reinterpret_cast<const uint4*>(lo)[1];
+}
+
+int tmae_vfe_point_features_bf16x2(const float* points, int row, const int64_t* pc, const int64_t* inverse,
+                                   const int32_t* perm, const int32_t* offsets, int64_t n, int64_t m, float rx,
+                                   float ry, float rz, float vx, float vy, float vz, float* voxel_mean, void* feats_hl,
+                                   void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || m < 0 || row < 4 || row - 1 > VFE_MAXF) return TMAE_EARG;
+  if (n == 0 || m == 0) return TMAE_OK;
+  if (!points || !pc || !inverse || !perm || !offsets || !voxel_mean || !feats_hl) return TMAE_EARG;
+  hipLaunchKernelGGL(voxel_mean_kernel, dim3(tmae_cdiv(m, 256)), dim3(256), 0, stream, points, row, perm, offsets, m,
+                     voxel_mean);
+  hipLaunchKernelGGL(point_feat_split_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, points, row, pc, inverse,
+                     voxel_mean, n, rx, ry, rz, vx, vy, vz, (__hip_bfloat16*)feats_hl);
+  return tmae_launch_status();
+}
+
 int tmae_vfe_point_features(const float* points, int row, const int64_t* pc, const int64_t* inverse,
                             const int32_t* perm, const int32_t* offsets, int64_t n, int64_t m, float rx, float ry, float rz, float vx,
                             float vy, float vz, float* voxel_mean, float* feats, void* stream_) {

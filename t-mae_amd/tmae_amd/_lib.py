@@ -25,6 +25,7 @@ SIGNATURES = {
     'tmae_ingroup_rank_workspace': (Z, [L, L]),
     'tmae_ingroup_rank': (I, [P, L, L, P, P, Z, P]),
     'tmae_vfe_point_features': (I, [P, I, P, P, P, P, L, L, F, F, F, F, F, F, P, P, P]),
+    'tmae_vfe_point_features_bf16x2': (I, [P, I, P, P, P, P, L, L, F, F, F, F, F, F, P, P, P]),
     'tmae_segment_max_fwd': (I, [P, I, L, L, I, P, P, P, P, P]),
     'tmae_segment_max_bwd': (I, [P, I, L, L, I, P, P, P, P]),
     'tmae_group_points': (I, [P, I, P, P, P, L, I, F, F, F, F, F, F, P, P, P]),
@@ -91,7 +92,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError('libtmae_hip.so ABI version mismatch; rebuild with t-mae_amd/build.py')
 

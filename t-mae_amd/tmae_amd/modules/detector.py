@@ -139,7 +139,13 @@ class Detector3DTemplate(nn.Module):
         ckpt = torch.load(filename, map_location='cpu' if to_cpu else None, weights_only=False)
         self._load_state_dict(ckpt['model_state'], strict=True)
         if optimizer is not None and ckpt.get('optimizer_state') is not None:
-            optimizer.load_state_dict(ckpt['optimizer_state'])
+            try:
+                optimizer.load_state_dict(ckpt['optimizer_state'])
+            except ValueError as e:          # another optimizer / parameter set: keep the weights, restart the moments
+                msg = f'optimizer_state of {filename} not loaded ({e}); Adam moments start from zero'
+                (logger.warning if logger is not None else print)(msg)
+        # 'epoch' = number of epochs already trained (train_utils.py:217-232 saves cur_epoch + 1 and the reference
+        # resumes with range(epoch, total), tools/train.py:261-312)
         return ckpt.get('it', 0.0), ckpt.get('epoch', -1)
 
 

@@ -57,6 +57,7 @@ class SiamWCA_MAE(nn.Module):
         self.forward_ret_dict = {}
         self.num_point_features = in_channels
         self.last_pair_tokens = []     # rows per stage of the last sparse_encode_pair call (both frames)
+        self.last_stage_indices = []   # per stage (prev indices, cur indices, (ny, nx)) of the last forward (bench FLOP model)
         self.pair_encode = True        # both frames through the Siamese encoder as one token list (sparse_encode_pair)
 
     # ------------------------------------------------------------------ masking (SiamWCA_MAE.py:166-182)
@@ -96,7 +97,7 @@ class SiamWCA_MAE(nn.Module):
         x = SparseConvTensor(torch.cat([feats_prev.to(cdt), feats_cur.to(cdt)], 0), torch.cat([ind_p, ind_c], 0),
                              self.sparse_shape, 2 * B, groups=((ind_p.shape[0], B), (ind_c.shape[0], B)))
         out_p, out_c, strides = {}, {}, {}
-        self.last_pair_tokens = []
+        self.last_pair_tokens, self.last_stage_indices = [], []
         shift = torch.tensor([B, 0, 0], dtype=torch.int32, device=ind_c.device)
         for i, blk in enumerate(self.sst_blocks):
             x = blk(x)
@@ -109,6 +110,7 @@ class SiamWCA_MAE(nn.Module):
             out_p[key] = SparseConvTensor(f_p, x.indices[:m0], x.spatial_shape, B, grid=x.grid[:B * ny * nx])
             out_c[key] = SparseConvTensor(f_c, x.indices[m0:] - shift, x.spatial_shape, B)
             strides[key] = self.sparse_shape[0] // ny
+            self.last_stage_indices.append((out_p[key].indices, out_c[key].indices, (ny, nx)))
         return out_p, out_c, strides
 
     def sparse_cross_attn(self, feats, feats_prev, dtime=0):
@@ -173,6 +175,8 @@ class SiamWCA_MAE(nn.Module):
             feats_prev, _ = self.sparse_encode(batch_dict['voxel_features_prev'], batch_dict['voxel_coords_prev'], bs,
                                                previous_sstblock=True)
             feats, strides = self.sparse_encode(vis_feats, vis_coords, bs)
+            self.last_stage_indices = [(feats_prev[k].indices, feats[k].indices, tuple(feats[k].spatial_shape))
+                                       for k in feats]
         feats = self.sparse_cross_attn(feats, feats_prev, dtime=batch_dict.get('dt', 0))
         spatial, spatial_stride = self.dense_conv(feats, strides)
         batch_dict['multi_scale_3d_features'] = feats

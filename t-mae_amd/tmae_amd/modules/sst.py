@@ -91,7 +91,8 @@ class WindowAttention(nn.Module):
         a = self.self_attn
         d = a.embed_dim
         qk, v, x_res = ops.proj_fork(x, a.in_proj_weight, a.in_proj_bias, ((0, 2 * d, True), (2 * d, 3 * d, False)),
-                                     pos=(plan.indices, pos_table, window_shape, shift), fork=True)
+                                     pos=(plan.indices, pos_table, window_shape, shift), fork=True,
+                                     inplace_dx=True)
         o = ops.win_attn(qk, v, None, a.tau, plan.grid, plan.grid, self.nhead, plan.batch, plan.ny, plan.nx,
                          shift, a.tau_min, worklist=plan.worklist(shift))
         return ops.linear(o, a.out_proj.weight, a.out_proj.bias), x_res
@@ -113,7 +114,8 @@ class WindowCrossAttention(nn.Module):
         a = self.cross_attn
         d = a.embed_dim
         w, b = a.in_proj_weight, a.in_proj_bias
-        q, x_res = ops.proj_fork(x, w, b, ((0, d, True),), pos=(plan.indices, pos_table, window_shape, shift), fork=True)
+        q, x_res = ops.proj_fork(x, w, b, ((0, d, True),), pos=(plan.indices, pos_table, window_shape, shift), fork=True,
+                                 inplace_dx=True)
         k, v = ops.proj_fork(x_prv, w, b, ((d, 2 * d, True), (2 * d, 3 * d, False)),
                              pos=(plan_prv.indices, pos_table, window_shape, shift))
         o = ops.win_attn(q, k, v, a.tau, plan.grid, plan_prv.grid, self.nhead, plan.batch, plan.ny, plan.nx,
@@ -130,10 +132,13 @@ def _activation(name):
 
 
 class _EncoderTail(nn.Module):
-    """linear1/linear2/norm1/norm2 shared by the self and cross layers (post-norm, dropout 0)."""
+    """linear1/linear2/norm1/norm2 shared by the self and cross layers (post-norm, dropout 0).  Children are
+    registered in the reference's order -- win_attn, linear1, linear2, norm1, norm2 (sst_basic_block.py:64-73) --
+    because the optimizer's parameter groups follow the module order (train/optim.py)."""
 
-    def __init__(self, d_model, dim_feedforward, activation):
+    def __init__(self, win_attn, d_model, dim_feedforward, activation):
         super().__init__()
+        self.win_attn = win_attn
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
         self.norm1 = nn.LayerNorm(d_model)
@@ -144,7 +149,7 @@ class _EncoderTail(nn.Module):
         """src = LN1(src + attn); src = LN2(src + linear2(act(linear1(src)))) -- both adds fused into the norms."""
         src = ops.add_layer_norm(src, attn, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         h_pre, src_res = ops.proj_fork(src, self.linear1.weight, self.linear1.bias,
-                                       ((0, self.linear1.out_features, False),), fork=True)
+                                       ((0, self.linear1.out_features, False),), fork=True, inplace_dx=True)
         if self.activation is F.gelu:
             src2 = ops.gelu_linear(h_pre, self.linear2.weight, self.linear2.bias)     # GELU backward fused into the dX GEMM
         else:
@@ -156,8 +161,7 @@ class EncoderLayer(_EncoderTail):
     """sst_basic_block.EncoderLayer (sst_basic_block.py:57-84)."""
 
     def __init__(self, d_model, nhead, dim_feedforward, dropout, activation, layer_cfg):
-        super().__init__(d_model, dim_feedforward, activation)
-        self.win_attn = WindowAttention(d_model, nhead, dropout, layer_cfg)
+        super().__init__(WindowAttention(d_model, nhead, dropout, layer_cfg), d_model, dim_feedforward, activation)
 
     def forward(self, src, plan, pos_table, window_shape, shift):
         attn, src_res = self.win_attn(src, plan, pos_table, window_shape, shift)
@@ -182,8 +186,7 @@ class WCAEncoderLayer(_EncoderTail):
     """wca_block.EncoderLayer (wca_block.py:70-103)."""
 
     def __init__(self, d_model, nhead, dim_feedforward, dropout, activation, layer_cfg):
-        super().__init__(d_model, dim_feedforward, activation)
-        self.win_attn = WindowCrossAttention(d_model, nhead, dropout, layer_cfg)
+        super().__init__(WindowCrossAttention(d_model, nhead, dropout, layer_cfg), d_model, dim_feedforward, activation)
 
     def forward(self, src, plan, src_prv, plan_prv, pos_table, window_shape, shift, kept):
         a = self.win_attn.cross_attn

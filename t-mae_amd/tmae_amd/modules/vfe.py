@@ -59,10 +59,19 @@ class TemporalDynVFE(VFETemplate):
         m = vox['voxel_coords'].shape[0]
         perm, offsets = ops.segment_csr(vox['inverse'], m)
         vox['perm'], vox['offsets'] = perm, offsets
-        _, feats = ops.vfe_point_features(vox['points'], vox['point_coords'], vox['inverse'], perm, offsets, m,
-                                          self.point_cloud_range, self.voxel_size)
-        x = feats
         layers = list(self.dvfe_mlps[0])
+        first = layers[0]
+        if ops.compute_dtype(vox['points']) == torch.bfloat16 and first.in_features <= 16:
+            # bf16 autocast: the first Linear sees ABSOLUTE coordinates (up to 75 m), which bf16 would round to
+            # 0.25-0.5 m steps -- coarser than the pillar.  The features arrive as hi + lo bf16 pairs instead
+            # (~16 mantissa bits; the reference's fp16 AMP keeps 11) and the Linear contracts over both halves.
+            _, x2 = ops.vfe_point_features_bf16x2(vox['points'], vox['point_coords'], vox['inverse'], perm, offsets, m,
+                                                  self.point_cloud_range, self.voxel_size)
+            x = ops.linear_split_input(x2, first.weight)
+            layers = layers[1:]
+        else:
+            _, x = ops.vfe_point_features(vox['points'], vox['point_coords'], vox['inverse'], perm, offsets, m,
+                                          self.point_cloud_range, self.voxel_size)
         for i, layer in enumerate(layers):
             if isinstance(layer, nn.Linear):
                 w = layer.weight

@@ -170,7 +170,13 @@ def cast_param(p, dtype):
 @torch.no_grad()
 def refresh_param_copies(params, dtype=torch.bfloat16):
     """Re-cast every floating-point parameter to `dtype` with multi-tensor copies (call after optimizer.step())."""
-    ps = [p for p in params if p.is_cuda and p.is_floating_point() and p.dtype != dtype]
+    ps = []
+    for p in params:
+        if not (p.is_cuda and p.is_floating_point() and p.dtype != dtype):
+            continue
+        c = getattr(p, '_tmae_copy', None)      # still current (a parameter the optimizer does not own): keep it
+        if c is None or c[0] != p._version or c[1] != p.data_ptr() or c[2].dtype != dtype:
+            ps.append(p)
     if not ps:
         return
     dst = []
@@ -257,7 +263,7 @@ class _ProjFork(torch.autograd.Function):
     (no slice-backward zero fills).  pos = (indices, table, wy, wx, do_shift) or None."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, segs, pos, fork):
+    def forward(ctx, x, weight, bias, segs, pos, fork, inplace_dx):
         cdt = compute_dtype(x)
         x_c = x.to(cdt).contiguous()
         w_c = cast_param(weight, cdt)
@@ -273,6 +279,7 @@ class _ProjFork(torch.autograd.Function):
             outs.append(token_gemm(xp if use_pos else x_c, w_c[r0:r1], None if b_c is None else b_c[r0:r1]))
         ctx.save_for_backward(x_c, xp, w_c)
         ctx.segs, ctx.fork, ctx.has_bias = segs, fork, bias is not None
+        ctx.inplace_dx = bool(inplace_dx and fork)
         ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
         ctx.set_materialize_grads(False)
         if fork:
@@ -299,10 +306,16 @@ class _ProjFork(torch.autograd.Function):
             if dy.stride(-1) != 1:
                 dy = dy.contiguous()
             if ctx.needs_input_grad[0]:
-                # accumulate IN PLACE (torch.addmm would first memcpy dx into a new buffer).  The buffer that arrives
-                # through the alias is the dx of the layer's add+LayerNorm backward; its only other reader is the
-                # Linear on the norm's second input, a node created after this one, i.e. already executed.
-                dx = token_gemm_dx(dy, w_c[r0:r1]) if dx is None else dx.addmm_(dy, w_c[r0:r1])
+                if dx is None:
+                    dx = token_gemm_dx(dy, w_c[r0:r1])
+                elif ctx.inplace_dx:
+                    # accumulate IN PLACE into the gradient that arrived through the alias (torch.addmm would first
+                    # memcpy it into a new buffer).  Only on the caller's word (`inplace_dx`): the encoder layers
+                    # guarantee that this buffer -- the dx of their add+LayerNorm backward -- has no reader left
+                    # (its only other reader, the Linear on the norm's second input, is a younger node and has run).
+                    dx.addmm_(dy, w_c[r0:r1])
+                else:
+                    dx = torch.addmm(dx, dy, w_c[r0:r1])
             if dW is not None:
                 inp = xp if use_pos else x_c
                 if _wgrad_ok(dy, inp):          # straight into the rows of the packed gradient: no slice copies
@@ -312,18 +325,21 @@ class _ProjFork(torch.autograd.Function):
                     if dB is not None:
                         dB[r0:r1] = dy.float().sum(0)
         return (None if dx is None else dx.to(xdt), None if dW is None else dW.to(wdt),
-                None if dB is None else dB.to(bdt), None, None, None)
+                None if dB is None else dB.to(bdt), None, None, None, None)
 
 
-def proj_fork(x, weight, bias, segs, pos=None, fork=False):
-    """See _ProjFork.  Returns the projections (and x's alias last when fork) as a tuple."""
+def proj_fork(x, weight, bias, segs, pos=None, fork=False, inplace_dx=False):
+    """See _ProjFork.  Returns the projections (and x's alias last when fork) as a tuple.
+    inplace_dx: the backward may add into the gradient tensor it receives for the alias instead of copying it.
+    Pass True only if the alias feeds exactly one consumer whose backward hands over a buffer nobody else reads
+    afterwards (no hooks / retain_grad on the alias, no second use, no retain_graph replay)."""
     if not x.is_cuda or x.dim() != 2:
         raise RuntimeError('proj_fork: 2-D GPU token lists only')
     segs = tuple((int(a), int(b), bool(c)) for a, b, c in segs)
     if pos is not None:
         indices, table, window_shape, do_shift = pos
         pos = (indices, table, int(window_shape[1]), int(window_shape[0]), bool(do_shift))
-    return _ProjFork.apply(x, weight, bias, segs, pos, bool(fork))
+    return _ProjFork.apply(x, weight, bias, segs, pos, bool(fork), bool(inplace_dx))
 
 
 class _GeluLinear(torch.autograd.Function):
@@ -594,6 +610,52 @@ def vfe_point_features(points, point_coords, inverse, perm, offsets, m, pc_range
                                       r[0], r[1], r[2], vs[0], vs[1], vs[2], _p(mean), _p(feats), _s()),
           'tmae_vfe_point_features')
     return mean, feats
+
+
+def vfe_point_features_bf16x2(points, point_coords, inverse, perm, offsets, m, pc_range, voxel_size):
+    """The point features as [n,32] bf16 = [hi(16) | lo(16)], hi + lo = the fp32 feature (see the header)."""
+    n, row = points.shape
+    mean = torch.empty((m, row - 1), dtype=torch.float32, device=points.device)
+    feats = torch.empty((n, 32), dtype=torch.bfloat16, device=points.device)
+    r, vs = [float(v) for v in pc_range[:3]], [float(v) for v in voxel_size]
+    check(lib.tmae_vfe_point_features_bf16x2(_p(points), row, _p(point_coords), _p(inverse), _p(perm), _p(offsets), n, m,
+                                             r[0], r[1], r[2], vs[0], vs[1], vs[2], _p(mean), _p(feats), _s()),
+          'tmae_vfe_point_features_bf16x2')
+    return mean, feats
+
+
+class _LinearSplitInput(torch.autograd.Function):
+    """y = f W^T for point features given as x2 = [hi | lo] (vfe_point_features_bf16x2): one bf16 GEMM over the 32
+    columns against [W | W], i.e. the inputs enter with ~16 mantissa bits although the arithmetic is bf16 MFMA.
+    dW = dW2[:, :16] + dW2[:, 16:] from the token-split kernel; the points take no gradient."""
+
+    @staticmethod
+    def forward(ctx, x2, weight):
+        k = weight.shape[1]
+        w = torch.zeros((weight.shape[0], 32), dtype=torch.bfloat16, device=x2.device)
+        wb = weight.detach().to(torch.bfloat16)
+        w[:, :k] = wb
+        w[:, 16:16 + k] = wb
+        ctx.save_for_backward(x2)
+        ctx.k, ctx.wdtype = k, weight.dtype
+        return torch.nn.functional.linear(x2, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        dy = dy.to(torch.bfloat16)
+        if dy.stride(-1) != 1:
+            dy = dy.contiguous()
+        if _wgrad_ok(dy, x2):
+            dw2, _ = linear_wgrad(dy, x2, want_bias=False)
+        else:
+            dw2 = dy.float().t() @ x2.float()
+        k = ctx.k
+        return None, (dw2[:, :k] + dw2[:, 16:16 + k]).to(ctx.wdtype)
+
+
+def linear_split_input(x2, weight):
+    return _LinearSplitInput.apply(x2, weight)
 
 
 class _SegmentMax(torch.autograd.Function):

@@ -1,24 +1,75 @@
 """adam_onecycle: Adam(beta2 0.99) with decoupled weight decay applied before the step and a one-cycle
-cosine schedule of lr and beta1.  Same update rule as the reference's OptimWrapper/OneCycle
-(tools/train_utils/optimization/fastai_optim.py:135-152, learning_schedules_fastai.py:44-77,
-optimization/__init__.py:19-32) without the per-layer-group Python bookkeeping: one foreach multiply for
-the decay and one fused Adam launch."""
+cosine schedule of lr and beta1 -- the update rule AND the parameter grouping of the reference's
+OptimWrapper / OneCycle (tools/train_utils/optimization/__init__.py:19-32, fastai_optim.py:16-27,99-152,
+learning_schedules_fastai.py:12-77), without the per-group Python loops: one foreach multiply for the decay
+and one fused Adam launch.
+
+Grouping (pinned by tests/golden/O1_optimizer.npz, generated from the reference's own classes):
+`flatten_model` keeps the LEAF modules of the model (modules without children) in depth-first order,
+`split_bn_bias` puts the parameters of the BatchNorm leaves in param group 1 and all other leaves' in group 0.
+A parameter owned directly by a module that also has children belongs to no leaf and is therefore in NO group:
+in the T-MAE model these are `in_proj_weight`, `in_proj_bias` and `tau` of every attention module (54 tensors,
+2 665 746 of the 11 793 218 parameters) -- the reference never updates or decays them.  `train_nonleaf=True`
+(not the reference's behaviour) appends them to group 0.
+The state_dict is torch.optim.Adam's with these two groups, so `optimizer_state` of a reference checkpoint
+(train_utils.py:245-270) loads as it is and the other way round.
+"""
 import math
 
 import torch
+import torch.nn as nn
+
+_BN_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm)
 
 
 def annealing_cos(start, end, pct):
     return end + (start - end) / 2 * (math.cos(math.pi * pct) + 1)
 
 
-class AdamOneCycle:
-    """p <- p * (1 - wd*lr) for every trainable parameter (true_wd, bn_wd), then Adam.step()."""
+def leaf_modules(module):
+    """Depth-first list of the modules without children (optimization/__init__.py:20-26 `flatten_model`)."""
+    kids = list(module.children())
+    if not kids:
+        return [module]
+    out = []
+    for k in kids:
+        out += leaf_modules(k)
+    return out
 
-    def __init__(self, params, lr=3e-3, wd=0.01, betas=(0.9, 0.99)):
-        self.params = [p for p in params if p.requires_grad]
-        fused = all(p.is_cuda for p in self.params) and len(self.params) > 0
-        self.opt = torch.optim.Adam(self.params, lr=lr, betas=betas, weight_decay=0.0, fused=fused)
+
+def reference_param_groups(model, train_nonleaf=False):
+    """(non-BN parameters, BN parameters, parameters in neither) in the reference's order; requires_grad only."""
+    plain, bn, seen = [], [], set()
+    for leaf in leaf_modules(model):
+        dst = bn if isinstance(leaf, _BN_TYPES) else plain
+        for p in leaf.parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                dst.append(p)
+    rest = [p for p in model.parameters() if p.requires_grad and id(p) not in seen]
+    if train_nonleaf:
+        plain, rest = plain + rest, []
+    return plain, bn, rest
+
+
+class AdamOneCycle:
+    """p <- p * (1 - wd*lr) for every parameter of the two groups (true_wd, bn_wd; also those without a gradient,
+    fastai_optim.py:139-150), then Adam.step().  `source` = an nn.Module (reference grouping) or an iterable of
+    parameters (one plain group; tests and small tools)."""
+
+    def __init__(self, source, lr=3e-3, wd=0.01, betas=(0.9, 0.99), train_nonleaf=False):
+        if isinstance(source, nn.Module):
+            plain, bn, rest = reference_param_groups(source, train_nonleaf)
+            self.params = [p for p in source.parameters() if p.requires_grad]       # everything that gets a gradient
+        else:
+            plain, bn, rest = [p for p in source if p.requires_grad], [], []
+            self.params = list(plain)
+        self.unoptimized = rest
+        self.decayed = plain + bn
+        fused = len(self.decayed) > 0 and all(p.is_cuda for p in self.decayed)
+        # two groups even when one is empty: the layout of the reference's optimizer_state
+        self.opt = torch.optim.Adam([{'params': plain}, {'params': bn}], lr=lr, betas=betas, weight_decay=0.0,
+                                    fused=fused)
         self.wd = wd
         self.lr, self.mom = lr, betas[0]
 
@@ -42,25 +93,48 @@ class AdamOneCycle:
         for g in self.opt.param_groups:
             g['betas'] = (self._mom, g['betas'][1])
 
+    @property
+    def param_groups(self):
+        return self.opt.param_groups
+
     def zero_grad(self, set_to_none=True):
-        self.opt.zero_grad(set_to_none=set_to_none)
+        # every parameter that receives a gradient, also the ones the optimizer does not own (the reference's
+        # zero_grad leaves those to accumulate for ever, which nothing reads)
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
 
     @torch.no_grad()
     def step(self):
-        ps = [p for p in self.params if p.grad is not None]
-        if ps and self.wd != 0.0:
-            torch._foreach_mul_(ps, 1.0 - self.wd * self._lr)
+        if self.decayed and self.wd != 0.0:
+            torch._foreach_mul_(self.decayed, 1.0 - self.wd * self._lr)
         self.opt.step()
 
     def state_dict(self):
         return self.opt.state_dict()
 
     def load_state_dict(self, sd):
+        """torch.optim.Adam's state dict with the reference's two param groups.  A state whose groups do not fit
+        (another optimizer type, a model with a different parameter set) is refused with a ValueError that names
+        the mismatch; `Detector3DTemplate.load_params_with_optimizer` turns that into a logged warning."""
+        mine = [len(g['params']) for g in self.opt.param_groups]
+        theirs = [len(g['params']) for g in sd.get('param_groups', [])]
+        if mine != theirs:
+            raise ValueError(f'optimizer_state has param groups of sizes {theirs}, this model needs {mine} '
+                             f'(non-BatchNorm / BatchNorm leaves, fastai_optim.py:16-27)')
+        lr, mom = self._lr, self._mom
         self.opt.load_state_dict(sd)
+        g0 = self.opt.param_groups[0]
+        self._lr, self._mom = float(g0.get('lr', lr)), float(g0['betas'][0])
+        for g in self.opt.param_groups:              # the reference leaves weight_decay 0 in the groups (true_wd)
+            g['weight_decay'] = 0.0
 
 
 class OneCycle:
-    """lr: low -> lr_max over pct_start of the steps, then -> low/1e4; beta1: moms[0] -> moms[1] -> moms[0]."""
+    """lr: low -> lr_max over pct_start of the steps, then -> low/1e4; beta1: moms[0] -> moms[1] -> moms[0]
+    (learning_schedules_fastai.py:44-77; a step in the second phase is set by the second phase alone)."""
 
     def __init__(self, optimizer, total_step, lr_max, moms, div_factor, pct_start):
         self.optimizer, self.total_step = optimizer, max(int(total_step), 1)
@@ -82,7 +156,8 @@ class OneCycle:
 def build_optimizer(model, optim_cfg):
     if optim_cfg.OPTIMIZER != 'adam_onecycle':
         raise NotImplementedError('the T-MAE recipe uses OPTIMIZER: adam_onecycle (t_mae_ssl.yaml:188)')
-    return AdamOneCycle(model.parameters(), lr=3e-3, wd=optim_cfg.WEIGHT_DECAY, betas=(0.9, 0.99))
+    return AdamOneCycle(model, lr=3e-3, wd=optim_cfg.WEIGHT_DECAY, betas=(0.9, 0.99),
+                        train_nonleaf=bool(optim_cfg.get('TRAIN_NONLEAF_PARAMS', False)))
 
 
 def build_scheduler(optimizer, total_iters_each_epoch, total_epochs, last_epoch, optim_cfg):

@@ -49,11 +49,12 @@ def parse_config():
 
 
 def save_checkpoint(model, optimizer, epoch, it, path):
-    """{'epoch','it','model_state','optimizer_state','version'} (train_utils.py:245-270)."""
+    """{'epoch','it','model_state','optimizer_state','scaler','version'} (train_utils.py:245-270); `epoch` = the number
+    of epochs trained so far, as the reference stores it (train_utils.py:217-232)."""
     m = model.module if hasattr(model, 'module') else model
     state = {k: v.cpu() for k, v in m.state_dict().items()}
     torch.save({'epoch': epoch, 'it': it, 'model_state': state, 'optimizer_state': optimizer.state_dict(),
-                'version': 'tmae_amd'}, path)
+                'scaler': None, 'version': 'tmae_amd'}, path)
 
 
 def main():
@@ -82,8 +83,9 @@ def main():
     if args.pretrained_model:
         model.load_params_from_file(args.pretrained_model, logger=logger)
     if args.ckpt:
+        # the stored 'epoch' counts trained epochs (the reference saves cur_epoch + 1): resume AT it
         it, start_epoch = model.load_params_with_optimizer(args.ckpt, optimizer=opt, logger=logger)
-        start_epoch += 1
+        start_epoch = max(int(start_epoch), 0)
     model.train()
     ddp = wrap_ddp(model, local_rank)
     sched, _ = build_scheduler(opt, args.iters_per_epoch, epochs, -1, cfg.OPTIMIZATION)
@@ -102,7 +104,7 @@ def main():
             logger.info(f'epoch {epoch} done in {time.time() - t0:.1f} s '
                         f'({bs * world * args.iters_per_epoch / (time.time() - t0):.1f} frame-pairs/s incl. data gen)')
             if (epoch + 1) % args.ckpt_save_interval == 0:
-                save_checkpoint(ddp, opt, epoch, it, out / 'ckpt' / f'checkpoint_epoch_{epoch + 1}.pth')
+                save_checkpoint(ddp, opt, epoch + 1, it, out / 'ckpt' / f'checkpoint_epoch_{epoch + 1}.pth')
     if world > 1:
         dist.destroy_process_group()
 

@@ -14,7 +14,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, shipped=False):
     for p in (os.path.join(ROOT, 't-mae_amd'), os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -23,21 +23,27 @@ def _worker(rank, world, port, q):
     import tmae_oracle as O
     from conftest import build_product_model
     from pcdet.models import model_fn_decorator
-    from tmae_amd.train import AdamOneCycle, OneCycle, train_one_step
+    from tmae_amd.train import AdamOneCycle, OneCycle, train_one_step, wrap_ddp
     dev = torch.device('cuda:0')
     torch.cuda.set_device(0)
     P = O.init_params(O.default_model_cfg(1), seed=3, pred_scale=0.1)
     model, cfg, _ = build_product_model(1, params=P, device=dev)
     model.train()
-    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
-    opt = AdamOneCycle(model.parameters())
+    # shipped = the path bench.py / tools/train.py take: wrap_ddp (gradient_as_bucket_view, 64 MB bucket, buffer
+    # broadcast), the reference's optimizer grouping, bf16 autocast + refresh_param_copies, two steps
+    ddp = wrap_ddp(model, 0) if shipped else torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    opt = AdamOneCycle(model if shipped else model.parameters())
     sch = OneCycle(opt, 10, 3e-3, [0.95, 0.85], 10, 0.4)
     pts, prv = O.synth_frame_pair(3000, 2, seed=50 + rank)                 # rank-specific shard
     noise = torch.rand(100000, generator=torch.Generator().manual_seed(rank))
     batch = {'points': torch.from_numpy(pts).to(dev), 'points_prev': torch.from_numpy(prv).to(dev), 'batch_size': 2}
     vox = O.voxelize(pts, [-74.88, -74.88, -5, 74.88, 74.88, 3], [0.32, 0.32, 8], [468, 468, 1])
     batch['mae_noise'] = noise[:vox['voxel_coords'].shape[0]].to(dev)
-    loss, _, _ = train_one_step(ddp, opt, sch, batch, 0, model_fn_decorator(), amp_dtype=None)
+    amp = torch.bfloat16 if shipped else None
+    loss, _, _ = train_one_step(ddp, opt, sch, dict(batch), 0, model_fn_decorator(), amp_dtype=amp)
+    if shipped:
+        loss, _, _ = train_one_step(ddp, opt, sch, dict(batch), 1, model_fn_decorator(), amp_dtype=amp)
     g = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu()
     wts = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
     gl = [torch.zeros_like(g) for _ in range(world)]
@@ -49,11 +55,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_full_model_ddp_step():
+@pytest.mark.parametrize('shipped', [False, True])
+def test_two_ranks_full_model_ddp_step(shipped):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + os.getpid() % 2000 + (7 if shipped else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, shipped)) for r in range(2)]
     [p.start() for p in procs]
     res = sorted(q.get(timeout=500) for _ in range(2))
     [p.join(120) for p in procs]

@@ -309,6 +309,60 @@ def test_attention_golden_fwd_bwd(case):
     np.testing.assert_allclose(W.grad.cpu().numpy(), g[pre + 'd_in_proj_weight'], atol=1e-3)
 
 
+@pytest.mark.parametrize('case', [0, 1, 2, 3])
+def test_attention_mfma_bf16_vs_reference_golden(case):
+    """The BENCHED attention path -- bf16 MFMA kernels driven by class-binned work lists -- straight against the real
+    reference CosineMultiheadAttention (F7), not via the fp32 kernel: relative L2 2e-2 (SURVEY 8c, F7 "bf16 2e-2 rel")
+    for the output and the q / k / v input gradients.  Case 2 sits at the temperature clamp (tau 0.005 -> 0.01): logits
+    reach +-100, and rounding q, k to bf16 alone (2^-9 relative per element, before any kernel arithmetic) moves them by
+    ~0.2 -- its bar is 0.1, stated here, not hidden in a shared constant."""
+    from tmae_amd import ops
+    g = golden('F7_attention')
+    pre = f'c{case}_'
+    E, H, T, nW, cross = [int(v) for v in g[pre + 'meta']]
+    W, bias = cu(g[pre + 'w_in_proj_weight']), cu(g[pre + 'w_in_proj_bias'])
+    Wo, bo = cu(g[pre + 'w_out_proj__weight']), cu(g[pre + 'w_out_proj__bias'])
+    tau = cu(g[pre + 'w_tau']).requires_grad_(True)
+    klens = (~g[pre + 'kpm']).sum(1)
+    qlens = g[pre + 'qlens']
+    kc, krow = _place(klens)
+    qc, qrow = _place(qlens) if cross else (kc, krow)
+    gq = ops.index_grid(cu(qc), 1, 468, 468)
+    gk = ops.index_grid(cu(kc), 1, 468, 468)
+    wl = ops.window_worklist(gq, gk, 1, 468, 468, False)
+    Xq = cu(_rows(g[pre + 'q'], qlens, qrow)).requires_grad_(True)
+    Xv = cu(_rows(g[pre + 'v'], klens, krow)).requires_grad_(True)
+    bf = torch.bfloat16
+    if cross:
+        Xk = cu(_rows(g[pre + 'k'], klens, krow)).requires_grad_(True)
+        q = F.linear(Xq, W[:E], bias[:E]).to(bf)
+        k = F.linear(Xk, W[E:2 * E], bias[E:2 * E]).to(bf)
+        v = F.linear(Xv, W[2 * E:], bias[2 * E:]).to(bf)
+        o = ops.win_attn(q, k, v, tau, gq, gk, H, 1, 468, 468, False, 0.01, worklist=wl)
+    else:
+        qk = F.linear(Xq, W[:2 * E], bias[:2 * E]).to(bf)
+        v = F.linear(Xv, W[2 * E:], bias[2 * E:]).to(bf)
+        o = ops.win_attn(qk, v, None, tau, gq, gk, H, 1, 468, 468, False, 0.01, worklist=wl)
+    assert o.dtype == bf
+    out = F.linear(o.float(), Wo, bo)
+    (out * cu(_rows(g[pre + 'gout'], qlens, qrow))).sum().backward()
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+    lim = 2e-2 if float(g[pre + 'tau']) >= 0.05 else 0.1
+    errs = {'out': rel(out.detach().cpu().numpy(), _rows(g[pre + 'out'], qlens, qrow)),
+            'dq': rel(Xq.grad.cpu().numpy(), _rows(g[pre + 'dq'], qlens, qrow)),
+            'dv': rel(Xv.grad.cpu().numpy(), _rows(g[pre + 'dv'], klens, krow))}
+    if cross:
+        errs['dk'] = rel(Xk.grad.cpu().numpy(), _rows(g[pre + 'dk'], klens, krow))
+    for name, e in errs.items():
+        assert e < lim, (case, name, e, errs)
+    dtau = float(np.asarray(g[pre + 'dtau']).reshape(-1)[0])
+    assert abs(float(tau.grad) - dtau) <= 3 * lim * max(1.0, abs(dtau)), (float(tau.grad), dtau)
+
+
 def test_attention_bf16_and_softmax_property():
     """bf16 I/O (fp32 softmax/normalise) stays within bf16 tolerance of the fp32 kernel; with V = 1 every
     attended row must come back as exactly-normalised ones (rows of P sum to 1) -- at stage-1 size."""
@@ -881,15 +935,150 @@ def test_e2e_waymo_shape_config(oracle):
 
 
 def test_e2e_bf16_autocast_close_to_fp32(oracle):
+    """The benched dtype: the whole step under bf16 autocast against the same step in fp32 (which the golden tests pin
+    to the reference) and against the reference's own loss.  Conditioned head (as F10): |loss difference| <= 2e-3
+    (measured 3-6e-4: bf16 keeps 8 mantissa bits through ~40 layers); default head: 1 % of the loss."""
     g = golden('F10_e2e_3stage')
     cfg = oracle.default_model_cfg(3)
-    P = oracle.init_params(cfg, seed=int(g['param_seed']))
-    model, _, _ = build_product_model(3, params=P, device=dev())
+    for scale, bar in ((float(g['pred_scale']), 2e-3), (1.0, None)):
+        P = oracle.init_params(cfg, seed=int(g['param_seed']), tau=float(g['tau']), pred_scale=scale)
+        model, _, _ = build_product_model(3, params=P, device=dev())
+        model.train()
+        loss, _ = _run_product(model, g['points'], g['points_prev'], g['noise'], int(g['batch_size']), amp=True)
+        g16 = {n: p.grad.clone() for n, p in model.named_parameters()}
+        l32, _ = _run_product(model, g['points'], g['points_prev'], g['noise'], int(g['batch_size']))
+        assert torch.isfinite(loss)
+        if bar is not None:
+            assert abs(float(loss) - float(l32)) < bar, (float(loss), float(l32))
+            assert abs(float(loss) - float(g['loss'])) < bar, (float(loss), float(g['loss']))
+        else:
+            assert abs(float(loss) - float(l32)) < 0.01 * max(1.0, abs(float(l32))), (float(loss), float(l32))
+        assert all(torch.isfinite(v).all() for v in g16.values())
+        # gradient direction of the big tensors survives bf16 (cosine against the fp32 gradient)
+        for n, p in model.named_parameters():
+            if p.numel() >= 16384 and p.grad.norm() > 0:
+                cos = torch.nn.functional.cosine_similarity(g16[n].flatten().double(), p.grad.flatten().double(), dim=0)
+                assert float(cos) > 0.98, (n, float(cos))
+
+
+def test_vfe_bf16_keeps_far_range_coordinates(oracle):
+    """Under bf16 autocast the VFE's first Linear must not see coordinates rounded to bf16 (0.5 m steps beyond 64 m):
+    points between 64 and 74 m, voxel features of the bf16 path vs the fp32 path and vs the oracle."""
+    from tmae_amd import ops
+    cfg = oracle.default_model_cfg(1)
+    P = oracle.init_params(cfg, seed=2)
+    rng = np.random.default_rng(5)
+    n = 20000
+    r = rng.uniform(64.5, 74.0, n)
+    th = rng.uniform(0, 2 * np.pi, n)
+    pts = np.stack([np.zeros(n), np.clip(r * np.cos(th), -74.8, 74.8), np.clip(r * np.sin(th), -74.8, 74.8),
+                    rng.normal(-1.5, 0.4, n), rng.uniform(0, 1, n)], 1).astype(np.float32)
+    model, _, _ = build_product_model(1, params=P, device=dev())
     model.train()
-    loss, _ = _run_product(model, g['points'], g['points_prev'], g['noise'], int(g['batch_size']), amp=True)
-    l32, _ = _run_product(model, g['points'], g['points_prev'], g['noise'], int(g['batch_size']))
-    assert torch.isfinite(loss) and abs(float(loss) - float(l32)) < 0.05 * max(1.0, abs(float(l32)))
-    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    out = {}
+    for amp in (False, True):
+        bd = {'points': cu(pts), 'points_prev': cu(pts), 'batch_size': 1}
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+            bd = model.vfe(bd)
+        out[amp] = bd['voxel_features'].float().cpu().numpy()
+    ref = oracle.vfe_forward({k: v for k, v in P.items()}, 'vfe.', pts, cfg)['voxel_features'].detach().numpy()
+    np.testing.assert_allclose(out[False], ref, rtol=1e-4, atol=1e-4)
+    scale = np.abs(ref).max()
+    err16 = np.abs(out[True] - ref).max() / scale
+    # bf16 activations (8 bits) after two BatchNorm'd layers: a few 1e-2 of the range; with bf16-rounded coordinates
+    # the f_center / f_cluster offsets (|.| < 0.32 m) drown in the 0.5 m rounding and this error is > 0.3
+    assert err16 < 0.05, err16
+    # direct check of the split representation: hi + lo reproduces the fp32 features to 2^-16 relative
+    v = ops.voxelize(cu(pts), 1, PCR, VS, GRID)
+    perm, offs = ops.segment_csr(v['inverse'], v['voxel_coords'].shape[0])
+    args = (v['points'], v['point_coords'], v['inverse'], perm, offs, v['voxel_coords'].shape[0], PCR, VS)
+    _, f32 = ops.vfe_point_features(*args)
+    _, hl = ops.vfe_point_features_bf16x2(*args)
+    rec = hl[:, :16].float() + hl[:, 16:].float()
+    assert (rec[:, :10] - f32).abs().max().item() <= 2.0 ** -16 * 75.0
+    assert (rec[:, 10:] == 0).all()
+
+
+def test_proj_fork_out_of_place_is_hook_safe():
+    """ops.proj_fork accumulates into the alias gradient in place only on the caller's word; the default path leaves
+    the tensor autograd handed over untouched (a hook / retain_grad on the alias sees the right values) and both
+    paths give the same gradients."""
+    from tmae_amd import ops
+    torch.manual_seed(0)
+    m, d = 9000, 128
+    x0 = torch.randn(m, d, device=dev()).bfloat16()
+    w = (torch.randn(2 * d, d, device=dev()) * 0.05).requires_grad_(True)
+    b = torch.zeros(2 * d, device=dev(), requires_grad=True)
+    res = {}
+    for inplace in (False, True):
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            h, alias = ops.proj_fork(x, w, b, ((0, 2 * d, False),), fork=True, inplace_dx=inplace)
+        seen = []
+        if not inplace:
+            alias.register_hook(lambda g_: seen.append(g_.clone()))
+            alias.retain_grad()
+        (h.float().sum() * 0.5 + (alias.float() * 3).sum()).backward()
+        res[inplace] = x.grad.float().clone()
+        if not inplace:
+            assert torch.equal(seen[0].float(), torch.full_like(seen[0].float(), 3.0))
+            assert torch.equal(alias.grad.float(), torch.full_like(alias.grad.float(), 3.0))    # not overwritten
+        w.grad = None
+    assert torch.allclose(res[False], res[True], rtol=2e-2, atol=2e-2)
+
+
+def test_e2e_full_size_120k_vs_oracle(oracle):
+    """BASELINE configs[1] size -- ONE 120 k-point frame pair, full 3-stage model, fp32 -- against the CPU oracle on the
+    same inputs, weights and masking noise (what bench.py reports as `parity`):
+    conditioned head (decoder_pred x 0.1): |loss difference| <= 1e-4 (the north-star bar), masks bit-exact, gradients of a
+    few parameters <= 5e-3 relative;
+    default head: the bar is 3x the oracle's OWN |loss(1 thread) - loss(all threads)|, measured here, floor 1e-4."""
+    pts, prv = oracle.synth_frame_pair(120000, 1, seed=0)
+    cfg = oracle.default_model_cfg(3)
+    vox = oracle.voxelize(pts, cfg['point_cloud_range'], cfg['voxel_size'], cfg['grid_size'])
+    noise = np.random.default_rng(0).random(vox['voxel_coords'].shape[0]).astype(np.float32)
+    nthr = torch.get_num_threads()
+    # --- conditioned head, forward + backward
+    P = oracle.init_params(cfg, seed=0, pred_scale=0.1)
+    model, _, _ = build_product_model(3, params=P, device=dev(), batch_size=1)
+    model.train()
+    loss, bd = _run_product(model, pts, prv, noise, 1)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    cap = {}
+    lo = oracle.forward_loss(Pg, pts, prv, noise, 1, cfg, cap)
+    lo.backward()
+    assert abs(float(lo) - float(loss)) < 1e-4, (float(lo), float(loss))
+    assert np.array_equal(bd['voxel_mae_mask'].cpu().numpy(), cap['mask'])
+    assert np.array_equal(bd['voxel_coords'].cpu().numpy(), cap['vfe_cur']['voxel_coords'])
+    feats = bd['multi_scale_3d_features']
+    for si in range(3):
+        assert feats[f'x_conv{si + 1}'].features.shape[0] == len(cap[f'cur_stage{si}']['indices'])
+    grads = dict(model.named_parameters())
+    for n in ('vfe.dvfe_mlps.0.0.weight', 'backbone_3d.sst_blocks.0.encoder_blocks.0.encoder_list.0.win_attn.self_attn.in_proj_weight',
+              'backbone_3d.sst_blocks.1.conv_down.0.weight', 'backbone_3d.sst_blocks.2.encoder_blocks.1.encoder_list.1.linear2.weight',
+              'backbone_3d.wca_blocks.1.encoder_blocks.0.encoder_list.0.win_attn.cross_attn.in_proj_weight',
+              'backbone_3d.decoder_conv_out.0.weight', 'backbone_3d.decoder_pred.weight'):
+        a, b = grads[n].grad.cpu(), Pg[n].grad
+        assert (a - b).abs().max().item() <= 5e-3 * max(1.0, b.abs().max().item()), n
+    # --- bf16 autocast on the same pair (the benched dtype)
+    l16, _ = _run_product(model, pts, prv, noise, 1, amp=True)
+    assert abs(float(l16) - float(lo)) < 3e-3, (float(l16), float(lo))
+    # --- default head, forward only
+    P1 = oracle.init_params(cfg, seed=0)
+    model1, _, _ = build_product_model(3, params=P1, device=dev(), batch_size=1)
+    model1.train()
+    with torch.no_grad():
+        ret, _, _ = model1({'points': cu(pts), 'points_prev': cu(prv), 'batch_size': 1, 'mae_noise': cu(noise)})
+        l_all = float(oracle.forward_loss(P1, pts, prv, noise, 1, cfg))
+        torch.set_num_threads(1)
+        try:
+            l_one = float(oracle.forward_loss(P1, pts, prv, noise, 1, cfg))
+        finally:
+            torch.set_num_threads(nthr)
+    spread = abs(l_one - l_all)
+    bar = max(3 * spread, 1e-4)
+    assert min(abs(float(ret['loss']) - l_all), abs(float(ret['loss']) - l_one)) <= bar, \
+        (float(ret['loss']), l_all, l_one, spread)
 
 
 def test_full_size_properties(oracle):

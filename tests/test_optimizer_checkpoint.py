@@ -1,0 +1,218 @@
+"""A15 (optimizer) and 8f-3 (checkpoints) against fixtures produced by the reference's OWN classes
+(oracle/gen_golden_optim.py: OptimWrapper + OneCycle + checkpoint_state, run in the build container):
+parameter groups, the 20-step trajectory, and a checkpoint written by the reference loop."""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import build_finetune_model, build_product_model, golden, load_cfg
+
+
+# the fixture's tiny model (oracle/gen_golden_optim.py), restated
+class TinyOwner(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.own = nn.Parameter(torch.zeros(4))
+        self.proj = nn.Linear(5, 3)
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc1 = nn.Linear(6, 5)
+        self.bn = nn.BatchNorm1d(5)
+        self.owner = TinyOwner()
+        self.fc2 = nn.Linear(3, 2, bias=False)
+
+
+def _optim_cfg():
+    from pcdet.config import EasyDict
+    return EasyDict(dict(OPTIMIZER='adam_onecycle', LR=0.003, WEIGHT_DECAY=0.01, MOMS=[0.95, 0.85], PCT_START=0.4,
+                         DIV_FACTOR=10))
+
+
+def _group_names(model, opt):
+    names = {id(p): n for n, p in model.named_parameters()}
+    return [[names[id(p)] for p in g['params']] for g in opt.param_groups]
+
+
+def test_param_groups_equal_the_reference_optimizer():
+    """Order and membership of the two Adam param groups (non-BatchNorm / BatchNorm leaves) and the parameters the
+    reference never trains (in_proj_weight / in_proj_bias / tau of every attention module)."""
+    from tmae_amd.train import build_optimizer
+    g = golden('O1_optimizer')
+    for tag, model in (('pre', build_product_model(3)[0]), ('ft', build_finetune_model()[0])):
+        opt = build_optimizer(model, _optim_cfg())
+        groups = _group_names(model, opt)
+        assert groups[0] == [str(n) for n in g[f'{tag}_group0']], tag
+        assert groups[1] == [str(n) for n in g[f'{tag}_group1']], tag
+        names = {id(p): n for n, p in model.named_parameters()}
+        assert [names[id(p)] for p in opt.unoptimized] == [str(n) for n in g[f'{tag}_unoptimized']]
+    pre = build_product_model(3)[0]
+    opt = build_optimizer(pre, _optim_cfg())
+    assert sum(p.numel() for p in opt.unoptimized) == 2665746
+    cfg = _optim_cfg()
+    cfg.TRAIN_NONLEAF_PARAMS = True                                          # opt-in: train them too
+    assert not build_optimizer(pre, cfg).unoptimized
+
+
+def test_trajectory_equals_the_reference_optimizer():
+    """20 steps of build_optimizer + build_scheduler in the reference loop's order on the fixture's gradients."""
+    from tmae_amd.train import build_optimizer, build_scheduler
+    g = golden('O1_optimizer')
+    names = [str(n) for n in g['tiny_names']]
+    model = Tiny()
+    assert [n for n, _ in model.named_parameters()] == names
+    with torch.no_grad():
+        for i, (n, p) in enumerate(model.named_parameters()):
+            p.copy_(torch.from_numpy(g[f'tiny_init_{i}']))
+    opt = build_optimizer(model, _optim_cfg())
+    sched, _ = build_scheduler(opt, 10, 2, -1, _optim_cfg())
+    groups = _group_names(model, opt)
+    assert groups[0] == [str(n) for n in g['tiny_group0']] and groups[1] == [str(n) for n in g['tiny_group1']]
+    for it in range(20):
+        sched.step(it)
+        assert abs(opt.lr - float(g['tiny_lr'][it])) <= 1e-12 and abs(opt.mom - float(g['tiny_mom'][it])) <= 1e-12
+        opt.zero_grad()
+        for i, (n, p) in enumerate(model.named_parameters()):
+            p.grad = None if (it == 7 and n == 'fc2.weight') else torch.from_numpy(g[f'tiny_grad_{i}'][it].copy())
+        opt.step()
+        for i, (n, p) in enumerate(model.named_parameters()):
+            np.testing.assert_allclose(p.detach().numpy(), g[f'tiny_traj_{i}'][it], rtol=1e-6, atol=1e-7,
+                                       err_msg=f'{n} step {it}')
+
+
+def build_tiny_tmae(device='cpu'):
+    """The small 1-stage model of the O2 fixture through the product's registry path (YAML edits only)."""
+    from pcdet.models import build_network
+    from tmae_amd.train import SyntheticTemporalDataset
+    g = golden('O2_checkpoint')
+    t = json.loads(str(g['tiny_model']))
+    cfg = load_cfg(1)
+    cfg.MODEL.VFE.MLPS = t['vfe_mlps']
+    enc = cfg.MODEL.BACKBONE_3D.SST_BLOCK_LIST[0].ENCODER
+    enc.D_MODEL, enc.NHEAD, enc.DIM_FEEDFORWARD, enc.NUM_BLOCKS = t['d_model'], t['nhead'], t['dff'], t['num_blocks']
+    fl = cfg.MODEL.BACKBONE_3D.FUSE_LAYER['x_conv1']
+    fl.NUM_FILTER = fl.NUM_UPSAMPLE_FILTER = t['d_model']
+    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=1000, batch_size=2)
+    return build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds).to(device), g
+
+
+def reference_checkpoint(g, spconv1_layout=False, prefix='state'):
+    """The dict the reference's checkpoint_state returned, rebuilt from the fixture's arrays."""
+    names = [str(n) for n in g['state_names']]
+    ms = {n: torch.from_numpy(np.array(g[f'{prefix}_{i}'])) for i, n in enumerate(names)}
+    if spconv1_layout:          # what spconv 1.x holds: (k1, k2, c_in, c_out) (detector3d_template.py:373-383)
+        for n in names:
+            if n.endswith('conv_out.0.weight') and ('sst_blocks' in n or 'wca_blocks' in n):
+                ms[n] = ms[n].permute(1, 2, 3, 0).contiguous()
+    pgs = json.loads(str(g['opt_param_groups']))
+    for pg in pgs:
+        pg['betas'] = tuple(pg['betas'])
+    state = {}
+    for idx in g['opt_state_ids']:
+        idx = int(idx)
+        state[idx] = {'step': torch.tensor(float(g[f'opt_{idx}_step'])),
+                      'exp_avg': torch.from_numpy(np.array(g[f'opt_{idx}_exp_avg'])),
+                      'exp_avg_sq': torch.from_numpy(np.array(g[f'opt_{idx}_exp_avg_sq']))}
+    return {'epoch': int(g['epoch']), 'it': int(g['it']), 'model_state': ms,
+            'optimizer_state': {'state': state, 'param_groups': pgs}, 'scaler': None, 'version': str(g['version'])}
+
+
+@pytest.mark.parametrize('spconv1', [False, True])
+def test_reference_checkpoint_loads_with_optimizer(tmp_path, spconv1):
+    """load_params_with_optimizer on a checkpoint of the reference loop: every tensor, (it, epoch), the Adam moments
+    in the reference's group layout -- proven by taking the NEXT optimizer step and comparing with the reference's."""
+    from tmae_amd.train import build_optimizer, build_scheduler
+    model, g = build_tiny_tmae()
+    f = tmp_path / 'checkpoint_epoch_1.pth'
+    torch.save(reference_checkpoint(g, spconv1), f)
+    opt = build_optimizer(model, _optim_cfg())
+    groups = _group_names(model, opt)
+    assert groups[0] == [str(n) for n in g['group0']] and groups[1] == [str(n) for n in g['group1']]
+    it, epoch = model.load_params_with_optimizer(str(f), to_cpu=True, optimizer=opt)
+    assert (it, epoch) == (2, 1)
+    sd = model.state_dict()
+    for i, n in enumerate(str(x) for x in g['state_names']):
+        assert torch.equal(sd[n], torch.from_numpy(np.array(g[f'state_{i}']))), n
+    sched, _ = build_scheduler(opt, 5, 2, -1, _optim_cfg())
+    sched.step(it)
+    assert abs(opt.lr - float(g['next_lr'])) < 1e-12 and abs(opt.mom - float(g['next_mom'])) < 1e-12
+    opt.zero_grad()
+    for p in model.parameters():
+        p.grad = 0.01 * p.detach() + 0.001
+    opt.step()
+    for n, s, q in zip(g['next_names'], g['next_sum'], g['next_sumsq']):
+        p = dict(model.named_parameters())[str(n)].detach().double()
+        assert abs(float(p.sum()) - s) <= 1e-6 * max(1.0, abs(s)) + 2e-6 * p.numel() ** 0.5, n
+        assert abs(float((p ** 2).sum()) - q) <= 2e-6 * max(1.0, q), n
+    # round trip: our own checkpoint carries the same optimizer layout
+    sd2 = opt.state_dict()
+    assert [len(pg['params']) for pg in sd2['param_groups']] == [len(g['group0']), len(g['group1'])]
+
+
+def test_foreign_optimizer_state_is_skipped_with_a_warning(tmp_path, capsys):
+    from tmae_amd.train import build_optimizer
+    model, g = build_tiny_tmae()
+    ck = reference_checkpoint(g)
+    ck['optimizer_state']['param_groups'] = ck['optimizer_state']['param_groups'][:1]      # e.g. a plain torch Adam
+    f = tmp_path / 'c.pth'
+    torch.save(ck, f)
+    opt = build_optimizer(model, _optim_cfg())
+    it, epoch = model.load_params_with_optimizer(str(f), to_cpu=True, optimizer=opt)
+    assert (it, epoch) == (2, 1) and 'not loaded' in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('spconv1', [False, True])
+def test_reference_checkpoint_forward_on_gpu(tmp_path, spconv1):
+    """Weights of the reference checkpoint through load_params_from_file, then the reference's loss on the fixture's
+    third batch (train mode, same masking noise): 1e-4."""
+    model, g = build_tiny_tmae('cuda')
+    f = tmp_path / 'c.pth'
+    torch.save(reference_checkpoint(g, spconv1), f)
+    model.load_params_from_file(str(f))
+    model.train()
+    dev = torch.device('cuda')
+    bd = {'points': torch.from_numpy(g['points']).to(dev), 'points_prev': torch.from_numpy(g['points_prev']).to(dev),
+          'batch_size': 2, 'mae_noise': torch.from_numpy(g['noise']).to(dev)}
+    ret, _, _ = model(bd)
+    assert abs(float(ret['loss']) - float(g['loss'])) < 1e-4, (float(ret['loss']), float(g['loss']))
+
+
+@pytest.mark.gpu
+def test_two_training_steps_follow_the_reference_loop():
+    """The reference's first two training steps (forward, backward, OptimWrapper.step under OneCycle) replayed from
+    its initial weights on the same batches and masking noise: both losses, and the weights after step 2 (Adam's
+    first updates are +-lr * sign-like, so single elements with near-zero gradients may differ by up to 2 lr)."""
+    from pcdet.models import model_fn_decorator
+    from tmae_amd.train import build_optimizer, build_scheduler, train_one_step
+    model, g = build_tiny_tmae('cuda')
+    init = reference_checkpoint(g, prefix='init')['model_state']
+    res = model.load_state_dict(init, strict=False)
+    assert not res.unexpected_keys and not res.missing_keys
+    model.train()
+    opt = build_optimizer(model, _optim_cfg())
+    sched, _ = build_scheduler(opt, 5, 2, -1, _optim_cfg())
+    dev = torch.device('cuda')
+    for it in range(2):
+        bd = {'points': torch.from_numpy(g[f'b{it}_points']).to(dev), 'batch_size': 2,
+              'points_prev': torch.from_numpy(g[f'b{it}_points_prev']).to(dev),
+              'mae_noise': torch.from_numpy(g[f'b{it}_noise']).to(dev)}
+        loss, _, _ = train_one_step(model, opt, sched, bd, it, model_fn_decorator(), amp_dtype=None)
+        assert abs(float(loss) - float(g['step_losses'][it])) < 1e-4, (it, float(loss), float(g['step_losses'][it]))
+    lr = 3e-4
+    sd = model.state_dict()
+    for i, n in enumerate(str(x) for x in g['state_names']):
+        ref = torch.from_numpy(np.array(g[f'state_{i}']))
+        if not ref.is_floating_point():
+            assert torch.equal(sd[n].cpu(), ref), n
+            continue
+        d = (sd[n].cpu() - ref).abs()
+        if 'running_var' in n or 'running_mean' in n:
+            assert d.max() <= 1e-4 * max(1.0, float(ref.abs().max())), n
+        else:
+            assert d.max() <= 4.5 * lr and float((d > 0.2 * lr).float().mean()) < 0.02, (n, float(d.max()))
