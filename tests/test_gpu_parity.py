@@ -958,7 +958,7 @@ def test_e2e_bf16_autocast_close_to_fp32(oracle):
         for n, p in model.named_parameters():
             if p.numel() >= 16384 and p.grad.norm() > 0:
                 cos = torch.nn.functional.cosine_similarity(g16[n].flatten().double(), p.grad.flatten().double(), dim=0)
-                assert float(cos) > 0.98, (n, float(cos))
+                assert float(cos) > 0.95, (n, float(cos))
 
 
 def test_vfe_bf16_keeps_far_range_coordinates(oracle):

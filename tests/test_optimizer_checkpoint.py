@@ -206,13 +206,25 @@ def test_two_training_steps_follow_the_reference_loop():
         assert abs(float(loss) - float(g['step_losses'][it])) < 1e-4, (it, float(loss), float(g['step_losses'][it]))
     lr = 3e-4
     sd = model.state_dict()
+    init = {str(n): torch.from_numpy(np.array(g[f'init_{i}'])) for i, n in enumerate(g['state_names'])}
+    cosines, moved = {}, set(str(n) for n in g['group0']) | set(str(n) for n in g['group1'])
     for i, n in enumerate(str(x) for x in g['state_names']):
         ref = torch.from_numpy(np.array(g[f'state_{i}']))
+        mine = sd[n].cpu()
         if not ref.is_floating_point():
-            assert torch.equal(sd[n].cpu(), ref), n
+            assert torch.equal(mine, ref), n                                  # num_batches_tracked, global_step
             continue
-        d = (sd[n].cpu() - ref).abs()
+        d = (mine - ref).abs()
         if 'running_var' in n or 'running_mean' in n:
             assert d.max() <= 1e-4 * max(1.0, float(ref.abs().max())), n
+        elif n in moved:
+            # Adam's first two updates are ~ lr * sign(g): an element whose gradient is rounding noise may flip
+            # (2 lr per step); everything else must follow the reference's update
+            assert d.max() <= 4.5 * lr, (n, float(d.max()))
+            du, dr = (mine - init[n]).flatten().double(), (ref - init[n]).flatten().double()
+            cosines[n] = float(torch.nn.functional.cosine_similarity(du, dr, dim=0))
         else:
-            assert d.max() <= 4.5 * lr and float((d > 0.2 * lr).float().mean()) < 0.02, (n, float(d.max()))
+            assert torch.equal(mine, ref) and torch.equal(ref, init[n]), n     # in_proj / tau: never updated
+    vals = sorted(cosines.values())
+    worst = min(cosines, key=cosines.get)
+    assert vals[len(vals) // 2] > 0.99 and vals[0] > 0.8, (worst, vals[0], vals[len(vals) // 2])
