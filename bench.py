@@ -149,7 +149,7 @@ def wgrad_roofline(model, batch, amp_dtype, iters=20):
 
 def attention_roofline(model, batch, amp_dtype, iters=20):
     """Times the dominant hand-written kernel of the step -- the ragged window attention backward
-    (`win_attn_bwd_mfma_kernel<16,{1,2,4}>`: one launch per tile class) on the stage-1 previous-frame tensors --
+    (`win_attn_bwd_mfma_kernel<16,NT,PAIR>`: one launch per window size class) on the stage-1 previous-frame tensors --
     through the C ABI with HIP events on torch's current stream (the stream the ABI launches on), nothing else in
     between.  Priced by its ALGORITHMIC HBM bytes: q,k,v,out,dout read once, dq,dk,dv written
     once, + lse + the dense index grid."""

@@ -46,30 +46,53 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// Row fragment of a token: channels [FR*g, FR*g+FR) of head `hoff`, FR = 8 (dh 32) or 4 (dh 16).
-// The load is UNCONDITIONAL (an absent token, tok < 0, reads row 0) and the zeroing happens at unpack time: a load under
-// `if (tok >= 0)` makes the compiler wait for it (s_waitcnt vmcnt(0)) before the next one can be issued, which turned the
-// K, V, Q, dO rows of a window into four back-to-back memory round trips.  All raw loads of a workgroup are issued
-// first, then unpacked.
+// Row fragment of a token: channels [FR*g, FR*g+FR) of head `hoff`, FR = 8 (dh 32) or 4 (dh 16), fetched with a
+// BUFFER load: the address is a wave-uniform descriptor + a 32-bit byte offset (one v_mad_u32_u24 instead of the
+// 64-bit multiply-add chain of a flat address -- these kernels are VALU-bound, profiles/round2_attention_pmc.md), and
+// an absent token (tok < 0) gets the offset 0xFFFFFFFF: the descriptor's range check returns zeros, so there is no
+// select at unpack time and no branch around the load (a load under `if (tok >= 0)` is waited for before the next one
+// is issued).  All raw loads of a workgroup are issued first, then unpacked.
 template <int FR> struct RawFrag;
 template <> struct RawFrag<8> { typedef u32x4 T; };
 template <> struct RawFrag<4> { typedef u32x2 T; };
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+// byte offset of (token row, byte column); rows and pitches stay below 2^24 (checked by the launcher)
+__device__ __forceinline__ unsigned row_off(int tok, unsigned ld_bytes, unsigned col_bytes) {
+  return tok < 0 ? 0xFFFFFFFFu : __umul24((unsigned)tok, ld_bytes) + col_bytes;
+}
 template <int FR>
-__device__ __forceinline__ typename RawFrag<FR>::T load_row_raw(const __hip_bfloat16* base, int64_t ld, int tok, int hoff,
-                                                                int g) {
-  const __hip_bfloat16* p = base + (int64_t)(tok < 0 ? 0 : tok) * ld + hoff + FR * g;
-  return *reinterpret_cast<const typename RawFrag<FR>::T*>(p);
+__device__ __forceinline__ typename RawFrag<FR>::T load_row_raw(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  if constexpr (FR == 8) return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+  else return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0));
 }
 
 template <int FR>
-__device__ __forceinline__ void unpack_row(const typename RawFrag<FR>::T& u, int tok, float* f) {
+__device__ __forceinline__ void unpack_row(const typename RawFrag<FR>::T& u, float* f) {
 #pragma unroll
   for (int j = 0; j < FR / 2; ++j) {
-    const unsigned w = tok < 0 ? 0u : u[j];
-    f[2 * j] = __uint_as_float(w << 16);
-    f[2 * j + 1] = __uint_as_float(w & 0xFFFF0000u);
+    f[2 * j] = __uint_as_float(u[j] << 16);
+    f[2 * j + 1] = __uint_as_float(u[j] & 0xFFFF0000u);
   }
+}
+
+// reductions over the 4 lanes {i, i+16, i+32, i+48} that share a token row: v_permlane16_swap / v_permlane32_swap
+// (gfx950) exchange register rows inside the VALU -- a __shfl_xor is an address computation plus a ds_bpermute
+// through the LDS crossbar and a wait.  swap(v, v) returns (even-row copy, odd-row copy): their sum / max is the
+// xor-16 (xor-32) butterfly step for every lane.
+__device__ __forceinline__ float quad_sum(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float quad_max(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 // L2-normalise a token row that is spread over the 4 lane groups (same lane&15), times `scale`.
@@ -78,8 +101,7 @@ __device__ __forceinline__ float normalize_frag(float* f, float scale) {
   float ss = 0.f;
 #pragma unroll
   for (int j = 0; j < FR; ++j) ss += f[j] * f[j];
-  ss += __shfl_xor(ss, 16, 64);
-  ss += __shfl_xor(ss, 32, 64);
+  ss = quad_sum(ss);
   const float nrm = fmaxf(sqrtf(ss), 1e-12f);
   const float inv = scale * fast_rcp(nrm);
 #pragma unroll
@@ -127,17 +149,16 @@ __device__ __forceinline__ void store_img_frag(char* row_base, int g, const type
   }
 }
 
-// FR consecutive channels of one token row as one 16-byte (FR 8) / 8-byte (FR 4) store
+// FR consecutive channels of one token row as one 16-byte (FR 8) / 8-byte (FR 4) buffer store; an offset of
+// 0xFFFFFFFF (absent token) is dropped by the range check: no branch around the store
 template <int FR>
-__device__ __forceinline__ void store_row_frag(__hip_bfloat16* p, const float* f) {
+__device__ __forceinline__ void store_row_frag(__amdgpu_buffer_rsrc_t rs, unsigned off, const float* f) {
   if constexpr (FR == 8) {
-    uint4 u;
-    u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]); u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
-    *reinterpret_cast<uint4*>(p) = u;
+    u32x4 u = {pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+    __builtin_amdgcn_raw_buffer_store_b128(u, rs, (int)off, 0, 0);
   } else {
-    uint2 u;
-    u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]);
-    *reinterpret_cast<uint2*>(p) = u;
+    u32x2 u = {pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3])};
+    __builtin_amdgcn_raw_buffer_store_b64(u, rs, (int)off, 0, 0);
   }
 }
 
@@ -149,12 +170,15 @@ __device__ __forceinline__ f32x4 mfma_s(const s16x4& a, const s16x4& b, f32x4 c)
 }
 
 // ------------------------------------------------------------------------------------------------
-// window work lists: the windows that hold both queries and keys, binned by the number of 16-token tiles they
-// need (class 0: <=16 tokens, 1: <=32, 2: <=64).  This is the reference's "region batching" (drop levels
-// 16/32/64, spt_backbone.py:47-71) reduced to three index lists -- no padded tensors.  The class selects a kernel
-// instantiation whose LDS images / register tiles are sized for it, so the ~85 % of windows with <=16 tokens run
-// at 4x the occupancy of a worst-case (64-token) workgroup.  layout: wl[0..2] = counts, wl[4 + c*nwin + j] = ids.
+// window work lists: the windows that hold both queries and keys, binned by size -- class 0: <= 8 tokens in both
+// frames (TWO such windows share one 16-row tile, see PAIR below), 1: <= 16, 2: <= 32, 3: <= 64.  This is the
+// reference's "region batching" (drop levels 16/32/64, spt_backbone.py:47-71) reduced to index lists -- no padded
+// tensors.  The class selects a kernel instantiation whose LDS images / register tiles are sized for it.
+// layout: wl[0..3] = counts, wl[8 + c*nwin + j] = (b << 16) | (wcx << 8) | wcy  (packed: decoding the flat window id
+// costs three integer divisions by run-time divisors, ~150 scalar instructions per wave).
 // ------------------------------------------------------------------------------------------------
+#define WL_HDR 8
+#define WL_CLASSES 4
 __global__ __launch_bounds__(256) void win_class_kernel(const int32_t* __restrict__ grid_q,
                                                        const int32_t* __restrict__ grid_k, int batch, int ny, int nx,
                                                        int Wy, int Wx, int sy, int sx, int8_t* __restrict__ cls) {
@@ -170,32 +194,34 @@ __global__ __launch_bounds__(256) void win_class_kernel(const int32_t* __restric
   const int Tq = __popcll(__ballot(tq >= 0)), Tk = __popcll(__ballot(tk >= 0));
   if (lane == 0) {
     const int t = max(Tq, Tk);
-    cls[dw] = (Tq > 0 && Tk > 0) ? (int8_t)(t <= 16 ? 0 : (t <= 32 ? 1 : 2)) : (int8_t)-1;
+    cls[dw] = (Tq > 0 && Tk > 0) ? (int8_t)(t <= 8 ? 0 : (t <= 16 ? 1 : (t <= 32 ? 2 : 3))) : (int8_t)-1;
   }
 }
 
 // compaction: one thread per window; a wave reserves its range with ONE atomic per class (list order only affects
 // scheduling, never results)
-__global__ __launch_bounds__(256) void win_worklist_kernel(const int8_t* __restrict__ cls, int64_t nwin,
+__global__ __launch_bounds__(256) void win_worklist_kernel(const int8_t* __restrict__ cls, int64_t nwin, int Wy, int Wx,
                                                           int32_t* __restrict__ wl) {
   const int lane = threadIdx.x & 63;
   const int64_t dw = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int c = dw < nwin ? (int)cls[dw] : -1;
+  const int wcy = (int)(dw % Wy), wcx = (int)((dw / Wy) % Wx), b = (int)(dw / ((int64_t)Wy * Wx));
+  const int32_t packed = (b << 16) | (wcx << 8) | wcy;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < WL_CLASSES; ++k) {
     const unsigned long long m = __ballot(c == k);
     if (m == 0ull) continue;
     int base = 0;
     if (lane == 0) base = atomicAdd(wl + k, __popcll(m));
     base = __shfl(base, 0, 64);
-    if (c == k) wl[4 + (int64_t)k * nwin + base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)dw;
+    if (c == k) wl[WL_HDR + (int64_t)k * nwin + base + __popcll(m & ((1ull << lane) - 1ull))] = packed;
   }
 }
 
 size_t tmae_window_worklist_size(int batch, int ny, int nx) {
   const int Wy = (ny + WIN - 1) / WIN + 1, Wx = (nx + WIN - 1) / WIN + 1;
   const size_t nwin = (size_t)batch * Wy * Wx;
-  return 4 + 3 * nwin + (nwin + 3) / 4;                 // counts | three lists | class bytes (scratch)
+  return WL_HDR + WL_CLASSES * nwin + (nwin + 3) / 4;                 // counts | the lists | class bytes (scratch)
 }
 
 int tmae_window_worklist(const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx, int do_shift,
@@ -204,37 +230,114 @@ int tmae_window_worklist(const int32_t* grid_q, const int32_t* grid_k, int batch
   hipStream_t stream = (hipStream_t)stream_;
   if (!grid_q || !grid_k || !worklist || batch <= 0 || ny <= 0 || nx <= 0) return TMAE_EARG;
   const int Wy = (ny + WIN - 1) / WIN + 1, Wx = (nx + WIN - 1) / WIN + 1;
+  if (Wy > 255 || Wx > 255 || batch > 32767) return TMAE_EARG;        // packed window coordinates
   const int s = do_shift ? WIN / 2 : WIN;
   const int64_t nwin = (int64_t)batch * Wy * Wx;
-  int8_t* cls = reinterpret_cast<int8_t*>(worklist + 4 + 3 * nwin);
-  hipMemsetAsync(worklist, 0, 16, stream);
+  int8_t* cls = reinterpret_cast<int8_t*>(worklist + WL_HDR + WL_CLASSES * nwin);
+  hipMemsetAsync(worklist, 0, WL_HDR * 4, stream);
   hipLaunchKernelGGL(win_class_kernel, dim3(tmae_cdiv(nwin, 4)), dim3(256), 0, stream, grid_q, grid_k, batch, ny, nx,
                      Wy, Wx, s, s, cls);
-  hipLaunchKernelGGL(win_worklist_kernel, dim3(tmae_cdiv(nwin, 256)), dim3(256), 0, stream, cls, nwin, worklist);
+  hipLaunchKernelGGL(win_worklist_kernel, dim3(tmae_cdiv(nwin, 256)), dim3(256), 0, stream, cls, nwin, Wy, Wx, worklist);
   return (int)hipGetLastError();
 }
 
-// resolves the window of this workgroup; returns false when the block has nothing to do
-__device__ __forceinline__ bool pick_window(const int32_t* __restrict__ wl, int cls, int64_t nwin, int64_t& dw) {
+// The tokens of this workgroup's window(s).  PAIR: TWO windows of <= 8 tokens share the 16 rows of the single tile --
+// rows 0-7 belong to list entry 2j, rows 8-15 to entry 2j+1 -- and a block-diagonal mask on the logits keeps them
+// apart (a masked probability is exactly 0, so every product that follows stays block-diagonal): the ~2/3 of all
+// windows that hold <= 8 tokens (all of the masked current frame's) cost half a wavefront each.
+// Wave 0 fills toks[side][slot] (-1 = no token); returns false when the block has nothing to do.
+struct WinInfo {
+  int Tq, Tk;            // tokens of the window (PAIR: of window A)
+  int TqB, TkB;          // PAIR: of window B
+  int dwin;              // flat id of window (A): the slot of its tau-gradient partial
+};
+
+template <bool PAIR>
+__device__ __forceinline__ bool find_tokens(const int32_t* __restrict__ wl, int cls, int64_t nwin,
+                                            const int32_t* __restrict__ grid_q, const int32_t* __restrict__ grid_k,
+                                            int ny, int nx, int Wy, int Wx, int sy, int sx, int (*toks)[64], int lane,
+                                            int w, WinInfo& wi) {
+  int b[2], wcy[2], wcx[2];
+  int nw = 1;
   if (wl) {
-    if ((int)blockIdx.x >= wl[cls]) return false;
-    dw = wl[4 + (int64_t)cls * nwin + blockIdx.x];
+    const int cnt = wl[cls];
+    const int e0 = PAIR ? 2 * (int)blockIdx.x : (int)blockIdx.x;
+    if (e0 >= cnt) return false;
+    const int32_t* list = wl + WL_HDR + (int64_t)cls * nwin;
+    const int p0 = list[e0];
+    b[0] = p0 >> 16; wcx[0] = (p0 >> 8) & 255; wcy[0] = p0 & 255;
+    if (PAIR && e0 + 1 < cnt) {
+      const int p1 = list[e0 + 1];
+      b[1] = p1 >> 16; wcx[1] = (p1 >> 8) & 255; wcy[1] = p1 & 255;
+      nw = 2;
+    }
   } else {
-    dw = blockIdx.x;
+    const unsigned u = blockIdx.x;                       // dense launch (no work list): one window per block
+    wcy[0] = (int)(u % (unsigned)Wy); wcx[0] = (int)((u / (unsigned)Wy) % (unsigned)Wx);
+    b[0] = (int)(u / (unsigned)(Wy * Wx));
+  }
+  wi.dwin = (b[0] * Wx + wcx[0]) * Wy + wcy[0];
+  wi.TqB = wi.TkB = 0;
+  int tq[2] = {-1, -1}, tk[2] = {-1, -1};
+#pragma unroll
+  for (int n = 0; n < (PAIR ? 2 : 1); ++n) {
+    if (n < nw) {
+      const int y = wcy[n] * WIN - sy + (lane >> 3), x = wcx[n] * WIN - sx + (lane & 7);
+      const bool in = y >= 0 && y < ny && x >= 0 && x < nx;
+      const int cell = (b[n] * ny + y) * nx + x;            // < 2^31: the grids are int32-indexed tensors
+      tq[n] = in ? grid_q[cell] : -1;
+      tk[n] = in ? grid_k[cell] : -1;
+    }
+  }
+  const unsigned long long mq0 = __ballot(tq[0] >= 0), mk0 = __ballot(tk[0] >= 0);
+  wi.Tq = __popcll(mq0);
+  wi.Tk = __popcll(mk0);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (PAIR) {
+    const unsigned long long mq1 = __ballot(tq[1] >= 0), mk1 = __ballot(tk[1] >= 0);
+    wi.TqB = __popcll(mq1);
+    wi.TkB = __popcll(mk1);
+    if (w == 0) {
+      if (lane < 16) { toks[0][lane] = -1; toks[1][lane] = -1; }
+      if (tq[0] >= 0) toks[0][__popcll(mq0 & below)] = tq[0];
+      if (tk[0] >= 0) toks[1][__popcll(mk0 & below)] = tk[0];
+      if (tq[1] >= 0) toks[0][8 + __popcll(mq1 & below)] = tq[1];
+      if (tk[1] >= 0) toks[1][8 + __popcll(mk1 & below)] = tk[1];
+    }
+  } else if (w == 0) {
+    toks[0][lane] = -1;
+    toks[1][lane] = -1;
+    if (tq[0] >= 0) toks[0][__popcll(mq0 & below)] = tq[0];
+    if (tk[0] >= 0) toks[1][__popcll(mk0 & below)] = tk[0];
   }
   return true;
+}
+
+// logit bias of key row `kr` (0..16*NT-1) for the lane's query column i: 0 where the key exists (PAIR: and belongs
+// to the query's window), else MASKED_LOGIT -- it enters through the MFMA's C operand, exp underflows to exactly 0
+template <bool PAIR>
+__device__ __forceinline__ float key_bias(int kr, int i, const WinInfo& wi) {
+  bool ok;
+  if (PAIR) ok = ((kr >> 3) == (i >> 3)) && ((kr & 7) < ((kr >> 3) ? wi.TkB : wi.Tk));
+  else ok = kr < wi.Tk;
+  return ok ? 0.f : MASKED_LOGIT;
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int DH, int NT>
+struct AttnBufs {          // byte sizes of the tensors for the buffer descriptors (launcher-checked < 2^31)
+  unsigned q, k, v, o, g, lse, dq, dk, dv;
+};
+
+template <int DH, int NT, bool PAIR>
 __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
     const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
     const __hip_bfloat16* __restrict__ v, int64_t ldv, int nhead, const int32_t* __restrict__ grid_q,
     const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx, int sy, int sx,
     const float* __restrict__ tau, float tau_min, __hip_bfloat16* __restrict__ out, int64_t ldo,
-    float* __restrict__ lse, const int32_t* __restrict__ wl, int cls, int64_t nwin) {
+    float* __restrict__ lse, const int32_t* __restrict__ wl, int cls, int64_t nwin, AttnBufs nb) {
+  static_assert(!PAIR || NT == 1, "two windows per tile: single-tile class only");
   constexpr int FR = DH / 4;                 // channels per lane in a row fragment
   constexpr int CT = DH / 16;                // 16-channel output tiles
   constexpr int RB = DH * 2 + 16;            // V image row pitch (bytes): 16-byte aligned, off the power of two
@@ -242,19 +345,18 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
   typedef typename Frag<DH>::T frag_t;
   __shared__ int toks[2][64];
   __shared__ __attribute__((aligned(16))) char vimg[4][ROWS * RB];
-  int64_t dw;
-  if (!pick_window(wl, cls, nwin, dw)) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
   const int head = blockIdx.y * 4 + w, hoff = head * DH;
-  const int wcy = (int)(dw % Wy), wcx = (int)((dw / Wy) % Wx), b = (int)(dw / ((int64_t)Wy * Wx));
-  const int y = wcy * WIN - sy + (lane >> 3), x = wcx * WIN - sx + (lane & 7);
-  const bool in = y >= 0 && y < ny && x >= 0 && x < nx;
-  const int64_t cell = ((int64_t)b * ny + y) * nx + x;
-  const int tq = in ? grid_q[cell] : -1, tk = in ? grid_k[cell] : -1;
-  const unsigned long long mq = __ballot(tq >= 0), mk = __ballot(tk >= 0);
-  if (mq == 0ull) return;
-  const int Tq = __popcll(mq), Tk = __popcll(mk);
+  WinInfo wi;
+  if (!find_tokens<PAIR>(wl, cls, nwin, grid_q, grid_k, ny, nx, Wy, Wx, sy, sx, toks, lane, w, wi)) return;
+  const int Tq = wi.Tq, Tk = wi.Tk;
+  const __amdgpu_buffer_rsrc_t rsq = make_rsrc(q, nb.q), rsk = make_rsrc(k, nb.k), rsv = make_rsrc(v, nb.v),
+                               rso = make_rsrc(out, nb.o), rsl = make_rsrc(lse, nb.lse);
+  const unsigned colb = (unsigned)(hoff + FR * g) * 2u;
+  if (Tq == 0) return;                        // (dense launch only) no queries here
   if (Tk == 0) {                              // (dense launch only) cross-attention window without keys: zero rows
+    __syncthreads();
+    const int tq = toks[0][lane];
     if (tq >= 0) {
       __hip_bfloat16* o = out + (int64_t)tq * ldo + hoff;
 #pragma unroll
@@ -263,36 +365,32 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
     }
     return;
   }
-  if (w == 0) {
-    if (tq >= 0) toks[0][__popcll(mq & ((1ull << lane) - 1ull))] = tq;
-    if (tk >= 0) toks[1][__popcll(mk & ((1ull << lane) - 1ull))] = tk;
-  }
   __syncthreads();
-  const int nq = (Tq + 15) >> 4, nk = (Tk + 15) >> 4;
+  const int nq = PAIR ? 1 : (Tq + 15) >> 4, nk = PAIR ? 1 : (Tk + 15) >> 4;
   const float inv_tau = 1.0f / fmaxf(tau[0], tau_min);
   // ---- all global row loads are issued here, one dependent round after the token ids
   frag_t kf[NT], kl[NT], qf[NT], ql[NT];
   typedef typename RawFrag<FR>::T raw_t;
   raw_t rk[NT], rv[NT], rq[NT];
-  int tokk_[NT], tokq_[NT];
+  int tokq_[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {                    // no branches here: every load of the wave is in flight at once
     const int slot = t * 16 + i;
-    tokk_[t] = slot < Tk ? toks[1][slot] : -1;
-    tokq_[t] = slot < Tq ? toks[0][slot] : -1;
-    rk[t] = load_row_raw<FR>(k, ldk, tokk_[t], hoff, g);
-    rv[t] = load_row_raw<FR>(v, ldv, tokk_[t], hoff, g);
-    rq[t] = load_row_raw<FR>(q, ldq, tokq_[t], hoff, g);
+    const int tokk = toks[1][slot];
+    tokq_[t] = toks[0][slot];
+    rk[t] = load_row_raw<FR>(rsk, row_off(tokk, (unsigned)ldk * 2u, colb));
+    rv[t] = load_row_raw<FR>(rsv, row_off(tokk, (unsigned)ldv * 2u, colb));
+    rq[t] = load_row_raw<FR>(rsq, row_off(tokq_[t], (unsigned)ldq * 2u, colb));
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int slot = t * 16 + i;
     float f[FR];
     if (t < nk) {                                   // wave-uniform
-      unpack_row<FR>(rk[t], tokk_[t], f);
+      unpack_row<FR>(rk[t], f);
       normalize_frag<FR>(f, 1.0f);
       split_frag<FR>(f, kf[t], kl[t]);
-      unpack_row<FR>(rv[t], tokk_[t], f);
+      unpack_row<FR>(rv[t], f);
       store_img_frag<DH>(&vimg[w][slot * RB], g, pack_frag<FR>(f));
     } else {
 #pragma unroll
@@ -303,7 +401,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
       store_img_frag<DH>(&vimg[w][slot * RB], g, z);                        // P is 0 there, but 0 * garbage = NaN
     }
     if (t < nq) {
-      unpack_row<FR>(rq[t], tokq_[t], f);
+      unpack_row<FR>(rq[t], f);
       normalize_frag<FR>(f, inv_tau);
       split_frag<FR>(f, qf[t], ql[t]);
     }
@@ -317,21 +415,20 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
     for (int ct = 0; ct < CT; ++ct)
       vf[kt][ct] = tr_read4(&vimg[w][(kt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3)]);
 
-  // key rows past Tk get a large negative logit through the MFMA's C operand (exp underflows to exactly 0): no
-  // per-element masking in the loops, and tiles kt >= nk need no special case
-  // (only where the 4*NT registers are free: the 64-token class would lose a resident wave and masks per element)
+  // key rows that do not exist (PAIR: or belong to the other window) get a large negative logit through the MFMA's C
+  // operand (exp underflows to exactly 0): no per-element masking in the loops, and tiles kt >= nk need no special
+  // case (only where the 4*NT registers are free: the 64-token class would lose a resident wave and masks per element)
   constexpr bool KB = NT <= 2;
   f32x4 kbias[KB ? NT : 1];
   if constexpr (KB) {
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) kbias[kt][r] = (kt * 16 + 4 * g + r < Tk) ? 0.f : MASKED_LOGIT;
+      for (int r = 0; r < 4; ++r) kbias[kt][r] = key_bias<PAIR>(kt * 16 + 4 * g + r, i, wi);
   }
 #pragma unroll
   for (int qt = 0; qt < NT; ++qt) {
     if (qt < nq) {
-      const int qslot = qt * 16 + i;
       f32x4 st[NT];
       float mx = -INFINITY;
 #pragma unroll
@@ -348,8 +445,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
           mx = fmaxf(mx, st[kt][r]);
         }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = quad_max(mx);
       float l = 0.f;
       s16x4 pf[NT];
 #pragma unroll
@@ -360,8 +456,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
           l += p;
           pf[kt][r] = f2bf(p);
         }
-      l += __shfl_xor(l, 16, 64);
-      l += __shfl_xor(l, 32, 64);
+      l = quad_sum(l);
       const float invl = fast_rcp(l);
       // O^T = V^T . P^T (swapped: rows = channels, column = query i): the V fragments serve as the A operand, the
       // probabilities stay where the S^T accumulators left them
@@ -373,25 +468,30 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
         for (int kt = 0; kt < NT; ++kt)
           if (kt < nk) o[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[kt][ct], pf[kt], o[ct], 0, 0, 0);
       }
-      // lane (g, i): query i, channels (DH/4) g + 4 ct + r -- DH/4 consecutive channels: one wide store
-      if (qslot < Tq) {
-        float of[FR];
+      // lane (g, i): query i, channels (DH/4) g + 4 ct + r -- DH/4 consecutive channels: one wide store (dropped by the
+      // descriptor's range check when the slot holds no query)
+      float of[FR];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) of[4 * ct + r] = o[ct][r] * invl;
-        store_row_frag<FR>(out + (int64_t)toks[0][qslot] * ldo + hoff + FR * g, of);
-      }
-      if (g == 0 && qslot < Tq) lse[(int64_t)toks[0][qslot] * nhead + head] = mx + __logf(l);
+        for (int r = 0; r < 4; ++r) of[4 * ct + r] = o[ct][r] * invl;
+      store_row_frag<FR>(rso, row_off(tokq_[qt], (unsigned)ldo * 2u, colb), of);
+      const unsigned loff = (g == 0 && tokq_[qt] >= 0) ? (unsigned)(tokq_[qt] * nhead + head) * 4u : 0xFFFFFFFFu;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mx + __logf(l)), rsl, (int)loff, 0, 0);
     }
   }
 }
 
 static int64_t class_grid(int cls, int64_t nwin, int64_t mq, int64_t mk) {
-  // class c windows hold > 16*c tokens (c = 1: >= 17, c = 2: >= 33) in one of the two frames
-  const int64_t bound = cls == 0 ? nwin : (mq + mk) / (cls == 1 ? 17 : 33);
+  // class 0: pairs of windows; class c > 0 windows hold >= 8 * 2^(c-1) + 1 tokens in one of the two frames
+  if (cls == 0) return (nwin + 1) / 2;
+  const int64_t bound = (mq + mk) / (cls == 1 ? 9 : (cls == 2 ? 17 : 33));
   return bound < nwin ? bound : nwin;
 }
+
+// buffer descriptors address with 32-bit byte offsets and row_off multiplies 24-bit factors
+static bool attn_sizes_ok(int64_t rows, int64_t ld) { return rows < (1 << 24) && ld * 2 < (1 << 24) && rows * ld * 2 < ((int64_t)1 << 31); }
+static unsigned attn_bytes(int64_t rows, int64_t ld, int width) { return rows > 0 ? (unsigned)(((rows - 1) * ld + width) * 2) : 0u; }
 
 int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                            int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
@@ -401,26 +501,36 @@ int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
   // 16-byte row fragments / V rows: bases and pitches must keep every head slice 16-byte aligned
   if ((ldq % 8) || (ldk % 8) || (ldv % 8) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15))
     return TMAE_EARG;
+  if (!attn_sizes_ok(mq, ldq) || !attn_sizes_ok(mk, ldk) || !attn_sizes_ok(mk, ldv) || !attn_sizes_ok(mq, ldo) ||
+      (int64_t)batch * ny * nx >= ((int64_t)1 << 31))
+    return TMAE_EARG;
   const int Wy = (ny + WIN - 1) / WIN + 1, Wx = (nx + WIN - 1) / WIN + 1;
   const int s = do_shift ? WIN / 2 : WIN;
   const int64_t nwin = (int64_t)batch * Wy * Wx;
-#define FWDM(DH, NT, CLS, GX)                                                                                        \
-  hipLaunchKernelGGL((win_attn_fwd_mfma_kernel<DH, NT>), dim3((unsigned)(GX), (unsigned)(nhead / 4)), dim3(256), 0,  \
-                     stream, (const __hip_bfloat16*)q, ldq, (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v,  \
-                     ldv, nhead, grid_q, grid_k, ny, nx, Wy, Wx, s, s, tau, tau_min, (__hip_bfloat16*)out, ldo, lse,  \
-                     worklist, CLS, nwin)
+  const int d = nhead * dh;
+  AttnBufs nb = {};
+  nb.q = attn_bytes(mq, ldq, d); nb.k = attn_bytes(mk, ldk, d); nb.v = attn_bytes(mk, ldv, d);
+  nb.o = attn_bytes(mq, ldo, d); nb.lse = (unsigned)(mq * nhead * 4);
+#define FWDM(DH, NT, PAIR, CLS, GX)                                                                                  \
+  hipLaunchKernelGGL((win_attn_fwd_mfma_kernel<DH, NT, PAIR>), dim3((unsigned)(GX), (unsigned)(nhead / 4)), dim3(256), \
+                     0, stream, (const __hip_bfloat16*)q, ldq, (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v, \
+                     ldv, nhead, grid_q, grid_k, ny, nx, Wy, Wx, s, s, tau, tau_min, (__hip_bfloat16*)out, ldo, lse, \
+                     worklist, CLS, nwin, nb)
   if (!worklist) {
-    if (dh == 32) FWDM(32, 4, 0, nwin); else FWDM(16, 4, 0, nwin);
+    if (dh == 32) FWDM(32, 4, false, 0, nwin); else FWDM(16, 4, false, 0, nwin);
   } else {
-    const int64_t g0 = class_grid(0, nwin, mq, mk), g1 = class_grid(1, nwin, mq, mk), g2 = class_grid(2, nwin, mq, mk);
+    const int64_t g0 = class_grid(0, nwin, mq, mk), g1 = class_grid(1, nwin, mq, mk), g2 = class_grid(2, nwin, mq, mk),
+                  g3 = class_grid(3, nwin, mq, mk);
     if (dh == 32) {
-      if (g0 > 0) FWDM(32, 1, 0, g0);
-      if (g1 > 0) FWDM(32, 2, 1, g1);
-      if (g2 > 0) FWDM(32, 4, 2, g2);
+      if (g0 > 0) FWDM(32, 1, true, 0, g0);
+      if (g1 > 0) FWDM(32, 1, false, 1, g1);
+      if (g2 > 0) FWDM(32, 2, false, 2, g2);
+      if (g3 > 0) FWDM(32, 4, false, 3, g3);
     } else {
-      if (g0 > 0) FWDM(16, 1, 0, g0);
-      if (g1 > 0) FWDM(16, 2, 1, g1);
-      if (g2 > 0) FWDM(16, 4, 2, g2);
+      if (g0 > 0) FWDM(16, 1, true, 0, g0);
+      if (g1 > 0) FWDM(16, 1, false, 1, g1);
+      if (g2 > 0) FWDM(16, 2, false, 2, g2);
+      if (g3 > 0) FWDM(16, 4, false, 3, g3);
     }
   }
 #undef FWDM
@@ -438,7 +548,7 @@ int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
 // rate of those stores was 16 % of the stage-1 kernel.)
 // NT = 4 is compiled for two waves per SIMD (the LDS images allow no more): 233 registers, no scratch.
 // ------------------------------------------------------------------------------------------------
-template <int DH, int NT>
+template <int DH, int NT, bool PAIR>
 __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel(
     const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
     const __hip_bfloat16* __restrict__ v, int64_t ldv, const __hip_bfloat16* __restrict__ outp, int64_t ldo,
@@ -446,7 +556,8 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
     const int32_t* __restrict__ grid_q, const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx, int sy,
     int sx, const float* __restrict__ tau, float tau_min, __hip_bfloat16* __restrict__ dq, int64_t lddq,
     __hip_bfloat16* __restrict__ dk, int64_t lddk, __hip_bfloat16* __restrict__ dv, int64_t lddv,
-    float* __restrict__ dtau_partial, const int32_t* __restrict__ wl, int cls, int64_t nwin) {
+    float* __restrict__ dtau_partial, const int32_t* __restrict__ wl, int cls, int64_t nwin, AttnBufs nb) {
+  static_assert(!PAIR || NT == 1, "two windows per tile: single-tile class only");
   constexpr int FR = DH / 4;
   constexpr int CT = DH / 16;
   constexpr int RB = DH * 2 + 16;
@@ -459,26 +570,22 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
   __shared__ float qnorm[4][ROWS], knorm[4][ROWS];
   constexpr int TP = 40;                                              // pitch (bytes) of the 16x16 bf16 transpose tiles
   __shared__ __attribute__((aligned(16))) char ptile[4][2][16 * TP];
-  int64_t dw;
-  if (!pick_window(wl, cls, nwin, dw)) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
   const int head = blockIdx.y * 4 + w, hoff = head * DH;
-  const int wcy = (int)(dw % Wy), wcx = (int)((dw / Wy) % Wx), b = (int)(dw / ((int64_t)Wy * Wx));
-  const int y = wcy * WIN - sy + (lane >> 3), x = wcx * WIN - sx + (lane & 7);
-  const bool in = y >= 0 && y < ny && x >= 0 && x < nx;
-  const int64_t cell = ((int64_t)b * ny + y) * nx + x;
-  const int tq = in ? grid_q[cell] : -1, tk = in ? grid_k[cell] : -1;
-  const unsigned long long mq = __ballot(tq >= 0), mk = __ballot(tk >= 0);
-  const int Tq = __popcll(mq), Tk = __popcll(mk);
-  float* dtp = dtau_partial + dw * nhead + head;
+  WinInfo wi;
+  if (!find_tokens<PAIR>(wl, cls, nwin, grid_q, grid_k, ny, nx, Wy, Wx, sy, sx, toks, lane, w, wi)) return;
+  const int Tq = wi.Tq, Tk = wi.Tk;
+  float* dtp = dtau_partial + (int64_t)wi.dwin * nhead + head;
   if (Tq == 0 || Tk == 0) {                   // (dense launch only) nothing attended here: zero gradients
+    __syncthreads();
     if (lane == 0) *dtp = 0.f;
-    if (Tq > 0 && tq >= 0) {
+    const int tq = toks[0][lane], tk = toks[1][lane];
+    if (tq >= 0) {
       __hip_bfloat16* p = dq + (int64_t)tq * lddq + hoff;
 #pragma unroll
       for (int c = 0; c < DH; ++c) p[c] = __float2bfloat16(0.f);
     }
-    if (Tk > 0 && tk >= 0 && grid_q != grid_k) {
+    if (tk >= 0 && grid_q != grid_k) {
       __hip_bfloat16* p1 = dk + (int64_t)tk * lddk + hoff;
       __hip_bfloat16* p2 = dv + (int64_t)tk * lddv + hoff;
 #pragma unroll
@@ -487,12 +594,12 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
     return;
   }
   const float tau_c = fmaxf(tau[0], tau_min), inv_tau = 1.0f / tau_c;
-  if (w == 0) {
-    if (tq >= 0) toks[0][__popcll(mq & ((1ull << lane) - 1ull))] = tq;
-    if (tk >= 0) toks[1][__popcll(mk & ((1ull << lane) - 1ull))] = tk;
-  }
+  const __amdgpu_buffer_rsrc_t rsq = make_rsrc(q, nb.q), rsk = make_rsrc(k, nb.k), rsv = make_rsrc(v, nb.v),
+                               rsg = make_rsrc(dout, nb.g), rsl = make_rsrc(lse, nb.lse), rsdq = make_rsrc(dq, nb.dq),
+                               rsdk = make_rsrc(dk, nb.dk), rsdv = make_rsrc(dv, nb.dv);
+  const unsigned colb = (unsigned)(hoff + FR * g) * 2u;
   __syncthreads();                                   // token lists visible
-  const int nq = (Tq + 15) >> 4, nk = (Tk + 15) >> 4;
+  const int nq = PAIR ? 1 : (Tq + 15) >> 4, nk = PAIR ? 1 : (Tk + 15) >> 4;
   // ---- every global row load of the workgroup is issued here (one dependent round after the token ids); the
   //      row-major LDS images are written from the same 16-byte fragments: lane (g,i) owns chunk g of row tile*16+i.
   frag_t kf[NT], kl[NT], vr[NT], qf[NT], ql[NT], gf[NT];
@@ -503,24 +610,25 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
 #pragma unroll
   for (int t = 0; t < NT; ++t) {                     // no branches here: every load of the wave is in flight at once
     const int slot = t * 16 + i;
-    tokk_[t] = slot < Tk ? toks[1][slot] : -1;
-    tokq_[t] = slot < Tq ? toks[0][slot] : -1;
-    rk[t] = load_row_raw<FR>(k, ldk, tokk_[t], hoff, g);
-    rv[t] = load_row_raw<FR>(v, ldv, tokk_[t], hoff, g);
-    rq[t] = load_row_raw<FR>(q, ldq, tokq_[t], hoff, g);
-    rg[t] = load_row_raw<FR>(dout, lddo, tokq_[t], hoff, g);
-    lse_i[t] = lse[(int64_t)(tokq_[t] < 0 ? 0 : tokq_[t]) * nhead + head];
+    tokk_[t] = toks[1][slot];
+    tokq_[t] = toks[0][slot];
+    rk[t] = load_row_raw<FR>(rsk, row_off(tokk_[t], (unsigned)ldk * 2u, colb));
+    rv[t] = load_row_raw<FR>(rsv, row_off(tokk_[t], (unsigned)ldv * 2u, colb));
+    rq[t] = load_row_raw<FR>(rsq, row_off(tokq_[t], (unsigned)ldq * 2u, colb));
+    rg[t] = load_row_raw<FR>(rsg, row_off(tokq_[t], (unsigned)lddo * 2u, colb));
+    const unsigned loff = tokq_[t] >= 0 ? (unsigned)(tokq_[t] * nhead + head) * 4u : 0xFFFFFFFFu;
+    lse_i[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsl, (int)loff, 0, 0));
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int slot = t * 16 + i;
     float f[FR];
     if (t < nk) {                                    // wave-uniform
-      unpack_row<FR>(rk[t], tokk_[t], f);
+      unpack_row<FR>(rk[t], f);
       const float nrm = normalize_frag<FR>(f, 1.0f);
       split_frag<FR>(f, kf[t], kl[t]);
       if (g == 0) knorm[w][slot] = nrm;
-      unpack_row<FR>(rv[t], tokk_[t], f);
+      unpack_row<FR>(rv[t], f);
       vr[t] = pack_frag<FR>(f);
     } else {
 #pragma unroll
@@ -529,13 +637,13 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
     store_img_frag<DH>(&kimg[w][slot * RB], g, kf[t]);
     if (tokq_[t] < 0 || t >= nq) lse_i[t] = INFINITY;                      // no query: p = exp(s - inf) = 0
     if (t < nq) {
-      unpack_row<FR>(rq[t], tokq_[t], f);
+      unpack_row<FR>(rq[t], f);
       const float nrm = normalize_frag<FR>(f, inv_tau);
       split_frag<FR>(f, qf[t], ql[t]);
       store_img_frag<DH>(&qimg[w][slot * RB], g, qf[t]);
       if (g == 0) qnorm[w][slot] = nrm;
       float gfl[FR];
-      unpack_row<FR>(rg[t], tokq_[t], gfl);
+      unpack_row<FR>(rg[t], gfl);
       gf[t] = pack_frag<FR>(gfl);                                        // exact: bf16 -> f32 -> bf16
       store_img_frag<DH>(&gimg[w][slot * RB], g, gf[t]);
     }
@@ -547,13 +655,13 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) { dKa[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dVa[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   float dtau_acc = 0.f;
-  constexpr bool KB = NT <= 2;             // MASKED_LOGIT on key rows past Tk through the C operand (see the forward)
+  constexpr bool KB = NT <= 2;             // MASKED_LOGIT on absent / foreign key rows through the C operand (see the forward)
   f32x4 kbias[KB ? NT : 1];
   if constexpr (KB) {
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) kbias[kt][r] = (kt * 16 + 4 * g + r < Tk) ? 0.f : MASKED_LOGIT;
+      for (int r = 0; r < 4; ++r) kbias[kt][r] = key_bias<PAIR>(kt * 16 + 4 * g + r, i, wi);
   }
 
 #pragma unroll
@@ -598,8 +706,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
           }
         }
       }
-      dacc += __shfl_xor(dacc, 16, 64);
-      dacc += __shfl_xor(dacc, 32, 64);
+      dacc = quad_sum(dacc);
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         if (kt < nk) {
@@ -647,7 +754,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
       }
       // dq = (dq-hat - q-hat (q-hat . dq-hat)) / |q|.  The products are taken transposed (rows = channels) over the
       // permuted images, so lane (g, i) holds channels FR g + 4 ct + r of query qt*16+i: the SAME channels as its own
-      // row fragment qf[qt] -- q-hat comes from registers, the dot product needs two shuffles, one wide store per lane
+      // row fragment qf[qt] -- q-hat comes from registers, the dot product is a quad reduction, one wide store per lane
       {
         float dqh[FR], qh[FR], dot = 0.f;
 #pragma unroll
@@ -658,17 +765,14 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
             dqh[4 * ct + r] = dQa[ct][r] * inv_tau;
             dot += qh[4 * ct + r] * dqh[4 * ct + r];
           }
-        dot += __shfl_xor(dot, 16, 64);
-        dot += __shfl_xor(dot, 32, 64);
-        if (qslot < Tq) {
-          const float nrm = qnorm[w][qslot];
-          if (nrm <= 1e-12f) dot = 0.f;
-          const float inv = fast_rcp(nrm);
-          float o[FR];
+        dot = quad_sum(dot);
+        const float nrm = qnorm[w][qslot];               // slots without a query: stale, the store below is dropped
+        if (nrm <= 1e-12f) dot = 0.f;
+        const float inv = fast_rcp(nrm);
+        float o[FR];
 #pragma unroll
-          for (int j = 0; j < FR; ++j) o[j] = (dqh[j] - qh[j] * dot) * inv;
-          store_row_frag<FR>(dq + (int64_t)toks[0][qslot] * lddq + hoff + FR * g, o);
-        }
+        for (int j = 0; j < FR; ++j) o[j] = (dqh[j] - qh[j] * dot) * inv;
+        store_row_frag<FR>(rsdq, row_off(tokq_[qt], (unsigned)lddq * 2u, colb), o);
       }
     }
   }
@@ -689,19 +793,15 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
           dvv[4 * ct + r] = dVa[kt][ct][r];
           dot += kh[4 * ct + r] * dkh[4 * ct + r];
         }
-      dot += __shfl_xor(dot, 16, 64);
-      dot += __shfl_xor(dot, 32, 64);
-      if (ks < Tk) {
-        const float nrm = knorm[w][ks];
-        if (nrm <= 1e-12f) dot = 0.f;
-        const float inv = fast_rcp(nrm);
-        const int tokk = toks[1][ks];
-        float o[FR];
+      dot = quad_sum(dot);
+      const float nrm = knorm[w][ks];
+      if (nrm <= 1e-12f) dot = 0.f;
+      const float inv = fast_rcp(nrm);
+      float o[FR];
 #pragma unroll
-        for (int j = 0; j < FR; ++j) o[j] = (dkh[j] - kh[j] * dot) * inv;
-        store_row_frag<FR>(dk + (int64_t)tokk * lddk + hoff + FR * g, o);
-        store_row_frag<FR>(dv + (int64_t)tokk * lddv + hoff + FR * g, dvv);
-      }
+      for (int j = 0; j < FR; ++j) o[j] = (dkh[j] - kh[j] * dot) * inv;
+      store_row_frag<FR>(rsdk, row_off(tokk_[kt], (unsigned)lddk * 2u, colb), o);
+      store_row_frag<FR>(rsdv, row_off(tokk_[kt], (unsigned)lddv * 2u, colb), dvv);
     }
   }
 }
@@ -713,27 +813,41 @@ int tmae_win_attn_bwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
                            void* dk, int64_t lddk, void* dv, int64_t lddv, float* dtau_partial,
                            const int32_t* worklist, hipStream_t stream) {
   if (nhead % 4 || (dh != 16 && dh != 32)) return TMAE_EARG;
+  if (!attn_sizes_ok(mq, ldq) || !attn_sizes_ok(mk, ldk) || !attn_sizes_ok(mk, ldv) || !attn_sizes_ok(mq, lddo) ||
+      !attn_sizes_ok(mq, lddq) || !attn_sizes_ok(mk, lddk) || !attn_sizes_ok(mk, lddv) ||
+      (int64_t)batch * ny * nx >= ((int64_t)1 << 31))
+    return TMAE_EARG;
+  if ((lddq % 4) || (lddk % 4) || (lddv % 4) || ((uintptr_t)dq & 7) || ((uintptr_t)dk & 7) || ((uintptr_t)dv & 7))
+    return TMAE_EARG;
   const int Wy = (ny + WIN - 1) / WIN + 1, Wx = (nx + WIN - 1) / WIN + 1;
   const int s = do_shift ? WIN / 2 : WIN;
   const int64_t nwin = (int64_t)batch * Wy * Wx;
-#define BWDM(DH, NT, CLS, GX)                                                                                        \
-  hipLaunchKernelGGL((win_attn_bwd_mfma_kernel<DH, NT>), dim3((unsigned)(GX), (unsigned)(nhead / 4)), dim3(256), 0,  \
-                     stream, (const __hip_bfloat16*)q, ldq, (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v,  \
+  const int d = nhead * dh;
+  AttnBufs nb = {};
+  nb.q = attn_bytes(mq, ldq, d); nb.k = attn_bytes(mk, ldk, d); nb.v = attn_bytes(mk, ldv, d);
+  nb.g = attn_bytes(mq, lddo, d); nb.lse = (unsigned)(mq * nhead * 4);
+  nb.dq = attn_bytes(mq, lddq, d); nb.dk = attn_bytes(mk, lddk, d); nb.dv = attn_bytes(mk, lddv, d);
+#define BWDM(DH, NT, PAIR, CLS, GX)                                                                                  \
+  hipLaunchKernelGGL((win_attn_bwd_mfma_kernel<DH, NT, PAIR>), dim3((unsigned)(GX), (unsigned)(nhead / 4)), dim3(256), \
+                     0, stream, (const __hip_bfloat16*)q, ldq, (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v, \
                      ldv, (const __hip_bfloat16*)out, ldo, (const __hip_bfloat16*)dout, lddo, lse, nhead, grid_q,     \
                      grid_k, ny, nx, Wy, Wx, s, s, tau, tau_min, (__hip_bfloat16*)dq, lddq, (__hip_bfloat16*)dk, lddk, \
-                     (__hip_bfloat16*)dv, lddv, dtau_partial, worklist, CLS, nwin)
+                     (__hip_bfloat16*)dv, lddv, dtau_partial, worklist, CLS, nwin, nb)
   if (!worklist) {
-    if (dh == 32) BWDM(32, 4, 0, nwin); else BWDM(16, 4, 0, nwin);
+    if (dh == 32) BWDM(32, 4, false, 0, nwin); else BWDM(16, 4, false, 0, nwin);
   } else {
-    const int64_t g0 = class_grid(0, nwin, mq, mk), g1 = class_grid(1, nwin, mq, mk), g2 = class_grid(2, nwin, mq, mk);
+    const int64_t g0 = class_grid(0, nwin, mq, mk), g1 = class_grid(1, nwin, mq, mk), g2 = class_grid(2, nwin, mq, mk),
+                  g3 = class_grid(3, nwin, mq, mk);
     if (dh == 32) {
-      if (g0 > 0) BWDM(32, 1, 0, g0);
-      if (g1 > 0) BWDM(32, 2, 1, g1);
-      if (g2 > 0) BWDM(32, 4, 2, g2);
+      if (g0 > 0) BWDM(32, 1, true, 0, g0);
+      if (g1 > 0) BWDM(32, 1, false, 1, g1);
+      if (g2 > 0) BWDM(32, 2, false, 2, g2);
+      if (g3 > 0) BWDM(32, 4, false, 3, g3);
     } else {
-      if (g0 > 0) BWDM(16, 1, 0, g0);
-      if (g1 > 0) BWDM(16, 2, 1, g1);
-      if (g2 > 0) BWDM(16, 4, 2, g2);
+      if (g0 > 0) BWDM(16, 1, true, 0, g0);
+      if (g1 > 0) BWDM(16, 1, false, 1, g1);
+      if (g2 > 0) BWDM(16, 2, false, 2, g2);
+      if (g3 > 0) BWDM(16, 4, false, 3, g3);
     }
   }
 #undef BWDM

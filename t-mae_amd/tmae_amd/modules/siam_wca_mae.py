@@ -3,6 +3,8 @@
 Host-side mirror of pcdet/models/backbones_3d/SiamWCA_MAE.py (same constructor kwargs, batch_dict keys,
 ``forward_ret_dict`` and parameter names) over the HIP operators of tmae_amd.ops.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -134,7 +136,12 @@ class SiamWCA_MAE(nn.Module):
             cat = torch.cat([self.decoder_deblocks[i](feats[src].dense())
                              for i, src in enumerate(self.model_cfg.FEATURES_SOURCE)], dim=1)
         conv, bn = self.decoder_conv_out[0], self.decoder_conv_out[1]
-        y = conv(cat)
+        nhwc = cat.permute(0, 2, 3, 1)
+        if (self.training and nhwc.is_contiguous() and ops.dense_conv3x3_ok(nhwc, conv)
+                and os.environ.get('TMAE_DENSE_WGRAD', '1') != '0'):
+            y = ops.dense_conv3x3(nhwc, conv.weight).permute(0, 3, 1, 2)     # weight gradient: our token-split kernel
+        else:
+            y = conv(cat)
         if (self.training and y.is_cuda and y.is_contiguous(memory_format=torch.channels_last)
                 and y.shape[1] in (64, 128, 256) and isinstance(self.decoder_conv_out[2], nn.ReLU)):
             # BatchNorm2d + ReLU over a channels-last tensor = the row kernels over [B*Y*X, C]

@@ -1117,6 +1117,72 @@ def deblocks_fusable(sources, training):
     return True
 
 
+_DENSE_NBR = {}
+
+
+def _dense_rulebook(batch, ny, nx, device):
+    """nbr [batch*ny*nx, 9] of a FULL grid (row = cell, -1 past the border): the sparse-conv rulebook of a dense 3x3
+    convolution with padding 1, built once per shape."""
+    key = (batch, ny, nx, device)
+    nbr = _DENSE_NBR.get(key)
+    if nbr is None:
+        n = batch * ny * nx
+        cells = torch.arange(n, device=device, dtype=torch.int32)
+        ind = torch.stack([cells // (ny * nx), (cells // nx) % ny, cells % nx], 1).contiguous()
+        nbr = _DENSE_NBR[key] = spconv_neighbors(ind, cells, batch, ny, nx, 1)
+    return nbr
+
+
+class _DenseConv3x3(torch.autograd.Function):
+    """Conv2d(cin, cout, 3, padding=1, bias=False) on a channels-last activation [B, Y, X, cin] (SiamWCA_MAE.py:100-115).
+    Forward and input gradient: the library's implicit GEMM; weight gradient: the token-split kernel of csrc/wgrad.hip
+    reading the 9 shifted rows of every cell through the dense rulebook (dW[cout, 9 cin] = dY^T . im2col(X), never
+    materialised) -- the library's wrw kernel ran at 0.5 PFLOP/s on this 1.75 M-cell x 3456 x 128 reduction."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, weight):
+        cdt = compute_dtype(x_nhwc)
+        x = x_nhwc.to(cdt)
+        w = cast_param(weight, cdt)
+        y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.contiguous(memory_format=torch.channels_last), padding=1)
+        ctx.save_for_backward(x, w)
+        ctx.meta = (x_nhwc.dtype, weight.dtype)
+        return y.permute(0, 2, 3, 1)
+
+    @staticmethod
+    def backward(ctx, dy_nhwc):
+        x, w = ctx.saved_tensors
+        B, Y, X, cin = x.shape
+        cout = w.shape[0]
+        dy = dy_nhwc.to(x.dtype).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(
+                dy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w.contiguous(memory_format=torch.channels_last), None,
+                [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1).to(ctx.meta[0])
+        n = B * Y * X
+        dy2, x2 = dy.view(n, cout), x.contiguous().view(n, cin)
+        nbr = _dense_rulebook(B, Y, X, x.device)
+        dw = torch.empty((cout, 9 * cin), dtype=torch.float32, device=x.device)
+        wsb = lib.tmae_linear_wgrad_workspace(n, cout, 9 * cin)
+        ws = _ws(wsb, x.device)
+        check(lib.tmae_spconv_wgrad(_p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(nbr), n, cout, cin, _p(dw), _p(ws),
+                                    wsb, _s()), 'tmae_spconv_wgrad')
+        dw = dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2).to(ctx.meta[1])
+        return dx, dw
+
+
+def dense_conv3x3_ok(x_nhwc, conv):
+    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
+            and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and x_nhwc.is_cuda and compute_dtype(x_nhwc) == torch.bfloat16 and conv.in_channels % 128 == 0
+            and conv.out_channels % 8 == 0 and x_nhwc.shape[0] * x_nhwc.shape[1] * x_nhwc.shape[2] >= 4096)
+
+
+def dense_conv3x3(x_nhwc, weight):
+    return _DenseConv3x3.apply(x_nhwc, weight)
+
+
 class _DenseGather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dense, grid, indices):

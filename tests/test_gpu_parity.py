@@ -426,8 +426,8 @@ def test_attention_mfma_bf16_fwd_bwd_vs_fp32_kernel():
                 if dt == torch.bfloat16:
                     # class-binned work lists (what the model uses) must give the dense-window kernel's numbers
                     wl = ops.window_worklist(gq, gk, 2, 234, 234, shift)
-                    cnt = wl[:3].cpu().numpy()
-                    assert cnt.sum() > 0 and cnt[0] > 0 and cnt[2] > 0          # the fixture populates the classes
+                    cnt = wl[:4].cpu().numpy()                                    # <= 8 (paired), <= 16, <= 32, <= 64 tokens
+                    assert cnt[0] > 1 and cnt[1] > 0 and cnt[3] > 0             # the fixture populates the classes
                     a2, b2, c2 = [None if t is None else t.detach().clone().requires_grad_(True) for t in (a, b_, c_)]
                     tau2 = torch.full((1, 1, 1), tauv, device=dev(), requires_grad=True)
                     o2 = ops.win_attn(a2, b2, c2, tau2, gq, gk, H, 2, 234, 234, shift, 0.01, worklist=wl)
@@ -733,6 +733,32 @@ def test_fused_decoder_head_vs_torch_dense():
                     assert rel <= 6e-2, (name, rel)
             assert (bn.running_mean - bn2.running_mean).abs().max().item() < 1e-4
             assert (bn.running_var - bn2.running_var).abs().max().item() < 1e-3
+
+
+def test_dense_conv3x3_own_wgrad_vs_torch():
+    """ops.dense_conv3x3 (library forward / dX, token-split weight gradient through the dense rulebook) against
+    torch's Conv2d in fp32 on the same bf16-representable data: y, dX, dW."""
+    from tmae_amd import ops
+    torch.manual_seed(3)
+    B, Y, X, cin, cout = 2, 52, 44, 128, 128
+    x = torch.randn(B, Y, X, cin, device=dev()).bfloat16()
+    w = (torch.randn(cout, cin, 3, 3, device=dev()) * 0.05).bfloat16().float().requires_grad_(True)
+    gy = torch.randn(B, Y, X, cout, device=dev()).bfloat16()
+    xa = x.clone().requires_grad_(True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y = ops.dense_conv3x3(xa, w)
+    y.backward(gy)
+    xr = x.float().requires_grad_(True)
+    wr = w.detach().clone().requires_grad_(True)
+    yr = F.conv2d(xr.permute(0, 3, 1, 2), wr, padding=1).permute(0, 2, 3, 1)
+    yr.backward(gy.float())
+
+    def rel(a, b):
+        return float((a.float() - b.float()).norm() / b.float().norm())
+    assert rel(y, yr) < 1e-2 and rel(xa.grad, xr.grad) < 1e-2
+    assert rel(w.grad, wr.grad) < 5e-3, rel(w.grad, wr.grad)
+    # borders included: the rulebook's -1 entries are the zero padding
+    assert (w.grad - wr.grad).abs().max().item() < 2e-2 * wr.grad.abs().max().item()
 
 
 def test_sparse_conv_golden_and_dense(oracle):
