@@ -7,7 +7,8 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 naive = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('naive_conv')]
 rest = rows[(max(naive) + 1) if naive else 0:]
 vk = [i for i, r in enumerate(rest) if 'vox_key_kernel' in r['Kernel_Name']]
-seg = rest[vk[-10]:vk[-4]]         # 3 timed steps (2 voxelisations each); the last 4 launches belong to the two roofline probes
+WARM, STEPS = 2, 3                  # bench.py --warmup 2 --steps 3: every step voxelises two frames (2 vox_key launches)
+seg = rest[vk[2 * WARM]:vk[2 * (WARM + STEPS)]]      # the 3 timed steps; what follows (FLOP-model forward, probes) is the tail
 t0, t1 = int(seg[0]['Start_Timestamp']), int(seg[-1]['End_Timestamp'])
 agg = collections.defaultdict(lambda: [0, 0])
 for r in seg:
@@ -25,7 +26,7 @@ for n, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
 # the roofline probes of bench.py (token_gemm_roofline, wgrad_roofline, attention_roofline): the launches after the last voxelisation of
 # the training steps (+1: the probe's own forward pass voxelises both frames once more); an op = one launch of each
 # kernel of its group, its duration = the sum of the per-kernel averages
-tail = rest[vk[-4]:]
+tail = rest[vk[2 * (WARM + STEPS)]:]
 def grid_of(r):
     return r.get('Grid_Size_X', r.get('Grid_Size', ''))
 

@@ -82,3 +82,67 @@ class SyntheticTemporalDataset:
             out['gt_boxes'] = synth_gt_boxes(self.batch_size, self.n_boxes, 7919 * self.rank + iteration,
                                              limit=float(self.point_cloud_range[3]) - 1.0)
         return out
+
+
+class SyntheticEvalLoader:
+    """Evaluation split of the synthetic data with the dataset / dataloader surface eval_one_epoch needs
+    (tools/eval_utils/eval_utils.py:24-161; once_temporal_dataset.py:552-600): `.dataset` (class_names, __len__,
+    generate_prediction_dicts, evaluation) and iteration over collated batches carrying `frame_id` and `gt_boxes`.
+    Sample s is generated from seed s alone; rank r of W iterates over the samples r, r + W, ... (DistributedSampler
+    order without shuffling, datasets/__init__.py:22-42)."""
+
+    def __init__(self, base: SyntheticTemporalDataset, num_samples, batch_size, rank=0, world=1, n_boxes=12):
+        self.base, self.num_samples, self.batch_size, self.rank, self.world = base, num_samples, batch_size, rank, world
+        self.n_boxes = n_boxes
+        self.class_names = base.class_names
+        self.dataset = self
+
+    def __len__(self):
+        return self.num_samples
+
+    def _sample(self, s):
+        pts, prv = synth_frame_pair(self.base.n_points, 1, 100000 + s, limit=float(self.base.point_cloud_range[3]),
+                                    extra_features=self.base.point_feature_encoder.num_point_features - 5)
+        gt = synth_gt_boxes(1, self.n_boxes, 200000 + s, limit=float(self.base.point_cloud_range[3]) - 1.0)[0]
+        return pts, prv, gt
+
+    def gt_anno(self, s):
+        gt = self._sample(s)[2]
+        gt = gt[np.abs(gt).sum(1) != 0]
+        return {'name': np.array(self.class_names)[gt[:, 7].astype(np.int64) - 1], 'boxes_3d': gt[:, :7].astype(np.float64)}
+
+    def __iter__(self):
+        mine = list(range(self.rank, self.num_samples, self.world))
+        for b0 in range(0, len(mine), self.batch_size):
+            ids = mine[b0:b0 + self.batch_size]
+            cur, prv, gts = [], [], []
+            for k, s in enumerate(ids):
+                p, q, g = self._sample(s)
+                p[:, 0], q[:, 0] = k, k
+                cur.append(p), prv.append(q), gts.append(g)
+            yield {'points': np.concatenate(cur), 'points_prev': np.concatenate(prv), 'batch_size': len(ids),
+                   'gt_boxes': np.stack(gts), 'frame_id': np.array([str(s) for s in ids])}
+
+    @staticmethod
+    def generate_prediction_dicts(batch_dict, pred_dicts, class_names, output_path=None):
+        """once_temporal_dataset.py:552-585: name / score / boxes_3d / frame_id per sample."""
+        if output_path is not None:
+            raise NotImplementedError('the reference does not write ONCE result files either (:583-584)')
+        annos = []
+        for index, box_dict in enumerate(pred_dicts):
+            scores = box_dict['pred_scores'].detach().cpu().numpy()
+            boxes = box_dict['pred_boxes'].detach().cpu().numpy()
+            labels = box_dict['pred_labels'].detach().cpu().numpy()
+            if scores.shape[0] == 0:
+                anno = {'name': np.zeros(0), 'score': np.zeros(0), 'boxes_3d': np.zeros((0, 7))}
+            else:
+                anno = {'name': np.array(class_names)[labels - 1], 'score': scores, 'boxes_3d': boxes}
+            anno['frame_id'] = batch_dict['frame_id'][index]
+            annos.append(anno)
+        return annos
+
+    def evaluation(self, det_annos, class_names, **kwargs):
+        """once_temporal_dataset.py:587-600: ONCE AP of the detections against the split's annotations."""
+        from ..eval import get_evaluation_results
+        gts = [self.gt_anno(int(a['frame_id'])) for a in det_annos]
+        return get_evaluation_results(gts, [dict(a) for a in det_annos], list(class_names))

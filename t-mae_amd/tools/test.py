@@ -1,0 +1,67 @@
+"""Evaluation driver with the reference's CLI surface (tools/test.py:20-60: --cfg_file --batch_size --ckpt --launcher
+--set ...): builds the detector through the registry, loads a checkpoint and runs eval_one_epoch.  The real ONCE loader
+is out of scope: `--synthetic` evaluates on deterministic ONCE-shape frame pairs with synthetic labels."""
+import argparse
+import os
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from pcdet.config import cfg, cfg_from_list, cfg_from_yaml_file, log_config_to_file  # noqa: E402
+from pcdet.models import build_network  # noqa: E402
+from pcdet.utils import common_utils  # noqa: E402
+from tmae_amd.eval import eval_one_epoch  # noqa: E402
+from tmae_amd.train import SyntheticEvalLoader, SyntheticTemporalDataset  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser(description='T-MAE evaluation on MI355X')
+    p.add_argument('--cfg_file', type=str, required=True)
+    p.add_argument('--batch_size', type=int, default=None)
+    p.add_argument('--extra_tag', type=str, default='default')
+    p.add_argument('--ckpt', type=str, default=None)
+    p.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
+    p.add_argument('--amp', action='store_true')
+    p.add_argument('--set', dest='set_cfgs', default=None, nargs=argparse.REMAINDER)
+    p.add_argument('--synthetic', action='store_true')
+    p.add_argument('--synthetic_points', type=int, default=120000)
+    p.add_argument('--synthetic_samples', type=int, default=32)
+    p.add_argument('--output_dir', type=str, default=None)
+    args = p.parse_args()
+    cfg_from_yaml_file(args.cfg_file, cfg)
+    cfg.TAG = Path(args.cfg_file).stem
+    if args.set_cfgs is not None:
+        cfg_from_list(args.set_cfgs, cfg)
+    if args.launcher == 'pytorch':
+        world, rank = common_utils.init_dist_pytorch(backend='nccl')
+    else:
+        world, rank = 1, 0
+        torch.cuda.set_device(0)
+    bs = args.batch_size or cfg.OPTIMIZATION.BATCH_SIZE_PER_GPU
+    out = Path(args.output_dir or (Path(cfg.ROOT_DIR) / 'output' / cfg.TAG / args.extra_tag / 'eval'))
+    out.mkdir(parents=True, exist_ok=True)
+    logger = common_utils.create_logger(out / f'log_eval_{time.strftime("%Y%m%d-%H%M%S")}.txt', rank=rank)
+    log_config_to_file(cfg, logger=logger)
+    if not args.synthetic:
+        raise NotImplementedError('the ONCE two-frame dataloader is outside this hot path (SURVEY 8f-2); use --synthetic')
+    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=args.synthetic_points, batch_size=bs, rank=rank)
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds, logger).cuda()
+    if args.ckpt:
+        model.load_params_from_file(args.ckpt, logger=logger)
+    loader = SyntheticEvalLoader(ds, args.synthetic_samples, bs, rank=rank, world=world)
+    cfg.LOCAL_RANK = int(os.environ.get('LOCAL_RANK', 0))
+    ret = eval_one_epoch(cfg, model, loader, 'synthetic', logger, dist_test=world > 1, result_dir=out,
+                         amp_dtype=torch.bfloat16 if args.amp else None)
+    if rank == 0:
+        logger.info({k: float(v) for k, v in ret.items()})
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
