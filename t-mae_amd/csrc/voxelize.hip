@@ -3,7 +3,6 @@
 // points with coalesced row reads; uniqueness comes from a dense occupancy grid (the pillar grid is
 // only batch*468*468 cells, L2-resident) + prefix sums instead of a 4-column int64 row sort.
 #include "common.h"
-#include <hipcub/hipcub.hpp>
 
 // ------------------------------------------------------------------------------------------------
 // voxelize
@@ -134,72 +133,67 @@ int tmae_voxelize(const float* points, int row, int64_t n, int batch, float rx, 
 // ------------------------------------------------------------------------------------------------
 // point -> group CSR (stable) and in-group rank
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void csr_keys_kernel(const int64_t* __restrict__ g, int64_t n,
-                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                      int32_t* __restrict__ cnt) {
+// Counting sort instead of a radix sort of (group, point) pairs: groups are voxels / windows with a handful of
+// members, so (1) integer counts per group + exclusive scan give the segment offsets, (2) every element takes a slot of
+// its segment through an atomic cursor (arbitrary order inside the segment), (3) every element counts the members of
+// its segment with a SMALLER element id -- its stable rank -- and moves there.  Deterministic and stable like the
+// sort it replaces (42 library launches per step), with sum(len^2) reads that stay in L2 (len ~ 2-3, <= a few hundred).
+__global__ __launch_bounds__(256) void csr_count_kernel(const int64_t* __restrict__ g, int64_t n,
+                                                       int32_t* __restrict__ cnt) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) atomicAdd(cnt + g[i], 1);   // integer count: deterministic
+}
+
+__global__ __launch_bounds__(256) void csr_scatter_kernel(const int64_t* __restrict__ g, int64_t n,
+                                                         const int32_t* __restrict__ offsets,
+                                                         int32_t* __restrict__ cursor, int32_t* __restrict__ tmp) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  uint32_t k = (uint32_t)g[i];
-  keys[i] = k;
-  vals[i] = (uint32_t)i;
-  atomicAdd(cnt + k, 1);   // integer count: deterministic
+  const int64_t k = g[i];
+  tmp[offsets[k] + atomicAdd(cursor + k, 1)] = (int32_t)i;
 }
 
-__global__ __launch_bounds__(256) void copy_u32_i32_kernel(const uint32_t* a, int32_t* b, int64_t n) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) b[i] = (int32_t)a[i];
-}
-
-static int bits_for(int64_t m) {
-  int b = 1;
-  while (b < 32 && (1ll << b) < m) ++b;
-  return b;
-}
-
-static size_t sort_temp_bytes(int64_t n, int bits) {
-  size_t bytes = 0;
-  hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                                    (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, bits,
-                                                    (hipStream_t)0);
-  if (e != hipSuccess || bytes == 0) {
-    (void)hipGetLastError();
-    bytes = (size_t)n * 16 + (1u << 20);   // no device to ask (CPU-only host): generous bound
-  }
-  return bytes;
+// slot j of the unordered segment image -> perm[offsets + stable rank]; rank_out (optional) [element] = that rank
+__global__ __launch_bounds__(256) void csr_rank_kernel(const int64_t* __restrict__ g, int64_t n,
+                                                      const int32_t* __restrict__ offsets,
+                                                      const int32_t* __restrict__ tmp, int32_t* __restrict__ perm,
+                                                      int64_t* __restrict__ rank_out) {
+  int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int32_t e = tmp[j];
+  const int64_t k = g[e];
+  const int lo = offsets[k], hi = offsets[k + 1];
+  int r = 0;
+  for (int t = lo; t < hi; ++t) r += tmp[t] < e;
+  if (perm) perm[lo + r] = e;
+  if (rank_out) rank_out[e] = r;
 }
 
 size_t tmae_segment_csr_workspace(int64_t n, int64_t m) {
-  return 4 * tmae_align((size_t)n * 4) + tmae_align((size_t)(m + 1) * 4) + tmae_scan_i32_workspace(m + 1) +
-         tmae_align(sort_temp_bytes(n, bits_for(m))) + 4096;
+  return tmae_align((size_t)n * 4) + 2 * tmae_align((size_t)(m + 1) * 4) + tmae_scan_i32_workspace(m + 1) + 4096;
 }
 
-// keys_sorted (optional out) receives the sorted group ids
-static int csr_build(const int64_t* g, int64_t n, int64_t m, int32_t* perm, int32_t* offsets, uint32_t** keys_sorted,
+static int csr_build(const int64_t* g, int64_t n, int64_t m, int32_t* perm, int32_t* offsets, int64_t* rank_out,
                      void* wsp, size_t ws_bytes, hipStream_t stream) {
   if (n < 0 || m < 0 || n >= (1ll << 31) || m >= (1ll << 31) || !offsets) return TMAE_EARG;
-  if (n > 0 && (!g || !perm)) return TMAE_EARG;
+  if (n > 0 && (!g || (!perm && !rank_out))) return TMAE_EARG;
   WsCarver ws(wsp, ws_bytes);
-  uint32_t* k_in = ws.take<uint32_t>((size_t)n);
-  uint32_t* k_out = ws.take<uint32_t>((size_t)n);
-  uint32_t* v_in = ws.take<uint32_t>((size_t)n);
-  uint32_t* v_out = ws.take<uint32_t>((size_t)n);
+  int32_t* tmp = ws.take<int32_t>((size_t)n);
   int32_t* cnt = ws.take<int32_t>((size_t)m + 1);
+  int32_t* cursor = ws.take<int32_t>((size_t)m + 1);
   size_t sb = tmae_scan_i32_workspace(m + 1);
   char* scanws = ws.take<char>(sb);
-  const int bits = bits_for(m);
-  size_t tb = sort_temp_bytes(n, bits);
-  char* temp = ws.take<char>(tb);
   if (!ws.ok) return TMAE_EWS;
   hipMemsetAsync(cnt, 0, (size_t)(m + 1) * 4, stream);
-  if (n > 0) {
-    hipLaunchKernelGGL(csr_keys_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, g, n, k_in, v_in, cnt);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, tb, k_in, k_out, v_in, v_out, (int)n, 0, bits, stream);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(copy_u32_i32_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, v_out, perm, n);
-  }
+  hipMemsetAsync(cursor, 0, (size_t)(m + 1) * 4, stream);
+  if (n > 0) hipLaunchKernelGGL(csr_count_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, g, n, cnt);
   int r = tmae_scan_i32(cnt, offsets, m + 1, nullptr, scanws, sb, stream);   // offsets[m] = n
   if (r) return r;
-  if (keys_sorted) *keys_sorted = k_out;
+  if (n > 0) {
+    hipLaunchKernelGGL(csr_scatter_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, g, n, offsets, cursor, tmp);
+    hipLaunchKernelGGL(csr_rank_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, g, n, offsets, tmp, perm,
+                       rank_out);
+  }
   return tmae_launch_status();
 }
 
@@ -209,18 +203,8 @@ int tmae_segment_csr(const int64_t* inverse, int64_t n, int64_t m, int32_t* perm
   return csr_build(inverse, n, m, perm, offsets, nullptr, ws, ws_bytes, (hipStream_t)stream);
 }
 
-__global__ __launch_bounds__(256) void rank_emit_kernel(const uint32_t* __restrict__ keys_sorted,
-                                                       const int32_t* __restrict__ perm,
-                                                       const int32_t* __restrict__ offsets, int64_t n,
-                                                       int64_t* __restrict__ out) {
-  int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  out[perm[j]] = j - offsets[keys_sorted[j]];
-}
-
 size_t tmae_ingroup_rank_workspace(int64_t n, int64_t num_groups) {
-  return tmae_segment_csr_workspace(n, num_groups) + tmae_align((size_t)n * 4) +
-         tmae_align((size_t)(num_groups + 1) * 4);
+  return tmae_segment_csr_workspace(n, num_groups) + tmae_align((size_t)(num_groups + 1) * 4);
 }
 
 int tmae_ingroup_rank(const int64_t* group, int64_t n, int64_t num_groups, int64_t* out, void* wsp, size_t ws_bytes,
@@ -230,14 +214,9 @@ int tmae_ingroup_rank(const int64_t* group, int64_t n, int64_t num_groups, int64
   if (n < 0 || num_groups < 0 || (n > 0 && (!group || !out))) return TMAE_EARG;
   if (n == 0) return TMAE_OK;
   WsCarver ws(wsp, ws_bytes);
-  int32_t* perm = ws.take<int32_t>((size_t)n);
   int32_t* offsets = ws.take<int32_t>((size_t)num_groups + 1);
   if (!ws.ok) return TMAE_EWS;
-  uint32_t* ks = nullptr;
-  int r = csr_build(group, n, num_groups, perm, offsets, &ks, ws.base + ws.used, ws.size - ws.used, stream);
-  if (r) return r;
-  hipLaunchKernelGGL(rank_emit_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, ks, perm, offsets, n, out);
-  return tmae_launch_status();
+  return csr_build(group, n, num_groups, nullptr, offsets, out, ws.base + ws.used, ws.size - ws.used, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

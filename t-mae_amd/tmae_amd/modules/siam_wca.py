@@ -26,6 +26,9 @@ class SiamWCA(nn.Module):
         for c in model_cfg.SST_BLOCK_LIST:
             self.sst_blocks.append(SSTBlockV1(c, in_channels, c.NAME))
             in_channels = c.ENCODER.D_MODEL
+        for blk, nxt in zip(list(self.sst_blocks)[:-1], list(self.sst_blocks)[1:]):   # consecutive strided stages: one sync
+            if blk.conv_down is not None and nxt.conv_down is not None:
+                getattr(blk.conv_down, '0').lookahead = True
         self.wca_blocks = nn.ModuleList([WCABlock(c, c.ENCODER.D_MODEL, c.NAME) for c in model_cfg.SST_BLOCK_LIST])
         in_channels = 0
         self.deblocks = nn.ModuleList()

@@ -33,6 +33,9 @@ class SiamWCA_MAE(nn.Module):
         for cfg in model_cfg.SST_BLOCK_LIST:
             self.sst_blocks.append(SSTBlockV1(cfg, in_channels, cfg.NAME))
             in_channels = cfg.ENCODER.D_MODEL
+        for blk, nxt in zip(list(self.sst_blocks)[:-1], list(self.sst_blocks)[1:]):      # consecutive strided stages share one sync
+            if blk.conv_down is not None and nxt.conv_down is not None:
+                getattr(blk.conv_down, '0').lookahead = True
         self.wca_blocks = nn.ModuleList()
         for cfg in model_cfg.SST_BLOCK_LIST:
             self.wca_blocks.append(WCABlock(cfg, cfg.ENCODER.D_MODEL, cfg.NAME))

@@ -58,6 +58,7 @@ class SparseConvolution(SparseModule):
             raise NotImplementedError('strided sparse conv: only k3 s2 p1 (spt_backbone.py:280-284)')
         self.in_channels, self.out_channels = in_channels, out_channels
         self.subm, self.stride, self.indice_key = subm, stride, indice_key
+        self.lookahead = False       # set by the backbone when another k3 s2 p1 conv follows on this conv's output sites
         self.weight = nn.Parameter(torch.empty(out_channels, 3, 3, in_channels))
         nn.init.kaiming_uniform_(self.weight.view(out_channels, -1), a=5 ** 0.5)
 
@@ -72,28 +73,49 @@ class SparseConvolution(SparseModule):
             y = ops.sparse_conv(x.features, self.weight, rb[0], rb[1])
             return x.replace_feature(y)
         rb = x._cache.get('down')
+        nxt = None
         if rb is None:
-            out_grid, out_ind, n_out, (oy, ox) = ops.spconv_down_outputs(x.grid, x.batch_size, ny, nx)
-            groups = None
-            if x.groups is None:
-                m_out = int(n_out.item())                           # one host sync per strided conv (output count)
-            else:                                                   # + the output rows of every sample group but the last
-                cells, counts = 0, [n_out.view(1).long()]
-                for _, nb in x.groups[:-1]:
-                    cells += nb * oy * ox
-                    counts.append((out_grid[:cells] >= 0).sum().view(1))
-                host = torch.cat(counts).cpu().tolist()             # still one sync
-                m_out = int(host[0])
-                ends = [int(v) for v in host[1:]] + [m_out]
-                groups = tuple((e - b, nb) for b, e, (_, nb) in zip([0] + ends[:-1], ends, x.groups))
-            out_ind = out_ind[:m_out]
-            nbr = ops.spconv_neighbors(out_ind, x.grid, x.batch_size, ny, nx, 2)
-            nbr_t = ops.spconv_neighbors_t(x.indices, out_grid, x.batch_size, oy, ox, 2)
-            rb = (nbr, nbr_t, out_ind, out_grid, (oy, ox), groups)
+            rb, nxt = _down_rulebooks(x, 2 if self.lookahead else 1)
             x._cache['down'] = rb
         nbr, nbr_t, out_ind, out_grid, oshape, groups = rb
         y = ops.sparse_conv(x.features, self.weight, nbr, nbr_t)
-        return SparseConvTensor(y, out_ind, oshape, x.batch_size, out_grid, groups=groups)
+        # the next strided conv's rulebook (built with this one, one host sync for both) travels in the output's cache
+        return SparseConvTensor(y, out_ind, oshape, x.batch_size, out_grid, groups=groups,
+                                cache=None if nxt is None else {'down': nxt})
+
+
+def _down_rulebooks(x, depth):
+    """Rulebooks of `depth` chained SparseConv2d(k3, s2, p1) levels starting at x's sites.  The output sites of a level
+    depend on the previous level's sites only (never on features), so all levels are enqueued first and their counts
+    -- output rows, and the rows of every sample group but the last -- come back in ONE host sync."""
+    levels, counts = [], []
+    grid, (ny, nx) = x.grid, x.spatial_shape
+    for _ in range(depth):
+        out_grid, out_ind, n_out, (oy, ox) = ops.spconv_down_outputs(grid, x.batch_size, ny, nx)
+        counts.append(n_out.view(1).long())
+        if x.groups is not None:
+            cells = 0
+            for _, nb in x.groups[:-1]:
+                cells += nb * oy * ox
+                counts.append((out_grid[:cells] >= 0).sum().view(1))
+        levels.append((grid, ny, nx, out_grid, out_ind, oy, ox))
+        grid, ny, nx = out_grid, oy, ox
+    host = torch.cat(counts).cpu().tolist()                       # the one sync
+    per = len(host) // depth
+    rbs, in_ind = [], x.indices
+    for d, (grid, ny, nx, out_grid, out_ind, oy, ox) in enumerate(levels):
+        h = host[d * per:(d + 1) * per]
+        m_out = int(h[0])
+        groups = None
+        if x.groups is not None:
+            ends = [int(v) for v in h[1:]] + [m_out]
+            groups = tuple((e - b, nb) for b, e, (_, nb) in zip([0] + ends[:-1], ends, x.groups))
+        out_ind = out_ind[:m_out]
+        nbr = ops.spconv_neighbors(out_ind, grid, x.batch_size, ny, nx, 2)
+        nbr_t = ops.spconv_neighbors_t(in_ind, out_grid, x.batch_size, oy, ox, 2)
+        rbs.append((nbr, nbr_t, out_ind, out_grid, (oy, ox), groups))
+        in_ind = out_ind
+    return rbs[0], (rbs[1] if depth > 1 else None)
 
 
 class SubMConv2d(SparseConvolution):

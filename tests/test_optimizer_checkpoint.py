@@ -198,13 +198,15 @@ def test_two_training_steps_follow_the_reference_loop():
     opt = build_optimizer(model, _optim_cfg())
     sched, _ = build_scheduler(opt, 5, 2, -1, _optim_cfg())
     dev = torch.device('cuda')
+    lrs = []
     for it in range(2):
+        sched.step(it)
+        lrs.append(opt.lr)
         bd = {'points': torch.from_numpy(g[f'b{it}_points']).to(dev), 'batch_size': 2,
               'points_prev': torch.from_numpy(g[f'b{it}_points_prev']).to(dev),
               'mae_noise': torch.from_numpy(g[f'b{it}_noise']).to(dev)}
         loss, _, _ = train_one_step(model, opt, sched, bd, it, model_fn_decorator(), amp_dtype=None)
         assert abs(float(loss) - float(g['step_losses'][it])) < 1e-4, (it, float(loss), float(g['step_losses'][it]))
-    lr = 3e-4
     sd = model.state_dict()
     init = {str(n): torch.from_numpy(np.array(g[f'init_{i}'])) for i, n in enumerate(g['state_names'])}
     cosines, moved = {}, set(str(n) for n in g['group0']) | set(str(n) for n in g['group1'])
@@ -220,9 +222,9 @@ def test_two_training_steps_follow_the_reference_loop():
             # between the CPU's and the GPU's summation orders
             assert d.max() <= 2e-3 * max(1.0, float(ref.abs().max())), n
         elif n in moved:
-            # Adam's first two updates are ~ lr * sign(g): an element whose gradient is rounding noise may flip
-            # (2 lr per step); everything else must follow the reference's update
-            assert d.max() <= 4.5 * lr, (n, float(d.max()))
+            # Adam's first two updates are ~ lr_t * sign(g) (the second up to ~1.4 lr_t): an element whose gradient
+            # is rounding noise may flip in both (2 |update| each); everything else must follow the reference's update
+            assert d.max() <= 2 * (lrs[0] + 1.5 * lrs[1]), (n, float(d.max()))
             du, dr = (mine - init[n]).flatten().double(), (ref - init[n]).flatten().double()
             cosines[n] = float(torch.nn.functional.cosine_similarity(du, dr, dim=0))
         else:
