@@ -203,6 +203,19 @@ int tmae_spconv_neighbors(const int32_t* out_indices, int64_t m_out, const int32
                           int batch, int ny, int nx, int stride, int32_t* nbr, void* stream);
 int tmae_spconv_neighbors_t(const int32_t* in_indices, int64_t m_in, const int32_t* grid_out,
                             int batch, int oy, int ox, int stride, int32_t* nbr_t, void* stream);
+/* A9  the sparse convolution itself (spconv SparseConv2d / SubMConv2d forward and input gradient,
+ * pcdet/utils/spconv_utils.py:37-56, spt_backbone.py:280-304) as an implicit GEMM over the rulebook: bf16 in / out,
+ * fp32 accumulation, no [m, 9 cin] im2col matrix.
+ *   fwd:      out [m_out, cout] = sum_t feat[nbr[o,t], :] . weight[:, t, :]^T      weight [cout, 9*cin] (spconv-2 layout
+ *             [cout,3,3,cin] flattened), nbr [m_out, 9] from tmae_spconv_neighbors (-1 = no neighbour)
+ *   bwd_data: din [m_in, cin] = sum_t dout[nbr_t[i,t], :] . weight_t[:, t, :]^T    weight_t [cin, 9*cout] with
+ *             weight_t[c, t*cout + n] = weight[n, t*cin + c], nbr_t from tmae_spconv_neighbors_t
+ * cin, cout in {128, 256} (multiples of 128); row pitches ld* in elements, multiples of 8; 16-byte aligned bases. */
+int tmae_spconv_fwd(const void* feat, int64_t ldf, int64_t m_in, int cin, const int32_t* nbr, int64_t m_out,
+                    const void* weight, int cout, void* out, int64_t ldo, void* stream);
+int tmae_spconv_bwd_data(const void* dout, int64_t lddo, int64_t m_out, int cout, const int32_t* nbr_t, int64_t m_in,
+                         const void* weight_t, int cin, void* din, int64_t lddi, void* stream);
+
 /* gather-GEMM form: cols [m_out, 9*c] = rows of feat selected by nbr (zeros where -1), to be
  * multiplied by the [cout, 9*c] view of the spconv-2 weight [cout,3,3,cin]; and its adjoint
  * din [m_in, c] = sum_t dcols[nbr_t[i,t], t*c:(t+1)*c]. */

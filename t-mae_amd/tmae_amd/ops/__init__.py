@@ -906,16 +906,50 @@ def _gather9(feat, nbr):
     return cols
 
 
+def _spconv_native_ok(f, cin, cout):
+    return (_SPCONV_NATIVE and f.dtype == torch.bfloat16 and cin in (128, 256) and cout in (128, 256)
+            and f.stride(1) == 1 and f.stride(0) % 8 == 0 and f.data_ptr() % 16 == 0)
+
+
+import os as _os
+_SPCONV_NATIVE = _os.environ.get('TMAE_SPCONV', 'native') != 'gather'
+
+
+def spconv_fwd(feat, nbr, w2d):
+    """out [m_out, cout] = implicit-GEMM sparse conv (csrc/spconv_igemm.hip); w2d [cout, 9*cin] bf16."""
+    m_out, cout, cin = nbr.shape[0], w2d.shape[0], feat.shape[1]
+    out = torch.empty((m_out, cout), dtype=torch.bfloat16, device=feat.device)
+    check(lib.tmae_spconv_fwd(_p(feat), feat.stride(0), feat.shape[0], cin, _p(nbr), m_out, _p(w2d), cout, _p(out), cout,
+                              _s()), 'tmae_spconv_fwd')
+    return out
+
+
+def spconv_bwd_data(dout, nbr_t, w2d, cin):
+    """din [m_in, cin] through the transposed rulebook; w2d [cout, 9*cin] (transposed copy made here, ~1 MB)."""
+    cout = w2d.shape[0]
+    m_in = nbr_t.shape[0]
+    wt = w2d.view(cout, 9, cin).permute(2, 1, 0).contiguous().view(cin, 9 * cout)
+    din = torch.empty((m_in, cin), dtype=torch.bfloat16, device=dout.device)
+    check(lib.tmae_spconv_bwd_data(_p(dout), dout.stride(0), dout.shape[0], cout, _p(nbr_t), m_in, _p(wt), cin, _p(din),
+                                   cin, _s()), 'tmae_spconv_bwd_data')
+    return din
+
+
 class _SparseConv(torch.autograd.Function):
-    """out[o] = sum_t W[:,t,:] in[nbr[o,t]] as gather + one GEMM; weight [cout,3,3,cin] (spconv-2 layout)."""
+    """out[o] = sum_t W[:,t,:] in[nbr[o,t]]; weight [cout,3,3,cin] (spconv-2 layout).  bf16 with 128 / 256 channels: the
+    native implicit GEMM (forward, input gradient) and the rulebook-reading token-split kernel (weight gradient) -- the
+    [m, 9 cin] im2col matrix never exists.  Other shapes / fp32: gather + one GEMM."""
 
     @staticmethod
     def forward(ctx, feat, weight, nbr, nbr_t):
         cdt = compute_dtype(feat)
         f = feat.to(cdt).contiguous()
         w = cast_param(weight, cdt).reshape(weight.shape[0], -1)
-        cols = _gather9(f, nbr)
-        out = cols @ w.t()
+        ctx.native = _spconv_native_ok(f, f.shape[1], w.shape[0]) and f.shape[0] > 0
+        if ctx.native:
+            out = spconv_fwd(f, nbr, w.contiguous())
+        else:
+            out = _gather9(f, nbr) @ w.t()
         ctx.save_for_backward(f, w, nbr, nbr_t)
         ctx.wshape, ctx.wdtype, ctx.fdtype = weight.shape, weight.dtype, feat.dtype
         return out
@@ -924,12 +958,15 @@ class _SparseConv(torch.autograd.Function):
     def backward(ctx, dout):
         f, w, nbr, nbr_t = ctx.saved_tensors
         dout = dout.to(f.dtype).contiguous()
-        dcols = token_gemm_dx(dout, w)                                # [m_out, 9*cin]: streaming kernel when it fits
-        din = torch.empty_like(f)
-        check(lib.tmae_spconv_gather_t(_p(dcols), _dt(dcols), dout.shape[0], f.shape[1], _p(nbr_t), f.shape[0],
-                                       _p(din), _s()), 'tmae_spconv_gather_t')
-        del dcols
         cin, cout = f.shape[1], dout.shape[1]
+        if ctx.native and dout.data_ptr() % 16 == 0:
+            din = spconv_bwd_data(dout, nbr_t, w.contiguous(), cin)
+        else:
+            dcols = token_gemm_dx(dout, w)                                # [m_out, 9*cin]: streaming kernel when it fits
+            din = torch.empty_like(f)
+            check(lib.tmae_spconv_gather_t(_p(dcols), _dt(dcols), dout.shape[0], f.shape[1], _p(nbr_t), f.shape[0],
+                                           _p(din), _s()), 'tmae_spconv_gather_t')
+            del dcols
         if dout.dtype == torch.bfloat16 and cin % 128 == 0 and cout % 8 == 0 and dout.shape[0] >= 4096:
             # token-split kernel reading the feature rows through the rulebook: no [m_out, 9*cin] matrix
             dw = torch.empty((cout, 9 * cin), dtype=torch.float32, device=f.device)
