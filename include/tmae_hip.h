@@ -210,7 +210,8 @@ int tmae_spconv_neighbors_t(const int32_t* in_indices, int64_t m_in, const int32
  *             [cout,3,3,cin] flattened), nbr [m_out, 9] from tmae_spconv_neighbors (-1 = no neighbour)
  *   bwd_data: din [m_in, cin] = sum_t dout[nbr_t[i,t], :] . weight_t[:, t, :]^T    weight_t [cin, 9*cout] with
  *             weight_t[c, t*cout + n] = weight[n, t*cin + c], nbr_t from tmae_spconv_neighbors_t
- * cin, cout in {128, 256} (multiples of 128); row pitches ld* in elements, multiples of 8; 16-byte aligned bases. */
+ * cin, cout in {128, 256, 384} (384: the dense decoder's concatenated input, SiamWCA_MAE.py:100-115, run through
+ * the rulebook of a full grid); row pitches ld* in elements, multiples of 8; 16-byte aligned bases. */
 int tmae_spconv_fwd(const void* feat, int64_t ldf, int64_t m_in, int cin, const int32_t* nbr, int64_t m_out,
                     const void* weight, int cout, void* out, int64_t ldo, void* stream);
 int tmae_spconv_bwd_data(const void* dout, int64_t lddo, int64_t m_out, int cout, const int32_t* nbr_t, int64_t m_in,

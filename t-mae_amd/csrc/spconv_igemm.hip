@@ -128,10 +128,10 @@ __global__ __launch_bounds__(256, 2) void spconv_igemm_kernel(const __hip_bfloat
 }
 
 // out [m_out, cout] bf16 = sparse conv of feat [m_in, cin] bf16 through the rulebook nbr [m_out, 9] with the weight
-// matrix W [cout, 9 * cin] bf16 (the spconv-2 layout [cout, 3, 3, cin] flattened).  cin in {128, 256}, cout % 128 == 0.
+// matrix W [cout, 9 * cin] bf16 (the spconv-2 layout [cout, 3, 3, cin] flattened).  cin in {128, 256, 384}, cout % 128 == 0.
 static int igemm_launch(const void* feat, int64_t ldf, int64_t m_in, int cin, const int32_t* nbr, int64_t m_out,
                         const void* w, int cout, void* out, int64_t ldo, hipStream_t stream) {
-  if (m_in < 0 || m_out < 0 || (cin != 128 && cin != 256) || cout <= 0 || (cout % IG_BN) || ldf < cin || ldo < cout ||
+  if (m_in < 0 || m_out < 0 || (cin != 128 && cin != 256 && cin != 384) || cout <= 0 || (cout % IG_BN) || ldf < cin || ldo < cout ||
       (ldf % 8) || (ldo % 8))
     return TMAE_EARG;
   if (m_out == 0) return TMAE_OK;
@@ -143,8 +143,11 @@ static int igemm_launch(const void* feat, int64_t ldf, int64_t m_in, int cin, co
   if (cin == 128)
     hipLaunchKernelGGL((spconv_igemm_kernel<128>), dim3((unsigned)grid), dim3(256), 0, stream, (const __hip_bfloat16*)feat,
                        ldf, nbr, m_out, (const __hip_bfloat16*)w, cout, (__hip_bfloat16*)out, ldo);
-  else
+  else if (cin == 256)
     hipLaunchKernelGGL((spconv_igemm_kernel<256>), dim3((unsigned)grid), dim3(256), 0, stream, (const __hip_bfloat16*)feat,
+                       ldf, nbr, m_out, (const __hip_bfloat16*)w, cout, (__hip_bfloat16*)out, ldo);
+  else
+    hipLaunchKernelGGL((spconv_igemm_kernel<384>), dim3((unsigned)grid), dim3(256), 0, stream, (const __hip_bfloat16*)feat,
                        ldf, nbr, m_out, (const __hip_bfloat16*)w, cout, (__hip_bfloat16*)out, ldo);
   return tmae_launch_status();
 }

@@ -141,7 +141,7 @@ class SiamWCA_MAE(nn.Module):
         conv, bn = self.decoder_conv_out[0], self.decoder_conv_out[1]
         nhwc = cat.permute(0, 2, 3, 1)
         if (self.training and nhwc.is_contiguous() and ops.dense_conv3x3_ok(nhwc, conv)
-                and os.environ.get('TMAE_DENSE_WGRAD', '1') != '0'):
+                and os.environ.get('TMAE_DENSE_CONV', 'native') != 'miopen'):
             y = ops.dense_conv3x3(nhwc, conv.weight).permute(0, 3, 1, 2)     # weight gradient: our token-split kernel
         else:
             y = conv(cat)

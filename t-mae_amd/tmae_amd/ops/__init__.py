@@ -1170,36 +1170,56 @@ def _dense_rulebook(batch, ny, nx, device):
     return nbr
 
 
+_DENSE_CONV = _os.environ.get('TMAE_DENSE_CONV', 'native')     # native: all three passes on our kernels; wgrad: only dW; miopen
+
+
 class _DenseConv3x3(torch.autograd.Function):
-    """Conv2d(cin, cout, 3, padding=1, bias=False) on a channels-last activation [B, Y, X, cin] (SiamWCA_MAE.py:100-115).
-    Forward and input gradient: the library's implicit GEMM; weight gradient: the token-split kernel of csrc/wgrad.hip
-    reading the 9 shifted rows of every cell through the dense rulebook (dW[cout, 9 cin] = dY^T . im2col(X), never
-    materialised) -- the library's wrw kernel ran at 0.5 PFLOP/s on this 1.75 M-cell x 3456 x 128 reduction."""
+    """Conv2d(cin, cout, 3, padding=1, bias=False) on a channels-last activation [B, Y, X, cin] (SiamWCA_MAE.py:100-115)
+    as a sparse conv over the rulebook of a FULL grid: forward and input gradient on the implicit-GEMM kernel of
+    csrc/spconv_igemm.hip, weight gradient on the token-split kernel of csrc/wgrad.hip (dW[cout, 9 cin] = dY^T .
+    im2col(X), never materialised).  The library's implicit GEMMs ran at 0.52-0.68 PFLOP/s on this shape."""
 
     @staticmethod
     def forward(ctx, x_nhwc, weight):
         cdt = compute_dtype(x_nhwc)
-        x = x_nhwc.to(cdt)
+        x = x_nhwc.to(cdt).contiguous()
         w = cast_param(weight, cdt)
-        y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.contiguous(memory_format=torch.channels_last), padding=1)
-        ctx.save_for_backward(x, w)
+        B, Y, X, cin = x.shape
+        cout = w.shape[0]
+        n = B * Y * X
+        ctx.native = _DENSE_CONV == 'native' and cin in (128, 256, 384) and cout % 128 == 0
+        if ctx.native:
+            nbr = _dense_rulebook(B, Y, X, x.device)
+            w2d = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
+            y = spconv_fwd(x.view(n, cin), nbr, w2d).view(B, Y, X, cout)
+            ctx.save_for_backward(x, w2d)
+        else:
+            y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.contiguous(memory_format=torch.channels_last),
+                                           padding=1).permute(0, 2, 3, 1)
+            ctx.save_for_backward(x, w)
         ctx.meta = (x_nhwc.dtype, weight.dtype)
-        return y.permute(0, 2, 3, 1)
+        return y
 
     @staticmethod
     def backward(ctx, dy_nhwc):
         x, w = ctx.saved_tensors
         B, Y, X, cin = x.shape
         cout = w.shape[0]
+        n = B * Y * X
         dy = dy_nhwc.to(x.dtype).contiguous()
+        nbr = _dense_rulebook(B, Y, X, x.device)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(
-                dy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w.contiguous(memory_format=torch.channels_last), None,
-                [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1).to(ctx.meta[0])
-        n = B * Y * X
-        dy2, x2 = dy.view(n, cout), x.contiguous().view(n, cin)
-        nbr = _dense_rulebook(B, Y, X, x.device)
+            if ctx.native:
+                nbr_t = _DENSE_NBR.get(('t', B, Y, X, x.device))
+                if nbr_t is None:                      # transposed rulebook of a stride-1 conv = flipped taps
+                    nbr_t = _DENSE_NBR[('t', B, Y, X, x.device)] = nbr.flip(1).contiguous()
+                dx = spconv_bwd_data(dy.view(n, cout), nbr_t, w, cin).view(B, Y, X, cin).to(ctx.meta[0])
+            else:
+                dx = torch.ops.aten.convolution_backward(
+                    dy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w.contiguous(memory_format=torch.channels_last), None,
+                    [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1).to(ctx.meta[0])
+        dy2, x2 = dy.view(n, cout), x.view(n, cin)
         dw = torch.empty((cout, 9 * cin), dtype=torch.float32, device=x.device)
         wsb = lib.tmae_linear_wgrad_workspace(n, cout, 9 * cin)
         ws = _ws(wsb, x.device)
