@@ -11,6 +11,7 @@
 // of one token: two 16-byte stores per token, four lanes per 128-byte line (the store shape csrc/token_gemm.hip found
 // decisive).  The input gradient is the same kernel on the transposed rulebook and the transposed weight.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -90,6 +91,9 @@ __global__ __launch_bounds__(256, 2) void spconv_igemm_kernel(const __hip_bfloat
   for (int step = 0; step < STEPS; ++step) {
     const int buf = step & 1;
     if (step + 1 < STEPS) gload(step + 1);
+    // keep the next slice's loads ABOVE the MFMA block (left alone, the scheduler sinks them into it and the wait for
+    // them lands ~250 cycles later: less than one L2 round trip under load)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < IG_BK / 32; ++ks) {
       bf16x8 af[4], bfr[4];
@@ -105,10 +109,155 @@ __global__ __launch_bounds__(256, 2) void spconv_igemm_kernel(const __hip_bfloat
         for (int mt = 0; mt < 4; ++mt)
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[mt], acc[nt][mt], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (step + 1 < STEPS) lstore(buf ^ 1);
     __syncthreads();
   }
   // rows 4g + r of column tile nt = output channels wn*64 + 16g + 4nt + r; column i = token wm*64 + mt*16 + i
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int64_t r = row0 + wm * 64 + mt * 16 + i;
+    if (r < m_out) {
+      __hip_bfloat16* p = out + r * ldo + n0 + wn * 64 + 16 * g;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u32x4 v;
+        v[0] = ig_bf16_bits(acc[2 * h][mt][0]) | (ig_bf16_bits(acc[2 * h][mt][1]) << 16);
+        v[1] = ig_bf16_bits(acc[2 * h][mt][2]) | (ig_bf16_bits(acc[2 * h][mt][3]) << 16);
+        v[2] = ig_bf16_bits(acc[2 * h + 1][mt][0]) | (ig_bf16_bits(acc[2 * h + 1][mt][1]) << 16);
+        v[3] = ig_bf16_bits(acc[2 * h + 1][mt][2]) | (ig_bf16_bits(acc[2 * h + 1][mt][3]) << 16);
+        *reinterpret_cast<u32x4*>(p + 8 * h) = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ring variant (the one that runs): 256-row x 128-column tile, 8 waves, the slices travel global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a 3-slot ring, two slices in flight behind a
+// COUNTED vmcnt, one raw s_barrier per slice (a __syncthreads() would drain the DMA queue with its vmcnt(0)).
+// LDS image: plain 128-byte rows (64 channels of one slice) with the 16-byte chunks XOR-swizzled by (row & 7); an
+// LDS-DMA instruction writes lane l at base + 16 l (8 rows x 8 chunks), so the swizzle is applied to the SOURCE chunk a
+// lane fetches and again to the chunk a fragment read addresses (conflict-free ds_read_b128 for the MFMA operand
+// layout).  The gather is the per-lane source address of the DMA; an absent neighbour fetches a row of zeros.
+// ------------------------------------------------------------------------------------------------
+#define IR_BM 256
+#define IR_STAGE (IR_BM * 128 + IG_BN * 128)           // 48 KB per ring slot
+__device__ __attribute__((aligned(256))) unsigned ig_zero_row[64];   // 256 bytes of zeros (static storage: zero-initialised)
+
+__device__ __forceinline__ void ig_glds16(const void* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int CIN>
+__global__ __launch_bounds__(512, 1) void spconv_igemm_ring_kernel(const __hip_bfloat16* __restrict__ feat, int64_t ldf,
+                                                                  const int32_t* __restrict__ nbr, int64_t m_out,
+                                                                  const __hip_bfloat16* __restrict__ W, int cout,
+                                                                  __hip_bfloat16* __restrict__ out, int64_t ldo) {
+  constexpr int KC = CIN / IG_BK;
+  constexpr int STEPS = 9 * KC;
+  extern __shared__ __attribute__((aligned(1024))) char ring[];        // 3 slots, then the rulebook tile
+  int* nb = reinterpret_cast<int*>(ring + 3 * IR_STAGE);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15;
+  const int nct = cout / IG_BN;
+  const int64_t bid = blockIdx.x;
+  // ids of one residue mod 8 share an XCD (and its L2): give every XCD a CONTIGUOUS range of row tiles -- a tile's
+  // neighbour rows (y +- 1: two tiles away in a 468-wide dense grid) then come from the same L2 -- and keep the column
+  // tiles of one row tile on adjacent ids of that XCD
+  const int64_t per_xcd = (int64_t)gridDim.x / (8 * nct);
+  const int64_t rt = (bid & 7) * per_xcd + (bid >> 3) / nct;
+  const int ct = (int)((bid >> 3) % nct);
+  const int64_t row0 = rt * IR_BM;
+  if (row0 >= m_out) return;
+  const int n0 = ct * IG_BN;
+  for (int e = tid; e < IR_BM * 9; e += 512) {
+    const int64_t r = row0 + e / 9;
+    nb[e] = r < m_out ? nbr[r * 9 + (e % 9)] : -1;
+  }
+  __syncthreads();
+  // ---- what this lane fetches in every slice: 4 gathered-row pieces (A) and 2 weight-row pieces (B)
+  const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;                   // row of the 8-row group, source chunk (swizzled)
+  const char* wsrc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int L = w * 16 + j * 8 + r8, s64 = L & 63;                   // LDS row L holds weight column n (16 consecutive
+    const int n = (L & 64) + 16 * ((s64 >> 2) & 3) + 4 * (s64 >> 4) + (s64 & 3);   // output channels per lane, see above)
+    wsrc[j] = reinterpret_cast<const char*>(W + (int64_t)(n0 + n) * (9 * CIN)) + chunk * 16;
+  }
+  const char* fbase = reinterpret_cast<const char*>(feat) + chunk * 16;
+  const char* zrow = reinterpret_cast<const char*>(ig_zero_row) + chunk * 16;
+  const int arow = w * 32 + r8;                                        // + 8 j
+  int src[4];
+  auto fetch_src = [&](int step) {
+    const int t = step / KC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) src[j] = nb[(arow + 8 * j) * 9 + t];     // four LDS reads, one wait
+  };
+  auto issue = [&](int step) {
+    const int t = step / KC, kc = step % KC, slot = step % 3;
+    char* sa = ring + slot * IR_STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // branch-free: both addresses are formed, a select picks (a branch around the 64-bit multiply costs an exec-mask
+      // round trip per piece)
+      const uintptr_t pa = (uintptr_t)fbase + (uintptr_t)(((int64_t)(src[j] < 0 ? 0 : src[j]) * ldf + kc * IG_BK) * 2);
+      const uintptr_t p = src[j] < 0 ? (uintptr_t)zrow : pa;
+      ig_glds16(reinterpret_cast<const void*>(p), sa + (w * 32 + 8 * j) * 128);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      ig_glds16(wsrc[j] + (t * CIN + kc * IG_BK) * 2, sa + IR_BM * 128 + (w * 16 + 8 * j) * 128);
+  };
+  const int wm = w & 3, wn = w >> 2;                   // wave tile: rows wm*64.., columns wn*64..
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  fetch_src(0);
+  issue(0);
+  fetch_src(1);
+  issue(1);
+  for (int step = 0; step < STEPS; ++step) {
+    // slice `step` has landed once every wave's 6 transfers of it are done: 6 of ours may stay in flight (slice step+1)
+    if (step + 1 < STEPS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bool more = step + 2 < STEPS;
+    if (more) fetch_src(step + 2);                     // rulebook entries of the slice issued below: their LDS latency
+    const char* sa = ring + (step % 3) * IR_STAGE;     // hides behind the first half of this slice's MFMAs
+    const char* sb = sa + IR_BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < IG_BK / 32; ++ks) {
+      if (ks == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(step + 2);                     // into the slot every wave finished reading before this barrier
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bf16x8 af[4], bfr[4];
+      const int c = ks * 4 + g;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int L = wn * 64 + nt * 16 + i;
+        af[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sb + L * 128 + ((c ^ (L & 7)) << 4)));
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int R = wm * 64 + mt * 16 + i;
+        bfr[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sa + R * 128 + ((c ^ (R & 7)) << 4)));
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[mt], acc[nt][mt], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot are done before it moves on
+  }
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int64_t r = row0 + wm * 64 + mt * 16 + i;
@@ -138,6 +287,26 @@ static int igemm_launch(const void* feat, int64_t ldf, int64_t m_in, int cin, co
   if (!feat || !nbr || !w || !out || m_in == 0) return TMAE_EARG;
   if (((uintptr_t)feat & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) return TMAE_EARG;
   const int nct = cout / IG_BN;
+  static const int impl = [] { const char* e = getenv("TMAE_IGEMM"); return e ? atoi(e) : 3; }();   // 2: register-staged 128x128
+  if (impl == 3) {
+    const int64_t rts = (m_out + IR_BM - 1) / IR_BM;
+    const int64_t grid = ((rts + 7) / 8) * 8 * nct;     // = 8 XCD residues x ceil(rts / 8) row tiles x nct column tiles
+    const int lds = 3 * IR_STAGE + IR_BM * 9 * 4;
+#define IR_LAUNCH(C)                                                                                                  \
+  do {                                                                                                                \
+    static bool attr = false;                                                                                         \
+    if (!attr) {                                                                                                      \
+      hipFuncSetAttribute((const void*)spconv_igemm_ring_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+      attr = true;                                                                                                    \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((spconv_igemm_ring_kernel<C>), dim3((unsigned)grid), dim3(512), lds, stream,                   \
+                       (const __hip_bfloat16*)feat, ldf, nbr, m_out, (const __hip_bfloat16*)w, cout,                  \
+                       (__hip_bfloat16*)out, ldo);                                                                    \
+  } while (0)
+    if (cin == 128) IR_LAUNCH(128); else if (cin == 256) IR_LAUNCH(256); else IR_LAUNCH(384);
+#undef IR_LAUNCH
+    return tmae_launch_status();
+  }
   const int64_t rts = (m_out + IG_BM - 1) / IG_BM;
   const int64_t grid = ((rts + 7) / 8) * 8 * nct;       // row tiles padded to a multiple of 8 (the XCD-aware id map)
   if (cin == 128)
