@@ -154,6 +154,7 @@ def vfe_forward(params, prefix, points, cfg):
     pfeat = x
     # make_fc_layers_GN: Linear(no bias) + BatchNorm1d(eps 1e-5) + ReLU, twice (network_utils.py:25-40)
     m = prefix + 'dvfe_mlps.0.'
+    x = x.to(params[m + '0.weight'].dtype)     # float64 parameters = the high-precision run of the same function
     x = F.linear(x, params[m + '0.weight'])
     x = F.relu(batch_norm_train(x, params[m + '1.weight'], params[m + '1.bias'], 1e-5))
     x = F.linear(x, params[m + '3.weight'])
@@ -724,7 +725,8 @@ def forward_loss(params, points, points_prev, noise, batch_size, cfg, capture=No
     pred = F.linear(vfeat, params[bp + 'decoder_pred.weight'], params[bp + 'decoder_pred.bias']).view(M, -1, 3)
     w = torch.from_numpy(mask)
     cap.update(pred_points=pred, gt_points=gt, group_inds=table)
-    return chamfer_distance(pred.float(), gt, w)
+    # SiamWCA_MAE.py:162 casts the prediction to fp32; float64 parameters (the high-precision run) stay float64
+    return chamfer_distance(pred if pred.dtype == torch.float64 else pred.float(), gt, w)
 
 
 # --------------------------------------------------------------------------- #
