@@ -120,8 +120,8 @@ def test_finetune_gradients_vs_float64_oracle(ft_oracle):
     """The fine-tune step's gradients against the oracle run in FLOAT64 (fixture G3d: per tensor the norm and four seeded
     +-1 projections).  fp32 cannot resolve this step's cancelling sums: the fp32 CPU oracle itself is ~2 % (median) off
     the float64 values, so the yardstick per tensor is the fp32 oracle's own error; the GPU (fp32 kernels, shifted
-    BatchNorm sums, token-split weight gradients) must stay within 3x of it, or within 5e-3 of the tensor's norm where the
-    CPU happened to be closer than that."""
+    BatchNorm sums, fp32 MFMA accumulation in the token-split weight gradients) is held to 4e-2 of each tensor's norm and
+    4e-3 in the median -- an order of magnitude inside the fp32 CPU path's own deviation."""
     g, d = golden('G3_finetune_e2e_3stage'), golden('G3d_finetune_grad64')
     cfg = ft_oracle.default_finetune_cfg(3)
     P = ft_oracle.init_finetune_params(cfg, seed=int(g['param_seed']), tau=float(g['tau']))
@@ -135,7 +135,7 @@ def test_finetune_gradients_vs_float64_oracle(ft_oracle):
     grads = dict(model.named_parameters())
     p64, p32 = d['proj64'], d['proj32']
     scale = float(np.median(p64[:, 0]))
-    worst = (0.0, None)
+    worst, rel, relc = (0.0, None), [], []
     for i, n in enumerate(str(x) for x in d['names']):
         gg = grads[n].grad.detach().double().flatten().cpu()
         gen = torch.Generator().manual_seed(100003 * (i + 1))
@@ -144,10 +144,15 @@ def test_finetune_gradients_vs_float64_oracle(ft_oracle):
             r = torch.randint(0, 2, (gg.numel(),), generator=gen, dtype=torch.int8).double() * 2 - 1
             mine.append(float((gg * r).sum()))
         err = np.abs(np.array(mine) - p64[i]).max()
-        bar = 3 * np.abs(p32[i] - p64[i]).max() + 5e-3 * p64[i, 0] + 1e-4 * scale
+        cpu = np.abs(p32[i] - p64[i]).max()
+        bar = 4e-2 * p64[i, 0] + 1e-4 * scale        # measured: median 1.1e-3, worst 2.8e-2 (a tau gradient) of the norm
         worst = max(worst, (err / bar, n))
+        rel.append(err / max(p64[i, 0], 1e-4 * scale))
+        relc.append(cpu / max(p64[i, 0], 1e-4 * scale))
         assert err <= bar, (n, err, bar, mine[0], p64[i, 0], p32[i, 0])
-    print('worst err / bar', worst)
+    assert np.median(rel) < 4e-3, np.median(rel)           # the fp32 CPU oracle: median 2.2e-2, worst 5.6 (!) of the norm
+    print('worst err / bar', worst, '| GPU error / norm: median %.2e max %.2e | CPU fp32 oracle: median %.2e max %.2e'
+          % (np.median(rel), np.max(rel), np.median(relc), np.max(relc)))
 
 
 def test_finetune_bf16_step_runs_and_is_close(ft_oracle):
