@@ -142,7 +142,6 @@ __global__ __launch_bounds__(256, 2) void spconv_igemm_kernel(const __hip_bfloat
 // layout).  The gather is the per-lane source address of the DMA; an absent neighbour fetches a row of zeros.
 // ------------------------------------------------------------------------------------------------
 #define IR_BM 256
-#define IR_STAGE (IR_BM * 128 + IG_BN * 128)           // 48 KB per ring slot
 __device__ __attribute__((aligned(256))) unsigned ig_zero_row[64];   // 256 bytes of zeros (static storage: zero-initialised)
 
 __device__ __forceinline__ void ig_glds16(const void* g, char* l) {
@@ -150,17 +149,26 @@ __device__ __forceinline__ void ig_glds16(const void* g, char* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int CIN>
+// BN = 128: 3 ring slots of 48 KB, two slices in flight.  BN = 256 (the 256-channel stages): the gathered rows are
+// fetched ONCE for all 256 output channels -- the per-CU gather rate (30-70 GB/s, MI355X_MICROARCH.md "Indexed rows"),
+// not the MFMAs, bounds this kernel -- with 2 slots of 64 KB and one slice in flight behind 64 MFMAs per wave.
+template <int CIN, int BN>
 __global__ __launch_bounds__(512, 1) void spconv_igemm_ring_kernel(const __hip_bfloat16* __restrict__ feat, int64_t ldf,
                                                                   const int32_t* __restrict__ nbr, int64_t m_out,
                                                                   const __hip_bfloat16* __restrict__ W, int cout,
                                                                   __hip_bfloat16* __restrict__ out, int64_t ldo) {
   constexpr int KC = CIN / IG_BK;
   constexpr int STEPS = 9 * KC;
-  extern __shared__ __attribute__((aligned(1024))) char ring[];        // 3 slots, then the rulebook tile
-  int* nb = reinterpret_cast<int*>(ring + 3 * IR_STAGE);
+  constexpr int NSLOT = BN == 128 ? 3 : 2;
+  constexpr int AHEAD = NSLOT - 1;                      // slices in flight ahead of the one being contracted
+  constexpr int STAGE = IR_BM * 128 + BN * 128;         // bytes per ring slot
+  constexpr int NT = BN / 32;                           // 16-column tiles per wave (wave tile 64 rows x BN/2 columns)
+  constexpr int BI = BN / 64;                           // weight-row DMA instructions per wave and slice
+  constexpr int NDMA = 4 + BI;                          // DMA instructions per wave and slice
+  extern __shared__ __attribute__((aligned(1024))) char ring[];        // NSLOT slots, then the rulebook tile
+  int* nb = reinterpret_cast<int*>(ring + NSLOT * STAGE);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15;
-  const int nct = cout / IG_BN;
+  const int nct = cout / BN;
   const int64_t bid = blockIdx.x;
   // ids of one residue mod 8 share an XCD (and its L2): give every XCD a CONTIGUOUS range of row tiles -- a tile's
   // neighbour rows (y +- 1: two tiles away in a 468-wide dense grid) then come from the same L2 -- and keep the column
@@ -170,19 +178,19 @@ __global__ __launch_bounds__(512, 1) void spconv_igemm_ring_kernel(const __hip_b
   const int ct = (int)((bid >> 3) % nct);
   const int64_t row0 = rt * IR_BM;
   if (row0 >= m_out) return;
-  const int n0 = ct * IG_BN;
+  const int n0 = ct * BN;
   for (int e = tid; e < IR_BM * 9; e += 512) {
     const int64_t r = row0 + e / 9;
     nb[e] = r < m_out ? nbr[r * 9 + (e % 9)] : -1;
   }
   __syncthreads();
-  // ---- what this lane fetches in every slice: 4 gathered-row pieces (A) and 2 weight-row pieces (B)
+  // ---- what this lane fetches in every slice: 4 gathered-row pieces (A) and BI weight-row pieces (B)
   const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;                   // row of the 8-row group, source chunk (swizzled)
-  const char* wsrc[2];
+  const char* wsrc[BI];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int L = w * 16 + j * 8 + r8, s64 = L & 63;                   // LDS row L holds weight column n (16 consecutive
-    const int n = (L & 64) + 16 * ((s64 >> 2) & 3) + 4 * (s64 >> 4) + (s64 & 3);   // output channels per lane, see above)
+  for (int j = 0; j < BI; ++j) {
+    const int L = w * (8 * BI) + j * 8 + r8, s64 = L & 63;             // LDS row L holds weight column n (16 consecutive
+    const int n = (L & ~63) + 16 * ((s64 >> 2) & 3) + 4 * (s64 >> 4) + (s64 & 3);  // output channels per lane, see above)
     wsrc[j] = reinterpret_cast<const char*>(W + (int64_t)(n0 + n) * (9 * CIN)) + chunk * 16;
   }
   const char* fbase = reinterpret_cast<const char*>(feat) + chunk * 16;
@@ -195,8 +203,8 @@ __global__ __launch_bounds__(512, 1) void spconv_igemm_ring_kernel(const __hip_b
     for (int j = 0; j < 4; ++j) src[j] = nb[(arow + 8 * j) * 9 + t];     // four LDS reads, one wait
   };
   auto issue = [&](int step) {
-    const int t = step / KC, kc = step % KC, slot = step % 3;
-    char* sa = ring + slot * IR_STAGE;
+    const int t = step / KC, kc = step % KC, slot = step % NSLOT;
+    char* sa = ring + slot * STAGE;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       // branch-free: both addresses are formed, a select picks (a branch around the 64-bit multiply costs an exec-mask
@@ -206,71 +214,82 @@ __global__ __launch_bounds__(512, 1) void spconv_igemm_ring_kernel(const __hip_b
       ig_glds16(reinterpret_cast<const void*>(p), sa + (w * 32 + 8 * j) * 128);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      ig_glds16(wsrc[j] + (t * CIN + kc * IG_BK) * 2, sa + IR_BM * 128 + (w * 16 + 8 * j) * 128);
+    for (int j = 0; j < BI; ++j)
+      ig_glds16(wsrc[j] + (t * CIN + kc * IG_BK) * 2, sa + IR_BM * 128 + (w * (8 * BI) + 8 * j) * 128);
   };
-  const int wm = w & 3, wn = w >> 2;                   // wave tile: rows wm*64.., columns wn*64..
-  f32x4 acc[4][4];
+  const int wm = w & 3, wn = w >> 2;                   // wave tile: rows wm*64.., columns wn*(BN/2)..
+  f32x4 acc[NT][4];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  fetch_src(0);
-  issue(0);
-  fetch_src(1);
-  issue(1);
+#pragma unroll
+  for (int p = 0; p < AHEAD; ++p) {
+    fetch_src(p);
+    issue(p);
+  }
   for (int step = 0; step < STEPS; ++step) {
-    // slice `step` has landed once every wave's 6 transfers of it are done: 6 of ours may stay in flight (slice step+1)
-    if (step + 1 < STEPS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // slice `step` has landed once every wave's NDMA transfers of it are done; with two slices ahead (BN = 128) the
+    // NDMA transfers of slice step+1 may stay in flight
+    if (AHEAD == 2 && step + 1 < STEPS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const bool more = step + 2 < STEPS;
-    if (more) fetch_src(step + 2);                     // rulebook entries of the slice issued below: their LDS latency
-    const char* sa = ring + (step % 3) * IR_STAGE;     // hides behind the first half of this slice's MFMAs
+    const bool more = step + AHEAD < STEPS;
+    if (more) fetch_src(step + AHEAD);                 // rulebook entries of the slice issued below: their LDS latency
+    const char* sa = ring + (step % NSLOT) * STAGE;    // hides behind the first half of this slice's MFMAs
     const char* sb = sa + IR_BM * 128;
 #pragma unroll
     for (int ks = 0; ks < IG_BK / 32; ++ks) {
       if (ks == 1) {
         __builtin_amdgcn_sched_barrier(0);
-        if (more) issue(step + 2);                     // into the slot every wave finished reading before this barrier
+        if (more) issue(step + AHEAD);                 // into the slot every wave finished reading before this barrier
         __builtin_amdgcn_sched_barrier(0);
       }
-      bf16x8 af[4], bfr[4];
+      bf16x8 bfr[4];
       const int c = ks * 4 + g;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int L = wn * 64 + nt * 16 + i;
-        af[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sb + L * 128 + ((c ^ (L & 7)) << 4)));
-      }
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int R = wm * 64 + mt * 16 + i;
         bfr[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sa + R * 128 + ((c ^ (R & 7)) << 4)));
       }
-      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int nh = 0; nh < NT / 4; ++nh) {
+        bf16x8 af[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[mt], acc[nt][mt], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+        for (int q = 0; q < 4; ++q) {
+          const int L = wn * (BN / 2) + (nh * 4 + q) * 16 + i;
+          af[q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sb + L * 128 + ((c ^ (L & 7)) << 4)));
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            acc[nh * 4 + q][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q], bfr[mt], acc[nh * 4 + q][mt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot are done before it moves on
   }
+  // rows 4g + r of column tile nt = output channels (slab nt/4) * 64 + 16g + 4(nt%4) + r; column i = token
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int64_t r = row0 + wm * 64 + mt * 16 + i;
     if (r < m_out) {
-      __hip_bfloat16* p = out + r * ldo + n0 + wn * 64 + 16 * g;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        u32x4 v;
-        v[0] = ig_bf16_bits(acc[2 * h][mt][0]) | (ig_bf16_bits(acc[2 * h][mt][1]) << 16);
-        v[1] = ig_bf16_bits(acc[2 * h][mt][2]) | (ig_bf16_bits(acc[2 * h][mt][3]) << 16);
-        v[2] = ig_bf16_bits(acc[2 * h + 1][mt][0]) | (ig_bf16_bits(acc[2 * h + 1][mt][1]) << 16);
-        v[3] = ig_bf16_bits(acc[2 * h + 1][mt][2]) | (ig_bf16_bits(acc[2 * h + 1][mt][3]) << 16);
-        *reinterpret_cast<u32x4*>(p + 8 * h) = v;
+      for (int sbk = 0; sbk < NT / 4; ++sbk) {
+        __hip_bfloat16* p = out + r * ldo + n0 + wn * (BN / 2) + sbk * 64 + 16 * g;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int t0 = sbk * 4 + 2 * h;
+          u32x4 v;
+          v[0] = ig_bf16_bits(acc[t0][mt][0]) | (ig_bf16_bits(acc[t0][mt][1]) << 16);
+          v[1] = ig_bf16_bits(acc[t0][mt][2]) | (ig_bf16_bits(acc[t0][mt][3]) << 16);
+          v[2] = ig_bf16_bits(acc[t0 + 1][mt][0]) | (ig_bf16_bits(acc[t0 + 1][mt][1]) << 16);
+          v[3] = ig_bf16_bits(acc[t0 + 1][mt][2]) | (ig_bf16_bits(acc[t0 + 1][mt][3]) << 16);
+          *reinterpret_cast<u32x4*>(p + 8 * h) = v;
+        }
       }
     }
   }
@@ -290,20 +309,27 @@ static int igemm_launch(const void* feat, int64_t ldf, int64_t m_in, int cin, co
   static const int impl = [] { const char* e = getenv("TMAE_IGEMM"); return e ? atoi(e) : 3; }();   // 2: register-staged 128x128
   if (impl == 3) {
     const int64_t rts = (m_out + IR_BM - 1) / IR_BM;
-    const int64_t grid = ((rts + 7) / 8) * 8 * nct;     // = 8 XCD residues x ceil(rts / 8) row tiles x nct column tiles
-    const int lds = 3 * IR_STAGE + IR_BM * 9 * 4;
-#define IR_LAUNCH(C)                                                                                                  \
+    static const int wide_off = [] { const char* e = getenv("TMAE_IGEMM_BN256"); return e && atoi(e) == 0; }();
+    const int bn = (cout % 256 == 0 && !wide_off) ? 256 : 128;
+    const int nctr = cout / bn;
+    const int64_t grid = ((rts + 7) / 8) * 8 * nctr;     // = 8 XCD residues x ceil(rts / 8) row tiles x column tiles
+    const int lds = (bn == 128 ? 3 : 2) * (IR_BM * 128 + bn * 128) + IR_BM * 9 * 4;
+#define IR_LAUNCH(C, B)                                                                                               \
   do {                                                                                                                \
     static bool attr = false;                                                                                         \
     if (!attr) {                                                                                                      \
-      hipFuncSetAttribute((const void*)spconv_igemm_ring_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+      (void)hipFuncSetAttribute((const void*)spconv_igemm_ring_kernel<C, B>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
       attr = true;                                                                                                    \
     }                                                                                                                 \
-    hipLaunchKernelGGL((spconv_igemm_ring_kernel<C>), dim3((unsigned)grid), dim3(512), lds, stream,                   \
+    hipLaunchKernelGGL((spconv_igemm_ring_kernel<C, B>), dim3((unsigned)grid), dim3(512), lds, stream,                \
                        (const __hip_bfloat16*)feat, ldf, nbr, m_out, (const __hip_bfloat16*)w, cout,                  \
                        (__hip_bfloat16*)out, ldo);                                                                    \
   } while (0)
-    if (cin == 128) IR_LAUNCH(128); else if (cin == 256) IR_LAUNCH(256); else IR_LAUNCH(384);
+    if (bn == 256) {
+      if (cin == 128) IR_LAUNCH(128, 256); else if (cin == 256) IR_LAUNCH(256, 256); else IR_LAUNCH(384, 256);
+    } else {
+      if (cin == 128) IR_LAUNCH(128, 128); else if (cin == 256) IR_LAUNCH(256, 128); else IR_LAUNCH(384, 128);
+    }
 #undef IR_LAUNCH
     return tmae_launch_status();
   }
