@@ -56,10 +56,13 @@ def parse():
 
 
 def _pmc(key):
-    f = os.path.join(ROOT, 'profiles', 'round1_pmc.json')       # rocprofv3 --pmc passes of --probe-only
-    if not os.path.exists(f):
-        return None
-    return json.load(open(f)).get(key, {}).get('traffic_bytes_per_op')
+    for name in ('round2_pmc.json', 'round1_pmc.json'):          # rocprofv3 --pmc passes of --probe-only (latest round first)
+        f = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(f):
+            v = json.load(open(f)).get(key, {}).get('traffic_bytes_per_op')
+            if v is not None:
+                return v
+    return None
 
 
 _STAGE2_TOKENS = []
@@ -111,7 +114,7 @@ def token_gemm_roofline(model, batch, amp_dtype, iters=20):
                       'token list; one launch per op)', 'bound': 'hbm', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
             'traffic': _pmc('token_gemm'),
-            'traffic_source': 'profiles/round1_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
+            'traffic_source': 'profiles/round2_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k}
 
 
@@ -143,7 +146,7 @@ def wgrad_roofline(model, batch, amp_dtype, iters=20):
                       'op = the kernel + its slab-reduction launch)', 'bound': 'hbm',
             'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': _pmc('wgrad'),
-            'traffic_source': 'profiles/round1_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
+            'traffic_source': 'profiles/round2_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k}
 
 
@@ -204,7 +207,7 @@ def attention_roofline(model, batch, amp_dtype, iters=20):
     return {'kernel': 'win_attn_bwd_mfma_kernel<16,NT> (stage-1 self-attention backward, previous frame; the op = its 3 '
                       'tile-class launches NT=1,2,4)', 'bound': 'hbm', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
-            'traffic_source': 'profiles/round1_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
+            'traffic_source': 'profiles/round2_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': int(m)}
 
 
@@ -233,6 +236,35 @@ def _oracle_case(O, n_points, stages, iters, pred_scale=1.0):
         if i > 0:                           # iteration 0 = warm-up (allocator, thread pool, first-touch)
             times.append(time.perf_counter() - t0)
     return times, float(loss), (cfg, pts, prv, noise)
+
+
+def igemm_roofline(batch_per_gpu, iters=10):
+    """`roofline_igemm`: the implicit-GEMM convolution kernel of csrc/spconv_igemm.hip (LDS-DMA ring variant) on its
+    heaviest launch of the step -- the dense decoder conv forward, B x 468 x 468 cells x (9 x 384) -> 128 channels through
+    the full-grid rulebook.  MFMA-bound by FLOPs (2 * cells * 3456 * 128), timed with HIP events on the launch stream."""
+    from tmae_amd import ops
+    dev = torch.device('cuda', torch.cuda.current_device())
+    B, Y, X = batch_per_gpu, 468, 468
+    n = B * Y * X
+    nbr = ops._dense_rulebook(B, Y, X, dev)
+    x = torch.randn(n, 384, device=dev).bfloat16()
+    w = (torch.randn(128, 9 * 384, device=dev) * 0.02).bfloat16()
+    for _ in range(2):
+        ops.spconv_fwd(x, nbr, w)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.spconv_fwd(x, nbr, w)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * n * 9 * 384 * 128
+    tf = flops / (ms * 1e-3) / 1e12
+    return {'kernel': 'spconv_igemm_ring_kernel<384,128> (dense decoder conv forward as an implicit GEMM over the full-grid '
+                      'rulebook; one launch per op)', 'bound': 'mfma', 'achieved': round(tf, 1),
+            'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_BF16_PEAK_TFLOPS, 5), 'traffic': None,
+            'ms_per_launch': round(ms, 4), 'algorithmic_flops': flops, 'cells': n}
 
 
 def cpu_baseline(n_points, iters=3):
@@ -453,7 +485,8 @@ def main():
     if args.probe_only:
         print(json.dumps({'roofline': token_gemm_roofline(model, dict(batches[0]), amp),
                           'roofline_wgrad': wgrad_roofline(model, dict(batches[0]), amp),
-                          'roofline_attention': attention_roofline(model, dict(batches[0]), amp)}), flush=True)
+                          'roofline_attention': attention_roofline(model, dict(batches[0]), amp),
+                          'roofline_igemm': igemm_roofline(args.batch_per_gpu)}), flush=True)
         return
 
     def log(msg):
@@ -526,6 +559,8 @@ def main():
         # round-1 history: the two kernels that led the profile before this one, still priced the same way
         line['roofline_wgrad'] = wgrad_roofline(model, dict(batches[0]), amp)
         line['roofline_attention'] = attention_roofline(model, dict(batches[0]), amp)
+        if args.task == 'pretrain' and amp is not None:
+            line['roofline_igemm'] = igemm_roofline(args.batch_per_gpu)
         if world == 1 and not args.no_cpu_baseline:
             log('timing the CPU oracle (cpu_baseline: warm-up + 3 iterations at C2 and C1) ...')
             line['cpu_baseline'], (O, loss_cpu, case) = cpu_baseline(args.cpu_points)
