@@ -217,6 +217,14 @@ int tmae_spconv_fwd(const void* feat, int64_t ldf, int64_t m_in, int cin, const 
 int tmae_spconv_bwd_data(const void* dout, int64_t lddo, int64_t m_out, int cout, const int32_t* nbr_t, int64_t m_in,
                          const void* weight_t, int cin, void* din, int64_t lddi, void* stream);
 
+/* A11  the dense decoder's Conv2d(cin, cout, 3, padding=1, bias=False) (SiamWCA_MAE.py:100-115) on a channels-last
+ * grid [batch, ny, nx, cin] bf16 -> [batch, ny, nx, cout] bf16, fp32 accumulation: halo-tiled implicit GEMM (a workgroup
+ * stages the 18x18 input halo of its 16x16 output block once per 64-channel slice).  weight [cout, 9*cin]: the
+ * [cout,3,3,cin] layout flattened.  cin in {128,256,384}, cout % 128 == 0.  Input gradient = the same call on dout with
+ * weight_t[c, ((2-ky)*3 + (2-kx))*cout + n] = weight[n, (ky*3+kx)*cin + c]. */
+int tmae_dense_conv3x3(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, void* out,
+                       void* stream);
+
 /* gather-GEMM form: cols [m_out, 9*c] = rows of feat selected by nbr (zeros where -1), to be
  * multiplied by the [cout, 9*c] view of the spconv-2 weight [cout,3,3,cin]; and its adjoint
  * din [m_in, c] = sum_t dcols[nbr_t[i,t], t*c:(t+1)*c]. */

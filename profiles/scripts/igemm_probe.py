@@ -37,6 +37,20 @@ t = timeit(lambda: ops.spconv_fwd(x, nbr, w))
 print(f'dense fwd  native {t:.3f} ms  {fl / t / 1e9:.0f} TFLOP/s')
 t = timeit(lambda: ops.spconv_bwd_data(dy, nbr_t, w, 384))
 print(f'dense dX   native {t:.3f} ms  {fl / t / 1e9:.0f} TFLOP/s')
+x4 = x.view(B, Y, X, 384)
+t = timeit(lambda: ops.dense_conv3x3_halo(x4, w))
+print(f'dense fwd  halo   {t:.3f} ms  {fl / t / 1e9:.0f} TFLOP/s')
+wt = w.view(128, 3, 3, 384).flip(1, 2).permute(3, 1, 2, 0).reshape(384, 9 * 128).contiguous()
+dy4 = dy.view(B, Y, X, 128)
+t = timeit(lambda: ops.dense_conv3x3_halo(dy4, wt))
+print(f'dense dX   halo   {t:.3f} ms  {fl / t / 1e9:.0f} TFLOP/s')
+ref = ops.spconv_fwd(x, nbr, w).view(B, Y, X, 128)
+got = ops.dense_conv3x3_halo(x4, w)
+print('halo vs ring fwd: max abs diff', float((ref.float() - got.float()).abs().max()), 'equal', bool(torch.equal(ref, got)))
+ref = ops.spconv_bwd_data(dy, nbr_t, w, 384).view(B, Y, X, 384)
+got = ops.dense_conv3x3_halo(dy4, wt)
+print('halo vs ring dX : max abs diff', float((ref.float() - got.float()).abs().max()), 'equal', bool(torch.equal(ref, got)))
+del x4, dy4, ref, got
 xc = x.view(B, Y, X, 384).permute(0, 3, 1, 2)
 wc = w.view(128, 3, 3, 384).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
 t = timeit(lambda: torch.nn.functional.conv2d(xc, wc, padding=1), 5)

@@ -360,3 +360,160 @@ int tmae_spconv_bwd_data(const void* dout, int64_t lddo, int64_t m_out, int cout
   (void)hipGetLastError();
   return igemm_launch(dout, lddo, m_out, cout, nbr_t, m_in, weight_t, cin, din, lddi, (hipStream_t)stream_);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Dense 3x3 convolution (padding 1) on a channels-last grid [B, Y, X, CIN] -- the decoder's conv (SiamWCA_MAE.py:100-115)
+// and its input gradient -- as a HALO-tiled implicit GEMM.  The ring kernel above re-gathers every input row once per tap
+// and is bound by the per-CU gather rate (~40 GB/s); here a workgroup owns a 16 x 16 block of cells and stages, per
+// 64-channel slice, the 18 x 18 halo of input rows ONCE (41 KB) -- the 9 taps read shifted rows of that LDS image -- so
+// only the weight slices (16 KB per tap, L2-resident) stream per step.  Same MFMA tiling, swizzle, LDS-DMA / counted
+// vmcnt / raw barrier scheme as the ring kernel; every wave issues exactly 3 transfers per tap step (2 weight pieces +
+// 1 halo piece of the NEXT channel slice, a dummy piece once the halo is complete) so that the counted wait is uniform.
+//   out[b, y, x, n] = sum_{ky,kx,c} in[b, y+ky-1, x+kx-1, c] * W[n, (ky*3+kx)*CIN + c]
+// ------------------------------------------------------------------------------------------------
+#define HC_HALO 328                                    // 18 x 18 = 324 halo rows, padded to 41 pieces of 8 rows
+#define HC_ABYTES (HC_HALO * 128)
+
+template <int CIN>
+__global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_bfloat16* __restrict__ in, int B, int Y,
+                                                                   int X, const __hip_bfloat16* __restrict__ W, int cout,
+                                                                   __hip_bfloat16* __restrict__ out) {
+  constexpr int KC = CIN / 64;
+  constexpr int STEPS = 9 * KC;
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  char* aimg = lds;                                    // 2 halo images (channel slices kc, kc+1)
+  char* bring = lds + 2 * HC_ABYTES;                   // 3 weight slots of 16 KB
+  char* scratch = bring + 3 * (IG_BN * 128);           // 1 KB sink of the dummy transfers
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15;
+  const int nct = cout / IG_BN;
+  const int bx = (X + 15) / 16, by = (Y + 15) / 16;
+  int bid = blockIdx.x;
+  const int ct = bid % nct; bid /= nct;
+  const int tx = bid % bx; bid /= bx;
+  const int ty = bid % by;
+  const int b = bid / by;
+  const int y0 = ty * 16, x0 = tx * 16, n0 = ct * IG_BN;
+  const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
+  // this lane's halo source per piece index p = step-in-slice * 8 + w: halo row h = 8 p + r8 -> cell (y0-1+h/18, x0-1+h%18)
+  const char* zrow = reinterpret_cast<const char*>(ig_zero_row) + chunk * 16;
+  const char* wsrc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int L = w * 16 + j * 8 + r8, s64 = L & 63;
+    const int n = (L & ~63) + 16 * ((s64 >> 2) & 3) + 4 * (s64 >> 4) + (s64 & 3);
+    wsrc[j] = reinterpret_cast<const char*>(W + (int64_t)(n0 + n) * (9 * CIN)) + chunk * 16;
+  }
+  auto issue_halo = [&](int kc, int p) {              // piece p (0..71; >= 41: dummy) of channel slice kc
+    const int h = 8 * p + r8;
+    const int hy = h / 18, hx = h - hy * 18;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool ok = p < 41 && h < 324 && y >= 0 && y < Y && x >= 0 && x < X && kc < KC;
+    const uintptr_t pa = (uintptr_t)in + ((uintptr_t)(((int64_t)b * Y + (ok ? y : 0)) * X + (ok ? x : 0)) * CIN + kc * 64) * 2 + chunk * 16;
+    const uintptr_t src = ok ? pa : (uintptr_t)zrow;
+    char* dst = p < 41 ? aimg + (kc & 1) * HC_ABYTES + p * 1024 : scratch;
+    ig_glds16(reinterpret_cast<const void*>(src), dst);
+  };
+  auto issue_w = [&](int step) {
+    const int kc = step / 9, t = step - kc * 9;
+    char* sb = bring + (step % 3) * (IG_BN * 128);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ig_glds16(wsrc[j] + (t * CIN + kc * 64) * 2, sb + (w * 16 + 8 * j) * 128);
+  };
+  // prologue: the whole halo of slice 0 (41 pieces: waves take 6 each, dummies past the end) and two weight slices
+#pragma unroll
+  for (int q = 0; q < 6; ++q) issue_halo(0, q * 8 + w);
+  issue_w(0);
+  issue_w(1);
+  const int wm = w & 3, wn = w >> 2;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int step = 0; step < STEPS; ++step) {
+    const int kc = step / 9, t = step - kc * 9, ky = t / 3, kx = t - ky * 3;
+    // weight slice `step` has landed once everything older than the newest transfers has: in flight stay the 3 issued
+    // during the previous step (weight slice step+1 + one halo piece); before step 0 only weight slice 1 (2 transfers)
+    if (step == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (step + 1 < STEPS) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* sa = aimg + (kc & 1) * HC_ABYTES;
+    const char* sb = bring + (step % 3) * (IG_BN * 128);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 1 && step + 2 < STEPS) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue_w(step + 2);                             // slot (step+2)%3: last read in step-1, finished before this barrier
+        issue_halo(kc + 1, t * 8 + w);                 // the other halo image: last read in slice kc-1
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bf16x8 af[4], bfr[4];
+      const int c = ks * 4 + g;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int L = wn * 64 + nt * 16 + i;
+        af[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sb + L * 128 + ((c ^ (L & 7)) << 4)));
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int R = (4 * wm + mt + ky) * 18 + i + kx;
+        bfr[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sa + R * 128 + ((c ^ (R & 7)) << 4)));
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[mt], acc[nt][mt], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int y = y0 + 4 * wm + mt, x = x0 + i;
+    if (y < Y && x < X) {
+      __hip_bfloat16* p = out + (((int64_t)b * Y + y) * X + x) * cout + n0 + wn * 64 + 16 * g;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        u32x4 v;
+        v[0] = ig_bf16_bits(acc[2 * h][mt][0]) | (ig_bf16_bits(acc[2 * h][mt][1]) << 16);
+        v[1] = ig_bf16_bits(acc[2 * h][mt][2]) | (ig_bf16_bits(acc[2 * h][mt][3]) << 16);
+        v[2] = ig_bf16_bits(acc[2 * h + 1][mt][0]) | (ig_bf16_bits(acc[2 * h + 1][mt][1]) << 16);
+        v[3] = ig_bf16_bits(acc[2 * h + 1][mt][2]) | (ig_bf16_bits(acc[2 * h + 1][mt][3]) << 16);
+        *reinterpret_cast<u32x4*>(p + 8 * h) = v;
+      }
+    }
+  }
+}
+
+// out [B, Y, X, cout] = conv3x3(in [B, Y, X, cin], padding 1) with weight [cout, 9 * cin] (taps ky-major, then kx, then
+// channel: the [cout, 3, 3, cin] layout flattened), bf16, fp32 accumulation.  cin in {128, 256, 384}, cout % 128 == 0.
+// The input gradient of such a conv is the same call on dout with weight_t[c, (2-ky)*3 + (2-kx), n] = weight[n, ky, kx, c].
+int tmae_dense_conv3x3(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, void* out,
+                       void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (batch <= 0 || ny <= 0 || nx <= 0 || (cin != 128 && cin != 256 && cin != 384) || cout <= 0 || (cout % IG_BN))
+    return TMAE_EARG;
+  if (!in || !weight || !out || ((uintptr_t)in & 15) || ((uintptr_t)weight & 15) || ((uintptr_t)out & 15)) return TMAE_EARG;
+  const int64_t blocks = (int64_t)batch * ((ny + 15) / 16) * ((nx + 15) / 16) * (cout / IG_BN);
+  if (blocks >= ((int64_t)1 << 31)) return TMAE_EARG;
+  const int lds = 2 * HC_ABYTES + 3 * (IG_BN * 128) + 1024;
+#define HC_LAUNCH(C)                                                                                                  \
+  do {                                                                                                                \
+    static bool attr = false;                                                                                         \
+    if (!attr) {                                                                                                      \
+      (void)hipFuncSetAttribute((const void*)dense_conv3x3_halo_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+      attr = true;                                                                                                    \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((dense_conv3x3_halo_kernel<C>), dim3((unsigned)blocks), dim3(512), lds, stream,               \
+                       (const __hip_bfloat16*)in, batch, ny, nx, (const __hip_bfloat16*)weight, cout,                 \
+                       (__hip_bfloat16*)out);                                                                         \
+  } while (0)
+  if (cin == 128) HC_LAUNCH(128); else if (cin == 256) HC_LAUNCH(256); else HC_LAUNCH(384);
+#undef HC_LAUNCH
+  return tmae_launch_status();
+}

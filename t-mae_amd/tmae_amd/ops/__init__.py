@@ -1170,7 +1170,7 @@ def _dense_rulebook(batch, ny, nx, device):
     return nbr
 
 
-_DENSE_CONV = _os.environ.get('TMAE_DENSE_CONV', 'native')     # native: all three passes on our kernels; wgrad: only dW; miopen
+_DENSE_CONV = _os.environ.get('TMAE_DENSE_CONV', 'halo')     # native: all three passes on our kernels; wgrad: only dW; miopen
 
 
 class _DenseConv3x3(torch.autograd.Function):
@@ -1187,11 +1187,13 @@ class _DenseConv3x3(torch.autograd.Function):
         B, Y, X, cin = x.shape
         cout = w.shape[0]
         n = B * Y * X
-        ctx.native = _DENSE_CONV == 'native' and cin in (128, 256, 384) and cout % 128 == 0
+        ctx.native = _DENSE_CONV in ('native', 'halo') and cin in (128, 256, 384) and cout % 128 == 0
         if ctx.native:
-            nbr = _dense_rulebook(B, Y, X, x.device)
             w2d = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
-            y = spconv_fwd(x.view(n, cin), nbr, w2d).view(B, Y, X, cout)
+            if _DENSE_CONV == 'halo':
+                y = dense_conv3x3_halo(x, w2d)
+            else:
+                y = spconv_fwd(x.view(n, cin), _dense_rulebook(B, Y, X, x.device), w2d).view(B, Y, X, cout)
             ctx.save_for_backward(x, w2d)
         else:
             y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.contiguous(memory_format=torch.channels_last),
@@ -1210,7 +1212,11 @@ class _DenseConv3x3(torch.autograd.Function):
         nbr = _dense_rulebook(B, Y, X, x.device)
         dx = None
         if ctx.needs_input_grad[0]:
-            if ctx.native:
+            if ctx.native and _DENSE_CONV == 'halo' and cout in (128, 256, 384) and cin % 128 == 0:
+                # weight_t[c, 2-ky, 2-kx, n] = w[n, ky, kx, c]: the input gradient is a conv of dY with the flipped taps
+                wt = w.view(cout, 3, 3, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * cout).contiguous()
+                dx = dense_conv3x3_halo(dy, wt).to(ctx.meta[0])
+            elif ctx.native:
                 nbr_t = _DENSE_NBR.get(('t', B, Y, X, x.device))
                 if nbr_t is None:                      # transposed rulebook of a stride-1 conv = flipped taps
                     nbr_t = _DENSE_NBR[('t', B, Y, X, x.device)] = nbr.flip(1).contiguous()
@@ -1227,6 +1233,15 @@ class _DenseConv3x3(torch.autograd.Function):
                                     wsb, _s()), 'tmae_spconv_wgrad')
         dw = dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2).to(ctx.meta[1])
         return dx, dw
+
+
+def dense_conv3x3_halo(x_nhwc, w2d):
+    """[B, Y, X, cin] bf16 (contiguous) x w2d [cout, 9*cin] bf16 -> [B, Y, X, cout] (csrc/spconv_igemm.hip, halo kernel)."""
+    B, Y, X, cin = x_nhwc.shape
+    cout = w2d.shape[0]
+    y = torch.empty((B, Y, X, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    check(lib.tmae_dense_conv3x3(_p(x_nhwc), B, Y, X, cin, _p(w2d), cout, _p(y), _s()), 'tmae_dense_conv3x3')
+    return y
 
 
 def dense_conv3x3_ok(x_nhwc, conv):
