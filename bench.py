@@ -239,32 +239,30 @@ def _oracle_case(O, n_points, stages, iters, pred_scale=1.0):
 
 
 def igemm_roofline(batch_per_gpu, iters=10):
-    """`roofline_igemm`: the implicit-GEMM convolution kernel of csrc/spconv_igemm.hip (LDS-DMA ring variant) on its
-    heaviest launch of the step -- the dense decoder conv forward, B x 468 x 468 cells x (9 x 384) -> 128 channels through
-    the full-grid rulebook.  MFMA-bound by FLOPs (2 * cells * 3456 * 128), timed with HIP events on the launch stream."""
+    """`roofline_igemm`: the heaviest MFMA-bound launch of the step -- the dense decoder conv forward (B x 468 x 468 cells,
+    384 -> 128 channels, 3 x 3) on the halo-tiled implicit-GEMM kernel of csrc/spconv_igemm.hip.  Priced by FLOPs
+    (2 * cells * 9 * 384 * 128) against the dense bf16 MFMA peak, timed with HIP events on the launch stream."""
     from tmae_amd import ops
     dev = torch.device('cuda', torch.cuda.current_device())
     B, Y, X = batch_per_gpu, 468, 468
-    n = B * Y * X
-    nbr = ops._dense_rulebook(B, Y, X, dev)
-    x = torch.randn(n, 384, device=dev).bfloat16()
+    x = torch.randn(B, Y, X, 384, device=dev).bfloat16()
     w = (torch.randn(128, 9 * 384, device=dev) * 0.02).bfloat16()
     for _ in range(2):
-        ops.spconv_fwd(x, nbr, w)
+        ops.dense_conv3x3_halo(x, w)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ops.spconv_fwd(x, nbr, w)
+        ops.dense_conv3x3_halo(x, w)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * n * 9 * 384 * 128
+    flops = 2.0 * B * Y * X * 9 * 384 * 128
     tf = flops / (ms * 1e-3) / 1e12
-    return {'kernel': 'spconv_igemm_ring_kernel<384,128> (dense decoder conv forward as an implicit GEMM over the full-grid '
-                      'rulebook; one launch per op)', 'bound': 'mfma', 'achieved': round(tf, 1),
-            'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_BF16_PEAK_TFLOPS, 5), 'traffic': None,
-            'ms_per_launch': round(ms, 4), 'algorithmic_flops': flops, 'cells': n}
+    return {'kernel': 'dense_conv3x3_halo_kernel<384> (dense decoder conv forward, halo-tiled implicit GEMM; one launch per '
+                      'op)', 'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(tf / MFMA_BF16_PEAK_TFLOPS, 5), 'traffic': None, 'ms_per_launch': round(ms, 4),
+            'algorithmic_flops': flops, 'cells': B * Y * X}
 
 
 def cpu_baseline(n_points, iters=3):

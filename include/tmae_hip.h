@@ -358,7 +358,8 @@ int tmae_focal_loss_bwd(const void* logits, int dtype, const float* target, int6
 
 /* Rotated boxes (x, y, z, dx, dy, dz, heading), pcdet/ops/iou3d_nms (iou3d_nms_utils.py:31-99, iou3d_nms_kernel.cu).
  * tmae_boxes_pairwise: out [na, nb] f32; mode 0 = BEV overlap area (boxes_overlap_bev_gpu), 1 = BEV IoU
- * (boxes_iou_bev_gpu), 2 = 3-D IoU (boxes_iou3d_gpu).
+ * (boxes_iou_bev_gpu), 2 = 3-D IoU (boxes_iou3d_gpu); mode | 4: PAIRED, out [na] = f(a[i], b[i]) with na == nb (the
+ * diagonal that IoULossCenterNet takes of the full matrix, loss_utils.py:411-420).
  * tmae_nms_bev: nms_gpu on boxes ALREADY sorted by descending score: keep [<= n] i64 = indices (into the sorted
  * list) of the boxes that survive, in score order; num_keep [1] i32.  Greedy pass runs on the device. */
 int tmae_boxes_pairwise(const float* boxes_a, int na, const float* boxes_b, int nb, int mode, float* out, void* stream);

@@ -1,5 +1,5 @@
 import os, sys, time, torch
-ROOT='/root/repo'
+ROOT=os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, os.path.join(ROOT, 't-mae_amd'))
 from pcdet.config import EasyDict, cfg_from_yaml_file
 from pcdet.models import model_fn_decorator

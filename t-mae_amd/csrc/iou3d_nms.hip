@@ -62,9 +62,11 @@ __device__ __forceinline__ float iou_bev_dev(const float* a, const float* b) {
 __global__ __launch_bounds__(256) void boxes_pairwise_kernel(const float* __restrict__ A, int na, const float* __restrict__ B,
                                                             int nb, int mode, float* __restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)na * nb) return;
-  const float* a = A + (e / nb) * 7;
-  const float* b = B + (e % nb) * 7;
+  const bool paired = (mode & 4) != 0;             // mode | 4: out[i] = f(A[i], B[i]) (na == nb), e.g. the IoU head's targets
+  mode &= 3;
+  if (e >= (paired ? (int64_t)na : (int64_t)na * nb)) return;
+  const float* a = A + (paired ? e : e / nb) * 7;
+  const float* b = B + (paired ? e : e % nb) * 7;
   float v;
   if (mode == 0) v = box_overlap_bev(a, b);
   else if (mode == 1) v = iou_bev_dev(a, b);
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64) void nms_select_kernel(const unsigned long long
 
 int tmae_boxes_pairwise(const float* boxes_a, int na, const float* boxes_b, int nb, int mode, float* out, void* stream_) {
   (void)hipGetLastError();
-  if (na < 0 || nb < 0 || mode < 0 || mode > 2) return TMAE_EARG;
+  if (na < 0 || nb < 0 || mode < 0 || (mode & 3) > 2 || mode > 6 || ((mode & 4) && na != nb)) return TMAE_EARG;
   if (na == 0 || nb == 0) return TMAE_OK;
   if (!boxes_a || !boxes_b || !out) return TMAE_EARG;
   hipLaunchKernelGGL(boxes_pairwise_kernel, dim3(tmae_cdiv((int64_t)na * nb, 256)), dim3(256), 0, (hipStream_t)stream_,

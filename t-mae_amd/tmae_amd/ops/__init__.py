@@ -1403,6 +1403,17 @@ def boxes_iou3d_gpu(boxes_a, boxes_b):
     return _boxes_pairwise(boxes_a, boxes_b, 2)
 
 
+def boxes_iou3d_paired(boxes_a, boxes_b):
+    """diag(boxes_iou3d_gpu(a, b)) without the matrix: out [n] (IoULossCenterNet's targets, loss_utils.py:411-420)."""
+    _need_cuda(boxes_a)
+    a = boxes_a[:, :7].contiguous().float()
+    b = boxes_b[:, :7].contiguous().float()
+    assert a.shape == b.shape
+    out = torch.empty((a.shape[0],), dtype=torch.float32, device=a.device)
+    check(lib.tmae_boxes_pairwise(_p(a), a.shape[0], _p(b), b.shape[0], 6, _p(out), _s()), 'tmae_boxes_pairwise')
+    return out
+
+
 def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
     """iou3d_nms_utils.nms_gpu (iou3d_nms_utils.py:84-99): indices of the kept boxes in descending score order.
     The suppression pass runs on the device; the only host sync is reading the number of kept boxes."""
