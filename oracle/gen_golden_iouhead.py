@@ -76,7 +76,7 @@ def main():
             gt[b, :n, 7] = cls
         x = torch.randn(B, 16, 96, 96)
         H.train()
-        dd = H({'spatial_features_2d': x, 'gt_boxes': torch.from_numpy(gt), 'batch_size': B})
+        dd = H({'spatial_features_2d': x, 'gt_boxes': torch.from_numpy(gt.copy()), 'batch_size': B})   # the reference relabels gt_boxes IN PLACE (center_head.py:199-203)
         loss, tb = H.get_loss()
         loss.backward()
         gnames = [n for n, p in H.named_parameters() if p.grad is not None]
