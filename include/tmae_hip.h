@@ -335,6 +335,21 @@ int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w,
  * sst_basic_block.py:81: linear2(gelu(linear1(src))): dX of linear2 and GeluBackward in one pass). */
 int tmae_token_gemm_dgelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias,
                           const void* aux, void* y, int64_t ldy, void* stream);
+/* The attention in-projections with the position embedding folded into the GEMM (q = k = src + pos, v = src:
+ * WindowAttention.forward sst_basic_block.py:45-52, wca_block.py:50-60; embedding of SSTInputLayer.get_pos_embed,
+ * spt_backbone.py:186-224).  The embedding depends only on the token's cell (xc, yc) inside its 8 x 8 window and is
+ * separable, pos[cell] = [ex[xc] | ey[yc]], so (x + pos) W^T = x W^T + Tx[xc] + Ty[yc]:
+ *   y [m,n] = [x | onehot(cells)] . w_aug[n, k+32]^T + bias,
+ * w_aug = [W | Tx_hi Ty_hi Tx_lo Ty_lo] (bf16; T* [n,8], hi + lo = the fp32 table, zero rows for projections that take
+ * no position, e.g. v), cells [m] u8 = xc | yc << 3 (tmae_window_cells).  k in {128, 256}, n % 64 == 0; otherwise as
+ * tmae_token_gemm.  One streaming pass over x; no [m,d] x + pos tensor exists. */
+int tmae_token_gemm_pos(const void* x, int64_t ldx, int64_t m, int k, const void* w_aug, int n, const void* bias,
+                        const uint8_t* cells, void* y, int64_t ldy, void* stream);
+/* cells [m] u8 and onehot [m,16] bf16 (columns 0..7 one-hot xc, 8..15 one-hot yc) of the tokens `indices` [m,3] (b,y,x)
+ * for window shape (wy, wx) <= 8 and the shift of the layer; dY^T . onehot (tmae_linear_wgrad, k = 16) is the position
+ * part of the in-projection weight gradient. */
+int tmae_window_cells(const int32_t* indices, int64_t m, int wy, int wx, int do_shift, uint8_t* cells, void* onehot,
+                      void* stream);
 
 /* ---- fine-tune path (BASELINE configs[4]): CenterHead ------------------------------------------------------
  * Target assignment of one head (CenterHead.assign_targets / assign_target_of_single_head, center_head.py:107-231;

@@ -45,21 +45,38 @@ __device__ __forceinline__ float dgelu(float x) {
   return cdf + x * e * 0.39894228040143267794f;
 }
 
+// POS variants (in-projections of the attention layers, q = k = x + pos, sst_basic_block.py:45-47): the position
+// embedding is a function of the token's cell inside its 8 x 8 window and separable -- pos[cell] = [ex[xc] | ey[yc]]
+// (spt_backbone.py:186-224) -- so (x + pos) W^T = x W^T + Tx[xc] + Ty[yc] with two 8-row tables per layer.  The tables
+// ride along as 32 extra contraction columns of W (hi and lo bf16 halves of Tx, Ty: the sum is exact to ~2^-17) and the
+// kernel contracts them against a one-hot fragment it makes from the token's cell byte (xc | yc << 3): one more MFMA
+// k-step on an idle matrix core instead of an elementwise pass that reads and writes [m, d].
+__device__ __forceinline__ bf16x8 pos_onehot(unsigned cell, int g) {
+  const unsigned sel = (g & 1) ? (cell >> 3) & 7u : cell & 7u;
+  const unsigned v = (sel & 1u) ? 0x3F800000u : 0x00003F80u, wi = sel >> 1;
+  const u32x4 u = {wi == 0u ? v : 0u, wi == 1u ? v : 0u, wi == 2u ? v : 0u, wi == 3u ? v : 0u};
+  return __builtin_bit_cast(bf16x8, u);
+}
+
 #define TG_NT 2      // cache policy of the y stores: nt (written once, streamed; measured 7 % faster than the default)
 #define TG_NCH (NTC * 16)   // output columns per W chunk (NTC 16-column tiles: 4, or 2 for K = 512)
 
-template <int K, int TT, int NW, int NTC, int EPI, int NCHT>
+template <int K, int TT, int NW, int NTC, int EPI, int NCHT, bool POS = false>
 __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bfloat16* __restrict__ x, int64_t ldx,
                                                            const __hip_bfloat16* __restrict__ W,
                                                            const __hip_bfloat16* __restrict__ bias,
                                                            __hip_bfloat16* __restrict__ y, int64_t ldy, int64_t m,
                                                            int N, unsigned ybytes,
-                                                           const __hip_bfloat16* __restrict__ aux) {
-  constexpr int KS = K / 32;             // MFMA k-steps
-  constexpr int PITCH = K * 2 + 16;      // bytes per W row in LDS: the +16 spreads the 16 rows of a tile over all banks
-  constexpr int CPR = K / 8;             // 16-byte chunks per W row
+                                                           const __hip_bfloat16* __restrict__ aux,
+                                                           const uint8_t* __restrict__ cells) {
+  constexpr int KX = K / 32;             // k-steps read from x
+  constexpr int KA = K + (POS ? 32 : 0); // W row length: the contraction incl. the position columns
+  constexpr int KS = KA / 32;            // MFMA k-steps
+  constexpr int PITCH = KA * 2 + 16;     // bytes per W row in LDS: the +16 spreads the 16 rows of a tile over all banks
+  constexpr int CPR = KA / 8;            // 16-byte chunks per W row
   constexpr int NTH = 64 * NW;           // threads per workgroup
   constexpr int WL = TG_NCH * CPR / NTH; // chunks per thread per W chunk
+  static_assert(TG_NCH * CPR % NTH == 0, "W chunk must divide over the threads");
   __shared__ __attribute__((aligned(16))) char wl[2][TG_NCH * PITCH];
   __shared__ __attribute__((aligned(16))) char bl[2][TG_NCH * 2];       // the chunk's bias values travel with its W rows
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15;
@@ -71,17 +88,18 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
   for (int tt = 0; tt < TT; ++tt) {
     const int64_t row = tok0 + tt * 16 + i;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < KX; ++ks) {
       u32x4 u = u32x4{0u, 0u, 0u, 0u};
       if (row < m) u = *reinterpret_cast<const u32x4*>(x + row * ldx + ks * 32 + g * 8);
       xf[tt][ks] = __builtin_bit_cast(bf16x8, u);
     }
+    if constexpr (POS) xf[tt][KX] = pos_onehot(row < m ? cells[row] : 0u, g);
   }
   u32x4 wr[WL], br;
 #define TG_WLOAD(chunk)                                                                               \
   _Pragma("unroll") for (int j = 0; j < WL; ++j) {                                                    \
     const int c_ = tid + NTH * j, row_ = c_ / CPR, ch_ = c_ % CPR;                                    \
-    wr[j] = *reinterpret_cast<const u32x4*>(W + (int64_t)((chunk) * TG_NCH + row_) * K + ch_ * 8);     \
+    wr[j] = *reinterpret_cast<const u32x4*>(W + (int64_t)((chunk) * TG_NCH + row_) * KA + ch_ * 8);    \
   }                                                                                                   \
   br = *reinterpret_cast<const u32x4*>(bias + (chunk) * TG_NCH + (tid & (TG_NCH / 8 - 1)) * 8);
 #define TG_WSTORE(buf)                                                                                \
@@ -232,13 +250,15 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
 // column groups of one token range get ids of the same residue mod 8, i.e. the same XCD: x comes from HBM once and
 // from that L2 for the other groups.
 // ------------------------------------------------------------------------------------------------
-template <int K, int NCH>
+template <int K, int NCH, bool POS = false>
 __global__ __launch_bounds__(512, 2) void token_gemm_res_kernel(const __hip_bfloat16* __restrict__ x, int64_t ldx,
                                                                const __hip_bfloat16* __restrict__ W,
                                                                const __hip_bfloat16* __restrict__ bias,
                                                                __hip_bfloat16* __restrict__ y, int64_t ldy, int64_t m,
-                                                               int ncg, unsigned ybytes) {
-  constexpr int KS = K / 32, PITCH = K * 2 + 16, CPR = K / 8, NTC = 4, TT = 2, NG = 64 * NCH;
+                                                               int ncg, unsigned ybytes,
+                                                               const uint8_t* __restrict__ cells) {
+  constexpr int KX = K / 32, KA = K + (POS ? 32 : 0);     // see token_gemm_kernel
+  constexpr int KS = KA / 32, PITCH = KA * 2 + 16, CPR = KA / 8, NTC = 4, TT = 2, NG = 64 * NCH;
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   char* wl = lds_raw;                                  // [NG][PITCH], rows permuted per 64-row chunk (see above)
   char* bl = lds_raw + NG * PITCH;                     // [NG] bf16
@@ -249,17 +269,19 @@ __global__ __launch_bounds__(512, 2) void token_gemm_res_kernel(const __hip_bflo
   // ---- prologue: the W slice (rows cg*NG ..) and its bias into LDS
   {
     constexpr int PER = NG * CPR / 512;                // 16-byte pieces per thread
-    const __hip_bfloat16* Ws = W + (int64_t)cg * NG * K;
+    constexpr int UB = PER % 8 == 0 ? 8 : 6;           // pieces in flight per round (18 = 3 x 6 with the position columns)
+    static_assert(NG * CPR % 512 == 0 && PER % UB == 0, "W slice must divide over the threads");
+    const __hip_bfloat16* Ws = W + (int64_t)cg * NG * KA;
 #pragma unroll
-    for (int b0 = 0; b0 < PER; b0 += 8) {
-      u32x4 r[8];
+    for (int b0 = 0; b0 < PER; b0 += UB) {
+      u32x4 r[UB];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < UB; ++q) {
         const int c_ = tid + 512 * (b0 + q), row_ = c_ / CPR, ch_ = c_ % CPR;
-        r[q] = *reinterpret_cast<const u32x4*>(Ws + (int64_t)row_ * K + ch_ * 8);
+        r[q] = *reinterpret_cast<const u32x4*>(Ws + (int64_t)row_ * KA + ch_ * 8);
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < UB; ++q) {
         const int c_ = tid + 512 * (b0 + q), row_ = c_ / CPR, ch_ = c_ % CPR, rr = row_ & 63;
         const int prow = (row_ & ~63) + 16 * ((rr >> 2) % NTC) + 4 * (rr / (4 * NTC)) + (rr & 3);
         *reinterpret_cast<u32x4*>(&wl[prow * PITCH + ch_ * 16]) = r[q];
@@ -268,19 +290,29 @@ __global__ __launch_bounds__(512, 2) void token_gemm_res_kernel(const __hip_bflo
     if (tid < NG / 8) *reinterpret_cast<u32x4*>(&bl[tid * 16]) = *reinterpret_cast<const u32x4*>(bias + cg * NG + tid * 8);
   }
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)ybytes, 0x00020000);
-  auto xload = [&](int64_t tile, bf16x8 (&xf)[TT][KS]) {
+  auto xload = [&](int64_t tile, bf16x8 (&xd)[TT][KX], unsigned (&cd)[TT]) {
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
       int64_t row = tile * 256 + w * 32 + tt * 16 + i;
       row = row < m ? row : m - 1;                     // unconditional (clamped) loads; rows >= m are never stored
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        xf[tt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(x + row * ldx + ks * 32 + g * 8));
+      for (int ks = 0; ks < KX; ++ks)
+        xd[tt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(x + row * ldx + ks * 32 + g * 8));
+      if constexpr (POS) cd[tt] = cells[row];
     }
   };
-  bf16x8 xf[TT][KS], xn[TT][KS];
+  bf16x8 xf[TT][KS], xn[TT][KX];
+  unsigned cn[TT] = {0u, 0u};
   int64_t tile = tg;
-  if (tile < ntiles) xload(tile, xf);
+  if (tile < ntiles) {
+    xload(tile, xn, cn);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+      for (int ks = 0; ks < KX; ++ks) xf[tt][ks] = xn[tt][ks];
+      if constexpr (POS) xf[tt][KX] = pos_onehot(cn[tt], g);
+    }
+  }
   __syncthreads();                                     // W slice visible; the only barrier of the kernel
   // two alternating sets of store-data registers, kept formally alive over the whole tile loop: a set is rewritten two
   // chunks after its stores were issued, and the compiler cannot recycle it for temporaries in between (either would
@@ -335,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void token_gemm_res_kernel(const __hip_bflo
 
   for (; tile < ntiles; tile += ntg) {
     const int64_t nxt = tile + ntg < ntiles ? tile + ntg : tile;     // past the end: re-load this tile (never used)
-    xload(nxt, xn);
+    xload(nxt, xn, cn);
     __builtin_amdgcn_sched_barrier(0);
     int voff[TT];                                       // byte offset of (row, 16g) in y; >= ybytes drops the store
 #pragma unroll
@@ -356,52 +388,75 @@ __global__ __launch_bounds__(512, 2) void token_gemm_res_kernel(const __hip_bflo
           asm volatile("" ::"v"(oS[c][h][tt].x), "v"(oS[c][h][tt].y), "v"(oS[c][h][tt].z), "v"(oS[c][h][tt].w));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt)
+    for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) xf[tt][ks] = xn[tt][ks];
+      for (int ks = 0; ks < KX; ++ks) xf[tt][ks] = xn[tt][ks];
+      if constexpr (POS) xf[tt][KX] = pos_onehot(cn[tt], g);
+    }
   }
 #undef TGR_CHUNK
 }
 
 static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
-                             int64_t ldy, const void* aux, void* stream_) {
+                             int64_t ldy, const void* aux, const void* cells, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || (k != 128 && k != 256 && k != 512) || n <= 0 || (n % 64) || ldx < k || ldy < n || (ldx % 8) || (ldy % 8))
     return TMAE_EARG;
+  if (cells && (aux || k == 512)) return TMAE_EARG;
   if (m == 0) return TMAE_OK;
   if (!x || !w || !y || !bias) return TMAE_EARG;          // no bias: pass a zero vector (keeps the kernel branch-free)
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 7)) return TMAE_EARG;
   const int64_t ybytes = ((m - 1) * ldy + n) * 2;                 // buffer stores address y with 32-bit byte offsets
   if (ybytes >= (int64_t)1 << 31) return TMAE_EARG;
+#define TG_ARGS (const __hip_bfloat16*)x, ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, (__hip_bfloat16*)y, \
+                ldy, m, n, (unsigned)ybytes
 #define TG_LAUNCH(KK, TT, NW, NTC, NCHT)                                                                            \
   do {                                                                                                              \
+    const dim3 grid_(tmae_cdiv(m, NW * TT * 16)), blk_(64 * NW);                                                    \
     if (aux)                                                                                                        \
-      hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW, NTC, 2, NCHT>), dim3(tmae_cdiv(m, NW * TT * 16)), dim3(64 * NW), 0, \
-                         stream, (const __hip_bfloat16*)x, ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, \
-                         (__hip_bfloat16*)y, ldy, m, n, (unsigned)ybytes, (const __hip_bfloat16*)aux);               \
+      hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW, NTC, 2, NCHT>), grid_, blk_, 0, stream, TG_ARGS,            \
+                         (const __hip_bfloat16*)aux, (const uint8_t*)nullptr);                                      \
     else                                                                                                            \
-      hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW, NTC, 0, NCHT>), dim3(tmae_cdiv(m, NW * TT * 16)), dim3(64 * NW), 0, \
-                         stream, (const __hip_bfloat16*)x, ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, \
-                         (__hip_bfloat16*)y, ldy, m, n, (unsigned)ybytes, (const __hip_bfloat16*)nullptr);           \
+      hipLaunchKernelGGL((token_gemm_kernel<KK, TT, NW, NTC, 0, NCHT>), grid_, blk_, 0, stream, TG_ARGS,            \
+                         (const __hip_bfloat16*)nullptr, (const uint8_t*)nullptr);                                  \
   } while (0)
+#define TG_LAUNCH_POS(KK, NCHT)                                                                                     \
+  hipLaunchKernelGGL((token_gemm_kernel<KK, 2, 4, 4, 0, NCHT, true>), dim3(tmae_cdiv(m, 128)), dim3(256), 0, stream, \
+                     TG_ARGS, (const __hip_bfloat16*)nullptr, (const uint8_t*)cells)
   // 4 waves x 32 tokens, 64-column chunks; contraction 512: 16 tokens per wave (64 x registers) and 32-column chunks
   // W-resident persistent kernel: contraction 256, 256-column groups, when there is at least one 256-token tile per CU
   static const int res_off = [] { const char* e = getenv("TMAE_TG_RES"); return e && atoi(e) == 0; }();
-  if (!aux && !res_off && k == 256 && (n == 256 || n == 512) && m >= 256 * 256) {
-    const int ncg = n / 256;
-    const int lds = 256 * (256 * 2 + 16) + 256 * 2;
+  if (!aux && !res_off && k == 256 && (n == 256 || n == 512 || (cells && n == 768)) && m >= 256 * 256) {
+    // column groups of 256; the workgroups of one token range sit on one XCD: 8 * ncg * (32 / ncg) workgroups
+    const int ncg = n / 256, grid = 8 * ncg * (32 / ncg);
+    const int lds = 256 * ((256 + (cells ? 32 : 0)) * 2 + 16) + 256 * 2;
     static bool attr_set = false;
     if (!attr_set) {
-      hipFuncSetAttribute((const void*)token_gemm_res_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipFuncSetAttribute((const void*)token_gemm_res_kernel<256, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          256 * (256 * 2 + 16) + 256 * 2);
+      hipFuncSetAttribute((const void*)token_gemm_res_kernel<256, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          256 * (288 * 2 + 16) + 256 * 2);
       attr_set = true;
     }
-    hipLaunchKernelGGL((token_gemm_res_kernel<256, 4>), dim3(256), dim3(512), lds, stream, (const __hip_bfloat16*)x, ldx,
-                       (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, (__hip_bfloat16*)y, ldy, m, ncg,
-                       (unsigned)ybytes);
+    if (cells)
+      hipLaunchKernelGGL((token_gemm_res_kernel<256, 4, true>), dim3(grid), dim3(512), lds, stream, (const __hip_bfloat16*)x,
+                         ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, (__hip_bfloat16*)y, ldy, m, ncg,
+                         (unsigned)ybytes, (const uint8_t*)cells);
+    else
+      hipLaunchKernelGGL((token_gemm_res_kernel<256, 4, false>), dim3(grid), dim3(512), lds, stream, (const __hip_bfloat16*)x,
+                         ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, (__hip_bfloat16*)y, ldy, m, ncg,
+                         (unsigned)ybytes, (const uint8_t*)nullptr);
     return tmae_launch_status();
   }
   // (the frequent widths run the fully unrolled chunk loop)
-  if (k == 128) {
+  if (cells) {
+    if (k == 128) {
+      if (n == 128) TG_LAUNCH_POS(128, 2); else if (n == 256) TG_LAUNCH_POS(128, 4);
+      else if (n == 384) TG_LAUNCH_POS(128, 6); else TG_LAUNCH_POS(128, 0);
+    } else {
+      TG_LAUNCH_POS(256, 0);
+    }
+  } else if (k == 128) {
     if (n == 128) TG_LAUNCH(128, 2, 4, 4, 2); else if (n == 256) TG_LAUNCH(128, 2, 4, 4, 4); else TG_LAUNCH(128, 2, 4, 4, 0);
   } else if (k == 256) {
     if (n == 256) TG_LAUNCH(256, 2, 4, 4, 4); else if (n == 512) TG_LAUNCH(256, 2, 4, 4, 8); else TG_LAUNCH(256, 2, 4, 4, 0);
@@ -409,18 +464,27 @@ static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const
     TG_LAUNCH(512, 1, 4, 2, 0);
   }
 #undef TG_LAUNCH
+#undef TG_LAUNCH_POS
+#undef TG_ARGS
   return tmae_launch_status();
 }
 
 int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
                     int64_t ldy, void* stream_) {
   (void)hipGetLastError();
-  return token_gemm_launch(x, ldx, m, k, w, n, bias, y, ldy, nullptr, stream_);
+  return token_gemm_launch(x, ldx, m, k, w, n, bias, y, ldy, nullptr, nullptr, stream_);
 }
 
 int tmae_token_gemm_dgelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias,
                           const void* aux, void* y, int64_t ldy, void* stream_) {
   (void)hipGetLastError();
   if (!aux || ((uintptr_t)aux & 15)) return TMAE_EARG;
-  return token_gemm_launch(x, ldx, m, k, w, n, bias, y, ldy, aux, stream_);
+  return token_gemm_launch(x, ldx, m, k, w, n, bias, y, ldy, aux, nullptr, stream_);
+}
+
+int tmae_token_gemm_pos(const void* x, int64_t ldx, int64_t m, int k, const void* w_aug, int n, const void* bias,
+                        const uint8_t* cells, void* y, int64_t ldy, void* stream_) {
+  (void)hipGetLastError();
+  if (!cells && m > 0) return TMAE_EARG;
+  return token_gemm_launch(x, ldx, m, k, w_aug, n, bias, y, ldy, nullptr, cells, stream_);
 }

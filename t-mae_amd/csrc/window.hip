@@ -218,3 +218,35 @@ int tmae_add_pos_embed(const void* x, int dtype, int64_t m, int d, const int32_t
   }
   return tmae_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Cell of every token inside its (shifted) window, in the two forms the position-folded in-projection uses
+// (token_gemm.hip POS variants): cells [m] = xc | yc << 3 for the forward's one-hot k-step, and onehot [m,16] bf16
+// (columns 0..7 = one-hot xc, 8..15 = one-hot yc), the operand whose product with dY gives the position part of the
+// in-projection weight gradient: dW[:, :d/2] += (dY^T onehot[:, :8]) ex, dW[:, d/2:] += (dY^T onehot[:, 8:]) ey.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void window_cells_kernel(const int32_t* __restrict__ ind, int64_t m, int wy, int wx,
+                                                          int sy, int sx, uint8_t* __restrict__ cells,
+                                                          uint4* __restrict__ onehot) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= m) return;
+  const unsigned yc = (unsigned)((ind[r * 3 + 1] + sy) % wy), xc = (unsigned)((ind[r * 3 + 2] + sx) % wx);
+  cells[r] = (uint8_t)(xc | (yc << 3));
+  const unsigned vx = (xc & 1u) ? 0x3F800000u : 0x00003F80u, ix = xc >> 1;
+  const unsigned vy = (yc & 1u) ? 0x3F800000u : 0x00003F80u, iy = yc >> 1;
+  onehot[2 * r] = make_uint4(ix == 0u ? vx : 0u, ix == 1u ? vx : 0u, ix == 2u ? vx : 0u, ix == 3u ? vx : 0u);
+  onehot[2 * r + 1] = make_uint4(iy == 0u ? vy : 0u, iy == 1u ? vy : 0u, iy == 2u ? vy : 0u, iy == 3u ? vy : 0u);
+}
+
+int tmae_window_cells(const int32_t* indices, int64_t m, int wy, int wx, int do_shift, uint8_t* cells, void* onehot,
+                      void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m < 0 || wy <= 0 || wx <= 0 || wy > 8 || wx > 8) return TMAE_EARG;
+  if (m == 0) return TMAE_OK;
+  if (!indices || !cells || !onehot || ((uintptr_t)onehot & 15)) return TMAE_EARG;
+  const int sy = do_shift ? wy / 2 : wy, sx = do_shift ? wx / 2 : wx;
+  hipLaunchKernelGGL(window_cells_kernel, dim3(tmae_cdiv(m, 256)), dim3(256), 0, stream, indices, m, wy, wx, sy, sx, cells,
+                     (uint4*)onehot);
+  return tmae_launch_status();
+}

@@ -79,6 +79,8 @@ SIGNATURES = {
     'tmae_frame_prepare': (I, [P, I, L, P, P, F, I, I, F, F, F, F, F, F, F, I, P, P, P, Z, P]),
     'tmae_token_gemm': (I, [P, L, L, I, P, I, P, P, L, P]),
     'tmae_token_gemm_dgelu': (I, [P, L, L, I, P, I, P, P, P, L, P]),
+    'tmae_token_gemm_pos': (I, [P, L, L, I, P, I, P, P, P, L, P]),
+    'tmae_window_cells': (I, [P, L, I, I, I, P, P, P]),
     'tmae_linear_wgrad_workspace': (Z, [L, I, I]),
     'tmae_linear_wgrad': (I, [P, L, P, L, L, I, I, P, P, P, Z, P]),
     'tmae_spconv_wgrad': (I, [P, L, P, L, P, L, I, I, P, P, Z, P]),

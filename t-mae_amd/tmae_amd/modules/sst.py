@@ -8,6 +8,7 @@ bucketing into padded [windows, T, C] tensors, no per-drop-level Python loop and
 dense index grid per sparse tensor and one ragged attention launch per layer.
 """
 import math
+import os
 from functools import partial
 
 import torch
@@ -67,12 +68,24 @@ class WindowPlan:
         self.batch, (self.ny, self.nx) = sp.batch_size, sp.spatial_shape
         self.key_grid = self.grid if other is None else other.grid
         self._wl = {}
+        self._cells = {}
 
     def worklist(self, shift):
         shift = bool(shift)
         if shift not in self._wl:
             self._wl[shift] = ops.window_worklist(self.grid, self.key_grid, self.batch, self.ny, self.nx, shift)
         return self._wl[shift]
+
+    def cells(self, shift, window_shape):
+        """(cells, onehot) of the tokens for this shift (ops.window_cells), shared by the layers of the stage."""
+        shift = bool(shift)
+        if shift not in self._cells:
+            self._cells[shift] = ops.window_cells(self.indices, window_shape, shift)
+        return self._cells[shift]
+
+
+# TMAE_POS_FOLD=0: the in-projections run on a materialised x + pos (two GEMMs) instead of the position-folded GEMM
+_POS_FOLD = os.environ.get('TMAE_POS_FOLD', '1') != '0'
 
 
 class WindowAttention(nn.Module):
@@ -90,6 +103,13 @@ class WindowAttention(nn.Module):
         Returns (attention output, x's alias for the residual branch): see ops.proj_fork."""
         a = self.self_attn
         d = a.embed_dim
+        if _POS_FOLD and ops._pos_proj_ok(x, d, 3 * d):
+            cells, onehot = plan.cells(shift, window_shape)
+            qkv, x_res = ops.pos_proj(x, a.in_proj_weight, a.in_proj_bias, 0, 3 * d, 0, 2 * d, cells, onehot,
+                                      ops.pos_axes(pos_table, window_shape), fork=True, inplace_dx=True)
+            o = ops.win_attn(qkv, None, None, a.tau, plan.grid, plan.grid, self.nhead, plan.batch, plan.ny, plan.nx,
+                             shift, a.tau_min, worklist=plan.worklist(shift))
+            return ops.linear(o, a.out_proj.weight, a.out_proj.bias), x_res
         qk, v, x_res = ops.proj_fork(x, a.in_proj_weight, a.in_proj_bias, ((0, 2 * d, True), (2 * d, 3 * d, False)),
                                      pos=(plan.indices, pos_table, window_shape, shift), fork=True,
                                      inplace_dx=True)
@@ -114,6 +134,15 @@ class WindowCrossAttention(nn.Module):
         a = self.cross_attn
         d = a.embed_dim
         w, b = a.in_proj_weight, a.in_proj_bias
+        if _POS_FOLD and ops._pos_proj_ok(x, d, d) and ops._pos_proj_ok(x_prv, d, 2 * d):
+            E = ops.pos_axes(pos_table, window_shape)
+            cells, onehot = plan.cells(shift, window_shape)
+            cells_p, onehot_p = plan_prv.cells(shift, window_shape)
+            q, x_res = ops.pos_proj(x, w, b, 0, d, 0, d, cells, onehot, E, fork=True, inplace_dx=True)
+            kv = ops.pos_proj(x_prv, w, b, d, 3 * d, d, 2 * d, cells_p, onehot_p, E)
+            o = ops.win_attn(q, kv, 'kv', a.tau, plan.grid, plan_prv.grid, self.nhead, plan.batch, plan.ny, plan.nx,
+                             shift, a.tau_min, worklist=plan.worklist(shift))
+            return o, x_res
         q, x_res = ops.proj_fork(x, w, b, ((0, d, True),), pos=(plan.indices, pos_table, window_shape, shift), fork=True,
                                  inplace_dx=True)
         k, v = ops.proj_fork(x_prv, w, b, ((d, 2 * d, True), (2 * d, 3 * d, False)),

@@ -342,6 +342,132 @@ def proj_fork(x, weight, bias, segs, pos=None, fork=False, inplace_dx=False):
     return _ProjFork.apply(x, weight, bias, segs, pos, bool(fork), bool(inplace_dx))
 
 
+def _derived(t, name, fn):
+    """fn(t), cached on the tensor object for as long as t keeps its storage and version counter (weights that the
+    optimizer does not own -- every attention in-projection under the reference's parameter grouping -- never change)."""
+    c = getattr(t, '_tmae_derived', None)
+    if c is None:
+        c = t._tmae_derived = {}
+    e = c.get(name)
+    if e is not None and e[0] == t._version and e[1] == t.data_ptr():
+        return e[2]
+    with torch.no_grad():
+        v = fn(t)
+    c[name] = (t._version, t.data_ptr(), v)
+    return v
+
+
+def window_cells(indices, window_shape, do_shift):
+    """(cells [m] u8 = xc | yc << 3, onehot [m,16] bf16) of the tokens inside their (shifted) windows."""
+    m = indices.shape[0]
+    cells = torch.empty((m,), dtype=torch.uint8, device=indices.device)
+    onehot = torch.empty((m, 16), dtype=torch.bfloat16, device=indices.device)
+    check(lib.tmae_window_cells(_p(indices), m, int(window_shape[1]), int(window_shape[0]), 1 if do_shift else 0,
+                                _p(cells), _p(onehot), _s()), 'tmae_window_cells')
+    return cells, onehot
+
+
+def pos_axes(pos_table, window_shape):
+    """E [16, d] f32, block diagonal: rows 0..7 = ex[xc] in columns :d/2, rows 8..15 = ey[yc] in columns d/2: -- the
+    separable halves of the in-window position embedding (pos[y * wx + x] = [ex[x] | ey[y]], spt_backbone.py:186-224)."""
+    def make(t):
+        wx, wy = int(window_shape[0]), int(window_shape[1])
+        d = t.shape[1]
+        h = d // 2
+        tab = t.float().view(wy, wx, d)
+        if not (torch.equal(tab[:, :, :h], tab[:1, :, :h].expand(wy, wx, h))
+                and torch.equal(tab[:, :, h:], tab[:, :1, h:].expand(wy, wx, d - h))):
+            raise RuntimeError('position table is not separable into x and y halves')
+        e = torch.zeros((16, d), dtype=torch.float32, device=t.device)
+        e[:wx, :h] = tab[0, :, :h]
+        e[8:8 + wy, h:] = tab[:, 0, h:]
+        return e
+    return _derived(pos_table, ('axes', int(window_shape[0]), int(window_shape[1])), make)
+
+
+def pos_fold_weight(weight, lo, hi, pos_rows, E):
+    """w_aug [hi-lo, d+32] bf16 = [W | Tx_hi Ty_hi Tx_lo Ty_lo] for rows lo:hi of `weight` (tmae_token_gemm_pos); T = W E^T
+    for the rows inside pos_rows = (p0, p1) (absolute row range that takes the position), zero elsewhere."""
+    def make(w):
+        ws = w[lo:hi].float()
+        t = torch.zeros((hi - lo, 16), dtype=torch.float32, device=w.device)
+        p0, p1 = pos_rows
+        if p1 > p0:
+            t[p0 - lo:p1 - lo] = ws[p0 - lo:p1 - lo] @ E.t()
+        t_hi = t.to(torch.bfloat16)
+        t_lo = (t - t_hi.float()).to(torch.bfloat16)
+        return torch.cat([ws.to(torch.bfloat16), t_hi, t_lo], dim=1).contiguous()
+    return _derived(weight, ('posfold', lo, hi, pos_rows, E.data_ptr()), make)
+
+
+def _pos_proj_ok(x, d, rows):
+    return (x.is_cuda and x.dim() == 2 and compute_dtype(x) == torch.bfloat16 and d in (128, 256) and rows % 64 == 0
+            and x.shape[0] >= _TOKEN_GEMM_MIN_ROWS and x.shape[0] * rows * 2 < 2 ** 31)
+
+
+class _PosProj(torch.autograd.Function):
+    """out [m, hi-lo] = (x [+ pos]) W[lo:hi]^T + b[lo:hi] -- the attention in-projections of ONE token list as one GEMM:
+    rows p0:p1 of W see x + pos (q, k), the others x (v).  The position embedding never touches [m,d]: forward through
+    the one-hot k-step of tmae_token_gemm_pos, backward as dW[p0:p1] += (dOut[:, p0:p1]^T onehot) E.
+    With `fork`, x itself comes back as a last output (residual branch) and its gradient is accumulated in place."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, lo, hi, p0, p1, cells, onehot, E, fork, inplace_dx):
+        x_c = x.to(torch.bfloat16).contiguous()
+        m, d = x_c.shape
+        w_aug = pos_fold_weight(weight, lo, hi, (p0, p1), E)
+        b_c = _zero_bias(hi - lo, x.device) if bias is None else cast_param(bias, torch.bfloat16)[lo:hi]
+        out = torch.empty((m, hi - lo), dtype=torch.bfloat16, device=x.device)
+        check(lib.tmae_token_gemm_pos(_p(x_c), x_c.stride(0), m, d, _p(w_aug), hi - lo, _p(b_c), _p(cells), _p(out),
+                                      hi - lo, _s()), 'tmae_token_gemm_pos')
+        ctx.save_for_backward(x_c, w_aug, onehot, E)
+        ctx.rng = (lo, hi, p0, p1, weight.shape[0])
+        ctx.fork, ctx.has_bias = fork, bias is not None
+        ctx.inplace_dx = bool(inplace_dx and fork)
+        ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        ctx.set_materialize_grads(False)
+        return (out, x.view_as(x)) if fork else out
+
+    @staticmethod
+    def backward(ctx, dout, dalias=None):
+        x_c, w_aug, onehot, E = ctx.saved_tensors
+        lo, hi, p0, p1, rows = ctx.rng
+        xdt, wdt, bdt = ctx.dtypes
+        m, d = x_c.shape
+        dx = dalias.to(torch.bfloat16) if dalias is not None else None
+        dW = dB = None
+        if dout is not None:
+            dout = dout.to(torch.bfloat16)
+            if dout.stride(-1) != 1:
+                dout = dout.contiguous()
+            w = w_aug[:, :d]                                   # the plain weight rows (pitch d + 32)
+            if ctx.needs_input_grad[0]:
+                if dx is None:
+                    dx = dout @ w
+                elif ctx.inplace_dx:
+                    dx.addmm_(dout, w)                         # see _ProjFork.backward
+                else:
+                    dx = torch.addmm(dx, dout, w)
+            if ctx.needs_input_grad[1]:
+                full = lo == 0 and hi == rows
+                mk = torch.empty if full else torch.zeros
+                dW = mk((rows, d), dtype=torch.float32, device=x_c.device)
+                want_b = ctx.has_bias and ctx.needs_input_grad[2]
+                dB = mk((rows,), dtype=torch.float32, device=x_c.device) if want_b else None
+                linear_wgrad(dout, x_c, want_b, out_w=dW[lo:hi], out_b=None if dB is None else dB[lo:hi])
+                if p1 > p0:
+                    st, _ = linear_wgrad(dout[:, p0 - lo:p1 - lo], onehot, False)      # [p1-p0, 16] = per-cell column sums
+                    dW[p0:p1].addmm_(st, E)
+        return (None if dx is None else dx.to(xdt), None if dW is None else dW.to(wdt),
+                None if dB is None else dB.to(bdt), None, None, None, None, None, None, None, None, None)
+
+
+def pos_proj(x, weight, bias, lo, hi, p0, p1, cells, onehot, E, fork=False, inplace_dx=False):
+    """See _PosProj (bf16 GPU path; callers check _pos_proj_ok first)."""
+    return _PosProj.apply(x, weight, bias, int(lo), int(hi), int(p0), int(p1), cells, onehot, E, bool(fork),
+                          bool(inplace_dx))
+
+
 class _GeluLinear(torch.autograd.Function):
     """y = gelu(h_pre) W^T + b, the second half of the encoder FFN (exact erf GELU, sst_basic_block.py:81).
     Backward: dW / db from the token-split kernel on h = gelu(h_pre); d h_pre = (dy W) * gelu'(h_pre) in ONE pass
@@ -792,44 +918,56 @@ def window_worklist(grid_q, grid_k, batch, ny, nx, do_shift):
 
 class _WinAttn(torch.autograd.Function):
     """Ragged window cosine attention over projected q/k/v.
-    Self mode (c is None): a = packed [m,2d] (q|k) from one GEMM over x+pos, b = v [m,d].
-    Cross mode: a = q [mq,d], b = k [mk,d], c = v [mk,d]."""
+    Self mode (c is None): a = packed [m,2d] (q|k) from one GEMM over x+pos, b = v [m,d]; b None too: a = [m,3d] (q|k|v).
+    Cross mode: a = q [mq,d], b = k [mk,d], c = v [mk,d]; c == 'kv': b = packed [mk,2d] (k|v)."""
 
     @staticmethod
     def _ptrs(a, b, c, d):
         es = a.element_size()
+        if b is None:
+            return (a.data_ptr(), 3 * d, a.data_ptr() + d * es, 3 * d, a.data_ptr() + 2 * d * es, 3 * d)
         if c is None:
             return (a.data_ptr(), 2 * d, a.data_ptr() + d * es, 2 * d, b.data_ptr(), d)
+        if isinstance(c, str):
+            return (a.data_ptr(), d, b.data_ptr(), 2 * d, b.data_ptr() + d * es, 2 * d)
         return (a.data_ptr(), d, b.data_ptr(), d, c.data_ptr(), d)
 
     @staticmethod
     def forward(ctx, a, b, c, tau, grid_q, grid_k, worklist, nhead, batch, ny, nx, do_shift, tau_min):
-        a, b = a.contiguous(), b.contiguous()
-        assert a.dtype == b.dtype
-        if c is None:
+        a = a.contiguous()
+        ctx.layout = 'qkv' if b is None else 'qk_v' if c is None else 'q_kv' if isinstance(c, str) else 'q_k_v'
+        if b is None:
+            d = a.shape[1] // 3
+            mq = mk = a.shape[0]
+        elif c is None:
+            b = b.contiguous()
             d = b.shape[1]
             mq = mk = a.shape[0]
         else:
-            c = c.contiguous()
-            assert c.dtype == a.dtype
+            b = b.contiguous()
+            if not isinstance(c, str):
+                c = c.contiguous()
+                assert c.dtype == a.dtype
             d = a.shape[1]
             mq, mk = a.shape[0], b.shape[0]
+        assert b is None or a.dtype == b.dtype
         dh = d // nhead
         q, ldq, k, ldk, v, ldv = _WinAttn._ptrs(a, b, c, d)
+        cross = ctx.layout in ('q_kv', 'q_k_v')
         tau32 = tau.detach().reshape(-1).float().contiguous()
         if a.dtype != torch.bfloat16:
             worklist = None                                  # the fp32 kernels walk the dense windows
         # with a work list, tokens of windows in no list are not written: start from zeros in cross mode
-        alloc = torch.zeros if (worklist is not None and c is not None) else torch.empty
+        alloc = torch.zeros if (worklist is not None and cross) else torch.empty
         out = alloc((mq, d), dtype=a.dtype, device=a.device)
         lse = alloc((mq, nhead), dtype=torch.float32, device=a.device)
         check(lib.tmae_win_attn_fwd(q, ldq, k, ldk, v, ldv, _dt(a), mq, mk, nhead, dh, _p(grid_q), _p(grid_k),
                                     batch, ny, nx, 1 if do_shift else 0, _p(tau32), float(tau_min), _p(out), d,
                                     _p(lse), _p(worklist), _s()), 'tmae_win_attn_fwd')
-        ctx.cross = c is not None
+        ctx.cross = cross
         ctx.has_wl = worklist is not None
-        ctx.save_for_backward(a, b, c if c is not None else b, tau32, grid_q, grid_k, out, lse,
-                              worklist if worklist is not None else grid_q)
+        ctx.save_for_backward(a, b if b is not None else a, c if torch.is_tensor(c) else a, tau32, grid_q, grid_k, out,
+                              lse, worklist if worklist is not None else grid_q)
         ctx.meta = (d, nhead, dh, batch, ny, nx, do_shift, tau_min, mq, mk, tau.shape, tau.dtype)
         return out
 
@@ -837,14 +975,20 @@ class _WinAttn(torch.autograd.Function):
     def backward(ctx, dout):
         a, b, c, tau32, grid_q, grid_k, out, lse, worklist = ctx.saved_tensors
         d, nhead, dh, batch, ny, nx, do_shift, tau_min, mq, mk, tshape, tdtype = ctx.meta
-        if not ctx.cross:
+        lay = ctx.layout
+        if lay == 'qkv':
+            b = None
+        if lay in ('qkv', 'qk_v'):
             c = None
+        elif lay == 'q_kv':
+            c = 'kv'
         if not ctx.has_wl:
             worklist = None
         dout = dout.contiguous()
-        alloc = torch.zeros_like if (worklist is not None and c is not None) else torch.empty_like
-        da, db = alloc(a), alloc(b)
-        dc = alloc(c) if c is not None else None
+        alloc = torch.zeros_like if (worklist is not None and ctx.cross) else torch.empty_like
+        da = alloc(a)
+        db = alloc(b) if b is not None else None
+        dc = alloc(c) if torch.is_tensor(c) else c
         q, ldq, k, ldk, v, ldv = _WinAttn._ptrs(a, b, c, d)
         dq, lddq, dk, lddk, dv, lddv = _WinAttn._ptrs(da, db, dc, d)
         nblk = lib.tmae_win_attn_num_blocks(batch, ny, nx, nhead, dh)
@@ -858,7 +1002,7 @@ class _WinAttn(torch.autograd.Function):
         psum = part.sum().reshape(1)                    # multi-block reduction; the finish kernel applies the clamp rule
         check(lib.tmae_win_attn_dtau(_p(psum), 1, _p(tau32), float(tau_min), _p(dtau), _s()), 'tmae_win_attn_dtau')
         dtau = dtau.reshape(tshape).to(tdtype)
-        return da, db, dc, dtau, None, None, None, None, None, None, None, None, None
+        return da, db, (dc if torch.is_tensor(dc) else None), dtau, None, None, None, None, None, None, None, None, None
 
 
 def win_attn(a, b, c, tau, grid_q, grid_k, nhead, batch, ny, nx, do_shift, tau_min, worklist=None):

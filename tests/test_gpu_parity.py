@@ -576,6 +576,78 @@ def test_token_gemm_kernel_vs_torch():
     assert dx.shape == (40000, 512) and (dx.float() - ref).abs().max().item() <= 2e-2 * float(ref.abs().max())
 
 
+def _pos_case(m, d, seed):
+    """Random tokens on a 468 x 468 grid + the module's position table."""
+    from tmae_amd.modules.sst import pos_embed_table
+    g = torch.Generator().manual_seed(seed)
+    ind = torch.stack([torch.zeros(m, dtype=torch.int64), torch.randint(0, 468, (m,), generator=g),
+                       torch.randint(0, 468, (m,), generator=g)], 1).int().to(dev())
+    table = pos_embed_table(d, [8, 8, 1], 10000).to(dev())
+    x = torch.randn(m, d, generator=g).to(dev()).bfloat16()
+    return ind, table, x
+
+
+@pytest.mark.parametrize('shift', [False, True])
+def test_pos_folded_in_projection_vs_materialised(shift):
+    """tmae_token_gemm_pos (position embedding as a one-hot k-step of the in-projection GEMM) vs the fp32 formula
+    (x + pos[cell]) W^T + b of WindowAttention.forward (sst_basic_block.py:45-52) on the same bf16 x / W: every
+    width the layers use (d = 128: 128 / 256 / 384 rows; d = 256: 256 / 512 / 768 rows, chunk-streaming kernel below
+    65 536 tokens and the W-resident one above), v rows without position; then the backward of ops.pos_proj (dx
+    accumulated into the alias gradient, dW incl. the position part, db) vs autograd of the formula."""
+    from tmae_amd import ops
+    sh = 4 if shift else 8
+    for (m, d, lo, hi, p0, p1) in ((20001, 128, 0, 384, 0, 256), (9000, 128, 0, 128, 0, 128), (30011, 128, 128, 384, 128, 256),
+                                   (12345, 256, 0, 768, 0, 512), (70003, 256, 0, 768, 0, 512), (66000, 256, 0, 256, 0, 256),
+                                   (131072, 256, 256, 768, 256, 512)):
+        ind, table, x = _pos_case(m, d, 7 + m % 5)
+        w = (torch.randn(3 * d, d, device=dev()) * 0.1)
+        b = torch.randn(3 * d, device=dev())
+        cells, onehot = ops.window_cells(ind, [8, 8, 1], shift)
+        yc, xc = (ind[:, 1].long() + sh) % 8, (ind[:, 2].long() + sh) % 8
+        assert torch.equal(cells.long(), xc + 8 * yc)
+        assert torch.equal(onehot.float().argmax(1), xc) and torch.equal(onehot[:, 8:].float().argmax(1), yc)
+        assert float(onehot.float().sum()) == 2 * m
+        E = ops.pos_axes(table, [8, 8, 1])
+        pos = table[yc * 8 + xc]                                        # [m, d] f32
+        assert torch.allclose(onehot.float() @ E, pos, atol=0, rtol=0)
+        wb = w.bfloat16().float()
+        xr = x.float().clone().requires_grad_(True)
+        wr = wb.clone().requires_grad_(True)
+        br = b.bfloat16().float().clone().requires_grad_(True)
+        rows = torch.arange(lo, hi, device=dev())
+        usep = ((rows >= p0) & (rows < p1)).float()[None, :]
+        ref = xr @ wr[lo:hi].t() + (pos @ wr[lo:hi].t()) * usep + br[lo:hi]
+        wp = torch.nn.Parameter(w.clone())
+        bp = torch.nn.Parameter(b.clone())
+        xin = x.clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out, alias = ops.pos_proj(xin, wp, bp, lo, hi, p0, p1, cells, onehot, E, fork=True)
+        assert out.shape == (m, hi - lo) and out.dtype == torch.bfloat16
+        scale = float(ref.abs().max())
+        assert (out.float() - ref).abs().max().item() <= 1e-2 * scale, (m, d, lo, hi)
+        gout = torch.randn(m, hi - lo, device=dev()).bfloat16()
+        galias = torch.randn(m, d, device=dev()).bfloat16()
+        torch.autograd.backward([out, alias], [gout, galias])
+        (ref * gout.float()).sum().backward()
+        dx_ref = xr.grad + galias.float()
+        assert (xin.grad.float() - dx_ref).abs().max().item() <= 2e-2 * float(dx_ref.abs().max())
+        for got, want, nm in ((wp.grad, wr.grad, 'dW'), (bp.grad, br.grad, 'db')):
+            assert got.shape == want.shape
+            err = (got - want).abs().max().item()
+            assert err <= 3e-3 * float(want.abs().max()), (nm, m, d, err, float(want.abs().max()))
+        if lo > 0:
+            assert float(wp.grad[:lo].abs().max()) == 0.0
+        # a second call finds the folded weight in the cache, an optimizer-style in-place update drops it
+        c0 = wp._tmae_derived
+        with torch.autocast('cuda', dtype=torch.bfloat16), torch.no_grad():
+            out2 = ops.pos_proj(xin, wp, bp, lo, hi, p0, p1, cells, onehot, E)
+            assert torch.equal(out2, out) and wp._tmae_derived is c0
+            wp.mul_(0.5)
+            out3 = ops.pos_proj(xin, wp, bp, lo, hi, p0, p1, cells, onehot, E)
+        ref3 = (ref - br[lo:hi]) * 0.5 + br[lo:hi]
+        assert (out3.float() - ref3).abs().max().item() <= 1e-2 * scale
+
+
 def test_gelu_linear_fused_backward_vs_torch():
     """ops.gelu_linear: forward = F.linear(F.gelu(x)); backward with the GELU derivative fused into the dX GEMM
     (tmae_token_gemm_dgelu) vs torch autograd in bf16, for both FFN shapes (d = 128 / dff = 256, d = 256 / dff = 512)."""
