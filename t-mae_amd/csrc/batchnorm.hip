@@ -67,22 +67,42 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
 }
 
 // mean / biased variance / rstd per channel from the partials (double accumulation, fixed order)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nblocks, int c, double m,
-                                                         float eps, float* __restrict__ mean,
-                                                         float* __restrict__ var, float* __restrict__ rstd) {
-  __shared__ double red[16][17][2];
+// (1024 threads = 16 channels x 64 partial rows each, four independent loads in flight per thread: with 256 threads the
+// 64 dependent round trips of a thread made this tiny kernel 16 us, 42 times per step)
+#define BN_FIN_RL 64
+__device__ __forceinline__ void bn_partial_sums(const float* __restrict__ part, int nblocks, int c, int ch, int rl,
+                                                double& a, double& b) {
+  a = 0.0; b = 0.0;
+  if (ch >= c) return;
+  int k = rl;
+  for (; k + 3 * BN_FIN_RL < nblocks; k += 4 * BN_FIN_RL) {
+    float u[4], v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u[q] = part[(int64_t)(k + q * BN_FIN_RL) * 2 * c + ch];
+      v[q] = part[(int64_t)(k + q * BN_FIN_RL) * 2 * c + c + ch];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a += u[q]; b += v[q]; }
+  }
+  for (; k < nblocks; k += BN_FIN_RL) { a += part[(int64_t)k * 2 * c + ch]; b += part[(int64_t)k * 2 * c + c + ch]; }
+}
+
+__global__ __launch_bounds__(16 * BN_FIN_RL) void bn_finalize_kernel(const float* __restrict__ part, int nblocks, int c,
+                                                                    double m, float eps, float* __restrict__ mean,
+                                                                    float* __restrict__ var, float* __restrict__ rstd) {
+  __shared__ double red[BN_FIN_RL][17][2];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cl;
-  double a = 0.0, b = 0.0;
-  if (ch < c)
-    for (int k = rl; k < nblocks; k += 16) { a += part[(int64_t)k * 2 * c + ch]; b += part[(int64_t)k * 2 * c + c + ch]; }
+  double a, b;
+  bn_partial_sums(part, nblocks, c, ch, rl, a, b);
   red[rl][cl][0] = a;
   red[rl][cl][1] = b;
   __syncthreads();
   if (rl == 0 && ch < c) {
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
+    for (int r = 0; r < BN_FIN_RL; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
     const double d = s1 / m;                                   // mean of (x - pivot)
     const double mu = (double)part[(int64_t)nblocks * 2 * c + ch] + d;
     double vr = s2 / m - d * d;
@@ -168,21 +188,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   bn_block_partial<C, LPR>(s1, s2, red, w, sub, cl, part);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int c,
-                                                             float* __restrict__ dbeta, float* __restrict__ dgamma) {
-  __shared__ double red[16][17][2];
+__global__ __launch_bounds__(16 * BN_FIN_RL) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks,
+                                                                        int c, float* __restrict__ dbeta,
+                                                                        float* __restrict__ dgamma) {
+  __shared__ double red[BN_FIN_RL][17][2];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int ch = blockIdx.x * 16 + cl;
-  double a = 0.0, b = 0.0;
-  if (ch < c)
-    for (int k = rl; k < nblocks; k += 16) { a += part[(int64_t)k * 2 * c + ch]; b += part[(int64_t)k * 2 * c + c + ch]; }
+  double a, b;
+  bn_partial_sums(part, nblocks, c, ch, rl, a, b);
   red[rl][cl][0] = a;
   red[rl][cl][1] = b;
   __syncthreads();
   if (rl == 0 && ch < c) {
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
+    for (int r = 0; r < BN_FIN_RL; ++r) { s1 += red[r][cl][0]; s2 += red[r][cl][1]; }
     dbeta[ch] = (float)s1;
     dgamma[ch] = (float)s2;
   }
@@ -263,13 +283,13 @@ int tmae_bn_relu_fwd(const void* x_, int dtype, int64_t m, int c, const float* g
     const float* x = (const float*)x_;
     float* y = (float*)y_;
     BN_DISPATCH(float, bn_stats_kernel, x, m, 1, part);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, (double)m, eps, mean, var, rstd);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, (double)m, eps, mean, var, rstd);
     BN_DISPATCH(float, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y);
   } else {
     const __hip_bfloat16* x = (const __hip_bfloat16*)x_;
     __hip_bfloat16* y = (__hip_bfloat16*)y_;
     BN_DISPATCH(__hip_bfloat16, bn_stats_kernel, x, m, 1, part);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, (double)m, eps, mean, var, rstd);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, (double)m, eps, mean, var, rstd);
     BN_DISPATCH(__hip_bfloat16, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y);
   }
   return tmae_launch_status();
@@ -293,13 +313,13 @@ int tmae_bn_relu_bwd(const void* dy_, const void* x_, int dtype, int64_t m, int 
     const float *dy = (const float*)dy_, *x = (const float*)x_;
     float* dx = (float*)dx_;
     BN_DISPATCH(float, bn_bwd_reduce_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, dbeta, dgamma);
     BN_DISPATCH(float, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, 1.0f / (float)m, dx);
   } else {
     const __hip_bfloat16 *dy = (const __hip_bfloat16*)dy_, *x = (const __hip_bfloat16*)x_;
     __hip_bfloat16* dx = (__hip_bfloat16*)dx_;
     BN_DISPATCH(__hip_bfloat16, bn_bwd_reduce_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, dbeta, dgamma);
     BN_DISPATCH(__hip_bfloat16, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, 1.0f / (float)m, dx);
   }
   return tmae_launch_status();
@@ -329,7 +349,7 @@ int tmae_bn_stats(const void* x_, int dtype, int64_t m, int c, double count, flo
   const int piv = count == (double)m ? 1 : 0;
   if (dtype == TMAE_F32) { const float* x = (const float*)x_; BN_DISPATCH(float, bn_stats_kernel, x, m, piv, part); }
   else { const __hip_bfloat16* x = (const __hip_bfloat16*)x_; BN_DISPATCH(__hip_bfloat16, bn_stats_kernel, x, m, piv, part); }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, count, eps, mean, var, rstd);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, count, eps, mean, var, rstd);
   return tmae_launch_status();
 }
 
@@ -352,7 +372,7 @@ int tmae_bn_bwd_sums(const void* dy_, const void* x_, int dtype, int64_t m, int 
     const __hip_bfloat16 *dy = (const __hip_bfloat16*)dy_, *x = (const __hip_bfloat16*)x_;
     BN_DISPATCH(__hip_bfloat16, bn_bwd_reduce_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, sum_dz, sum_dz_xhat);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, sum_dz, sum_dz_xhat);
   return tmae_launch_status();
 }
 

@@ -11,7 +11,8 @@ import torch  # noqa: F401  MUST precede the CDLL below: torch bundles its own l
 #                     would put a second HIP runtime in the process (torch's pointers/streams would be foreign to it)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libtmae_hip.so')
+# TMAE_LIB_PATH: another build of the same library (A/B runs of one kernel on one box); the default is the in-tree build
+LIB_PATH = os.environ.get('TMAE_LIB_PATH') or os.path.join(_HERE, 'lib', 'libtmae_hip.so')
 
 P, I, L, F, D, Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 

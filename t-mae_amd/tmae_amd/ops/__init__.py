@@ -95,8 +95,16 @@ def token_gemm_dx(dy, w, force=False):
     """dx [m,k] = dy [m,n] @ w[n,k]: the same kernel on w^T (contraction n in {128,256}, k % 64 == 0)."""
     n, k = w.shape
     if (force or _tg_ok(dy, n, k)) and w.dtype == torch.bfloat16:
-        return token_gemm(dy, w.t().contiguous(), None, force)
+        return token_gemm(dy, _transposed(w), None, force)
     return dy @ w
+
+
+def _transposed(w):
+    """w^T contiguous; for a whole (non-view) weight copy it is kept with the tensor until the weight changes (one
+    transpose launch per dX GEMM per step otherwise, ~60)."""
+    if w._base is None and not w.requires_grad:
+        return _derived(w, 'T', lambda t: t.t().contiguous())
+    return w.t().contiguous()
 
 
 # ----------------------------------------------------------------------------- BatchNorm running statistics
@@ -499,7 +507,7 @@ class _GeluLinear(torch.autograd.Function):
                 m = dy.shape[0]
                 dhp = torch.empty((m, k), dtype=torch.bfloat16, device=dy.device)
                 zb = _zero_bias(k, dy.device)
-                wt = w_c.t().contiguous()
+                wt = _transposed(w_c)
                 check(lib.tmae_token_gemm_dgelu(_p(dy), dy.stride(0), m, n, _p(wt), k, _p(zb), _p(hp), _p(dhp), k, _s()),
                       'tmae_token_gemm_dgelu')
             else:
@@ -595,10 +603,13 @@ class _BatchNormReLU(torch.autograd.Function):
         ctx.relu, ctx.bounds = relu, bounds
         ctx.dtypes = (weight.dtype, bias.dtype)
         ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)       # no zero-filled "gradients" for the statistics outputs (2 fills per layer)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, dy, _m, _v):
+        if dy is None:
+            return (None,) * 6
         x, mean, rstd, g32, b32 = ctx.saved_tensors
         dy = dy.to(x.dtype).contiguous()
         m, c = x.shape
@@ -796,10 +807,13 @@ class _SegmentMax(torch.autograd.Function):
         ctx.save_for_backward(inverse, argmax)
         ctx.n = n
         ctx.mark_non_differentiable(argmax)
+        ctx.set_materialize_grads(False)
         return out, argmax
 
     @staticmethod
     def backward(ctx, dout, _):
+        if dout is None:
+            return (None,) * 5
         inverse, argmax = ctx.saved_tensors
         dout = dout.contiguous()
         m, c = dout.shape
@@ -1202,11 +1216,14 @@ class _DeblocksToDense(torch.autograd.Function):
                     [(args[4 * i].dtype, args[4 * i + 1].dtype, args[4 * i + 2].dtype, args[4 * i + 3].dtype)
                      for i in range(n_src)])
         ctx.mark_non_differentiable(*stats)
+        ctx.set_materialize_grads(False)
         return (cat, *stats)
 
     @staticmethod
     def backward(ctx, dcat, *_unused):
         n_src, shapes, batch, ny, nx, couts, count, dts = ctx.meta
+        if dcat is None:
+            return (None,) * (5 + 4 * n_src)
         saved = ctx.saved_tensors
         ctot = sum(couts)
         dev = dcat.device
