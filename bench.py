@@ -50,6 +50,8 @@ def parse():
                     help='once = BASELINE configs[1] (the metric); waymo = configs[3] shape: 5 point features, z in [-2,4), '
                          '6 m pillars (use with --points 180000)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--skip-unread-gradients', action='store_true',
+                    help='variant, not the reference step: no gradients for the parameters its optimizer never owns')
     ap.add_argument('--cpu-points', type=int, default=120000)
     ap.add_argument('--probe-only', action='store_true', help='only time the roofline kernel (for PMC runs)')
     return ap.parse_args()
@@ -461,8 +463,10 @@ def main():
     torch.manual_seed(0)
     model = build_model_from_cfg(cfg, ds).to(dev)
     model.train()
+    if args.skip_unread_gradients:
+        cfg.OPTIMIZATION.SKIP_UNREAD_GRADIENTS = True
+    opt = build_optimizer(model, cfg.OPTIMIZATION)      # before the DDP wrap: it fixes the set of reduced parameters
     ddp = wrap_ddp(model, local_rank)
-    opt = build_optimizer(model, cfg.OPTIMIZATION)
     sched, _ = build_scheduler(opt, 1000, cfg.OPTIMIZATION.NUM_EPOCHS, -1, cfg.OPTIMIZATION)
     model_func = model_fn_decorator()
     amp = torch.bfloat16 if args.dtype == 'bf16' else None
@@ -536,7 +540,9 @@ def main():
                                    f'encoder + temporal cross-attn + decoder + Chamfer, fwd+bwd+Adam one-cycle',
                        'batch_per_gpu': args.batch_per_gpu, 'global_batch': args.batch_per_gpu * world,
                        'parallelism': f'dp{world}', 'grid': '468x468x1', 'final_loss': round(loss_val, 5),
-                       'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)},
+                       'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                       **({'variant': 'skip_unread_gradients (not the reference step: see DESIGN.md)'}
+                          if args.skip_unread_gradients else {})},
             'ranks': ranks_seen, 'collective_backend': 'nccl (RCCL)' if world > 1 else None,
             'rank_ms_per_step': {'min': round(1e3 * min(per_rank) / args.steps, 3),
                                  'max': round(1e3 * max(per_rank) / args.steps, 3)},

@@ -97,6 +97,16 @@ class AdamOneCycle:
     def param_groups(self):
         return self.opt.param_groups
 
+    def skip_unread_gradients(self):
+        """Stop autograd from computing the gradients of the parameters in no group (NOT the reference's behaviour,
+        off by default; OPTIMIZATION.SKIP_UNREAD_GRADIENTS).  Under AMP the reference's step never reads them
+        (train_utils.py:86-97: gradient clipping only in the non-AMP branch, GradScaler looks at the optimizer's own
+        parameters), so the weights evolve identically -- but `p.grad` of those parameters stays None, and with
+        clipping (non-AMP) they DO enter the total norm: do not use it there."""
+        for p in self.unoptimized:
+            p.requires_grad_(False)
+        self.params = [p for p in self.params if p.requires_grad]
+
     def zero_grad(self, set_to_none=True):
         # every parameter that receives a gradient, also the ones the optimizer does not own (the reference's
         # zero_grad leaves those to accumulate for ever, which nothing reads)
@@ -156,8 +166,11 @@ class OneCycle:
 def build_optimizer(model, optim_cfg):
     if optim_cfg.OPTIMIZER != 'adam_onecycle':
         raise NotImplementedError('the T-MAE recipe uses OPTIMIZER: adam_onecycle (t_mae_ssl.yaml:188)')
-    return AdamOneCycle(model, lr=3e-3, wd=optim_cfg.WEIGHT_DECAY, betas=(0.9, 0.99),
-                        train_nonleaf=bool(optim_cfg.get('TRAIN_NONLEAF_PARAMS', False)))
+    opt = AdamOneCycle(model, lr=3e-3, wd=optim_cfg.WEIGHT_DECAY, betas=(0.9, 0.99),
+                       train_nonleaf=bool(optim_cfg.get('TRAIN_NONLEAF_PARAMS', False)))
+    if optim_cfg.get('SKIP_UNREAD_GRADIENTS', False):
+        opt.skip_unread_gradients()
+    return opt
 
 
 def build_scheduler(optimizer, total_iters_each_epoch, total_epochs, last_epoch, optim_cfg):

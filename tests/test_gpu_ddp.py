@@ -29,7 +29,7 @@ def _worker(rank, world, port, q, shipped=False):
     P = O.init_params(O.default_model_cfg(1), seed=3, pred_scale=0.1)
     model, cfg, _ = build_product_model(1, params=P, device=dev)
     model.train()
-    # shipped = the path bench.py / tools/train.py take: wrap_ddp (gradient_as_bucket_view, 64 MB bucket, buffer
+    # shipped = the path bench.py / tools/train.py take: wrap_ddp (gradient_as_bucket_view, 25 MB buckets, buffer
     # broadcast), the reference's optimizer grouping, bf16 autocast + refresh_param_copies, two steps
     ddp = wrap_ddp(model, 0) if shipped else torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
     assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)

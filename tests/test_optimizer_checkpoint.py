@@ -232,3 +232,37 @@ def test_two_training_steps_follow_the_reference_loop():
     vals = sorted(cosines.values())
     worst = min(cosines, key=cosines.get)
     assert vals[len(vals) // 2] > 0.99 and vals[0] > 0.8, (worst, vals[0], vals[len(vals) // 2])
+
+
+def test_skip_unread_gradients_leaves_the_trained_weights_unchanged():
+    """OPTIMIZATION.SKIP_UNREAD_GRADIENTS (opt-in): parameters in no optimizer group stop receiving gradients; the
+    owned parameters follow the same trajectory (no clipping, as in the reference's AMP branch)."""
+    import copy
+    import torch.nn as nn
+    from tmae_amd.train.optim import AdamOneCycle
+
+    class Attn(nn.Module):                       # a parameter next to a child module: owned by no leaf
+        def __init__(self):
+            super().__init__()
+            self.in_proj = nn.Parameter(torch.randn(6, 6) * 0.3)
+            self.out = nn.Linear(6, 6)
+
+        def forward(self, x):
+            return self.out(torch.tanh(x @ self.in_proj.t()))
+
+    torch.manual_seed(0)
+    a = nn.Sequential(Attn(), nn.BatchNorm1d(6), nn.Linear(6, 3))
+    b = copy.deepcopy(a)
+    oa, ob = AdamOneCycle(a, lr=1e-2), AdamOneCycle(b, lr=1e-2)
+    assert len(oa.unoptimized) == 1
+    ob.skip_unread_gradients()
+    assert not b[0].in_proj.requires_grad and all(p.requires_grad for p in ob.params)
+    x = torch.randn(16, 6)
+    for _ in range(4):
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            m(x).square().mean().backward()
+            o.step()
+    assert a[0].in_proj.grad is not None and b[0].in_proj.grad is None
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
