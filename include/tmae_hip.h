@@ -261,6 +261,16 @@ int tmae_chamfer_bwd(const float* pred, const float* gt, const float* weights, c
 size_t tmae_linear_wgrad_workspace(int64_t m, int n, int k);
 int tmae_linear_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k,
                       float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
+/* The same pass for the attention in-projections with the position embedding folded into the GEMM
+ * (tmae_token_gemm_pos): besides dw / db it returns dcell [16, n] f32, the per-cell column sums of dy --
+ * dcell[c, j] = sum of dy[i, j] over the tokens i with xc == c (c < 8) / yc == c - 8 (c >= 8), for the output columns
+ * j < pos_n (the others are not defined) -- so that dW[:pos_n] += dcell[:, :pos_n]^T . E (E [16,k]: the separable embedding)
+ * completes the gradient of (x + pos) W^T (one pass over dy with the 128-tile kernel; for n, k >= 256 the 256-tile
+ * kernel plus a narrow second pass over dy[:, :pos_n]).  cells: u8 xc | yc << 3 per token, 8-byte
+ * aligned, readable up to round_up(m, 32) + 64 bytes (tmae_window_cells callers pad the buffer).  Same workspace. */
+int tmae_linear_wgrad_cells(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k,
+                            const uint8_t* cells, int pos_n, float* dw, float* db, float* dcell, void* ws,
+                            size_t ws_bytes, void* stream);
 
 /* Weight gradient of the 3x3 sparse conv without materialising the gathered [m_out, 9*cin] matrix: the token-split
  * kernel reads row nbr[o,t] of feat [m_in, cin] (bf16) for the column block of tap t.  dw [cout, 9*cin] f32 = the
@@ -346,8 +356,9 @@ int tmae_token_gemm_dgelu(const void* x, int64_t ldx, int64_t m, int k, const vo
 int tmae_token_gemm_pos(const void* x, int64_t ldx, int64_t m, int k, const void* w_aug, int n, const void* bias,
                         const uint8_t* cells, void* y, int64_t ldy, void* stream);
 /* cells [m] u8 and onehot [m,16] bf16 (columns 0..7 one-hot xc, 8..15 one-hot yc) of the tokens `indices` [m,3] (b,y,x)
- * for window shape (wy, wx) <= 8 and the shift of the layer; dY^T . onehot (tmae_linear_wgrad, k = 16) is the position
- * part of the in-projection weight gradient. */
+ * for window shape (wy, wx) <= 8 and the shift of the layer; onehot (may be NULL) is the explicit operand of the
+ * position part of the in-projection weight gradient, dY^T . onehot -- tmae_linear_wgrad_cells computes that product
+ * from `cells` inside the weight-gradient pass. */
 int tmae_window_cells(const int32_t* indices, int64_t m, int wy, int wx, int do_shift, uint8_t* cells, void* onehot,
                       void* stream);
 

@@ -692,9 +692,14 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
       // all key tiles that computed every logit, exp and dP twice (the 64-token class recomputed them: these kernels
       // are VALU-bound and exp runs at quarter rate).  O is the bf16-rounded forward output, so sum_j dS_ij is zero
       // only to ~2^-9 |D_i|; the tau gradient sum_ij dS_ij s_ij is therefore accumulated with the row-centred logit
-      // s_ij - lse_i = log P_ij (exact identity when sum_j dS_ij = 0): the row residual then enters multiplied by
-      // P log P <= 1/e per entry, not by logits of size 1/tau.
+      // s_ij - lse_i = log P_ij (exact identity when sum_j dS_ij = 0), and the row residual R_i = sum_j dS_ij
+      // (= D*_i - D_i, the error of D_i) is removed exactly: with dS*_ij = dS_ij - P_ij R_i,
+      //   sum_j dS*_ij log P_ij = sum_j dS_ij log P_ij - R_i sum_j P_ij log P_ij
+      // -- two more accumulations per entry (R_i, sum_j P log P) and the gradient of tau is as exact as with the first
+      // pass (without the correction the rounding of O left zero-mean noise of the size of the gradient itself over
+      // ~1e5 query rows at tau = 0.05).
       const float dacc = dsum[qt];
+      float rres = 0.f, plogp = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         if (kt < nk) {
@@ -717,6 +722,8 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
             const float p = pT[r];
             const float ds = p * (dP[r] - dacc);
             dtau_acc += ds * sT[r];                        // p = 0 entries: 0 * finite
+            rres += ds;
+            plogp += p * sT[r];
             dsT[r] = f2bf(ds);
             pTb[r] = f2bf(p);
           }
@@ -741,6 +748,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
           }
         }
       }
+      dtau_acc -= 0.25f * quad_sum(rres) * quad_sum(plogp);      // every lane of the quad holds the row's sums
       // dq = (dq-hat - q-hat (q-hat . dq-hat)) / |q|.  The products are taken transposed (rows = channels) over the
       // permuted images, so lane (g, i) holds channels FR g + 4 ct + r of query qt*16+i: the SAME channels as its own
       // row fragment qf[qt] -- q-hat comes from registers, the dot product is a quad reduction, one wide store per lane

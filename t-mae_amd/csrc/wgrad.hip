@@ -42,12 +42,19 @@ __device__ __forceinline__ bf16x8 load_frag(const char* img, int cb, int lane) {
   return *reinterpret_cast<bf16x8*>(&v);
 }
 
-template <bool G>          // G: X rows are gathered through nbr (sparse-conv rulebook)
+// CL (attention in-projections, ops.pos_proj): the kernel also returns the PER-CELL column sums of dY,
+//   dcell[c, n] = sum over the tokens whose window cell has xc == c (c < 8) / yc == c - 8 (c >= 8) of dY[m, n],
+// for the output rows n < pos_n -- the position part of the weight gradient is dcell^T . E (16 x k), so dY is not
+// streamed a second time against a one-hot matrix.  cells [>= round_up(M, 32) + 64] u8 = xc | yc << 3.
+// Here: the ones-vector MFMA of the bias gradient becomes a one-hot MFMA (16 cell columns), built per step from the
+// cell bytes of the lane's 8 tokens.
+template <bool G, bool CL>          // G: X rows are gathered through nbr (sparse-conv rulebook)
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
                                                    const __hip_bfloat16* __restrict__ X, int64_t ldx, int64_t M,
                                                    int N, int K, int rows_per_split, float* __restrict__ slab,
                                                    int64_t count, bool has_bias, int NB, int KB, int S,
-                                                   const int32_t* __restrict__ nbr, int cin) {
+                                                   const int32_t* __restrict__ nbr, int cin,
+                                                   const uint8_t* __restrict__ cells, int pos_n) {
   __shared__ __attribute__((aligned(16))) char lds[2][2][WG_MS * 256];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w >> 1, wk = w & 1;
   // XCD-aware 1-D grid: block ids are dealt round-robin over the 8 XCDs (speed only, never correctness), so all
@@ -63,10 +70,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
   const int64_t m_end = min(M, m_begin + (int64_t)rows_per_split);
   const int steps = m_end > m_begin ? (int)((m_end - m_begin + WG_MS - 1) / WG_MS) : 0;
   const bool want_bias = has_bias && kblk == 0 && wk == 0;     // wave-uniform
+  const bool cell_wave = CL && kblk == 0 && wk == 0;           // writes the cell block of its rows (zeros if n0 >= pos_n)
+  const bool want_cells = cell_wave && n0 < pos_n;
   // gathered X (sparse conv): column block k0 lies inside tap k0 / cin; row m reads feature row nbr[m, tap]
   const int tap = G ? k0 / cin : 0, c0 = G ? k0 % cin : k0;
   float* __restrict__ slab_w = slab + (int64_t)s * count;
   float* __restrict__ slab_b = slab_w + (int64_t)N * K;
+  float* __restrict__ slab_c = slab_b + N;                     // [16][N] per-cell sums (CL)
 
   // register staging, two slices deep: while slice st is contracted out of LDS, the loads of slices st+1 and st+2
   // are in flight (32 KB per workgroup) -- one slice of prefetch left the kernel latency-bound at ~2.5 TB/s.
@@ -79,6 +89,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
   bool oky[2][2], okx[2][2];
   int xi[2][2] = {{0, 0}, {0, 0}};     // gathered mode: feature-row ids, fetched one slice before their row loads so
                                        // the row loads never wait on an index load (no dependent round trip)
+  uint2 c8[2] = {{0u, 0u}, {0u, 0u}};  // CL: cell bytes of the lane's 8 tokens (8g .. 8g+7 of the slice)
+  const uint8_t* __restrict__ baseC = CL ? cells + m_begin + 8 * (lane >> 4) : nullptr;
   const int rows_here = (int)(m_end - m_begin);
   const char* __restrict__ baseY = reinterpret_cast<const char*>(dY + m_begin * ldy);
   const char* __restrict__ baseX = reinterpret_cast<const char*>(G ? X : X + m_begin * ldx);
@@ -94,6 +106,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
     }
   };
   auto gload = [&](int step, int P) {
+    if constexpr (CL) {                 // (slices up to one past the end are staged: the cells buffer is padded for that)
+      if (want_cells) c8[P] = *reinterpret_cast<const uint2*>(baseC + (unsigned)step * WG_MS);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
@@ -122,7 +137,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
     }
   };
 
-  f32x4 acc[4][4], accb[4];
+  f32x4 acc[4][4], accb[4], accs[CL ? 4 : 1];
+#pragma unroll
+  for (int a = 0; a < (CL ? 4 : 1); ++a) accs[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -144,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
   auto step = [&](int st, int P) {      // P == st & 1, a literal at both call sites
     // no branches around the loads / LDS writes (slices past the end read clamped rows and stage zeros): the
     // compiler's wait-count bookkeeping turns conservative (vmcnt(0)) at every control-flow join
+    const uint2 ccur = c8[P]; // CL: this slice's cell bytes, before the register set is refilled
     iload(st + 3, P ^ 1);     // index loads first: vmcnt retires in order, and the next step's row
     gload(st + 2, P);         // loads must be able to wait for the ids without draining these
     __builtin_amdgcn_sched_barrier(0);   // keep the loads up here and their consumers below the MFMAs: left alone, the
@@ -161,6 +179,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
     if (want_bias) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
+    }
+    if constexpr (CL) {
+      if (want_cells) {
+        // one-hot B fragment of THIS slice (its cell bytes were loaded two steps ago with the rows): column lane & 15
+        // = cell slot (0..7 xc, 8..15 yc), the lane's 8 tokens 8g .. 8g+7
+        const int ci_ = lane & 15;
+        const unsigned want_ = (unsigned)(ci_ & 7), sh_ = ci_ < 8 ? 0u : 3u;
+        unsigned wds[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned src = j < 2 ? ccur.x : ccur.y;
+          const unsigned ca = (src >> (16 * (j & 1))) & 0xFFu, cb = (src >> (16 * (j & 1) + 8)) & 0xFFu;
+          wds[j] = ((((ca >> sh_) & 7u) == want_) ? 0x00003F80u : 0u) | ((((cb >> sh_) & 7u) == want_) ? 0x3F800000u : 0u);
+        }
+        const u32x4 ohu = {wds[0], wds[1], wds[2], wds[3]};
+        const bf16x8 oh = __builtin_bit_cast(bf16x8, ohu);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) accs[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], oh, accs[a], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     lwrite(P ^ 1, P ^ 1);
@@ -184,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
         if (k < K) slab_w[(int64_t)n * K + k] = acc[a][b][r];
       }
       if (want_bias && ci == 0) slab_b[n] = accb[a][r];
+      if constexpr (CL) { if (cell_wave) slab_c[(int64_t)ci * N + n] = accs[a][r]; }
     }
   }
 }
@@ -197,6 +235,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
 // staged dY chunks (a thread always stages the same 8 columns), not with an extra MFMA: no accumulator registers.
 // ------------------------------------------------------------------------------------------------
 #define WG2_B 256
+// (No per-cell sums here: the kernel has no registers left for a one-hot MFMA, and LDS float atomics from the staged
+// dY chunks -- tried -- made it 12x slower.  The launcher takes them from a second, narrow pass of the 128-tile kernel.)
 template <bool G>
 __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
                                                          const __hip_bfloat16* __restrict__ X, int64_t ldx, int64_t M,
@@ -348,7 +388,8 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
 #define WG_RG 16
 __global__ __launch_bounds__(64 * WG_RG) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits,
                                                                  int64_t count, int n, int k, float* __restrict__ dw,
-                                                                 float* __restrict__ db) {
+                                                                 float* __restrict__ db, float* __restrict__ dc,
+                                                                 int ldc) {
   __shared__ float4 red[WG_RG][64];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t e = ((int64_t)blockIdx.x * 64 + lane) * 4;
@@ -371,7 +412,11 @@ __global__ __launch_bounds__(64 * WG_RG) void wgrad_reduce_kernel(const float* _
     for (int j = 0; j < 4; ++j) {
       const int64_t idx = e + j;
       if (idx < nk) dw[idx] = tv[j];
-      else if (db && idx < nk + n) db[idx - nk] = tv[j];
+      else if (idx < nk + n) { if (db) db[idx - nk] = tv[j]; }
+      else if (dc && idx < nk + 17 * (int64_t)n) {                             // [16][n] per-cell sums -> pitch ldc
+        const int64_t e2 = idx - nk - n;
+        dc[(e2 / n) * ldc + e2 % n] = tv[j];
+      }
     }
   }
 }
@@ -406,66 +451,85 @@ static void wgrad_plan(int64_t m, int n, int k, int& splits, int& rows_per_split
   rows_per_split = (int)rows;
 }
 
-// slab row = [n*k weight partials | n bias partials | pad to a multiple of 4 floats]
-static int64_t slab_count(int n, int k) { return (((int64_t)n * k + n) + 3) / 4 * 4; }
+// slab row = [n*k weight partials | n bias partials | (cells: 16*n per-cell partials) | pad to a multiple of 4 floats]
+static int64_t slab_count(int n, int k, bool cl = false) { return (((int64_t)n * k + n + (cl ? 16 * n : 0)) + 3) / 4 * 4; }
 
 size_t tmae_linear_wgrad_workspace(int64_t m, int n, int k) {
   int splits, rows;
   wgrad_plan(m, n, k, splits, rows);
-  return tmae_align((size_t)splits * slab_count(n, k) * 4) + 1024;
+  return tmae_align((size_t)splits * slab_count(n, k, true) * 4) + tmae_align((size_t)n * 8 * 4) + 1024;   // (cells variant too)
 }
 
 static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k, float* dw,
-                        float* db, const int32_t* nbr, int cin, void* wsp, size_t ws_bytes, hipStream_t stream) {
+                        float* db, const int32_t* nbr, int cin, const uint8_t* cells, int pos_n, float* dc, int ldc,
+                        void* wsp, size_t ws_bytes, hipStream_t stream) {
   if (m < 0 || n <= 0 || k <= 0 || !dw || (n % 8) || (k % 8) || (ldy % 8) || (ldx % 8)) return TMAE_EARG;
   if (nbr && (cin <= 0 || cin % WG_BK || k != 9 * cin || (((uintptr_t)nbr) & 3))) return TMAE_EARG;
+  if (cells && (nbr || !dc || pos_n < 0 || pos_n > n || ldc < n || (((uintptr_t)cells) & 7))) return TMAE_EARG;
   if (m > 0 && (!dy || !x)) return TMAE_EARG;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return TMAE_EARG;
+  if (cells && wgrad_big_tile(n, k)) {
+    // the 256-tile kernel for dW / db, then the per-cell sums from a narrow pass of the 128-tile kernel over the
+    // position columns of dY and the first 8 columns of x (its [pos_n, 8] "weight gradient" goes to scratch)
+    int r = wgrad_launch(dy, ldy, x, ldx, m, n, k, dw, db, nullptr, 0, nullptr, 0, nullptr, 0, wsp, ws_bytes, stream);
+    if (r || pos_n == 0) return r;
+    const int pn = (pos_n + 7) / 8 * 8;
+    const size_t tail = tmae_align((size_t)n * 8 * 4);
+    if (ws_bytes < tail) return TMAE_EWS;
+    float* scratch = reinterpret_cast<float*>(static_cast<char*>(wsp) + (ws_bytes - tail) / 256 * 256);
+    return wgrad_launch(dy, ldy, x, ldx, m, pn, 8, scratch, nullptr, nullptr, 0, cells, pos_n, dc, ldc, wsp,
+                        (ws_bytes - tail) / 256 * 256, stream);
+  }
   int splits, rows;
   wgrad_plan(m, n, k, splits, rows);
-  const int64_t count = slab_count(n, k);
+  const bool cl = cells != nullptr;
+  const int64_t count = slab_count(n, k, cl);
   // the kernels address a workgroup's rows with 32-bit byte offsets from its first row
   if ((int64_t)rows * (ldy > ldx ? ldy : ldx) * 2 >= (int64_t)1 << 31 || (nbr && (int64_t)rows * 36 >= (int64_t)1 << 31)) return TMAE_EARG;
   WsCarver ws(wsp, ws_bytes);
   float* slab = ws.take<float>((size_t)splits * count);
   if (!ws.ok) return TMAE_EWS;
   // without a bias the slabs' bias columns stay unwritten; the reduction discards those sums
+#define WG_ARGS (const __hip_bfloat16*)dy, ldy, (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, \
+                KB, splits, nbr, cin
   if (wgrad_big_tile(n, k)) {
     const int NB = (n + WG2_B - 1) / WG2_B, KB = (k + WG2_B - 1) / WG2_B;
     const unsigned nblocks = 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
-    if (nbr)
-      hipLaunchKernelGGL(wgrad256_kernel<true>, dim3(nblocks), dim3(512), 0, stream, (const __hip_bfloat16*)dy, ldy,
-                         (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr,
-                         cin);
-    else
-      hipLaunchKernelGGL(wgrad256_kernel<false>, dim3(nblocks), dim3(512), 0, stream, (const __hip_bfloat16*)dy, ldy,
-                         (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr,
-                         cin);
+    if (nbr) hipLaunchKernelGGL((wgrad256_kernel<true>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
+    else hipLaunchKernelGGL((wgrad256_kernel<false>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
   } else {
     const int NB = (n + WG_BN - 1) / WG_BN, KB = (k + WG_BK - 1) / WG_BK;
     const unsigned nblocks = 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
-    if (nbr)
-      hipLaunchKernelGGL(wgrad_kernel<true>, dim3(nblocks), dim3(256), 0, stream, (const __hip_bfloat16*)dy, ldy,
-                         (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr, cin);
-    else
-      hipLaunchKernelGGL(wgrad_kernel<false>, dim3(nblocks), dim3(256), 0, stream, (const __hip_bfloat16*)dy, ldy,
-                         (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, KB, splits, nbr, cin);
+    if (nbr) hipLaunchKernelGGL((wgrad_kernel<true, false>), dim3(nblocks), dim3(256), 0, stream, WG_ARGS, cells, pos_n);
+    else if (cl) hipLaunchKernelGGL((wgrad_kernel<false, true>), dim3(nblocks), dim3(256), 0, stream, WG_ARGS, cells, pos_n);
+    else hipLaunchKernelGGL((wgrad_kernel<false, false>), dim3(nblocks), dim3(256), 0, stream, WG_ARGS, cells, pos_n);
   }
+#undef WG_ARGS
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tmae_cdiv(count / 4, 64)), dim3(64 * WG_RG), 0, stream, slab, splits,
-                     count, n, k, dw, db);
+                     count, n, k, dw, db, dc, ldc);
   return tmae_launch_status();
 }
 
 int tmae_linear_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k, float* dw,
                       float* db, void* wsp, size_t ws_bytes, void* stream_) {
   (void)hipGetLastError();
-  return wgrad_launch(dy, ldy, x, ldx, m, n, k, dw, db, nullptr, 0, wsp, ws_bytes, (hipStream_t)stream_);
+  return wgrad_launch(dy, ldy, x, ldx, m, n, k, dw, db, nullptr, 0, nullptr, 0, nullptr, 0, wsp, ws_bytes,
+                      (hipStream_t)stream_);
+}
+
+int tmae_linear_wgrad_cells(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k,
+                            const uint8_t* cells, int pos_n, float* dw, float* db, float* dcell, void* wsp,
+                            size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();
+  if (!cells || !dcell) return TMAE_EARG;
+  return wgrad_launch(dy, ldy, x, ldx, m, n, k, dw, db, nullptr, 0, cells, pos_n, dcell, n, wsp, ws_bytes,
+                      (hipStream_t)stream_);
 }
 
 int tmae_spconv_wgrad(const void* dy, int64_t ldy, const void* feat, int64_t ldf, const int32_t* nbr, int64_t m_out,
                       int cout, int cin, float* dw, void* wsp, size_t ws_bytes, void* stream_) {
   (void)hipGetLastError();
   if (!nbr) return TMAE_EARG;
-  return wgrad_launch(dy, ldy, feat, ldf, m_out, cout, 9 * cin, dw, nullptr, nbr, cin, wsp, ws_bytes,
-                      (hipStream_t)stream_);
+  return wgrad_launch(dy, ldy, feat, ldf, m_out, cout, 9 * cin, dw, nullptr, nbr, cin, nullptr, 0, nullptr, 0, wsp,
+                      ws_bytes, (hipStream_t)stream_);
 }

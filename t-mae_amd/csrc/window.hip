@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void window_cells_kernel(const int32_t* __rest
   cells[r] = (uint8_t)(xc | (yc << 3));
   const unsigned vx = (xc & 1u) ? 0x3F800000u : 0x00003F80u, ix = xc >> 1;
   const unsigned vy = (yc & 1u) ? 0x3F800000u : 0x00003F80u, iy = yc >> 1;
+  if (!onehot) return;
   onehot[2 * r] = make_uint4(ix == 0u ? vx : 0u, ix == 1u ? vx : 0u, ix == 2u ? vx : 0u, ix == 3u ? vx : 0u);
   onehot[2 * r + 1] = make_uint4(iy == 0u ? vy : 0u, iy == 1u ? vy : 0u, iy == 2u ? vy : 0u, iy == 3u ? vy : 0u);
 }
@@ -244,7 +245,7 @@ int tmae_window_cells(const int32_t* indices, int64_t m, int wy, int wx, int do_
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || wy <= 0 || wx <= 0 || wy > 8 || wx > 8) return TMAE_EARG;
   if (m == 0) return TMAE_OK;
-  if (!indices || !cells || !onehot || ((uintptr_t)onehot & 15)) return TMAE_EARG;
+  if (!indices || !cells || ((uintptr_t)onehot & 15)) return TMAE_EARG;
   const int sy = do_shift ? wy / 2 : wy, sx = do_shift ? wx / 2 : wx;
   hipLaunchKernelGGL(window_cells_kernel, dim3(tmae_cdiv(m, 256)), dim3(256), 0, stream, indices, m, wy, wx, sy, sx, cells,
                      (uint4*)onehot);

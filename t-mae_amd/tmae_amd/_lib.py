@@ -84,6 +84,7 @@ SIGNATURES = {
     'tmae_window_cells': (I, [P, L, I, I, I, P, P, P]),
     'tmae_linear_wgrad_workspace': (Z, [L, I, I]),
     'tmae_linear_wgrad': (I, [P, L, P, L, L, I, I, P, P, P, Z, P]),
+    'tmae_linear_wgrad_cells': (I, [P, L, P, L, L, I, I, P, I, P, P, P, P, Z, P]),
     'tmae_spconv_wgrad': (I, [P, L, P, L, P, L, I, I, P, P, Z, P]),
 }
 

@@ -77,7 +77,7 @@ class WindowPlan:
         return self._wl[shift]
 
     def cells(self, shift, window_shape):
-        """(cells, onehot) of the tokens for this shift (ops.window_cells), shared by the layers of the stage."""
+        """cell bytes of the tokens for this shift (ops.window_cells), shared by the layers of the stage."""
         shift = bool(shift)
         if shift not in self._cells:
             self._cells[shift] = ops.window_cells(self.indices, window_shape, shift)
@@ -104,9 +104,9 @@ class WindowAttention(nn.Module):
         a = self.self_attn
         d = a.embed_dim
         if _POS_FOLD and ops._pos_proj_ok(x, d, 3 * d):
-            cells, onehot = plan.cells(shift, window_shape)
-            qkv, x_res = ops.pos_proj(x, a.in_proj_weight, a.in_proj_bias, 0, 3 * d, 0, 2 * d, cells, onehot,
-                                      ops.pos_axes(pos_table, window_shape), fork=True, inplace_dx=True)
+            qkv, x_res = ops.pos_proj(x, a.in_proj_weight, a.in_proj_bias, 0, 3 * d, 0, 2 * d,
+                                      plan.cells(shift, window_shape), ops.pos_axes(pos_table, window_shape), fork=True,
+                                      inplace_dx=True)
             o = ops.win_attn(qkv, None, None, a.tau, plan.grid, plan.grid, self.nhead, plan.batch, plan.ny, plan.nx,
                              shift, a.tau_min, worklist=plan.worklist(shift))
             return ops.linear(o, a.out_proj.weight, a.out_proj.bias), x_res
@@ -136,10 +136,8 @@ class WindowCrossAttention(nn.Module):
         w, b = a.in_proj_weight, a.in_proj_bias
         if _POS_FOLD and ops._pos_proj_ok(x, d, d) and ops._pos_proj_ok(x_prv, d, 2 * d):
             E = ops.pos_axes(pos_table, window_shape)
-            cells, onehot = plan.cells(shift, window_shape)
-            cells_p, onehot_p = plan_prv.cells(shift, window_shape)
-            q, x_res = ops.pos_proj(x, w, b, 0, d, 0, d, cells, onehot, E, fork=True, inplace_dx=True)
-            kv = ops.pos_proj(x_prv, w, b, d, 3 * d, d, 2 * d, cells_p, onehot_p, E)
+            q, x_res = ops.pos_proj(x, w, b, 0, d, 0, d, plan.cells(shift, window_shape), E, fork=True, inplace_dx=True)
+            kv = ops.pos_proj(x_prv, w, b, d, 3 * d, d, 2 * d, plan_prv.cells(shift, window_shape), E)
             o = ops.win_attn(q, kv, 'kv', a.tau, plan.grid, plan_prv.grid, self.nhead, plan.batch, plan.ny, plan.nx,
                              shift, a.tau_min, worklist=plan.worklist(shift))
             return o, x_res

@@ -201,10 +201,12 @@ def refresh_param_copies(params, dtype=torch.bfloat16):
 
 # ----------------------------------------------------------------------------- token-list Linear
 
-def linear_wgrad(dy, x, want_bias=True, out_w=None, out_b=None):
+def linear_wgrad(dy, x, want_bias=True, out_w=None, out_b=None, cells=None, pos_n=0):
     """dW [n,k] f32 = dy^T @ x, db [n] f32 = column sums of dy; dy [m,n], x [m,k] bf16 (row-major, last dim
     contiguous).  One streaming pass, token axis split over the chip (csrc/wgrad.hip).  out_w / out_b: contiguous f32
-    destinations (e.g. a row slice of a packed gradient) written in place of fresh tensors."""
+    destinations (e.g. a row slice of a packed gradient) written in place of fresh tensors.
+    cells (ops.window_cells): also returns dcell [16, n] f32, the per-cell column sums of dy[:, :pos_n]
+    (tmae_linear_wgrad_cells) -- the return value is then (dw, db, dcell)."""
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(1) == 1 and x.stride(1) == 1
     m, n = dy.shape
     k = x.shape[1]
@@ -220,6 +222,11 @@ def linear_wgrad(dy, x, want_bias=True, out_w=None, out_b=None):
         db = torch.empty((n,), dtype=torch.float32, device=dy.device) if want_bias else None
     wsb = lib.tmae_linear_wgrad_workspace(m, n, k)
     ws = _ws(wsb, dy.device)
+    if cells is not None:
+        dcell = torch.empty((16, n), dtype=torch.float32, device=dy.device)
+        check(lib.tmae_linear_wgrad_cells(_p(dy), dy.stride(0), _p(x), x.stride(0), m, n, k, _p(cells), int(pos_n), _p(dw),
+                                          _p(db), _p(dcell), _p(ws), wsb, _s()), 'tmae_linear_wgrad_cells')
+        return dw, db, dcell
     check(lib.tmae_linear_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), m, n, k, _p(dw), _p(db), _p(ws), wsb, _s()),
           'tmae_linear_wgrad')
     return dw, db
@@ -365,14 +372,17 @@ def _derived(t, name, fn):
     return v
 
 
-def window_cells(indices, window_shape, do_shift):
-    """(cells [m] u8 = xc | yc << 3, onehot [m,16] bf16) of the tokens inside their (shifted) windows."""
+def window_cells(indices, window_shape, do_shift, want_onehot=False):
+    """cells [m] u8 = xc | yc << 3 of the tokens inside their (shifted) windows -- a view of a zero-padded buffer of
+    round_up(m, 32) + 64 bytes, which tmae_linear_wgrad_cells may read past m -- and, on request, the explicit one-hot
+    matrix [m,16] bf16 (columns 0..7 xc, 8..15 yc)."""
     m = indices.shape[0]
-    cells = torch.empty((m,), dtype=torch.uint8, device=indices.device)
-    onehot = torch.empty((m, 16), dtype=torch.bfloat16, device=indices.device)
+    buf = torch.zeros(((m + 31) // 32 * 32 + 64,), dtype=torch.uint8, device=indices.device)
+    cells = buf[:m]
+    onehot = torch.empty((m, 16), dtype=torch.bfloat16, device=indices.device) if want_onehot else None
     check(lib.tmae_window_cells(_p(indices), m, int(window_shape[1]), int(window_shape[0]), 1 if do_shift else 0,
                                 _p(cells), _p(onehot), _s()), 'tmae_window_cells')
-    return cells, onehot
+    return (cells, onehot) if want_onehot else cells
 
 
 def pos_axes(pos_table, window_shape):
@@ -415,12 +425,14 @@ def _pos_proj_ok(x, d, rows):
 
 class _PosProj(torch.autograd.Function):
     """out [m, hi-lo] = (x [+ pos]) W[lo:hi]^T + b[lo:hi] -- the attention in-projections of ONE token list as one GEMM:
-    rows p0:p1 of W see x + pos (q, k), the others x (v).  The position embedding never touches [m,d]: forward through
-    the one-hot k-step of tmae_token_gemm_pos, backward as dW[p0:p1] += (dOut[:, p0:p1]^T onehot) E.
+    rows p0:p1 of W (p0 == lo) see x + pos (q, k), the others x (v).  The position embedding never touches [m,d]: forward
+    through the one-hot k-step of tmae_token_gemm_pos, backward as dW[p0:p1] += dcell^T E with the per-cell column sums of
+    dOut[:, p0:p1] that the weight-gradient pass returns (tmae_linear_wgrad_cells).
     With `fork`, x itself comes back as a last output (residual branch) and its gradient is accumulated in place."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, lo, hi, p0, p1, cells, onehot, E, fork, inplace_dx):
+    def forward(ctx, x, weight, bias, lo, hi, p0, p1, cells, E, fork, inplace_dx):
+        assert p0 == lo
         x_c = x.to(torch.bfloat16).contiguous()
         m, d = x_c.shape
         w_aug = pos_fold_weight(weight, lo, hi, (p0, p1), E)
@@ -428,7 +440,7 @@ class _PosProj(torch.autograd.Function):
         out = torch.empty((m, hi - lo), dtype=torch.bfloat16, device=x.device)
         check(lib.tmae_token_gemm_pos(_p(x_c), x_c.stride(0), m, d, _p(w_aug), hi - lo, _p(b_c), _p(cells), _p(out),
                                       hi - lo, _s()), 'tmae_token_gemm_pos')
-        ctx.save_for_backward(x_c, w_aug, onehot, E)
+        ctx.save_for_backward(x_c, w_aug, cells, E)
         ctx.rng = (lo, hi, p0, p1, weight.shape[0])
         ctx.fork, ctx.has_bias = fork, bias is not None
         ctx.inplace_dx = bool(inplace_dx and fork)
@@ -438,7 +450,7 @@ class _PosProj(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, dalias=None):
-        x_c, w_aug, onehot, E = ctx.saved_tensors
+        x_c, w_aug, cells, E = ctx.saved_tensors
         lo, hi, p0, p1, rows = ctx.rng
         xdt, wdt, bdt = ctx.dtypes
         m, d = x_c.shape
@@ -462,18 +474,17 @@ class _PosProj(torch.autograd.Function):
                 dW = mk((rows, d), dtype=torch.float32, device=x_c.device)
                 want_b = ctx.has_bias and ctx.needs_input_grad[2]
                 dB = mk((rows,), dtype=torch.float32, device=x_c.device) if want_b else None
-                linear_wgrad(dout, x_c, want_b, out_w=dW[lo:hi], out_b=None if dB is None else dB[lo:hi])
+                _, _, dcell = linear_wgrad(dout, x_c, want_b, out_w=dW[lo:hi], out_b=None if dB is None else dB[lo:hi],
+                                           cells=cells, pos_n=p1 - p0)
                 if p1 > p0:
-                    st, _ = linear_wgrad(dout[:, p0 - lo:p1 - lo], onehot, False)      # [p1-p0, 16] = per-cell column sums
-                    dW[p0:p1].addmm_(st, E)
+                    dW[p0:p1].addmm_(dcell[:, :p1 - p0].t(), E)
         return (None if dx is None else dx.to(xdt), None if dW is None else dW.to(wdt),
-                None if dB is None else dB.to(bdt), None, None, None, None, None, None, None, None, None)
+                None if dB is None else dB.to(bdt), None, None, None, None, None, None, None, None)
 
 
-def pos_proj(x, weight, bias, lo, hi, p0, p1, cells, onehot, E, fork=False, inplace_dx=False):
+def pos_proj(x, weight, bias, lo, hi, p0, p1, cells, E, fork=False, inplace_dx=False):
     """See _PosProj (bf16 GPU path; callers check _pos_proj_ok first)."""
-    return _PosProj.apply(x, weight, bias, int(lo), int(hi), int(p0), int(p1), cells, onehot, E, bool(fork),
-                          bool(inplace_dx))
+    return _PosProj.apply(x, weight, bias, int(lo), int(hi), int(p0), int(p1), cells, E, bool(fork), bool(inplace_dx))
 
 
 class _GeluLinear(torch.autograd.Function):

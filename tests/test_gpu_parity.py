@@ -389,11 +389,14 @@ def test_attention_bf16_and_softmax_property():
             assert torch.isfinite(ones16.float()).all() and (ones16.float() - 1).abs().max().item() < 1.5e-2
 
 
-def test_attention_mfma_bf16_fwd_bwd_vs_fp32_kernel():
+@pytest.mark.parametrize('seed', [11, 12, 13])
+def test_attention_mfma_bf16_fwd_bwd_vs_fp32_kernel(seed):
     """The bf16 MFMA kernels (forward + backward) against the fp32 kernels (which the golden tests pin to the
-    reference) on the same inputs: self- and cross-attention, dh 16 and 32, both shifts, tau at and above the clamp."""
+    reference) on the same inputs: self- and cross-attention, dh 16 and 32, both shifts, tau at and above the clamp.
+    (Seeded: the tau gradient is a sum over ~1e5 query rows whose rounding noise a lucky draw can hide.)"""
     from tmae_amd import ops
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
 
     def cloud(n, b):
         c = np.unique(np.stack([rng.integers(0, b, n), rng.integers(0, 234, n), rng.integers(0, 234, n)], 1), axis=0)
@@ -602,7 +605,7 @@ def test_pos_folded_in_projection_vs_materialised(shift):
         ind, table, x = _pos_case(m, d, 7 + m % 5)
         w = (torch.randn(3 * d, d, device=dev()) * 0.1)
         b = torch.randn(3 * d, device=dev())
-        cells, onehot = ops.window_cells(ind, [8, 8, 1], shift)
+        cells, onehot = ops.window_cells(ind, [8, 8, 1], shift, want_onehot=True)
         yc, xc = (ind[:, 1].long() + sh) % 8, (ind[:, 2].long() + sh) % 8
         assert torch.equal(cells.long(), xc + 8 * yc)
         assert torch.equal(onehot.float().argmax(1), xc) and torch.equal(onehot[:, 8:].float().argmax(1), yc)
@@ -621,7 +624,7 @@ def test_pos_folded_in_projection_vs_materialised(shift):
         bp = torch.nn.Parameter(b.clone())
         xin = x.clone().requires_grad_(True)
         with torch.autocast('cuda', dtype=torch.bfloat16):
-            out, alias = ops.pos_proj(xin, wp, bp, lo, hi, p0, p1, cells, onehot, E, fork=True)
+            out, alias = ops.pos_proj(xin, wp, bp, lo, hi, p0, p1, cells, E, fork=True)
         assert out.shape == (m, hi - lo) and out.dtype == torch.bfloat16
         scale = float(ref.abs().max())
         assert (out.float() - ref).abs().max().item() <= 1e-2 * scale, (m, d, lo, hi)
@@ -640,10 +643,10 @@ def test_pos_folded_in_projection_vs_materialised(shift):
         # a second call finds the folded weight in the cache, an optimizer-style in-place update drops it
         c0 = wp._tmae_derived
         with torch.autocast('cuda', dtype=torch.bfloat16), torch.no_grad():
-            out2 = ops.pos_proj(xin, wp, bp, lo, hi, p0, p1, cells, onehot, E)
+            out2 = ops.pos_proj(xin, wp, bp, lo, hi, p0, p1, cells, E)
             assert torch.equal(out2, out) and wp._tmae_derived is c0
             wp.mul_(0.5)
-            out3 = ops.pos_proj(xin, wp, bp, lo, hi, p0, p1, cells, onehot, E)
+            out3 = ops.pos_proj(xin, wp, bp, lo, hi, p0, p1, cells, E)
         ref3 = (ref - br[lo:hi]) * 0.5 + br[lo:hi]
         assert (out3.float() - ref3).abs().max().item() <= 1e-2 * scale
 
