@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
 #define WG2_B 256
 // (No per-cell sums here: the kernel has no registers left for a one-hot MFMA, and LDS float atomics from the staged
 // dY chunks -- tried -- made it 12x slower.  The launcher takes them from a second, narrow pass of the 128-tile kernel.)
-template <bool G>
+template <bool G, int NTL = 0>      // NTL: bit 0 / 1 = dY / X rows are loaded with the non-temporal policy (read by one workgroup only)
 __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
                                                          const __hip_bfloat16* __restrict__ X, int64_t ldx, int64_t M,
                                                          int N, int K, int rows_per_split, float* __restrict__ slab,
@@ -283,14 +283,16 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
     for (int i = 0; i < 2; ++i) {
       const int r = step * WG_MS + r0 + 16 * i, rc = min(r, rows_here - 1);
       oky[P][i] = r < rows_here && coly;
-      ry[P][i] = *reinterpret_cast<const u32x4*>(baseY + (unsigned)rc * pitchY);
+      if constexpr (NTL & 1) ry[P][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(baseY + (unsigned)rc * pitchY));
+      else ry[P][i] = *reinterpret_cast<const u32x4*>(baseY + (unsigned)rc * pitchY);
       if constexpr (G) {
         const int xr = xi[P][i];
         okx[P][i] = r < rows_here && colx && xr >= 0;
         rx[P][i] = *reinterpret_cast<const u32x4*>(baseX + (int64_t)max(xr, 0) * pitchX);
       } else {
         okx[P][i] = r < rows_here && colx;
-        rx[P][i] = *reinterpret_cast<const u32x4*>(baseX + (unsigned)rc * pitchX);
+        if constexpr (NTL & 2) rx[P][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(baseX + (unsigned)rc * pitchX));
+        else rx[P][i] = *reinterpret_cast<const u32x4*>(baseX + (unsigned)rc * pitchX);
       }
     }
   };
@@ -496,7 +498,16 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
     const int NB = (n + WG2_B - 1) / WG2_B, KB = (k + WG2_B - 1) / WG2_B;
     const unsigned nblocks = 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
     if (nbr) hipLaunchKernelGGL((wgrad256_kernel<true>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
-    else hipLaunchKernelGGL((wgrad256_kernel<false>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
+    else {
+      // dY columns belong to one n-block each: with a single k-block nobody re-reads them; likewise X with one n-block
+      // (measured on the priced shape: -3 %; TMAE_WGRAD_NT=0 turns it off)
+      static const int ntl_env = [] { const char* e = getenv("TMAE_WGRAD_NT"); return e ? atoi(e) : 3; }();
+      const int ntl = ntl_env & ((KB == 1 ? 1 : 0) | (NB == 1 ? 2 : 0));
+      if (ntl == 1) hipLaunchKernelGGL((wgrad256_kernel<false, 1>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
+      else if (ntl == 2) hipLaunchKernelGGL((wgrad256_kernel<false, 2>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
+      else if (ntl == 3) hipLaunchKernelGGL((wgrad256_kernel<false, 3>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
+      else hipLaunchKernelGGL((wgrad256_kernel<false, 0>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
+    }
   } else {
     const int NB = (n + WG_BN - 1) / WG_BN, KB = (k + WG_BK - 1) / WG_BK;
     const unsigned nblocks = 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
