@@ -1,6 +1,11 @@
 """SSTBEVBackbone (pcdet/models/backbones_2d/sst_bev_backbone.py:6-43): a stack of 3x3 Conv2d (+dilation) +
-BatchNorm2d(eps 1e-3, momentum 0.01) + ReLU with residual shortcuts.  The convolutions are MIOpen's (channels-last);
-the norm + ReLU run on the row kernels of csrc/batchnorm.hip over the [B*Y*X, C] view."""
+BatchNorm2d(eps 1e-3, momentum 0.01) + ReLU with residual shortcuts.  In bf16 training the undilated 128 -> 128
+convolutions run on the halo-tiled implicit GEMM of csrc/spconv_igemm.hip (forward and input gradient) and the
+token-split weight-gradient kernel (ops.dense_conv3x3; TMAE_DENSE_CONV=miopen: the library's), the dilated one and
+everything in fp32 on MIOpen (channels-last); the norm + ReLU run on the row kernels of csrc/batchnorm.hip over the
+[B*Y*X, C] view."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -10,7 +15,12 @@ from .. import ops
 def conv_bn_relu_nhwc(seq, x):
     """seq = Sequential(Conv2d, BatchNorm2d, ReLU) on a channels-last tensor; fused norm+ReLU in training."""
     conv, bn = seq[0], seq[1]
-    y = conv(x)
+    nhwc = x.permute(0, 2, 3, 1)
+    if (bn.training and os.environ.get('TMAE_DENSE_CONV', 'halo') != 'miopen' and nhwc.is_contiguous()
+            and ops.dense_conv3x3_ok(nhwc, conv) and conv.out_channels % 128 == 0):
+        y = ops.dense_conv3x3(nhwc, conv.weight).permute(0, 3, 1, 2)
+    else:
+        y = conv(x)
     if (bn.training and y.is_cuda and y.is_contiguous(memory_format=torch.channels_last)
             and y.shape[1] in (64, 128, 256) and len(seq) == 3 and isinstance(seq[2], nn.ReLU)):
         b, c, ny, nx = y.shape
