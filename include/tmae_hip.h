@@ -224,6 +224,10 @@ int tmae_spconv_bwd_data(const void* dout, int64_t lddo, int64_t m_out, int cout
  * weight_t[c, ((2-ky)*3 + (2-kx))*cout + n] = weight[n, (ky*3+kx)*cin + c]. */
 int tmae_dense_conv3x3(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, void* out,
                        void* stream);
+/* The same convolution with dilation d in {1, 2} and padding d (the dilated conv of SSTBEVBackbone,
+ * sst_bev_backbone.py:20-30, t_mae.yaml:107-112): 16 x 16 cell blocks with a (16 + 2d)^2 halo. */
+int tmae_dense_conv3x3_dilated(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout,
+                               int dilation, void* out, void* stream);
 
 /* gather-GEMM form: cols [m_out, 9*c] = rows of feat selected by nbr (zeros where -1), to be
  * multiplied by the [cout, 9*c] view of the spconv-2 weight [cout,3,3,cin]; and its adjoint

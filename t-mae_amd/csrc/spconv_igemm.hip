@@ -371,15 +371,20 @@ int tmae_spconv_bwd_data(const void* dout, int64_t lddo, int64_t m_out, int cout
 // 1 halo piece of the NEXT channel slice, a dummy piece once the halo is complete) so that the counted wait is uniform.
 //   out[b, y, x, n] = sum_{ky,kx,c} in[b, y+ky-1, x+kx-1, c] * W[n, (ky*3+kx)*CIN + c]
 // ------------------------------------------------------------------------------------------------
-#define HC_HALO 328                                    // 18 x 18 = 324 halo rows, padded to 41 pieces of 8 rows
-#define HC_ABYTES (HC_HALO * 128)
+// DIL = dilation (1: 18 x 18 halo = 41 pieces of 8 rows, 41 KB per image; 2 -- the third conv of SSTBEVBackbone,
+// sst_bev_backbone.py:20-30 with t_mae.yaml:107-112 -- 20 x 20 = 50 pieces, 50 KB: 2 images + 3 weight slots = 149 KB).
+template <int DIL> struct HaloGeom {
+  static constexpr int HW = 16 + 2 * DIL, NH = HW * HW, NP = (NH + 7) / 8, ABYTES = NP * 8 * 128, PQ = (NP + 7) / 8;
+};
 
-template <int CIN>
+template <int CIN, int DIL = 1>
 __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_bfloat16* __restrict__ in, int B, int Y,
                                                                    int X, const __hip_bfloat16* __restrict__ W, int cout,
                                                                    __hip_bfloat16* __restrict__ out) {
   constexpr int KC = CIN / 64;
   constexpr int STEPS = 9 * KC;
+  constexpr int HW = HaloGeom<DIL>::HW, NH = HaloGeom<DIL>::NH, NP = HaloGeom<DIL>::NP, HC_ABYTES = HaloGeom<DIL>::ABYTES;
+  static_assert(NP <= 72, "a channel slice has 9 x 8 halo transfers");
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* aimg = lds;                                    // 2 halo images (channel slices kc, kc+1)
   char* bring = lds + 2 * HC_ABYTES;                   // 3 weight slots of 16 KB
@@ -403,14 +408,14 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
     const int n = (L & ~63) + 16 * ((s64 >> 2) & 3) + 4 * (s64 >> 4) + (s64 & 3);
     wsrc[j] = reinterpret_cast<const char*>(W + (int64_t)(n0 + n) * (9 * CIN)) + chunk * 16;
   }
-  auto issue_halo = [&](int kc, int p) {              // piece p (0..71; >= 41: dummy) of channel slice kc
+  auto issue_halo = [&](int kc, int p) {              // piece p (0..71; >= NP: dummy) of channel slice kc
     const int h = 8 * p + r8;
-    const int hy = h / 18, hx = h - hy * 18;
-    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-    const bool ok = p < 41 && h < 324 && y >= 0 && y < Y && x >= 0 && x < X && kc < KC;
+    const int hy = h / HW, hx = h - hy * HW;
+    const int y = y0 - DIL + hy, x = x0 - DIL + hx;
+    const bool ok = p < NP && h < NH && y >= 0 && y < Y && x >= 0 && x < X && kc < KC;
     const uintptr_t pa = (uintptr_t)in + ((uintptr_t)(((int64_t)b * Y + (ok ? y : 0)) * X + (ok ? x : 0)) * CIN + kc * 64) * 2 + chunk * 16;
     const uintptr_t src = ok ? pa : (uintptr_t)zrow;
-    char* dst = p < 41 ? aimg + (kc & 1) * HC_ABYTES + p * 1024 : scratch;
+    char* dst = p < NP ? aimg + (kc & 1) * HC_ABYTES + p * 1024 : scratch;
     ig_glds16(reinterpret_cast<const void*>(src), dst);
   };
   auto issue_w = [&](int step) {
@@ -419,9 +424,9 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
 #pragma unroll
     for (int j = 0; j < 2; ++j) ig_glds16(wsrc[j] + (t * CIN + kc * 64) * 2, sb + (w * 16 + 8 * j) * 128);
   };
-  // prologue: the whole halo of slice 0 (41 pieces: waves take 6 each, dummies past the end) and two weight slices
+  // prologue: the whole halo of slice 0 (NP pieces: waves take PQ each, dummies past the end) and two weight slices
 #pragma unroll
-  for (int q = 0; q < 6; ++q) issue_halo(0, q * 8 + w);
+  for (int q = 0; q < HaloGeom<DIL>::PQ; ++q) issue_halo(0, q * 8 + w);
   issue_w(0);
   issue_w(1);
   const int wm = w & 3, wn = w >> 2;
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
       }
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const int R = (4 * wm + mt + ky) * 18 + i + kx;
+        const int R = (4 * wm + mt + ky * DIL) * HW + i + kx * DIL;
         bfr[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sa + R * 128 + ((c ^ (R & 7)) << 4)));
       }
       __builtin_amdgcn_s_setprio(1);
@@ -489,31 +494,47 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   }
 }
 
-// out [B, Y, X, cout] = conv3x3(in [B, Y, X, cin], padding 1) with weight [cout, 9 * cin] (taps ky-major, then kx, then
-// channel: the [cout, 3, 3, cin] layout flattened), bf16, fp32 accumulation.  cin in {128, 256, 384}, cout % 128 == 0.
-// The input gradient of such a conv is the same call on dout with weight_t[c, (2-ky)*3 + (2-kx), n] = weight[n, ky, kx, c].
-int tmae_dense_conv3x3(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, void* out,
-                       void* stream_) {
-  (void)hipGetLastError();
-  hipStream_t stream = (hipStream_t)stream_;
-  if (batch <= 0 || ny <= 0 || nx <= 0 || (cin != 128 && cin != 256 && cin != 384) || cout <= 0 || (cout % IG_BN))
+// out [B, Y, X, cout] = conv3x3(in [B, Y, X, cin], padding = dilation) with weight [cout, 9 * cin] (taps ky-major, then
+// kx, then channel: the [cout, 3, 3, cin] layout flattened), bf16, fp32 accumulation.  cin in {128, 256, 384},
+// cout % 128 == 0, dilation in {1, 2}.  The input gradient of such a conv is the same call on dout with
+// weight_t[c, (2-ky)*3 + (2-kx), n] = weight[n, ky, kx, c].
+static int dense_conv3x3_launch(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, int dil,
+                                void* out, hipStream_t stream) {
+  if (batch <= 0 || ny <= 0 || nx <= 0 || (cin != 128 && cin != 256 && cin != 384) || cout <= 0 || (cout % IG_BN) ||
+      (dil != 1 && dil != 2))
     return TMAE_EARG;
   if (!in || !weight || !out || ((uintptr_t)in & 15) || ((uintptr_t)weight & 15) || ((uintptr_t)out & 15)) return TMAE_EARG;
   const int64_t blocks = (int64_t)batch * ((ny + 15) / 16) * ((nx + 15) / 16) * (cout / IG_BN);
   if (blocks >= ((int64_t)1 << 31)) return TMAE_EARG;
-  const int lds = 2 * HC_ABYTES + 3 * (IG_BN * 128) + 1024;
-#define HC_LAUNCH(C)                                                                                                  \
+#define HC_LAUNCH(C, D)                                                                                               \
   do {                                                                                                                \
+    const int lds = 2 * HaloGeom<D>::ABYTES + 3 * (IG_BN * 128) + 1024;                                               \
     static bool attr = false;                                                                                         \
     if (!attr) {                                                                                                      \
-      (void)hipFuncSetAttribute((const void*)dense_conv3x3_halo_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+      (void)hipFuncSetAttribute((const void*)dense_conv3x3_halo_kernel<C, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
       attr = true;                                                                                                    \
     }                                                                                                                 \
-    hipLaunchKernelGGL((dense_conv3x3_halo_kernel<C>), dim3((unsigned)blocks), dim3(512), lds, stream,               \
+    hipLaunchKernelGGL((dense_conv3x3_halo_kernel<C, D>), dim3((unsigned)blocks), dim3(512), lds, stream,            \
                        (const __hip_bfloat16*)in, batch, ny, nx, (const __hip_bfloat16*)weight, cout,                 \
                        (__hip_bfloat16*)out);                                                                         \
   } while (0)
-  if (cin == 128) HC_LAUNCH(128); else if (cin == 256) HC_LAUNCH(256); else HC_LAUNCH(384);
+  if (dil == 1) {
+    if (cin == 128) HC_LAUNCH(128, 1); else if (cin == 256) HC_LAUNCH(256, 1); else HC_LAUNCH(384, 1);
+  } else {
+    if (cin == 128) HC_LAUNCH(128, 2); else if (cin == 256) HC_LAUNCH(256, 2); else HC_LAUNCH(384, 2);
+  }
 #undef HC_LAUNCH
   return tmae_launch_status();
+}
+
+int tmae_dense_conv3x3(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, void* out,
+                       void* stream_) {
+  (void)hipGetLastError();
+  return dense_conv3x3_launch(in, batch, ny, nx, cin, weight, cout, 1, out, (hipStream_t)stream_);
+}
+
+int tmae_dense_conv3x3_dilated(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout,
+                               int dilation, void* out, void* stream_) {
+  (void)hipGetLastError();
+  return dense_conv3x3_launch(in, batch, ny, nx, cin, weight, cout, dilation, out, (hipStream_t)stream_);
 }

@@ -1,8 +1,8 @@
 """SSTBEVBackbone (pcdet/models/backbones_2d/sst_bev_backbone.py:6-43): a stack of 3x3 Conv2d (+dilation) +
-BatchNorm2d(eps 1e-3, momentum 0.01) + ReLU with residual shortcuts.  In bf16 training the undilated 128 -> 128
-convolutions run on the halo-tiled implicit GEMM of csrc/spconv_igemm.hip (forward and input gradient) and the
-token-split weight-gradient kernel (ops.dense_conv3x3; TMAE_DENSE_CONV=miopen: the library's), the dilated one and
-everything in fp32 on MIOpen (channels-last); the norm + ReLU run on the row kernels of csrc/batchnorm.hip over the
+BatchNorm2d(eps 1e-3, momentum 0.01) + ReLU with residual shortcuts.  In bf16 training the 128 -> 128
+convolutions (dilation 1 and 2) run on the halo-tiled implicit GEMM of csrc/spconv_igemm.hip (forward and input gradient)
+and the token-split weight-gradient kernel (ops.dense_conv3x3; TMAE_DENSE_CONV=miopen: the library's), everything in fp32
+on MIOpen (channels-last); the norm + ReLU run on the row kernels of csrc/batchnorm.hip over the
 [B*Y*X, C] view."""
 import os
 
@@ -18,7 +18,7 @@ def conv_bn_relu_nhwc(seq, x):
     nhwc = x.permute(0, 2, 3, 1)
     if (bn.training and os.environ.get('TMAE_DENSE_CONV', 'halo') != 'miopen' and nhwc.is_contiguous()
             and ops.dense_conv3x3_ok(nhwc, conv) and conv.out_channels % 128 == 0):
-        y = ops.dense_conv3x3(nhwc, conv.weight).permute(0, 3, 1, 2)
+        y = ops.dense_conv3x3(nhwc, conv.weight, conv.dilation[0]).permute(0, 3, 1, 2)
     else:
         y = conv(x)
     if (bn.training and y.is_cuda and y.is_contiguous(memory_format=torch.channels_last)

@@ -1329,16 +1329,27 @@ def deblocks_fusable(sources, training):
 _DENSE_NBR = {}
 
 
-def _dense_rulebook(batch, ny, nx, device):
+def _dense_rulebook(batch, ny, nx, device, dil=1):
     """nbr [batch*ny*nx, 9] of a FULL grid (row = cell, -1 past the border): the sparse-conv rulebook of a dense 3x3
-    convolution with padding 1, built once per shape."""
-    key = (batch, ny, nx, device)
+    convolution with padding = dilation, built once per shape."""
+    key = (batch, ny, nx, device) if dil == 1 else (batch, ny, nx, device, dil)
     nbr = _DENSE_NBR.get(key)
     if nbr is None:
         n = batch * ny * nx
         cells = torch.arange(n, device=device, dtype=torch.int32)
-        ind = torch.stack([cells // (ny * nx), (cells // nx) % ny, cells % nx], 1).contiguous()
-        nbr = _DENSE_NBR[key] = spconv_neighbors(ind, cells, batch, ny, nx, 1)
+        if dil == 1:
+            ind = torch.stack([cells // (ny * nx), (cells // nx) % ny, cells % nx], 1).contiguous()
+            nbr = spconv_neighbors(ind, cells, batch, ny, nx, 1)
+        else:
+            y, x = (cells // nx) % ny, cells % nx
+            cols = []
+            for ky in range(3):
+                for kx in range(3):
+                    yy, xx = y + (ky - 1) * dil, x + (kx - 1) * dil
+                    ok = (yy >= 0) & (yy < ny) & (xx >= 0) & (xx < nx)
+                    cols.append(torch.where(ok, cells + ((ky - 1) * nx + (kx - 1)) * dil, torch.full_like(cells, -1)))
+            nbr = torch.stack(cols, 1).contiguous()
+        _DENSE_NBR[key] = nbr
     return nbr
 
 
@@ -1352,7 +1363,7 @@ class _DenseConv3x3(torch.autograd.Function):
     im2col(X), never materialised).  The library's implicit GEMMs ran at 0.52-0.68 PFLOP/s on this shape."""
 
     @staticmethod
-    def forward(ctx, x_nhwc, weight):
+    def forward(ctx, x_nhwc, weight, dil=1):
         cdt = compute_dtype(x_nhwc)
         x = x_nhwc.to(cdt).contiguous()
         w = cast_param(weight, cdt)
@@ -1360,16 +1371,17 @@ class _DenseConv3x3(torch.autograd.Function):
         cout = w.shape[0]
         n = B * Y * X
         ctx.native = _DENSE_CONV in ('native', 'halo') and cin in (128, 256, 384) and cout % 128 == 0
+        ctx.dil = dil
         if ctx.native:
             w2d = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
-            if _DENSE_CONV == 'halo':
-                y = dense_conv3x3_halo(x, w2d)
+            if _DENSE_CONV == 'halo' or dil != 1:
+                y = dense_conv3x3_halo(x, w2d, dil)
             else:
                 y = spconv_fwd(x.view(n, cin), _dense_rulebook(B, Y, X, x.device), w2d).view(B, Y, X, cout)
             ctx.save_for_backward(x, w2d)
         else:
             y = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.contiguous(memory_format=torch.channels_last),
-                                           padding=1).permute(0, 2, 3, 1)
+                                           padding=dil, dilation=dil).permute(0, 2, 3, 1)
             ctx.save_for_backward(x, w)
         ctx.meta = (x_nhwc.dtype, weight.dtype)
         return y
@@ -1381,13 +1393,14 @@ class _DenseConv3x3(torch.autograd.Function):
         cout = w.shape[0]
         n = B * Y * X
         dy = dy_nhwc.to(x.dtype).contiguous()
-        nbr = _dense_rulebook(B, Y, X, x.device)
+        dil = ctx.dil
+        nbr = _dense_rulebook(B, Y, X, x.device, dil)
         dx = None
         if ctx.needs_input_grad[0]:
-            if ctx.native and _DENSE_CONV == 'halo' and cout in (128, 256, 384) and cin % 128 == 0:
+            if ctx.native and (_DENSE_CONV == 'halo' or dil != 1) and cout in (128, 256, 384) and cin % 128 == 0:
                 # weight_t[c, 2-ky, 2-kx, n] = w[n, ky, kx, c]: the input gradient is a conv of dY with the flipped taps
                 wt = w.view(cout, 3, 3, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * cout).contiguous()
-                dx = dense_conv3x3_halo(dy, wt).to(ctx.meta[0])
+                dx = dense_conv3x3_halo(dy, wt, dil).to(ctx.meta[0])
             elif ctx.native:
                 nbr_t = _DENSE_NBR.get(('t', B, Y, X, x.device))
                 if nbr_t is None:                      # transposed rulebook of a stride-1 conv = flipped taps
@@ -1396,7 +1409,7 @@ class _DenseConv3x3(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(
                     dy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w.contiguous(memory_format=torch.channels_last), None,
-                    [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1).to(ctx.meta[0])
+                    [1, 1], [dil, dil], [dil, dil], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1).to(ctx.meta[0])
         dy2, x2 = dy.view(n, cout), x.view(n, cin)
         dw = torch.empty((cout, 9 * cin), dtype=torch.float32, device=x.device)
         wsb = lib.tmae_linear_wgrad_workspace(n, cout, 9 * cin)
@@ -1404,27 +1417,32 @@ class _DenseConv3x3(torch.autograd.Function):
         check(lib.tmae_spconv_wgrad(_p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(nbr), n, cout, cin, _p(dw), _p(ws),
                                     wsb, _s()), 'tmae_spconv_wgrad')
         dw = dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2).to(ctx.meta[1])
-        return dx, dw
+        return dx, dw, None
 
 
-def dense_conv3x3_halo(x_nhwc, w2d):
-    """[B, Y, X, cin] bf16 (contiguous) x w2d [cout, 9*cin] bf16 -> [B, Y, X, cout] (csrc/spconv_igemm.hip, halo kernel)."""
+def dense_conv3x3_halo(x_nhwc, w2d, dil=1):
+    """[B, Y, X, cin] bf16 (contiguous) x w2d [cout, 9*cin] bf16 -> [B, Y, X, cout] (csrc/spconv_igemm.hip, halo kernel);
+    padding = dilation in {1, 2}."""
     B, Y, X, cin = x_nhwc.shape
     cout = w2d.shape[0]
     y = torch.empty((B, Y, X, cout), dtype=torch.bfloat16, device=x_nhwc.device)
-    check(lib.tmae_dense_conv3x3(_p(x_nhwc), B, Y, X, cin, _p(w2d), cout, _p(y), _s()), 'tmae_dense_conv3x3')
+    if dil == 1:
+        check(lib.tmae_dense_conv3x3(_p(x_nhwc), B, Y, X, cin, _p(w2d), cout, _p(y), _s()), 'tmae_dense_conv3x3')
+    else:
+        check(lib.tmae_dense_conv3x3_dilated(_p(x_nhwc), B, Y, X, cin, _p(w2d), cout, int(dil), _p(y), _s()),
+              'tmae_dense_conv3x3_dilated')
     return y
 
 
 def dense_conv3x3_ok(x_nhwc, conv):
-    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
-            and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.dilation in ((1, 1), (2, 2))
+            and conv.padding == conv.dilation and conv.stride == (1, 1) and conv.groups == 1 and conv.bias is None
             and x_nhwc.is_cuda and compute_dtype(x_nhwc) == torch.bfloat16 and conv.in_channels % 128 == 0
             and conv.out_channels % 8 == 0 and x_nhwc.shape[0] * x_nhwc.shape[1] * x_nhwc.shape[2] >= 4096)
 
 
-def dense_conv3x3(x_nhwc, weight):
-    return _DenseConv3x3.apply(x_nhwc, weight)
+def dense_conv3x3(x_nhwc, weight, dilation=1):
+    return _DenseConv3x3.apply(x_nhwc, weight, int(dilation))
 
 
 class _DenseGather(torch.autograd.Function):

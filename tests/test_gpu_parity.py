@@ -810,22 +810,24 @@ def test_fused_decoder_head_vs_torch_dense():
             assert (bn.running_var - bn2.running_var).abs().max().item() < 1e-3
 
 
-def test_dense_conv3x3_own_wgrad_vs_torch():
-    """ops.dense_conv3x3 (library forward / dX, token-split weight gradient through the dense rulebook) against
-    torch's Conv2d in fp32 on the same bf16-representable data: y, dX, dW."""
+@pytest.mark.parametrize('dil,cin,cout', [(1, 128, 128), (2, 128, 128), (1, 384, 128), (2, 256, 256)])
+def test_dense_conv3x3_own_wgrad_vs_torch(dil, cin, cout):
+    """ops.dense_conv3x3 (halo-tiled implicit GEMM forward / dX, token-split weight gradient through the dense rulebook)
+    against torch's Conv2d in fp32 on the same bf16-representable data: y, dX, dW; dilation 1 (decoder conv,
+    SiamWCA_MAE.py:100-115) and 2 (SSTBEVBackbone, sst_bev_backbone.py:20-30), grid sizes that are no multiple of 16."""
     from tmae_amd import ops
     torch.manual_seed(3)
-    B, Y, X, cin, cout = 2, 52, 44, 128, 128
+    B, Y, X = 2, 52, 44
     x = torch.randn(B, Y, X, cin, device=dev()).bfloat16()
     w = (torch.randn(cout, cin, 3, 3, device=dev()) * 0.05).bfloat16().float().requires_grad_(True)
     gy = torch.randn(B, Y, X, cout, device=dev()).bfloat16()
     xa = x.clone().requires_grad_(True)
     with torch.autocast('cuda', dtype=torch.bfloat16):
-        y = ops.dense_conv3x3(xa, w)
+        y = ops.dense_conv3x3(xa, w, dil)
     y.backward(gy)
     xr = x.float().requires_grad_(True)
     wr = w.detach().clone().requires_grad_(True)
-    yr = F.conv2d(xr.permute(0, 3, 1, 2), wr, padding=1).permute(0, 2, 3, 1)
+    yr = F.conv2d(xr.permute(0, 3, 1, 2), wr, padding=dil, dilation=dil).permute(0, 2, 3, 1)
     yr.backward(gy.float())
 
     def rel(a, b):
