@@ -1,5 +1,5 @@
-"""Which Python lines issue the small torch (aten) launches of one training step: torch.profiler with stacks, one step,
-aten ops grouped by the innermost frame inside this repo.   python3 profiles/scripts/torch_ops_census.py > out.txt"""
+"""Which aten ops (with input shapes) one training step launches: torch.profiler, one step, grouped by op + shapes.
+python3 profiles/scripts/torch_ops_census.py [finetune] > out.txt"""
 import collections, os, sys, torch
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, os.path.join(ROOT, 't-mae_amd'))
@@ -8,14 +8,17 @@ from pcdet.models import model_fn_decorator
 from tmae_amd.train import (SyntheticTemporalDataset, build_model_from_cfg, build_optimizer, build_scheduler, train_one_step)
 from torch.profiler import profile, ProfilerActivity
 dev = torch.device('cuda', 0)
-cfg = cfg_from_yaml_file(os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae_ssl.yaml'), EasyDict())
-ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=120000, batch_size=8, rank=0)
+FT = len(sys.argv) > 1 and sys.argv[1] == 'finetune'
+cfg = cfg_from_yaml_file(os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae.yaml' if FT else 't_mae_ssl.yaml'), EasyDict())
+ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=120000, batch_size=8, rank=0, n_boxes=40 if FT else 0)
 torch.manual_seed(0)
 model = build_model_from_cfg(cfg, ds).to(dev).train()
 opt = build_optimizer(model, cfg.OPTIMIZATION)
 sched, _ = build_scheduler(opt, 1000, cfg.OPTIMIZATION.NUM_EPOCHS, -1, cfg.OPTIMIZATION)
 b = ds.batch(0)
 batch = {'points': torch.from_numpy(b['points']).to(dev), 'points_prev': torch.from_numpy(b['points_prev']).to(dev), 'batch_size': b['batch_size']}
+if 'gt_boxes' in b:
+    batch['gt_boxes'] = torch.from_numpy(b['gt_boxes']).to(dev)
 fn = model_fn_decorator()
 for i in range(3):
     train_one_step(model, opt, sched, dict(batch), i, fn, amp_dtype=torch.bfloat16)

@@ -19,13 +19,20 @@ def conv_bn_relu_nhwc(seq, x):
     if (bn.training and os.environ.get('TMAE_DENSE_CONV', 'halo') != 'miopen' and nhwc.is_contiguous()
             and ops.dense_conv3x3_ok(nhwc, conv) and conv.out_channels % 128 == 0):
         y = ops.dense_conv3x3(nhwc, conv.weight, conv.dilation[0]).permute(0, 3, 1, 2)
+        fused = True
     else:
-        y = conv(x)
-    if (bn.training and y.is_cuda and y.is_contiguous(memory_format=torch.channels_last)
+        fused = (bn.training and x.is_cuda and conv.out_channels in (64, 128, 256) and len(seq) == 3
+                 and isinstance(seq[2], nn.ReLU))
+        # a bias in front of the training-mode norm (USE_BIAS_BEFORE_NORM) is folded away: see ops.batch_norm_relu
+        y = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups) \
+            if (fused and conv.bias is not None) else conv(x)
+    if (fused and y.is_contiguous(memory_format=torch.channels_last)
             and y.shape[1] in (64, 128, 256) and len(seq) == 3 and isinstance(seq[2], nn.ReLU)):
         b, c, ny, nx = y.shape
-        rows = ops.batch_norm_relu(y.permute(0, 2, 3, 1).reshape(b * ny * nx, c), bn, relu=True)
+        rows = ops.batch_norm_relu(y.permute(0, 2, 3, 1).reshape(b * ny * nx, c), bn, relu=True, pre_bias=conv.bias)
         return rows.view(b, ny, nx, c).permute(0, 3, 1, 2)
+    if fused and conv.bias is not None:
+        y = y + conv.bias.view(1, -1, 1, 1).to(y.dtype)
     y = bn(y)
     return seq[2](y) if len(seq) > 2 else y
 

@@ -643,10 +643,31 @@ class _BatchNormReLU(torch.autograd.Function):
         return dx, dg.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None, None
 
 
-def batch_norm_relu(x, bn, relu=True, groups=None):
+class _DeadBias(torch.autograd.Function):
+    """y = x, with `bias` attached to the graph and an all-zero gradient: a per-channel bias in front of a training-mode
+    BatchNorm drops out of its output, and its gradient -- the sum of a zero-mean BatchNorm input gradient -- is zero."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        ctx.meta = (bias.shape, bias.dtype, bias.device)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, dtype, device = ctx.meta
+        return dy, torch.zeros(shape, dtype=dtype, device=device)
+
+
+def batch_norm_relu(x, bn, relu=True, groups=None, pre_bias=None):
     """nn.BatchNorm1d `bn` (+ ReLU) over the rows of x [m,c]; fused HIP kernels in training mode for c in
     {64,128,256}; updates bn's running statistics like torch does.  `groups` (row counts summing to m): each row
-    range is a separate BatchNorm call (own batch statistics, running statistics updated in order)."""
+    range is a separate BatchNorm call (own batch statistics, running statistics updated in order).
+    pre_bias [c]: the result for x + pre_bias WITHOUT adding it (a conv bias before the norm, USE_BIAS_BEFORE_NORM,
+    center_head.py:19-27): the normalised output does not depend on it, its gradient is exactly zero, only the running
+    mean sees it -- saves an elementwise pass over the activation forward and a column reduction backward."""
+    if pre_bias is not None and not (x.is_cuda and x.dim() == 2 and bn.training and x.shape[1] in (64, 128, 256)
+                                     and groups is None and x.shape[0] > 1 and x.dtype in (torch.float32, torch.bfloat16)):
+        x, pre_bias = x + pre_bias.to(x.dtype), None
     sizes = [int(x.shape[0])] if groups is None else [int(g) for g in groups]
     assert sum(sizes) == x.shape[0]
     if (x.is_cuda and x.dim() == 2 and bn.training and x.shape[1] in (64, 128, 256) and min(sizes) > 1
@@ -655,6 +676,9 @@ def batch_norm_relu(x, bn, relu=True, groups=None):
         for g in sizes:
             bounds.append(bounds[-1] + g)
         y, mean, var = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.eps, relu, tuple(bounds))
+        if pre_bias is not None:
+            y = _DeadBias.apply(y, pre_bias)
+            mean = mean + pre_bias.detach().float()
         if bn.track_running_stats:
             for g, m in enumerate(sizes):
                 _bn_running_update(bn, mean[g], var[g], m)
