@@ -546,7 +546,7 @@ int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
 // so the normalisation Jacobian reads q-hat / k-hat from registers and every gradient row leaves in 16-byte
 // (dh 32) / 8-byte (dh 16) stores.  (With rows = tokens each lane wrote 2 bytes per (row, tile): the L2 request
 // rate of those stores was 16 % of the stage-1 kernel.)
-// NT = 4 is compiled for two waves per SIMD (the LDS images allow no more), no scratch.
+// NT = 4 is compiled for two waves per SIMD (the LDS images allow no more): 233 registers, no scratch.
 // ------------------------------------------------------------------------------------------------
 template <int DH, int NT, bool PAIR>
 __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel(
@@ -595,8 +595,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
   }
   const float tau_c = fmaxf(tau[0], tau_min), inv_tau = 1.0f / tau_c;
   const __amdgpu_buffer_rsrc_t rsq = make_rsrc(q, nb.q), rsk = make_rsrc(k, nb.k), rsv = make_rsrc(v, nb.v),
-                               rsg = make_rsrc(dout, nb.g), rso = make_rsrc(outp, nb.o), rsl = make_rsrc(lse, nb.lse),
-                               rsdq = make_rsrc(dq, nb.dq),
+                               rsg = make_rsrc(dout, nb.g), rsl = make_rsrc(lse, nb.lse), rsdq = make_rsrc(dq, nb.dq),
                                rsdk = make_rsrc(dk, nb.dk), rsdv = make_rsrc(dv, nb.dv);
   const unsigned colb = (unsigned)(hoff + FR * g) * 2u;
   __syncthreads();                                   // token lists visible
@@ -604,9 +603,9 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
   // ---- every global row load of the workgroup is issued here (one dependent round after the token ids); the
   //      row-major LDS images are written from the same 16-byte fragments: lane (g,i) owns chunk g of row tile*16+i.
   frag_t kf[NT], kl[NT], vr[NT], qf[NT], ql[NT], gf[NT];
-  float lse_i[NT], dsum[NT];              // dsum[t] = D of query t*16+i = dO . O (= sum_j P_ij dP_ij), see below
+  float lse_i[NT];
   typedef typename RawFrag<FR>::T raw_t;
-  raw_t rk[NT], rv[NT], rq[NT], rg[NT], ro[NT];
+  raw_t rk[NT], rv[NT], rq[NT], rg[NT];
   int tokk_[NT], tokq_[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {                     // no branches here: every load of the wave is in flight at once
@@ -617,7 +616,6 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
     rv[t] = load_row_raw<FR>(rsv, row_off(tokk_[t], (unsigned)ldv * 2u, colb));
     rq[t] = load_row_raw<FR>(rsq, row_off(tokq_[t], (unsigned)ldq * 2u, colb));
     rg[t] = load_row_raw<FR>(rsg, row_off(tokq_[t], (unsigned)lddo * 2u, colb));
-    ro[t] = load_row_raw<FR>(rso, row_off(tokq_[t], (unsigned)ldo * 2u, colb));
     const unsigned loff = tokq_[t] >= 0 ? (unsigned)(tokq_[t] * nhead + head) * 4u : 0xFFFFFFFFu;
     lse_i[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsl, (int)loff, 0, 0));
   }
@@ -630,28 +628,23 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
       const float nrm = normalize_frag<FR>(f, 1.0f);
       split_frag<FR>(f, kf[t], kl[t]);
       if (g == 0) knorm[w][slot] = nrm;
-      vr[t] = __builtin_bit_cast(frag_t, rv[t]);                            // the raw bf16 row piece IS the fragment
+      unpack_row<FR>(rv[t], f);
+      vr[t] = pack_frag<FR>(f);
     } else {
 #pragma unroll
       for (int j = 0; j < FR; ++j) { kf[t][j] = 0; kl[t][j] = 0; vr[t][j] = 0; }
     }
     store_img_frag<DH>(&kimg[w][slot * RB], g, kf[t]);
-    // no query: p = exp(s - lse) = 0 with a FINITE exponent (it also multiplies dS = 0 in the tau gradient)
-    if (tokq_[t] < 0 || t >= nq) lse_i[t] = 1e30f;
-    dsum[t] = 0.f;
+    if (tokq_[t] < 0 || t >= nq) lse_i[t] = INFINITY;                      // no query: p = exp(s - inf) = 0
     if (t < nq) {
       unpack_row<FR>(rq[t], f);
       const float nrm = normalize_frag<FR>(f, inv_tau);
       split_frag<FR>(f, qf[t], ql[t]);
       store_img_frag<DH>(&qimg[w][slot * RB], g, qf[t]);
       if (g == 0) qnorm[w][slot] = nrm;
-      float gfl[FR], ofl[FR], dd = 0.f;
+      float gfl[FR];
       unpack_row<FR>(rg[t], gfl);
-      unpack_row<FR>(ro[t], ofl);
-#pragma unroll
-      for (int j = 0; j < FR; ++j) dd += gfl[j] * ofl[j];
-      dsum[t] = quad_sum(dd);
-      gf[t] = __builtin_bit_cast(frag_t, rg[t]);
+      gf[t] = pack_frag<FR>(gfl);                                        // exact: bf16 -> f32 -> bf16
       store_img_frag<DH>(&gimg[w][slot * RB], g, gf[t]);
     }
   }
@@ -662,8 +655,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) { dKa[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dVa[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   float dtau_acc = 0.f;
-  constexpr bool KB = true;                // MASKED_LOGIT on absent / foreign key rows through the C operand (see the forward);
-                                           // since the single-pass loop the 64-token class has the 16 registers too
+  constexpr bool KB = NT <= 2;             // MASKED_LOGIT on absent / foreign key rows through the C operand (see the forward)
   f32x4 kbias[KB ? NT : 1];
   if constexpr (KB) {
 #pragma unroll
@@ -687,19 +679,14 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
       f32x4 dQa[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) dQa[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // ONE pass over the key tiles.  dS_ij = P_ij (dP_ij - D_i) needs D_i = sum_j P_ij dP_ij of the whole row; it is
-      // taken as dO_i . O_i from the saved output (one more 16-byte row load per query) instead of a first pass over
-      // all key tiles that computed every logit, exp and dP twice (the 64-token class recomputed them: these kernels
-      // are VALU-bound and exp runs at quarter rate).  O is the bf16-rounded forward output, so sum_j dS_ij is zero
-      // only to ~2^-9 |D_i|; the tau gradient sum_ij dS_ij s_ij is therefore accumulated with the row-centred logit
-      // s_ij - lse_i = log P_ij (exact identity when sum_j dS_ij = 0), and the row residual R_i = sum_j dS_ij
-      // (= D*_i - D_i, the error of D_i) is removed exactly: with dS*_ij = dS_ij - P_ij R_i,
-      //   sum_j dS*_ij log P_ij = sum_j dS_ij log P_ij - R_i sum_j P_ij log P_ij
-      // -- two more accumulations per entry (R_i, sum_j P log P) and the gradient of tau is as exact as with the first
-      // pass (without the correction the rounding of O left zero-mean noise of the size of the gradient itself over
-      // ~1e5 query rows at tau = 0.05).
-      const float dacc = dsum[qt];
-      float rres = 0.f, plogp = 0.f;
+      // pass 1 over the key tiles: logits, probabilities and dP; D_i = sum_j P_ij dP_ij is taken from THESE values
+      // (not from dO . O with the bf16-rounded saved output), so that sum_j dS_ij = 0 holds to fp32 rounding --
+      // the tau gradient sum_ij dS_ij s_ij is a difference of large terms and is biased otherwise
+      // NT == 4: the tiles are recomputed in pass 2 (4 MFMAs + 4 exps per tile pair, far below the budget of this
+      // latency-bound kernel) instead of being held in 48 registers, which keeps two waves per SIMD resident.
+      constexpr bool RECOMP = NT >= 4;
+      f32x4 sTk[RECOMP ? 1 : NT], pTk[RECOMP ? 1 : NT], dPk[RECOMP ? 1 : NT];
+      float dacc = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         if (kt < nk) {
@@ -709,12 +696,31 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
           sT = mfma_s(kf[kt], ql[qt], sT);
           sT = mfma_s(kf[kt], qf[qt], sT);
           const f32x4 dP = mfma_s(vr[kt], gf[qt], z);
-          f32x4 pT;
+          if constexpr (!RECOMP) { sTk[kt] = sT; dPk[kt] = dP; }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            sT[r] -= lse_i[qt];                            // log P_ij
-            pT[r] = __expf(sT[r]);
-            if constexpr (!KB) { if (kt * 16 + 4 * g + r >= Tk) pT[r] = 0.f; }
+            float p = __expf(sT[r] - lse_i[qt]);
+            if constexpr (!KB) { if (kt * 16 + 4 * g + r >= Tk) p = 0.f; }
+            if constexpr (!RECOMP) pTk[kt][r] = p;
+            dacc += p * dP[r];
+          }
+        }
+      }
+      dacc = quad_sum(dacc);
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        if (kt < nk) {
+          f32x4 sT, dP, pT;
+          if constexpr (RECOMP) {
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            sT = mfma_s(kl[kt], qf[qt], z);
+            sT = mfma_s(kf[kt], ql[qt], sT);
+            sT = mfma_s(kf[kt], qf[qt], sT);
+            dP = mfma_s(vr[kt], gf[qt], z);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pT[r] = (kt * 16 + 4 * g + r < Tk) ? __expf(sT[r] - lse_i[qt]) : 0.f;
+          } else {
+            sT = sTk[kt]; dP = dPk[kt]; pT = pTk[kt];
           }
           s16x4 dsT, pTb;
 #pragma unroll
@@ -722,8 +728,6 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
             const float p = pT[r];
             const float ds = p * (dP[r] - dacc);
             dtau_acc += ds * sT[r];                        // p = 0 entries: 0 * finite
-            rres += ds;
-            plogp += p * sT[r];
             dsT[r] = f2bf(ds);
             pTb[r] = f2bf(p);
           }
@@ -748,7 +752,6 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
           }
         }
       }
-      dtau_acc -= 0.25f * quad_sum(rres) * quad_sum(plogp);      // every lane of the quad holds the row's sums
       // dq = (dq-hat - q-hat (q-hat . dq-hat)) / |q|.  The products are taken transposed (rows = channels) over the
       // permuted images, so lane (g, i) holds channels FR g + 4 ct + r of query qt*16+i: the SAME channels as its own
       // row fragment qf[qt] -- q-hat comes from registers, the dot product is a quad reduction, one wide store per lane
@@ -816,14 +819,13 @@ int tmae_win_attn_bwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
     return TMAE_EARG;
   if ((lddq % 4) || (lddk % 4) || (lddv % 4) || ((uintptr_t)dq & 7) || ((uintptr_t)dk & 7) || ((uintptr_t)dv & 7))
     return TMAE_EARG;
-  if (!attn_sizes_ok(mq, ldo) || (ldo % 8) || (lddo % 8) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15)) return TMAE_EARG;
   const int Wy = (ny + WIN - 1) / WIN + 1, Wx = (nx + WIN - 1) / WIN + 1;
   const int s = do_shift ? WIN / 2 : WIN;
   const int64_t nwin = (int64_t)batch * Wy * Wx;
   const int d = nhead * dh;
   AttnBufs nb = {};
   nb.q = attn_bytes(mq, ldq, d); nb.k = attn_bytes(mk, ldk, d); nb.v = attn_bytes(mk, ldv, d);
-  nb.g = attn_bytes(mq, lddo, d); nb.o = attn_bytes(mq, ldo, d); nb.lse = (unsigned)(mq * nhead * 4);
+  nb.g = attn_bytes(mq, lddo, d); nb.lse = (unsigned)(mq * nhead * 4);
   nb.dq = attn_bytes(mq, lddq, d); nb.dk = attn_bytes(mk, lddk, d); nb.dv = attn_bytes(mk, lddv, d);
 #define BWDM(DH, NT, PAIR, CLS, GX)                                                                                  \
   hipLaunchKernelGGL((win_attn_bwd_mfma_kernel<DH, NT, PAIR>), dim3((unsigned)(GX), (unsigned)(nhead / 4)), dim3(256), \

@@ -755,6 +755,33 @@ def test_batchnorm_relu_kernel_vs_torch():
         assert int(u.num_batches_tracked) == int(v.num_batches_tracked) > 0
 
 
+def test_conv_bias_before_batchnorm_is_folded_exactly():
+    """USE_BIAS_BEFORE_NORM (center_head.py:19-27): conv(bias) -> BatchNorm2d(train) -> ReLU through
+    modules.bev_backbone.conv_bn_relu_nhwc (bias folded away: ops.batch_norm_relu pre_bias) against the plain torch
+    modules: output, input / weight gradients, a zero bias gradient where torch's is rounding noise, running statistics."""
+    import copy
+    from tmae_amd.modules.bev_backbone import conv_bn_relu_nhwc
+    torch.manual_seed(2)
+    seq = torch.nn.Sequential(torch.nn.Conv2d(32, 64, 3, padding=1, bias=True), torch.nn.BatchNorm2d(64, eps=1e-3, momentum=0.01),
+                              torch.nn.ReLU()).to(dev()).train()
+    seq[0].bias.data.normal_(0, 2.0)
+    ref = copy.deepcopy(seq)
+    x = torch.randn(2, 32, 40, 36, device=dev()).contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    g = torch.randn(2, 64, 40, 36, device=dev()).contiguous(memory_format=torch.channels_last)
+    ya = conv_bn_relu_nhwc(seq, xa)
+    yb = ref(xb)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(seq[0].weight.grad, ref[0].weight.grad, rtol=1e-3, atol=1e-3)
+    assert torch.allclose(seq[1].weight.grad, ref[1].weight.grad, rtol=1e-3, atol=1e-3)
+    assert float(seq[0].bias.grad.abs().max()) == 0.0 and float(ref[0].bias.grad.abs().max()) < 1e-2
+    assert torch.allclose(seq[1].running_mean, ref[1].running_mean, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(seq[1].running_var, ref[1].running_var, rtol=1e-4, atol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------ A9 / A11
 
 def test_fused_decoder_head_vs_torch_dense():
