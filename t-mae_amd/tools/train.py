@@ -40,7 +40,24 @@ def parse_config():
     p.add_argument('--synthetic_points', type=int, default=120000)
     p.add_argument('--iters_per_epoch', type=int, default=100)
     p.add_argument('--output_dir', type=str, default=None)
+    # the rest of the reference's command line (tools/train.py:37-131, tools/scripts/once_train.sh): accepted so that its
+    # launch lines run unchanged; what has no meaning here says so when it is used
+    p.add_argument('--tcp_port', type=int, default=18888, help='unused: the rendezvous comes from the launcher environment')
+    p.add_argument('--sync_bn', action='store_true', help='not supported: BatchNorm statistics are per rank (SYNC_BN off in the shipped configs)')
+    p.add_argument('--merge_all_iters_to_one_epoch', action='store_true')
+    p.add_argument('--max_waiting_mins', type=int, default=1)
+    p.add_argument('--start_epoch', type=int, default=0)
+    p.add_argument('--num_epochs_to_eval', type=int, default=0, help='evaluate the last N checkpoints after training (fine-tune configs)')
+    p.add_argument('--save_to_file', action='store_true')
+    p.add_argument('--fuse_conv_bn', action='store_true')
+    p.add_argument('--wandb', action='store_true', help='ignored (no network)')
+    p.add_argument('--wandb_proj_name', type=str, default='t-mae-0.05')
+    p.add_argument('--fixed_gap_eval', type=int, default=None)
     args = p.parse_args()
+    if args.sync_bn:
+        raise NotImplementedError('--sync_bn: the BatchNorm kernels keep per-rank statistics (the shipped recipes do not use it)')
+    if args.merge_all_iters_to_one_epoch:
+        raise NotImplementedError('--merge_all_iters_to_one_epoch is not used by the T-MAE recipes')
     cfg_from_yaml_file(args.cfg_file, cfg)
     cfg.TAG = Path(args.cfg_file).stem
     if args.set_cfgs is not None:
@@ -105,6 +122,23 @@ def main():
                         f'({bs * world * args.iters_per_epoch / (time.time() - t0):.1f} frame-pairs/s incl. data gen)')
             if (epoch + 1) % args.ckpt_save_interval == 0:
                 save_checkpoint(ddp, opt, epoch + 1, it, out / 'ckpt' / f'checkpoint_epoch_{epoch + 1}.pth')
+                # keep the newest --max_ckpt_save_num checkpoints (train_utils.py:217-232)
+                kept = sorted((out / 'ckpt').glob('checkpoint_epoch_*.pth'), key=lambda p_: p_.stat().st_mtime)
+                for old_ckpt in kept[:max(len(kept) - args.max_ckpt_save_num, 0)]:
+                    old_ckpt.unlink()
+    # --num_epochs_to_eval N (tools/train.py:335-372 -> repeat_eval_ckpt): evaluate the last N checkpoints of a detector
+    if args.num_epochs_to_eval > 0 and cfg.MODEL.get('DENSE_HEAD', None) is not None:
+        from tmae_amd.eval import eval_one_epoch
+        from tmae_amd.train import SyntheticEvalLoader
+        cfg.LOCAL_RANK = local_rank
+        ckpts = sorted((out / 'ckpt').glob('checkpoint_epoch_*.pth'), key=lambda p_: p_.stat().st_mtime)
+        for ck in ckpts[-args.num_epochs_to_eval:]:
+            model.load_params_from_file(str(ck), logger=logger)
+            loader = SyntheticEvalLoader(ds, 4 * bs, bs, rank=rank, world=world)
+            ret = eval_one_epoch(cfg, model, loader, ck.stem, logger, dist_test=world > 1, result_dir=out / 'eval' / ck.stem,
+                                 amp_dtype=amp)
+            if rank == 0:
+                logger.info({k: float(v) for k, v in ret.items()})
     if world > 1:
         dist.destroy_process_group()
 

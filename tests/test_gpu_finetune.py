@@ -346,3 +346,23 @@ def test_iou_head_multi_class_nms_vs_reference():
         assert len(s) == len(rs) and np.array_equal(l, rl), (k, len(s), len(rs))
         np.testing.assert_allclose(s, rs, rtol=2e-4, atol=1e-5)
         np.testing.assert_allclose(b, rb, rtol=2e-4, atol=2e-4)
+
+
+def test_train_cli_accepts_the_reference_launch_line(tmp_path):
+    """tools/train.py with the flags of the reference's own launch line (tools/scripts/once_train.sh:17-20: --workers
+    --extra_tag --max_ckpt_save_num 1 --num_epochs_to_eval 1 --amp --fixed_gap_eval 1) on the fine-tune config: two short
+    epochs, one checkpoint kept, the last one evaluated."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = tmp_path / 'run'
+    cmd = [sys.executable, os.path.join(ROOT, 't-mae_amd', 'tools', 'train.py'), '--cfg_file',
+           os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae.yaml'), '--workers', '8', '--extra_tag', 't',
+           '--max_ckpt_save_num', '1', '--num_epochs_to_eval', '1', '--amp', '--fixed_gap_eval', '1', '--synthetic',
+           '--synthetic_points', '20000', '--iters_per_epoch', '2', '--epochs', '2', '--batch_size', '2', '--output_dir', str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ck = sorted(p.name for p in (out / 'ckpt').glob('*.pth'))
+    assert ck == ['checkpoint_epoch_2.pth'], ck
+    assert 'EVALUATION' in (r.stdout + r.stderr) or any((out / 'eval').rglob('*'))
