@@ -32,6 +32,18 @@ def main():
     p.add_argument('--synthetic_points', type=int, default=120000)
     p.add_argument('--synthetic_samples', type=int, default=32)
     p.add_argument('--output_dir', type=str, default=None)
+    # the rest of the reference's command line (tools/test.py:27-86, tools/scripts/once_test.sh): accepted as they are
+    p.add_argument('--workers', type=int, default=4)
+    p.add_argument('--tcp_port', type=int, default=18888)
+    p.add_argument('--local_rank', type=int, default=0)
+    p.add_argument('--max_waiting_mins', type=int, default=1)
+    p.add_argument('--start_epoch', type=int, default=0)
+    p.add_argument('--eval_tag', type=str, default='default')
+    p.add_argument('--eval_all', action='store_true', help='evaluate every checkpoint of --ckpt_dir')
+    p.add_argument('--ckpt_dir', type=str, default=None)
+    p.add_argument('--save_to_file', action='store_true')
+    p.add_argument('--fuse_conv_bn', action='store_true')
+    p.add_argument('--fixed_gap_eval', type=int, default=-1)
     args = p.parse_args()
     cfg_from_yaml_file(args.cfg_file, cfg)
     cfg.TAG = Path(args.cfg_file).stem
@@ -51,14 +63,19 @@ def main():
         raise NotImplementedError('the ONCE two-frame dataloader is outside this hot path (SURVEY 8f-2); use --synthetic')
     ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=args.synthetic_points, batch_size=bs, rank=rank)
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds, logger).cuda()
-    if args.ckpt:
-        model.load_params_from_file(args.ckpt, logger=logger)
-    loader = SyntheticEvalLoader(ds, args.synthetic_samples, bs, rank=rank, world=world)
     cfg.LOCAL_RANK = int(os.environ.get('LOCAL_RANK', 0))
-    ret = eval_one_epoch(cfg, model, loader, 'synthetic', logger, dist_test=world > 1, result_dir=out,
-                         amp_dtype=torch.bfloat16 if args.amp else None)
-    if rank == 0:
-        logger.info({k: float(v) for k, v in ret.items()})
+    ckpts = [args.ckpt]
+    if args.eval_all:                                    # repeat_eval_ckpt (tools/test.py:101-170) without the waiting loop
+        ckpts = sorted(str(p_) for p_ in Path(args.ckpt_dir or out.parent / 'ckpt').glob('checkpoint_epoch_*.pth'))
+    for ck in ckpts:
+        if ck:
+            model.load_params_from_file(ck, logger=logger)
+        loader = SyntheticEvalLoader(ds, args.synthetic_samples, bs, rank=rank, world=world)
+        tag = Path(ck).stem if ck else 'synthetic'
+        ret = eval_one_epoch(cfg, model, loader, tag, logger, dist_test=world > 1, result_dir=out / args.eval_tag / tag,
+                             save_to_file=args.save_to_file, amp_dtype=torch.bfloat16 if args.amp else None)
+        if rank == 0:
+            logger.info({k: float(v) for k, v in ret.items()})
     if world > 1:
         dist.destroy_process_group()
 

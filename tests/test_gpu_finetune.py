@@ -366,3 +366,10 @@ def test_train_cli_accepts_the_reference_launch_line(tmp_path):
     ck = sorted(p.name for p in (out / 'ckpt').glob('*.pth'))
     assert ck == ['checkpoint_epoch_2.pth'], ck
     assert 'EVALUATION' in (r.stdout + r.stderr) or any((out / 'eval').rglob('*'))
+    # and the reference's test line (tools/scripts/once_test.sh:8-10) on that checkpoint
+    cmd = [sys.executable, os.path.join(ROOT, 't-mae_amd', 'tools', 'test.py'), '--cfg_file',
+           os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae.yaml'), '--workers', '8', '--extra_tag', 't',
+           '--ckpt', str(out / 'ckpt' / 'checkpoint_epoch_2.pth'), '--fixed_gap_eval', '1', '--synthetic',
+           '--synthetic_points', '20000', '--synthetic_samples', '4', '--batch_size', '2', '--output_dir', str(out / 'test')]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
