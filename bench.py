@@ -50,6 +50,8 @@ def parse():
                     help='once = BASELINE configs[1] (the metric); waymo = configs[3] shape: 5 point features, z in [-2,4), '
                          '6 m pillars (use with --points 180000)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the short fine-tune / Waymo-shape runs that fill the `secondary` field of the N = 1 line')
     ap.add_argument('--skip-unread-gradients', action='store_true',
                     help='variant, not the reference step: no gradients for the parameters its optimizer never owns')
     ap.add_argument('--cpu-points', type=int, default=120000)
@@ -414,6 +416,28 @@ def step_flops(model, batch, amp):
             'head_chamfer': head, 'stages': detail}
 
 
+def secondary_runs(args, log):
+    """Short runs of the two other measured configurations of BASELINE.json -- configs[4] (fine-tune step, CenterPoint head)
+    and configs[3] (Waymo-shaped pre-training input, 180 k points, 5 point features) -- as CHILD processes of this one after
+    its own measurement is complete (3 warm-up + 8 timed steps each, same barrier / synchronize bracket): reported next to
+    the headline line, never part of `value`."""
+    import subprocess
+    out = {}
+    for name, extra in (('finetune_configs4', ['--task', 'finetune']),
+                        ('waymo_shape_configs3', ['--shape', 'waymo', '--points', '180000'])):
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', '8', '--warmup', '3', '--no-cpu-baseline',
+               '--no-secondary', '--batch-per-gpu', str(args.batch_per_gpu), '--dtype', args.dtype] + extra
+        log(f'secondary run: {" ".join(extra)} ...')
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            out[name] = {'ms_per_step': d['ms_per_step'], 'value': d['value'], 'unit': d['unit'], 'steps': d['steps'],
+                         'workload': d['config']['workload'], 'final_loss': d['config']['final_loss']}
+        except Exception as e:                      # a failed side run must not cost the headline line
+            out[name] = {'error': f'{type(e).__name__}: {e}'[:300]}
+    return out
+
+
 def _self_launch(args):
     """`python bench.py --gpus N` without a launcher: start N rank processes through torch.distributed.run BEFORE this
     process touches the GPU (nothing here has made a HIP call yet), relay their output and exit with their code."""
@@ -536,8 +560,10 @@ def main():
             'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'configs[{1 if args.shape == "once" else 3}]: {"ONCE" if args.shape == "once" else "Waymo"}-shape synthetic {args.points}-pt frame-pairs, full 3-stage SST '
-                                   f'encoder + temporal cross-attn + decoder + Chamfer, fwd+bwd+Adam one-cycle',
+            'config': {'workload': (f'configs[{1 if args.shape == "once" else 3}]: {"ONCE" if args.shape == "once" else "Waymo"}-shape synthetic {args.points}-pt frame-pairs, full 3-stage SST '
+                                    f'encoder + temporal cross-attn + decoder + Chamfer, fwd+bwd+Adam one-cycle') if args.task == 'pretrain' else
+                                   (f'configs[4]: ONCE-shape synthetic {args.points}-pt frame-pairs with 40 boxes, SiamWCA encoder (both frames '
+                                    f'unmasked) + SSTBEVBackbone + CenterHead losses, fwd+bwd+Adam one-cycle'),
                        'batch_per_gpu': args.batch_per_gpu, 'global_batch': args.batch_per_gpu * world,
                        'parallelism': f'dp{world}', 'grid': '468x468x1', 'final_loss': round(loss_val, 5),
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
@@ -573,6 +599,9 @@ def main():
                 line['parity'] = chamfer_parity(O, loss_cpu, case, dev)
                 line['chamfer_abs_err_fp32'] = line['parity']['default_head']['chamfer_abs_err_fp32']
                 line['chamfer_abs_err_bf16'] = line['parity']['default_head']['chamfer_abs_err_bf16']
+        if (world == 1 and not args.no_secondary and not args.no_cpu_baseline and args.task == 'pretrain'
+                and args.shape == 'once' and not args.skip_unread_gradients):
+            line['secondary'] = secondary_runs(args, log)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
