@@ -234,7 +234,7 @@ int tmae_window_worklist(const int32_t* grid_q, const int32_t* grid_k, int batch
   const int s = do_shift ? WIN / 2 : WIN;
   const int64_t nwin = (int64_t)batch * Wy * Wx;
   int8_t* cls = reinterpret_cast<int8_t*>(worklist + WL_HDR + WL_CLASSES * nwin);
-  hipMemsetAsync(worklist, 0, WL_HDR * 4, stream);
+  (void)hipMemsetAsync(worklist, 0, WL_HDR * 4, stream);
   hipLaunchKernelGGL(win_class_kernel, dim3(tmae_cdiv(nwin, 4)), dim3(256), 0, stream, grid_q, grid_k, batch, ny, nx,
                      Wy, Wx, s, s, cls);
   hipLaunchKernelGGL(win_worklist_kernel, dim3(tmae_cdiv(nwin, 256)), dim3(256), 0, stream, cls, nwin, Wy, Wx, worklist);

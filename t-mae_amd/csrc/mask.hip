@@ -108,7 +108,7 @@ int tmae_random_mask(const float* noise, const int32_t* sample_offsets, int64_t 
   char* scanws = ws.take<char>(sb);
   if (!ws.ok) return TMAE_EWS;
   if (m > 0) {
-    hipMemsetAsync(keepflag, 0, (size_t)m * 4, stream);
+    (void)hipMemsetAsync(keepflag, 0, (size_t)m * 4, stream);
     hipLaunchKernelGGL(mask_select_kernel, dim3(batch), dim3(MASK_THREADS), 0, stream, noise, sample_offsets,
                        keep_frac, mask, keepflag);
   }

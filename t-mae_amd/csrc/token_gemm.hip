@@ -432,9 +432,9 @@ static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const
     const int lds = 256 * ((256 + (cells ? 32 : 0)) * 2 + 16) + 256 * 2;
     static bool attr_set = false;
     if (!attr_set) {
-      hipFuncSetAttribute((const void*)token_gemm_res_kernel<256, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)token_gemm_res_kernel<256, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                           256 * (256 * 2 + 16) + 256 * 2);
-      hipFuncSetAttribute((const void*)token_gemm_res_kernel<256, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)token_gemm_res_kernel<256, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                           256 * (288 * 2 + 16) + 256 * 2);
       attr_set = true;
     }

@@ -109,7 +109,7 @@ int tmae_voxelize(const float* points, int row, int64_t n, int batch, float rx, 
   char* scan1 = ws.take<char>(s1);
   char* scan2 = ws.take<char>(s2);
   if (!ws.ok) return TMAE_EWS;
-  hipMemsetAsync(occ, 0, (size_t)cells * 4, stream);
+  (void)hipMemsetAsync(occ, 0, (size_t)cells * 4, stream);
   if (n > 0)
     hipLaunchKernelGGL(vox_key_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, points, row, n, batch, rx, ry, rz,
                        vx, vy, vz, gx, gy, gz, flag, key);
@@ -184,8 +184,8 @@ static int csr_build(const int64_t* g, int64_t n, int64_t m, int32_t* perm, int3
   size_t sb = tmae_scan_i32_workspace(m + 1);
   char* scanws = ws.take<char>(sb);
   if (!ws.ok) return TMAE_EWS;
-  hipMemsetAsync(cnt, 0, (size_t)(m + 1) * 4, stream);
-  hipMemsetAsync(cursor, 0, (size_t)(m + 1) * 4, stream);
+  (void)hipMemsetAsync(cnt, 0, (size_t)(m + 1) * 4, stream);
+  (void)hipMemsetAsync(cursor, 0, (size_t)(m + 1) * 4, stream);
   if (n > 0) hipLaunchKernelGGL(csr_count_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, g, n, cnt);
   int r = tmae_scan_i32(cnt, offsets, m + 1, nullptr, scanws, sb, stream);   // offsets[m] = n
   if (r) return r;

@@ -26,7 +26,7 @@ int tmae_index_grid(const int32_t* indices, int64_t m, int batch, int ny, int nx
   (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || batch <= 0 || ny <= 0 || nx <= 0 || !grid || (m > 0 && !indices)) return TMAE_EARG;
-  hipMemsetAsync(grid, 0xFF, (size_t)batch * ny * nx * 4, stream);
+  (void)hipMemsetAsync(grid, 0xFF, (size_t)batch * ny * nx * 4, stream);
   if (m > 0)
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(tmae_cdiv(m, 256)), dim3(256), 0, stream, indices, m, batch, ny, nx,
                        grid);

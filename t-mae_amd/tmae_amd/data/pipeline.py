@@ -7,7 +7,6 @@ HIP launches on the raw scans instead of numpy on dataloader workers.
 The random draws are made on the host with `np.random` in the reference's call order (flip per axis, rotation enable
 + angle, scaling enable + factor, one permutation of the kept points of both frames), so a run seeded like the
 reference reproduces its batches (tests/golden/D1).  One host sync per batch (the kept-point counts)."""
-import math
 
 import numpy as np
 import torch

@@ -5,7 +5,6 @@ device by one HIP launch per head (the reference loops over samples and boxes on
 one fused kernel; evaluation decodes the boxes with torch top-K / gathers and runs the rotated NMS of csrc/iou3d_nms.hip."""
 import copy
 
-import numpy as np
 import torch
 import torch.nn as nn
 from torch.nn.init import kaiming_normal_

@@ -2,10 +2,8 @@
 without masking: both frames through the Siamese SST blocks, window cross-attention per scale, dense BEV fusion.
 Same kernels and the same module tree as SiamWCA_MAE; the fusion modules are called `deblocks` / `conv_out` here
 (SiamWCA.py:517-548), so pre-trained `sst_blocks.*` / `wca_blocks.*` weights load by name."""
-import torch
 import torch.nn as nn
 
-from .. import ops
 from .siam_wca_mae import SiamWCA_MAE
 from .sst import SSTBlockV1, WCABlock
 

@@ -7,7 +7,6 @@ so reference checkpoints load unchanged.  What differs is the execution: there i
 bucketing into padded [windows, T, C] tensors, no per-drop-level Python loop and no host sync -- one
 dense index grid per sparse tensor and one ragged attention launch per layer.
 """
-import math
 import os
 from functools import partial
 

@@ -1,7 +1,6 @@
 """One training step of the T-MAE pre-training loop (tools/train_utils/train_utils.py:59-100) and the
 data-parallel wrapper (tools/train.py:283-289): one process per GPU, DDP over RCCL ('nccl' on ROCm),
 bf16 autocast (no GradScaler needed), decoupled-decay Adam one-cycle."""
-import os
 
 import torch
 import torch.distributed as dist
