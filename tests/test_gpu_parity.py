@@ -1241,6 +1241,23 @@ def test_e2e_full_size_120k_vs_oracle(oracle):
     # --- bf16 autocast on the same pair (the benched dtype)
     l16, _ = _run_product(model, pts, prv, noise, 1, amp=True)
     assert abs(float(l16) - float(lo)) < 3e-3, (float(l16), float(lo))
+    # ... and its gradients (the position-folded in-projections run here: > 8192 tokens per stage): in-projection weights
+    # incl. their position part, an FFN weight, a sparse conv and the decoder conv against the oracle's fp32 gradients.
+    # The bar is what bf16 activations allow on ONE frame pair -- these gradients are sums of ~1e5 cancelling rows:
+    # cosine 0.96-0.99 / relative error 0.11-0.27, the same with the position embedding folded or materialised
+    # (profiles/scripts/pf_check.py) -- not a kernel tolerance (those are pinned by the operator tests above)
+    for n in ('backbone_3d.sst_blocks.0.encoder_blocks.0.encoder_list.0.win_attn.self_attn.in_proj_weight',
+              'backbone_3d.sst_blocks.0.encoder_blocks.1.encoder_list.1.win_attn.self_attn.in_proj_bias',
+              'backbone_3d.sst_blocks.1.encoder_blocks.0.encoder_list.1.win_attn.self_attn.in_proj_weight',
+              'backbone_3d.sst_blocks.2.encoder_blocks.1.encoder_list.0.win_attn.self_attn.in_proj_weight',
+              'backbone_3d.wca_blocks.1.encoder_blocks.0.encoder_list.0.win_attn.cross_attn.in_proj_weight',
+              'backbone_3d.wca_blocks.2.encoder_blocks.0.encoder_list.1.win_attn.cross_attn.in_proj_weight',
+              'backbone_3d.sst_blocks.2.encoder_blocks.1.encoder_list.1.linear2.weight',
+              'backbone_3d.sst_blocks.1.conv_down.0.weight', 'backbone_3d.decoder_conv_out.0.weight'):
+        a, b = grads[n].grad.float().cpu().reshape(-1), Pg[n].grad.reshape(-1)
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        assert cos > 0.93 and rel < 0.4, (n, cos, rel)
     # --- default head, forward only
     P1 = oracle.init_params(cfg, seed=0)
     model1, _, _ = build_product_model(3, params=P1, device=dev(), batch_size=1)
