@@ -359,12 +359,13 @@ int tmae_token_gemm_dgelu(const void* x, int64_t ldx, int64_t m, int k, const vo
  * tmae_token_gemm.  One streaming pass over x; no [m,d] x + pos tensor exists. */
 int tmae_token_gemm_pos(const void* x, int64_t ldx, int64_t m, int k, const void* w_aug, int n, const void* bias,
                         const uint8_t* cells, void* y, int64_t ldy, void* stream);
-/* cells [m] u8 and onehot [m,16] bf16 (columns 0..7 one-hot xc, 8..15 one-hot yc) of the tokens `indices` [m,3] (b,y,x)
+/* cells [cells_len >= m] u8 (entries m .. cells_len-1 are written as zeros: the padding tmae_linear_wgrad_cells may read)
+ * and onehot [m,16] bf16 (columns 0..7 one-hot xc, 8..15 one-hot yc) of the tokens `indices` [m,3] (b,y,x)
  * for window shape (wy, wx) <= 8 and the shift of the layer; onehot (may be NULL) is the explicit operand of the
  * position part of the in-projection weight gradient, dY^T . onehot -- tmae_linear_wgrad_cells computes that product
  * from `cells` inside the weight-gradient pass. */
-int tmae_window_cells(const int32_t* indices, int64_t m, int wy, int wx, int do_shift, uint8_t* cells, void* onehot,
-                      void* stream);
+int tmae_window_cells(const int32_t* indices, int64_t m, int64_t cells_len, int wy, int wx, int do_shift, uint8_t* cells,
+                      void* onehot, void* stream);
 
 /* ---- fine-tune path (BASELINE configs[4]): CenterHead ------------------------------------------------------
  * Target assignment of one head (CenterHead.assign_targets / assign_target_of_single_head, center_head.py:107-231;

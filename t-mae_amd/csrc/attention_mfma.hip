@@ -181,7 +181,11 @@ __device__ __forceinline__ f32x4 mfma_s(const s16x4& a, const s16x4& b, f32x4 c)
 #define WL_CLASSES 4
 __global__ __launch_bounds__(256) void win_class_kernel(const int32_t* __restrict__ grid_q,
                                                        const int32_t* __restrict__ grid_k, int batch, int ny, int nx,
-                                                       int Wy, int Wx, int sy, int sx, int8_t* __restrict__ cls) {
+                                                       int Wy, int Wx, int sy, int sx, int8_t* __restrict__ cls,
+                                                       int32_t* __restrict__ wl_hdr) {
+  // the list counters are zeroed HERE (the compaction kernel that adds to them is the next launch on the stream): one
+  // memset dispatch less per work list
+  if (blockIdx.x == 0 && threadIdx.x < WL_HDR) wl_hdr[threadIdx.x] = 0;
   const int lane = threadIdx.x & 63;
   const int64_t nwin = (int64_t)batch * Wy * Wx;
   const int64_t dw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -234,9 +238,8 @@ int tmae_window_worklist(const int32_t* grid_q, const int32_t* grid_k, int batch
   const int s = do_shift ? WIN / 2 : WIN;
   const int64_t nwin = (int64_t)batch * Wy * Wx;
   int8_t* cls = reinterpret_cast<int8_t*>(worklist + WL_HDR + WL_CLASSES * nwin);
-  (void)hipMemsetAsync(worklist, 0, WL_HDR * 4, stream);
   hipLaunchKernelGGL(win_class_kernel, dim3(tmae_cdiv(nwin, 4)), dim3(256), 0, stream, grid_q, grid_k, batch, ny, nx,
-                     Wy, Wx, s, s, cls);
+                     Wy, Wx, s, s, cls, worklist);
   hipLaunchKernelGGL(win_worklist_kernel, dim3(tmae_cdiv(nwin, 256)), dim3(256), 0, stream, cls, nwin, Wy, Wx, worklist);
   return (int)hipGetLastError();
 }

@@ -225,11 +225,14 @@ int tmae_add_pos_embed(const void* x, int dtype, int64_t m, int d, const int32_t
 // (columns 0..7 = one-hot xc, 8..15 = one-hot yc), the operand whose product with dY gives the position part of the
 // in-projection weight gradient: dW[:, :d/2] += (dY^T onehot[:, :8]) ex, dW[:, d/2:] += (dY^T onehot[:, 8:]) ey.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void window_cells_kernel(const int32_t* __restrict__ ind, int64_t m, int wy, int wx,
-                                                          int sy, int sx, uint8_t* __restrict__ cells,
+__global__ __launch_bounds__(256) void window_cells_kernel(const int32_t* __restrict__ ind, int64_t m, int64_t m_pad,
+                                                          int wy, int wx, int sy, int sx, uint8_t* __restrict__ cells,
                                                           uint4* __restrict__ onehot) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r >= m) return;
+  if (r >= m) {                       // the padding tmae_linear_wgrad_cells may read: zeros, written here (no fill launch)
+    if (r < m_pad) cells[r] = 0;
+    return;
+  }
   const unsigned yc = (unsigned)((ind[r * 3 + 1] + sy) % wy), xc = (unsigned)((ind[r * 3 + 2] + sx) % wx);
   cells[r] = (uint8_t)(xc | (yc << 3));
   const unsigned vx = (xc & 1u) ? 0x3F800000u : 0x00003F80u, ix = xc >> 1;
@@ -239,15 +242,15 @@ __global__ __launch_bounds__(256) void window_cells_kernel(const int32_t* __rest
   onehot[2 * r + 1] = make_uint4(iy == 0u ? vy : 0u, iy == 1u ? vy : 0u, iy == 2u ? vy : 0u, iy == 3u ? vy : 0u);
 }
 
-int tmae_window_cells(const int32_t* indices, int64_t m, int wy, int wx, int do_shift, uint8_t* cells, void* onehot,
-                      void* stream_) {
+int tmae_window_cells(const int32_t* indices, int64_t m, int64_t cells_len, int wy, int wx, int do_shift, uint8_t* cells,
+                      void* onehot, void* stream_) {
   (void)hipGetLastError();
   hipStream_t stream = (hipStream_t)stream_;
-  if (m < 0 || wy <= 0 || wx <= 0 || wy > 8 || wx > 8) return TMAE_EARG;
-  if (m == 0) return TMAE_OK;
+  if (m < 0 || cells_len < m || wy <= 0 || wx <= 0 || wy > 8 || wx > 8) return TMAE_EARG;
+  if (cells_len == 0) return TMAE_OK;
   if (!indices || !cells || ((uintptr_t)onehot & 15)) return TMAE_EARG;
   const int sy = do_shift ? wy / 2 : wy, sx = do_shift ? wx / 2 : wx;
-  hipLaunchKernelGGL(window_cells_kernel, dim3(tmae_cdiv(m, 256)), dim3(256), 0, stream, indices, m, wy, wx, sy, sx, cells,
-                     (uint4*)onehot);
+  hipLaunchKernelGGL(window_cells_kernel, dim3(tmae_cdiv(cells_len, 256)), dim3(256), 0, stream, indices, m, cells_len, wy,
+                     wx, sy, sx, cells, (uint4*)onehot);
   return tmae_launch_status();
 }

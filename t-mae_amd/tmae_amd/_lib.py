@@ -82,7 +82,7 @@ SIGNATURES = {
     'tmae_token_gemm': (I, [P, L, L, I, P, I, P, P, L, P]),
     'tmae_token_gemm_dgelu': (I, [P, L, L, I, P, I, P, P, P, L, P]),
     'tmae_token_gemm_pos': (I, [P, L, L, I, P, I, P, P, P, L, P]),
-    'tmae_window_cells': (I, [P, L, I, I, I, P, P, P]),
+    'tmae_window_cells': (I, [P, L, L, I, I, I, P, P, P]),
     'tmae_linear_wgrad_workspace': (Z, [L, I, I]),
     'tmae_linear_wgrad': (I, [P, L, P, L, L, I, I, P, P, P, Z, P]),
     'tmae_linear_wgrad_cells': (I, [P, L, P, L, L, I, I, P, I, P, P, P, P, Z, P]),

@@ -377,11 +377,11 @@ def window_cells(indices, window_shape, do_shift, want_onehot=False):
     round_up(m, 32) + 64 bytes, which tmae_linear_wgrad_cells may read past m -- and, on request, the explicit one-hot
     matrix [m,16] bf16 (columns 0..7 xc, 8..15 yc)."""
     m = indices.shape[0]
-    buf = torch.zeros(((m + 31) // 32 * 32 + 64,), dtype=torch.uint8, device=indices.device)
+    buf = torch.empty(((m + 31) // 32 * 32 + 64,), dtype=torch.uint8, device=indices.device)    # the kernel zeroes the tail
     cells = buf[:m]
     onehot = torch.empty((m, 16), dtype=torch.bfloat16, device=indices.device) if want_onehot else None
-    check(lib.tmae_window_cells(_p(indices), m, int(window_shape[1]), int(window_shape[0]), 1 if do_shift else 0,
-                                _p(cells), _p(onehot), _s()), 'tmae_window_cells')
+    check(lib.tmae_window_cells(_p(indices), m, buf.shape[0], int(window_shape[1]), int(window_shape[0]),
+                                1 if do_shift else 0, _p(buf), _p(onehot), _s()), 'tmae_window_cells')
     return (cells, onehot) if want_onehot else cells
 
 
