@@ -158,7 +158,8 @@ int tmae_win_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
  * d loss / d max(tau,tau_min) (summed by the caller; n entries = tmae_win_attn_num_blocks). */
 int64_t tmae_win_attn_num_blocks(int batch, int ny, int nx, int nhead, int dh);
 /* dtau[0] = tau >= tau_min ? -(sum of the n partials) / tau : 0  -- the chain rule through
- * clamp(tau, min=tau_min) of cosine_msa.py:150-152; fixed-order sum, one launch. */
+ * clamp(tau, min=tau_min) of cosine_msa.py:150-152; fixed-order sum over up to 64 strips, one launch.  Calls must be
+ * ordered on one stream (a module-scope ticket counter picks the block that finishes). */
 int tmae_win_attn_dtau(const float* dtau_partial, int64_t n, const float* tau, float tau_min, float* dtau,
                        void* stream);
 int tmae_win_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,

@@ -310,15 +310,27 @@ static inline void attn_dims(int ny, int nx, int& Wy, int& Wx) {
   Wx = (nx + WIN - 1) / WIN + 1;
 }
 
-// sum of the per-(window, head-group) tau partials, fixed order: thread t sums elements t, t+1024, ...; LDS tree
+// sum of the per-(window, head) tau partials in a fixed order, ONE launch for any n: block b sums its contiguous strip
+// (thread t the elements t, t+1024, ... of it; LDS tree) into strip_sum[b]; the block that takes the last ticket adds the
+// strip sums in the order b = 0, 1, ... and applies the clamp rule.  (The caller used to reduce the ~1e5..5e5 partials with
+// a library reduction first: two more launches per attention module and step.)  The ticket counter and the strip sums
+// are module-scope device variables: calls must be ordered on one stream (they are: the training stream).
+#define DTAU_MAX_BLOCKS 64
+__device__ unsigned dtau_ticket = 0;
+__device__ float dtau_strip_sum[DTAU_MAX_BLOCKS];
+
 __global__ __launch_bounds__(1024) void dtau_finish_kernel(const float* __restrict__ part, int64_t n,
                                                           const float* __restrict__ tau, float tau_min,
                                                           float* __restrict__ dtau) {
   __shared__ float red[1024];
+  __shared__ bool last;
+  const int nb = gridDim.x;
+  const int64_t per = (n + nb - 1) / nb;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int64_t e = threadIdx.x;
-  for (; e + 3072 < n; e += 4096) { a0 += part[e]; a1 += part[e + 1024]; a2 += part[e + 2048]; a3 += part[e + 3072]; }
-  for (; e < n; e += 1024) a0 += part[e];
+  int64_t e = lo + threadIdx.x;
+  for (; e + 3072 < hi; e += 4096) { a0 += part[e]; a1 += part[e + 1024]; a2 += part[e + 2048]; a3 += part[e + 3072]; }
+  for (; e < hi; e += 1024) a0 += part[e];
   red[threadIdx.x] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   for (int s = 512; s > 0; s >>= 1) {
@@ -326,8 +338,18 @@ __global__ __launch_bounds__(1024) void dtau_finish_kernel(const float* __restri
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    dtau_strip_sum[blockIdx.x] = red[0];
+    __threadfence();                                           // the strip sum is visible before the ticket is taken
+    last = atomicAdd(&dtau_ticket, 1u) == (unsigned)(nb - 1);
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    __threadfence();
+    float tot = 0.f;
+    for (int b = 0; b < nb; ++b) tot += __hip_atomic_load(&dtau_strip_sum[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float t = tau[0];
-    dtau[0] = t >= tau_min ? -red[0] / t : 0.f;
+    dtau[0] = t >= tau_min ? -tot / t : 0.f;
+    dtau_ticket = 0;                                           // ready for the next call on the stream
   }
 }
 
@@ -335,8 +357,11 @@ int tmae_win_attn_dtau(const float* dtau_partial, int64_t n, const float* tau, f
                        void* stream_) {
   (void)hipGetLastError();
   if (n < 0 || !tau || !dtau || (n > 0 && !dtau_partial)) return TMAE_EARG;
-  hipLaunchKernelGGL(dtau_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream_, dtau_partial, n, tau, tau_min,
-                     dtau);
+  int64_t nb = (n + 8191) / 8192;                              // >= 8 elements per thread and block
+  if (nb < 1) nb = 1;
+  if (nb > DTAU_MAX_BLOCKS) nb = DTAU_MAX_BLOCKS;
+  hipLaunchKernelGGL(dtau_finish_kernel, dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream_, dtau_partial, n, tau,
+                     tau_min, dtau);
   return tmae_launch_status();
 }
 

@@ -1048,8 +1048,8 @@ class _WinAttn(torch.autograd.Function):
                                     _s()), 'tmae_win_attn_bwd')
         # d/d tau of logits = cos / max(tau, tau_min): -(1/tau_c) * sum dS*s, zero in the clamped branch
         dtau = torch.empty((1,), dtype=torch.float32, device=a.device)
-        psum = part.sum().reshape(1)                    # multi-block reduction; the finish kernel applies the clamp rule
-        check(lib.tmae_win_attn_dtau(_p(psum), 1, _p(tau32), float(tau_min), _p(dtau), _s()), 'tmae_win_attn_dtau')
+        # fixed-order multi-block sum of the partials + the clamp rule, one launch
+        check(lib.tmae_win_attn_dtau(_p(part), nblk, _p(tau32), float(tau_min), _p(dtau), _s()), 'tmae_win_attn_dtau')
         dtau = dtau.reshape(tshape).to(tdtype)
         return da, db, (dc if torch.is_tensor(dc) else None), dtau, None, None, None, None, None, None, None, None, None
 
