@@ -135,8 +135,8 @@ class WindowCrossAttention(nn.Module):
         w, b = a.in_proj_weight, a.in_proj_bias
         if _POS_FOLD and ops._pos_proj_ok(x, d, d) and ops._pos_proj_ok(x_prv, d, 2 * d):
             E = ops.pos_axes(pos_table, window_shape)
-            q, x_res = ops.pos_proj(x, w, b, 0, d, 0, d, plan.cells(shift, window_shape), E, fork=True, inplace_dx=True)
-            kv = ops.pos_proj(x_prv, w, b, d, 3 * d, d, 2 * d, plan_prv.cells(shift, window_shape), E)
+            q, kv, x_res = ops.pos_proj_cross(x, x_prv, w, b, plan.cells(shift, window_shape),
+                                              plan_prv.cells(shift, window_shape), E, inplace_dx=True)
             o = ops.win_attn(q, kv, 'kv', a.tau, plan.grid, plan_prv.grid, self.nhead, plan.batch, plan.ny, plan.nx,
                              shift, a.tau_min, worklist=plan.worklist(shift))
             return o, x_res

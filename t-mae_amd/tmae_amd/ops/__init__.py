@@ -482,6 +482,78 @@ class _PosProj(torch.autograd.Function):
                 None if dB is None else dB.to(bdt), None, None, None, None, None, None, None, None)
 
 
+class _PosProjCross(torch.autograd.Function):
+    """The in-projections of a cross-attention layer (wca_block.py:50-60) as ONE autograd node:
+        q  [mq, d]  = (x_q + pos) W[:d]^T + b[:d]            (rows 0:d take the position)
+        kv [mk, 2d] = [(x_kv + pos) W[d:2d]^T | x_kv W[2d:]^T] + b[d:]
+    plus x_q's alias for the residual branch.  Two position-folded GEMMs forward; backward writes the two row ranges of ONE
+    [3d, d] weight gradient (as two separate nodes each returned a zero-padded full-size gradient that autograd then
+    added: two fills and two adds per layer and parameter)."""
+
+    @staticmethod
+    def forward(ctx, x_q, x_kv, weight, bias, cells_q, cells_k, E, inplace_dx):
+        xq, xk = x_q.to(torch.bfloat16).contiguous(), x_kv.to(torch.bfloat16).contiguous()
+        d = xq.shape[1]
+        wq = pos_fold_weight(weight, 0, d, (0, d), E)
+        wkv = pos_fold_weight(weight, d, 3 * d, (d, 2 * d), E)
+        b_c = _zero_bias(3 * d, x_q.device) if bias is None else cast_param(bias, torch.bfloat16)
+        q = torch.empty((xq.shape[0], d), dtype=torch.bfloat16, device=x_q.device)
+        kv = torch.empty((xk.shape[0], 2 * d), dtype=torch.bfloat16, device=x_q.device)
+        check(lib.tmae_token_gemm_pos(_p(xq), xq.stride(0), xq.shape[0], d, _p(wq), d, _p(b_c), _p(cells_q), _p(q), d, _s()),
+              'tmae_token_gemm_pos')
+        check(lib.tmae_token_gemm_pos(_p(xk), xk.stride(0), xk.shape[0], d, _p(wkv), 2 * d, _p(b_c[d:]), _p(cells_k), _p(kv),
+                                      2 * d, _s()), 'tmae_token_gemm_pos')
+        ctx.save_for_backward(xq, xk, wq, wkv, cells_q, cells_k, E)
+        ctx.has_bias, ctx.inplace_dx = bias is not None, bool(inplace_dx)
+        ctx.dtypes = (x_q.dtype, x_kv.dtype, weight.dtype, None if bias is None else bias.dtype)
+        ctx.set_materialize_grads(False)
+        return q, kv, x_q.view_as(x_q)
+
+    @staticmethod
+    def backward(ctx, dq, dkv, dalias):
+        xq, xk, wq, wkv, cells_q, cells_k, E = ctx.saved_tensors
+        qdt, kdt, wdt, bdt = ctx.dtypes
+        d = xq.shape[1]
+        dxq = dalias.to(torch.bfloat16) if dalias is not None else None
+        dxk = None
+
+        def cont(t):
+            t = t.to(torch.bfloat16)
+            return t if t.stride(-1) == 1 else t.contiguous()
+        dq = None if dq is None else cont(dq)
+        dkv = None if dkv is None else cont(dkv)
+        if ctx.needs_input_grad[0] and dq is not None:
+            if dxq is None:
+                dxq = dq @ wq[:, :d]
+            elif ctx.inplace_dx:
+                dxq.addmm_(dq, wq[:, :d])                      # see _ProjFork.backward
+            else:
+                dxq = torch.addmm(dxq, dq, wq[:, :d])
+        if ctx.needs_input_grad[1] and dkv is not None:
+            dxk = dkv @ wkv[:, :d]
+        dW = dB = None
+        if ctx.needs_input_grad[2]:
+            mk = torch.empty if (dq is not None and dkv is not None) else torch.zeros
+            dW = mk((3 * d, d), dtype=torch.float32, device=xq.device)
+            want_b = ctx.has_bias and ctx.needs_input_grad[3]
+            dB = mk((3 * d,), dtype=torch.float32, device=xq.device) if want_b else None
+            if dq is not None:
+                _, _, dc = linear_wgrad(dq, xq, want_b, out_w=dW[:d], out_b=None if dB is None else dB[:d], cells=cells_q,
+                                        pos_n=d)
+                dW[:d].addmm_(dc.t(), E)
+            if dkv is not None:
+                _, _, dc = linear_wgrad(dkv, xk, want_b, out_w=dW[d:], out_b=None if dB is None else dB[d:], cells=cells_k,
+                                        pos_n=d)
+                dW[d:2 * d].addmm_(dc[:, :d].t(), E)
+        return (None if dxq is None else dxq.to(qdt), None if dxk is None else dxk.to(kdt),
+                None if dW is None else dW.to(wdt), None if dB is None else dB.to(bdt), None, None, None, None)
+
+
+def pos_proj_cross(x_q, x_kv, weight, bias, cells_q, cells_k, E, inplace_dx=False):
+    """See _PosProjCross: (q [mq,d], kv [mk,2d], alias of x_q)."""
+    return _PosProjCross.apply(x_q, x_kv, weight, bias, cells_q, cells_k, E, bool(inplace_dx))
+
+
 def pos_proj(x, weight, bias, lo, hi, p0, p1, cells, E, fork=False, inplace_dx=False):
     """See _PosProj (bf16 GPU path; callers check _pos_proj_ok first)."""
     return _PosProj.apply(x, weight, bias, int(lo), int(hi), int(p0), int(p1), cells, E, bool(fork), bool(inplace_dx))
