@@ -338,6 +338,12 @@ size_t tmae_column_sums_workspace(int64_t rows, int c);
 int tmae_column_sums(const void* x, int dtype, int64_t rows, int c, float* out, void* ws, size_t ws_bytes,
                      void* stream);
 
+/* bf16 copies of fp32 parameter matrices after the optimizer step (what autocast reads: torch casts a weight on every
+ * use; the dX GEMMs of the token-list Linears additionally want W^T): ONE launch for a list of matrices.
+ * table (device, 8-byte aligned): `count` entries of five int64 -- src (fp32 [n,k]), dst (bf16 [n,k]), dstT (bf16 [k,n] or
+ * 0), n | k << 32, index of the entry's first 32 x 32 tile -- entries ordered by that index; total_tiles = their sum. */
+int tmae_multi_cast_transpose(const void* table, int count, int64_t total_tiles, void* stream);
+
 /* Token-list Linear in bf16 (fp32 accumulate):  y[m,n] = x[m,k] . w[n,k]^T (+ bias[n]) -- the in-/out-projections
  * and FFN layers of EncoderLayer (sst_basic_block.py:45-83, F.linear) and, on w^T, their input gradients.
  * k in {128, 256, 512}, n a multiple of 64; ldx / ldy = row pitches in elements (column slices of packed buffers are

@@ -80,6 +80,7 @@ SIGNATURES = {
     'tmae_frame_prepare_workspace': (Z, [L]),
     'tmae_frame_prepare': (I, [P, I, L, P, P, F, I, I, F, F, F, F, F, F, F, I, P, P, P, Z, P]),
     'tmae_token_gemm': (I, [P, L, L, I, P, I, P, P, L, P]),
+    'tmae_multi_cast_transpose': (I, [P, I, L, P]),
     'tmae_token_gemm_dgelu': (I, [P, L, L, I, P, I, P, P, P, L, P]),
     'tmae_token_gemm_pos': (I, [P, L, L, I, P, I, P, P, P, L, P]),
     'tmae_window_cells': (I, [P, L, L, I, I, I, P, P, P]),

@@ -100,8 +100,18 @@ def token_gemm_dx(dy, w, force=False):
 
 
 def _transposed(w):
-    """w^T contiguous; for a whole (non-view) weight copy it is kept with the tensor until the weight changes (one
-    transpose launch per dX GEMM per step otherwise, ~60)."""
+    """w^T contiguous.  For a bf16 copy managed by refresh_param_copies the transposed copy is made there, together with
+    the cast, in ONE launch for all weights that asked for it (the first request of a weight registers it; until the next
+    refresh it is transposed on the spot); other whole weights are cached until their version counter moves."""
+    st = getattr(w, '_tmae_stamp', None)
+    if st is not None and w.dim() == 2:
+        T = getattr(w, '_tmae_T', None)
+        if T is not None and T[0] == st:
+            return T[1]
+        with torch.no_grad():
+            t = w.t().contiguous()
+        w._tmae_T = (st, t)                               # refresh_param_copies rewrites this buffer from now on
+        return t
     if w._base is None and not w.requires_grad:
         return _derived(w, 'T', lambda t: t.t().contiguous())
     return w.t().contiguous()
@@ -187,16 +197,53 @@ def refresh_param_copies(params, dtype=torch.bfloat16):
             ps.append(p)
     if not ps:
         return
-    dst = []
+    dst, plain, mats = [], [], []
     for p in ps:
         c = getattr(p, '_tmae_copy', None)
         if c is None or c[2].dtype != dtype or c[2].shape != p.shape:
             c = [0, 0, torch.empty_like(p, dtype=dtype)]
             p._tmae_copy = c
-        dst.append(c[2])
-    torch._foreach_copy_(dst, ps)
+        # weights whose transposed copy is in use (ops._transposed): cast + transpose in the one-launch kernel
+        if (dtype == torch.bfloat16 and p.dtype == torch.float32 and p.dim() == 2 and p.is_contiguous()
+                and getattr(c[2], '_tmae_T', None) is not None):
+            mats.append(p)
+        else:
+            plain.append(p)
+            dst.append(c[2])
+    if plain:
+        torch._foreach_copy_(dst, plain)
+    if mats:
+        _multi_cast_transpose(mats)
     for p in ps:
-        p._tmae_copy[0], p._tmae_copy[1] = p._version, p.data_ptr()
+        c = p._tmae_copy
+        c[0], c[1] = p._version, p.data_ptr()
+        c[2]._tmae_stamp = getattr(c[2], '_tmae_stamp', 0) + 1
+        T = getattr(c[2], '_tmae_T', None)
+        if T is not None:                                 # rewritten above (mats) or stale (plain: dropped)
+            c[2]._tmae_T = (c[2]._tmae_stamp, T[1]) if id(p) in _MCT_DONE else None
+    _MCT_DONE.clear()
+
+
+_MCT_TABLES = {}
+_MCT_DONE = set()
+
+
+def _multi_cast_transpose(mats):
+    """fp32 matrices -> their bf16 copies and transposed bf16 copies (tmae_multi_cast_transpose); the descriptor table is
+    built once per set of buffers."""
+    key = tuple((p.data_ptr(), p._tmae_copy[2].data_ptr(), p._tmae_copy[2]._tmae_T[1].data_ptr()) for p in mats)
+    ent = _MCT_TABLES.get(key)
+    if ent is None:
+        rows, tile0 = [], 0
+        for p in mats:
+            n, k = p.shape
+            rows.append([p.data_ptr(), p._tmae_copy[2].data_ptr(), p._tmae_copy[2]._tmae_T[1].data_ptr(), n | (k << 32), tile0])
+            tile0 += ((n + 31) // 32) * ((k + 31) // 32)
+        ent = _MCT_TABLES[key] = (torch.tensor(rows, dtype=torch.int64, device=mats[0].device), tile0)
+        if len(_MCT_TABLES) > 8:
+            _MCT_TABLES.pop(next(iter(_MCT_TABLES)))
+    check(lib.tmae_multi_cast_transpose(_p(ent[0]), len(mats), ent[1], _s()), 'tmae_multi_cast_transpose')
+    _MCT_DONE.update(id(p) for p in mats)
 
 
 # ----------------------------------------------------------------------------- token-list Linear

@@ -651,6 +651,36 @@ def test_pos_folded_in_projection_vs_materialised(shift):
         assert (out3.float() - ref3).abs().max().item() <= 1e-2 * scale
 
 
+def test_refresh_param_copies_casts_and_transposes_in_one_launch():
+    """ops.refresh_param_copies: after a weight's transposed bf16 copy was used once (the dX GEMM of ops.linear), the
+    refresh writes the bf16 copy AND its transpose with tmae_multi_cast_transpose; three optimizer-style updates of
+    matrices with ragged sizes, results against plain casts; the backward keeps using the refreshed transposes."""
+    from tmae_amd import ops
+    torch.manual_seed(1)
+    ws = [torch.nn.Parameter(torch.randn(n, k, device=dev()) * 0.1) for n, k in ((256, 128), (128, 256), (512, 256), (200, 72))]
+    x = [torch.randn(9000, w.shape[1], device=dev()).bfloat16().requires_grad_(True) for w in ws]
+    for step in range(4):
+        for w, xi in zip(ws, x):
+            w.grad = None
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y = ops.linear(xi, w, None)
+            y.sum().backward()
+            ref = (torch.ones_like(y).float() @ w.detach().bfloat16().float()).bfloat16()
+            assert torch.allclose(xi.grad.float(), ref.float(), rtol=2e-2, atol=2e-2), step
+            xi.grad = None
+        with torch.no_grad():
+            for w in ws:
+                w.add_(torch.randn_like(w) * 0.01)                   # the optimizer step
+        ops.refresh_param_copies(ws)
+        for w in ws:
+            c = w._tmae_copy
+            assert c[0] == w._version and torch.equal(c[2], w.detach().bfloat16())
+            T = getattr(c[2], '_tmae_T', None)
+            if step >= 1 and w.shape[0] in (128, 256) and w.shape[1] % 64 == 0:   # shapes whose dX runs on the token GEMM (on W^T)
+                assert T is not None and T[0] == c[2]._tmae_stamp
+                assert torch.equal(T[1], w.detach().bfloat16().t().contiguous())
+
+
 def test_gelu_linear_fused_backward_vs_torch():
     """ops.gelu_linear: forward = F.linear(F.gelu(x)); backward with the GELU derivative fused into the dX GEMM
     (tmae_token_gemm_dgelu) vs torch autograd in bf16, for both FFN shapes (d = 128 / dff = 256, d = 256 / dff = 512)."""
