@@ -12,6 +12,22 @@ static inline int tmae_launch_status() { return (int)hipGetLastError(); }
 static inline size_t tmae_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline unsigned tmae_cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: remember per (call site, device) that it has been
+// raised (a process-wide flag would leave the second device of a process at the 64 KB default), thread-safe, and hand
+// the error back instead of dropping it.
+struct TmaeLdsAttr { unsigned long long done = 0; };
+static inline int tmae_allow_lds(TmaeLdsAttr& a, const void* func, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(&a.done, __ATOMIC_ACQUIRE) & bit) return 0;
+  e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  __atomic_fetch_or(&a.done, bit, __ATOMIC_RELEASE);
+  return 0;
+}
+
 // Carves 256-byte aligned sub-buffers out of the caller's workspace.
 struct WsCarver {
   char* base;

@@ -316,11 +316,8 @@ static int igemm_launch(const void* feat, int64_t ldf, int64_t m_in, int cin, co
     const int lds = (bn == 128 ? 3 : 2) * (IR_BM * 128 + bn * 128) + IR_BM * 9 * 4;
 #define IR_LAUNCH(C, B)                                                                                               \
   do {                                                                                                                \
-    static bool attr = false;                                                                                         \
-    if (!attr) {                                                                                                      \
-      (void)hipFuncSetAttribute((const void*)spconv_igemm_ring_kernel<C, B>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-      attr = true;                                                                                                    \
-    }                                                                                                                 \
+    static TmaeLdsAttr attr;                                                                                          \
+    if (int e_ = tmae_allow_lds(attr, (const void*)spconv_igemm_ring_kernel<C, B>, lds)) return e_;                   \
     hipLaunchKernelGGL((spconv_igemm_ring_kernel<C, B>), dim3((unsigned)grid), dim3(512), lds, stream,                \
                        (const __hip_bfloat16*)feat, ldf, nbr, m_out, (const __hip_bfloat16*)w, cout,                  \
                        (__hip_bfloat16*)out, ldo);                                                                    \
@@ -509,11 +506,8 @@ static int dense_conv3x3_launch(const void* in, int batch, int ny, int nx, int c
 #define HC_LAUNCH(C, D)                                                                                               \
   do {                                                                                                                \
     const int lds = 2 * HaloGeom<D>::ABYTES + 3 * (IG_BN * 128) + 1024;                                               \
-    static bool attr = false;                                                                                         \
-    if (!attr) {                                                                                                      \
-      (void)hipFuncSetAttribute((const void*)dense_conv3x3_halo_kernel<C, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-      attr = true;                                                                                                    \
-    }                                                                                                                 \
+    static TmaeLdsAttr attr;                                                                                          \
+    if (int e_ = tmae_allow_lds(attr, (const void*)dense_conv3x3_halo_kernel<C, D>, lds)) return e_;                  \
     hipLaunchKernelGGL((dense_conv3x3_halo_kernel<C, D>), dim3((unsigned)blocks), dim3(512), lds, stream,            \
                        (const __hip_bfloat16*)in, batch, ny, nx, (const __hip_bfloat16*)weight, cout,                 \
                        (__hip_bfloat16*)out);                                                                         \

@@ -430,14 +430,10 @@ static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const
     // column groups of 256; the workgroups of one token range sit on one XCD: 8 * ncg * (32 / ncg) workgroups
     const int ncg = n / 256, grid = 8 * ncg * (32 / ncg);
     const int lds = 256 * ((256 + (cells ? 32 : 0)) * 2 + 16) + 256 * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)token_gemm_res_kernel<256, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          256 * (256 * 2 + 16) + 256 * 2);
-      (void)hipFuncSetAttribute((const void*)token_gemm_res_kernel<256, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          256 * (288 * 2 + 16) + 256 * 2);
-      attr_set = true;
-    }
+    static TmaeLdsAttr attr_plain, attr_pos;
+    if (int e_ = cells ? tmae_allow_lds(attr_pos, (const void*)token_gemm_res_kernel<256, 4, true>, lds)
+                       : tmae_allow_lds(attr_plain, (const void*)token_gemm_res_kernel<256, 4, false>, lds))
+      return e_;
     if (cells)
       hipLaunchKernelGGL((token_gemm_res_kernel<256, 4, true>), dim3(grid), dim3(512), lds, stream, (const __hip_bfloat16*)x,
                          ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, (__hip_bfloat16*)y, ldy, m, ncg,

@@ -231,7 +231,10 @@ _MCT_DONE = set()
 def _multi_cast_transpose(mats):
     """fp32 matrices -> their bf16 copies and transposed bf16 copies (tmae_multi_cast_transpose); the descriptor table is
     built once per set of buffers."""
-    key = tuple((p.data_ptr(), p._tmae_copy[2].data_ptr(), p._tmae_copy[2]._tmae_T[1].data_ptr()) for p in mats)
+    # shapes are part of the key: the table bakes n | k << 32 and the tile offsets, and the caching allocator hands the
+    # same blocks to a rebuilt model whose weights have the same byte sizes but other shapes
+    key = tuple((p.data_ptr(), p._tmae_copy[2].data_ptr(), p._tmae_copy[2]._tmae_T[1].data_ptr(), tuple(p.shape))
+                for p in mats)
     ent = _MCT_TABLES.get(key)
     if ent is None:
         rows, tile0 = [], 0
@@ -1545,9 +1548,9 @@ class _DenseConv3x3(torch.autograd.Function):
                 wt = w.view(cout, 3, 3, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * cout).contiguous()
                 dx = dense_conv3x3_halo(dy, wt, dil).to(ctx.meta[0])
             elif ctx.native:
-                nbr_t = _DENSE_NBR.get(('t', B, Y, X, x.device))
+                nbr_t = _DENSE_NBR.get(('t', B, Y, X, dil, x.device))
                 if nbr_t is None:                      # transposed rulebook of a stride-1 conv = flipped taps
-                    nbr_t = _DENSE_NBR[('t', B, Y, X, x.device)] = nbr.flip(1).contiguous()
+                    nbr_t = _DENSE_NBR[('t', B, Y, X, dil, x.device)] = nbr.flip(1).contiguous()
                 dx = spconv_bwd_data(dy.view(n, cout), nbr_t, w, cin).view(B, Y, X, cin).to(ctx.meta[0])
             else:
                 dx = torch.ops.aten.convolution_backward(

@@ -44,6 +44,8 @@ def main():
     p.add_argument('--save_to_file', action='store_true')
     p.add_argument('--fuse_conv_bn', action='store_true')
     p.add_argument('--fixed_gap_eval', type=int, default=-1)
+    p.add_argument('--random_init', action='store_true',
+                   help='evaluate the randomly initialised model (smoke runs only: the AP figures mean nothing)')
     args = p.parse_args()
     cfg_from_yaml_file(args.cfg_file, cfg)
     cfg.TAG = Path(args.cfg_file).stem
@@ -61,17 +63,35 @@ def main():
     log_config_to_file(cfg, logger=logger)
     if not args.synthetic:
         raise NotImplementedError('the ONCE two-frame dataloader is outside this hot path (SURVEY 8f-2); use --synthetic')
+    if args.eval_all:                                    # repeat_eval_ckpt (tools/test.py:101-170) without the waiting loop
+        ckpt_dir = Path(args.ckpt_dir or out.parent / 'ckpt')
+
+        def epoch_of(p_):
+            try:
+                return int(p_.stem.rsplit('_', 1)[1])
+            except (IndexError, ValueError):
+                return -1
+        ckpts = [str(p_) for p_ in sorted(ckpt_dir.glob('checkpoint_epoch_*.pth'), key=epoch_of)
+                 if epoch_of(p_) >= args.start_epoch]
+        if not ckpts:
+            raise FileNotFoundError(f'--eval_all: no checkpoint_epoch_*.pth (epoch >= {args.start_epoch}) in {ckpt_dir}')
+    elif args.ckpt:
+        if not Path(args.ckpt).is_file():
+            raise FileNotFoundError(f'--ckpt {args.ckpt} does not exist')
+        ckpts = [args.ckpt]
+    elif args.random_init:
+        logger.warning('evaluating RANDOMLY INITIALISED weights (--random_init): the figures below are not results')
+        ckpts = [None]
+    else:                                                # the reference requires a checkpoint (tools/test.py:53-58,195)
+        raise ValueError('give --ckpt <file>, or --eval_all with --ckpt_dir, or --random_init for a smoke run')
     ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=args.synthetic_points, batch_size=bs, rank=rank)
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds, logger).cuda()
     cfg.LOCAL_RANK = int(os.environ.get('LOCAL_RANK', 0))
-    ckpts = [args.ckpt]
-    if args.eval_all:                                    # repeat_eval_ckpt (tools/test.py:101-170) without the waiting loop
-        ckpts = sorted(str(p_) for p_ in Path(args.ckpt_dir or out.parent / 'ckpt').glob('checkpoint_epoch_*.pth'))
     for ck in ckpts:
         if ck:
             model.load_params_from_file(ck, logger=logger)
         loader = SyntheticEvalLoader(ds, args.synthetic_samples, bs, rank=rank, world=world)
-        tag = Path(ck).stem if ck else 'synthetic'
+        tag = Path(ck).stem if ck else 'random_init'
         ret = eval_one_epoch(cfg, model, loader, tag, logger, dist_test=world > 1, result_dir=out / args.eval_tag / tag,
                              save_to_file=args.save_to_file, amp_dtype=torch.bfloat16 if args.amp else None)
         if rank == 0:

@@ -70,8 +70,23 @@ def save_checkpoint(model, optimizer, epoch, it, path):
     of epochs trained so far, as the reference stores it (train_utils.py:217-232)."""
     m = model.module if hasattr(model, 'module') else model
     state = {k: v.cpu() for k, v in m.state_dict().items()}
+    tmp = Path(str(path) + '.tmp')                       # readers never see a partly written file
     torch.save({'epoch': epoch, 'it': it, 'model_state': state, 'optimizer_state': optimizer.state_dict(),
-                'scaler': None, 'version': 'tmae_amd'}, path)
+                'scaler': None, 'version': 'tmae_amd'}, tmp)
+    os.replace(tmp, path)
+
+
+def _ckpt_epoch(p):
+    try:
+        return int(p.stem.rsplit('_', 1)[1])
+    except (IndexError, ValueError):
+        return -1
+
+
+def list_checkpoints(ckpt_dir):
+    """checkpoint_epoch_<N>.pth of `ckpt_dir`, ascending in N (epoch numbers, not mtimes: every rank and every file
+    system orders them the same way)."""
+    return sorted((p for p in Path(ckpt_dir).glob('checkpoint_epoch_*.pth') if _ckpt_epoch(p) >= 0), key=_ckpt_epoch)
 
 
 def main():
@@ -123,7 +138,7 @@ def main():
             if (epoch + 1) % args.ckpt_save_interval == 0:
                 save_checkpoint(ddp, opt, epoch + 1, it, out / 'ckpt' / f'checkpoint_epoch_{epoch + 1}.pth')
                 # keep the newest --max_ckpt_save_num checkpoints (train_utils.py:217-232)
-                kept = sorted((out / 'ckpt').glob('checkpoint_epoch_*.pth'), key=lambda p_: p_.stat().st_mtime)
+                kept = list_checkpoints(out / 'ckpt')
                 for old_ckpt in kept[:max(len(kept) - args.max_ckpt_save_num, 0)]:
                     old_ckpt.unlink()
     # --num_epochs_to_eval N (tools/train.py:335-372 -> repeat_eval_ckpt): evaluate the last N checkpoints of a detector
@@ -131,8 +146,13 @@ def main():
         from tmae_amd.eval import eval_one_epoch
         from tmae_amd.train import SyntheticEvalLoader
         cfg.LOCAL_RANK = local_rank
-        ckpts = sorted((out / 'ckpt').glob('checkpoint_epoch_*.pth'), key=lambda p_: p_.stat().st_mtime)
-        for ck in ckpts[-args.num_epochs_to_eval:]:
+        # rank 0 has finished writing / pruning before anybody lists the directory, and every rank evaluates the list rank 0
+        # saw (a rank that globbed by itself could see a file about to be pruned: mismatched all_gather_object calls)
+        names = [[str(p_) for p_ in list_checkpoints(out / 'ckpt')[-args.num_epochs_to_eval:]]] if rank == 0 else [None]
+        if world > 1:
+            dist.barrier()
+            dist.broadcast_object_list(names, src=0)
+        for ck in map(Path, names[0]):
             model.load_params_from_file(str(ck), logger=logger)
             loader = SyntheticEvalLoader(ds, 4 * bs, bs, rank=rank, world=world)
             ret = eval_one_epoch(cfg, model, loader, ck.stem, logger, dist_test=world > 1, result_dir=out / 'eval' / ck.stem,
