@@ -7,9 +7,9 @@
 // and the 128 weight rows through LDS -- register-staged one slice ahead (issue the next slice's global loads, contract
 // the current one, write the next one into the other LDS buffer, one barrier per slice).
 // bf16 in, fp32 accumulate (v_mfma_f32_16x16x32_bf16), bf16 out.  The products are taken "swapped" (rows = output
-// channels, column = token) over weight rows permuted in LDS so that a lane ends up with 16 CONSECUTIVE output channels
-// of one token: two 16-byte stores per token, four lanes per 128-byte line (the store shape csrc/token_gemm.hip found
-// decisive).  The input gradient is the same kernel on the transposed rulebook and the transposed weight.
+// channels, column = token) over weight rows permuted in LDS so that a pair of column tiles gives a lane 8 CONSECUTIVE
+// output channels and the four lanes of a token 32: two 16-byte stores per lane, each instruction writing a contiguous
+// 64-byte segment per token (no holes inside a line: csrc/token_gemm.hip, csrc/token_gemm_wreg.hip).  The input gradient is the same kernel on the transposed rulebook and the transposed weight.
 #include "common.h"
 #include <stdlib.h>
 
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void spconv_igemm_kernel(const __hip_bfloat
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = lrow + 32 * j, s = n & 63;
-    brow[j] = (n & 64) + 16 * ((s >> 2) & 3) + 4 * (s >> 4) + (s & 3);
+    brow[j] = (n & 64) + 16 * (2 * (s >> 5) + ((s >> 2) & 1)) + 4 * ((s >> 3) & 3) + (s & 3);
   }
   u32x4 ra[4], rb[4];
   int src[4];
@@ -113,12 +113,13 @@ __global__ __launch_bounds__(256, 2) void spconv_igemm_kernel(const __hip_bfloat
     if (step + 1 < STEPS) lstore(buf ^ 1);
     __syncthreads();
   }
-  // rows 4g + r of column tile nt = output channels wn*64 + 16g + 4nt + r; column i = token wm*64 + mt*16 + i
+  // rows 4g + r of column tile nt = output channels wn*64 + 32 (nt / 2) + 8g + 4 (nt % 2) + r; column i = token wm*64 + mt*16 + i
+  // (a tile pair = 8 consecutive channels per lane: every store instruction writes 64 contiguous bytes per token)
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int64_t r = row0 + wm * 64 + mt * 16 + i;
     if (r < m_out) {
-      __hip_bfloat16* p = out + r * ldo + n0 + wn * 64 + 16 * g;
+      __hip_bfloat16* p = out + r * ldo + n0 + wn * 64 + 8 * g;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         u32x4 v;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void spconv_igemm_kernel(const __hip_bfloat
         v[1] = ig_bf16_bits(acc[2 * h][mt][2]) | (ig_bf16_bits(acc[2 * h][mt][3]) << 16);
         v[2] = ig_bf16_bits(acc[2 * h + 1][mt][0]) | (ig_bf16_bits(acc[2 * h + 1][mt][1]) << 16);
         v[3] = ig_bf16_bits(acc[2 * h + 1][mt][2]) | (ig_bf16_bits(acc[2 * h + 1][mt][3]) << 16);
-        *reinterpret_cast<u32x4*>(p + 8 * h) = v;
+        *reinterpret_cast<u32x4*>(p + 32 * h) = v;
       }
     }
   }
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(512, 1) void spconv_igemm_ring_kernel(const __hip_b
 #pragma unroll
   for (int j = 0; j < BI; ++j) {
     const int L = w * (8 * BI) + j * 8 + r8, s64 = L & 63;             // LDS row L holds weight column n (16 consecutive
-    const int n = (L & ~63) + 16 * ((s64 >> 2) & 3) + 4 * (s64 >> 4) + (s64 & 3);  // output channels per lane, see above)
+    const int n = (L & ~63) + 32 * (s64 >> 5) + 8 * ((s64 >> 2) & 3) + 4 * ((s64 >> 4) & 1) + (s64 & 3);  // output channels per lane, see above)
     wsrc[j] = reinterpret_cast<const char*>(W + (int64_t)(n0 + n) * (9 * CIN)) + chunk * 16;
   }
   const char* fbase = reinterpret_cast<const char*>(feat) + chunk * 16;
@@ -272,14 +273,14 @@ __global__ __launch_bounds__(512, 1) void spconv_igemm_ring_kernel(const __hip_b
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot are done before it moves on
   }
-  // rows 4g + r of column tile nt = output channels (slab nt/4) * 64 + 16g + 4(nt%4) + r; column i = token
+  // rows 4g + r of column tile nt = output channels (slab nt/4) * 64 + 32 ((nt%4) / 2) + 8g + 4 (nt % 2) + r; column i = token
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int64_t r = row0 + wm * 64 + mt * 16 + i;
     if (r < m_out) {
 #pragma unroll
       for (int sbk = 0; sbk < NT / 4; ++sbk) {
-        __hip_bfloat16* p = out + r * ldo + n0 + wn * (BN / 2) + sbk * 64 + 16 * g;
+        __hip_bfloat16* p = out + r * ldo + n0 + wn * (BN / 2) + sbk * 64 + 8 * g;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int t0 = sbk * 4 + 2 * h;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(512, 1) void spconv_igemm_ring_kernel(const __hip_b
           v[1] = ig_bf16_bits(acc[t0][mt][2]) | (ig_bf16_bits(acc[t0][mt][3]) << 16);
           v[2] = ig_bf16_bits(acc[t0 + 1][mt][0]) | (ig_bf16_bits(acc[t0 + 1][mt][1]) << 16);
           v[3] = ig_bf16_bits(acc[t0 + 1][mt][2]) | (ig_bf16_bits(acc[t0 + 1][mt][3]) << 16);
-          *reinterpret_cast<u32x4*>(p + 8 * h) = v;
+          *reinterpret_cast<u32x4*>(p + 32 * h) = v;
         }
       }
     }
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int L = w * 16 + j * 8 + r8, s64 = L & 63;
-    const int n = (L & ~63) + 16 * ((s64 >> 2) & 3) + 4 * (s64 >> 4) + (s64 & 3);
+    const int n = (L & ~63) + 32 * (s64 >> 5) + 8 * ((s64 >> 2) & 3) + 4 * ((s64 >> 4) & 1) + (s64 & 3);
     wsrc[j] = reinterpret_cast<const char*>(W + (int64_t)(n0 + n) * (9 * CIN)) + chunk * 16;
   }
   auto issue_halo = [&](int kc, int p) {              // piece p (0..71; >= NP: dummy) of channel slice kc
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   for (int mt = 0; mt < 4; ++mt) {
     const int y = y0 + 4 * wm + mt, x = x0 + i;
     if (y < Y && x < X) {
-      __hip_bfloat16* p = out + (((int64_t)b * Y + y) * X + x) * cout + n0 + wn * 64 + 16 * g;
+      __hip_bfloat16* p = out + (((int64_t)b * Y + y) * X + x) * cout + n0 + wn * 64 + 8 * g;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         u32x4 v;
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
         v[1] = ig_bf16_bits(acc[2 * h][mt][2]) | (ig_bf16_bits(acc[2 * h][mt][3]) << 16);
         v[2] = ig_bf16_bits(acc[2 * h + 1][mt][0]) | (ig_bf16_bits(acc[2 * h + 1][mt][1]) << 16);
         v[3] = ig_bf16_bits(acc[2 * h + 1][mt][2]) | (ig_bf16_bits(acc[2 * h + 1][mt][3]) << 16);
-        *reinterpret_cast<u32x4*>(p + 8 * h) = v;
+        *reinterpret_cast<u32x4*>(p + 32 * h) = v;
       }
     }
   }

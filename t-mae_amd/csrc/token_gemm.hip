@@ -9,8 +9,11 @@
 // W streams through LDS in chunks of 64 output columns (double buffered; W is at most a few hundred KB and stays in
 // L2), each chunk is contracted against the resident x fragments with v_mfma_f32_16x16x32_bf16 in the swapped
 // orientation (rows = output columns n, columns = tokens): a lane then holds 4 consecutive n of one token, i.e. one
-// 8-byte piece per tile; the W rows of a chunk are permuted in LDS so that the four tiles give a lane 16 CONSECUTIVE
-// columns (two 16-byte stores; four lanes cover a 128-byte line of y), bias added in fp32 before the rounding.
+// 8-byte piece per tile; the W rows of a chunk are permuted in LDS so that a PAIR of tiles gives a lane 8 consecutive
+// columns and the four lanes of a token (g = 0..3) 32 consecutive ones: every store instruction writes a contiguous
+// 64-byte segment per token (round 3: with 16 consecutive columns per lane an instruction wrote 16-byte pieces with
+// 16-byte holes, and the L2 request rate -- not bytes -- bounded the stores: csrc/token_gemm_wreg.hip).  Bias added in
+// fp32 before the rounding.
 //
 // Measured (MI355X, m = 470 k): 5.4 TB/s at k = n = 128, 5.3 at k = 128 / n = 256, 4.1 at k = n = 256, 3.1 at
 // k = 256 / n = 512 -- ahead of hipBLASLt (3.0-3.4 TB/s) on every shape it supports; a trivial copy kernel with the
@@ -18,8 +21,9 @@
 // What the ablations of the n = 512 case say (each term removed alone, 250 us total): x loads 100 us, stores 70 us,
 // MFMAs 40 us, W loads 30 us, LDS reads 12 us -- nearly additive, i.e. the phases of a workgroup do not overlap, and
 // the x loads of a starting workgroup queue behind the other workgroups' stores (without stores they cost 30 us).
-// Hence token_gemm_res_kernel below for the heavy shapes (contraction 256, N = 256 / 512): W resident in LDS, x
-// prefetched a tile ahead, no barriers -- 4.2-4.8 TB/s.
+// Hence, for the heavy shapes, csrc/token_gemm_wreg.hip (round 3: W in registers, x through an LDS-DMA ring, full-line
+// stores: 5.0-6.1 TB/s); it replaced round 1's W-resident-in-LDS kernel (4.2-4.8 TB/s).  This kernel keeps the small
+// token lists (< 32 k tokens), contraction 512 and the GELU-derivative epilogue.
 // The store width also decides: with one 8-byte store per tile (32-byte segments per row) the kernel ran at
 // 2.9 TB/s, the partial-line requests saturate the L2 request rate long before its bandwidth.
 #include "common.h"
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
 #define TG_WSTORE(buf)                                                                                \
   _Pragma("unroll") for (int j = 0; j < WL; ++j) {                                                    \
     const int c_ = tid + NTH * j, row_ = c_ / CPR, ch_ = c_ % CPR;                                    \
-    *reinterpret_cast<u32x4*>(&wl[buf][(16 * ((row_ >> 2) % NTC) + 4 * (row_ / (4 * NTC)) + (row_ & 3)) * PITCH + ch_ * 16]) = wr[j]; \
+    *reinterpret_cast<u32x4*>(&wl[buf][(16 * (2 * (row_ >> 5) + ((row_ >> 2) & 1)) + 4 * ((row_ >> 3) & 3) + (row_ & 3)) * PITCH + ch_ * 16]) = wr[j]; \
   }                                                                                                   \
   *reinterpret_cast<u32x4*>(&bl[buf][(tid & (TG_NCH / 8 - 1)) * 16]) = br;   /* every thread (same data): under `if (tid < 8)` the compiler sinks the LOAD into the branch and follows it with vmcnt(0) */
   const int nch = NCHT ? NCHT : N / TG_NCH;     // NCHT > 0: the chunk loop is fully unrolled (straight-line code)
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     const int64_t row = tok0 + tt * 16 + i;
-    voff[tt] = row < m ? (int)((row * ldy + 4 * NTC * g) * 2) : (int)ybytes;
+    voff[tt] = row < m ? (int)((row * ldy + 8 * g) * 2) : (int)ybytes;
   }
   u32x4 oA[NTC / 2][TT], oB[NTC / 2][TT];             // [16-byte piece of the lane's 4*NTC columns][token tile]
 #pragma unroll
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-      for (int h = 0; h < NTC / 2; ++h) auxr[h][tt] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff[tt] + h * 16, 0, 0);
+      for (int h = 0; h < NTC / 2; ++h) auxr[h][tt] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff[tt] + h * 64, 0, 0);
   }
   TG_WSTORE(0)
   {
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
     f32x4 acc[NTC][TT];                                                                                     \
     uint2 bcur[NTC];           /* packed bf16 bias of the lane's 4 columns per tile (zeros if none) */     \
     _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt)                                                      \
-      bcur[nt] = *reinterpret_cast<const uint2*>(&bl[buf][(4 * NTC * g + 4 * nt) * 2]);                     \
+      bcur[nt] = *reinterpret_cast<const uint2*>(&bl[buf][(32 * (nt >> 1) + 8 * g + 4 * (nt & 1)) * 2]);                     \
     _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt)                                                      \
       _Pragma("unroll") for (int tt = 0; tt < TT; ++tt) acc[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};            \
     _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                     \
@@ -185,8 +189,8 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
     TG_KEEP(oprev) /* the previous chunk's store data stayed untouched while its stores drained */          \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     TG_WSTORE((buf) ^ 1) /* chunk c+1 (loaded before the previous chunk's stores) -> the other buffer */     \
-    /* C layout: rows 4g + r of tile t = output columns 16g + 4t + r (W rows are permuted in LDS), column = token i: */ \
-    /* a lane holds 16 consecutive columns of one token = two 16-byte stores, 4 lanes cover a 128-byte line */        \
+    /* C layout: rows 4g + r of tile t = output columns 32 (t / 2) + 8g + 4 (t % 2) + r (W rows are permuted in LDS), */ \
+    /* column = token i: a tile pair = 8 consecutive columns per lane, 64 contiguous bytes per token and store */      \
     _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
       _Pragma("unroll") for (int h = 0; h < NTC / 2; ++h) {                                                 \
         unsigned w_[4];                                                                                     \
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
       if (more) {                                                                                           \
         _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                   \
           _Pragma("unroll") for (int h = 0; h < NTC / 2; ++h)                                               \
-            auxr[h][tt] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff[tt] + h * 16, ((c) + 1) * (TG_NCH * 2), 0); \
+            auxr[h][tt] = __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff[tt] + h * 64, ((c) + 1) * (TG_NCH * 2), 0); \
       }                                                                                                     \
     }                                                                                                       \
     /* issue the loads of chunk c+2 BEFORE this chunk's stores */                                           \
@@ -217,7 +221,14 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
       _Pragma("unroll") for (int h = 0; h < NTC / 2; ++h)                                                   \
-        __builtin_amdgcn_raw_buffer_store_b128(ocur[h][tt], yrsrc, voff[tt] + h * 16, (c) * (TG_NCH * 2), (NCHT || K == 256) ? TG_NT : 0); \
+        __builtin_amdgcn_raw_buffer_store_b128(ocur[h][tt], yrsrc, voff[tt] + h * 64, (c) * (TG_NCH * 2), (NCHT || K == 256) ? TG_NT : 0); \
+    /* gfx950: a VALU write to the data registers of a 16-byte buffer store in the two issue slots after it corrupts the  \
+       store (seen in round 3: one dword, lanes 12-15 of every 16, a few tiles per launch).  The compiler pads that hazard \
+       only for stores WITHOUT an SGPR offset (GCNHazardRecognizer::createsVALUHazard), and these stores carry the chunk    \
+       offset in an SGPR: pad by hand */                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    asm volatile("s_nop 1" ::: "memory");                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
     __syncthreads();                                                                                        \
   }
 
@@ -237,164 +248,6 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
   }
 #undef TG_CHUNK
 #undef TG_KEEP
-}
-
-// ------------------------------------------------------------------------------------------------
-// W-resident variant (contraction K, 64 * NCH output columns per workgroup): one workgroup per CU keeps its whole W
-// slice in LDS (256 x 256 bf16 = 132 KB with the row padding) and walks over 256-token tiles (32 tokens per
-// wavefront, 8 wavefronts).  After the prologue there is no barrier and no W traffic: a wavefront issues the x loads of
-// its NEXT tile, contracts the current one chunk by chunk out of LDS, stores, and only then takes over the prefetched
-// fragments -- the only loads it ever waits for are older than every store in flight (vmcnt retires in order), so
-// neither the HBM latency of x (which the chunk-streaming kernel above exposes at every workgroup start, queued behind
-// the other workgroups' stores) nor the stores ever stall it.  N > 64 * NCH: column groups; the workgroups of the
-// column groups of one token range get ids of the same residue mod 8, i.e. the same XCD: x comes from HBM once and
-// from that L2 for the other groups.
-// ------------------------------------------------------------------------------------------------
-template <int K, int NCH, bool POS = false>
-__global__ __launch_bounds__(512, 2) void token_gemm_res_kernel(const __hip_bfloat16* __restrict__ x, int64_t ldx,
-                                                               const __hip_bfloat16* __restrict__ W,
-                                                               const __hip_bfloat16* __restrict__ bias,
-                                                               __hip_bfloat16* __restrict__ y, int64_t ldy, int64_t m,
-                                                               int ncg, unsigned ybytes,
-                                                               const uint8_t* __restrict__ cells) {
-  constexpr int KX = K / 32, KA = K + (POS ? 32 : 0);     // see token_gemm_kernel
-  constexpr int KS = KA / 32, PITCH = KA * 2 + 16, CPR = KA / 8, NTC = 4, TT = 2, NG = 64 * NCH;
-  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  char* wl = lds_raw;                                  // [NG][PITCH], rows permuted per 64-row chunk (see above)
-  char* bl = lds_raw + NG * PITCH;                     // [NG] bf16
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15;
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int cg = j % ncg, tg = (j / ncg) * 8 + xcd, ntg = gridDim.x / ncg;
-  const int64_t ntiles = (m + 255) / 256;
-  // ---- prologue: the W slice (rows cg*NG ..) and its bias into LDS
-  {
-    constexpr int PER = NG * CPR / 512;                // 16-byte pieces per thread
-    constexpr int UB = PER % 8 == 0 ? 8 : 6;           // pieces in flight per round (18 = 3 x 6 with the position columns)
-    static_assert(NG * CPR % 512 == 0 && PER % UB == 0, "W slice must divide over the threads");
-    const __hip_bfloat16* Ws = W + (int64_t)cg * NG * KA;
-#pragma unroll
-    for (int b0 = 0; b0 < PER; b0 += UB) {
-      u32x4 r[UB];
-#pragma unroll
-      for (int q = 0; q < UB; ++q) {
-        const int c_ = tid + 512 * (b0 + q), row_ = c_ / CPR, ch_ = c_ % CPR;
-        r[q] = *reinterpret_cast<const u32x4*>(Ws + (int64_t)row_ * KA + ch_ * 8);
-      }
-#pragma unroll
-      for (int q = 0; q < UB; ++q) {
-        const int c_ = tid + 512 * (b0 + q), row_ = c_ / CPR, ch_ = c_ % CPR, rr = row_ & 63;
-        const int prow = (row_ & ~63) + 16 * ((rr >> 2) % NTC) + 4 * (rr / (4 * NTC)) + (rr & 3);
-        *reinterpret_cast<u32x4*>(&wl[prow * PITCH + ch_ * 16]) = r[q];
-      }
-    }
-    if (tid < NG / 8) *reinterpret_cast<u32x4*>(&bl[tid * 16]) = *reinterpret_cast<const u32x4*>(bias + cg * NG + tid * 8);
-  }
-  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)ybytes, 0x00020000);
-  auto xload = [&](int64_t tile, bf16x8 (&xd)[TT][KX], unsigned (&cd)[TT]) {
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-      int64_t row = tile * 256 + w * 32 + tt * 16 + i;
-      row = row < m ? row : m - 1;                     // unconditional (clamped) loads; rows >= m are never stored
-#pragma unroll
-      for (int ks = 0; ks < KX; ++ks)
-        xd[tt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(x + row * ldx + ks * 32 + g * 8));
-      if constexpr (POS) cd[tt] = cells[row];
-    }
-  };
-  bf16x8 xf[TT][KS], xn[TT][KX];
-  unsigned cn[TT] = {0u, 0u};
-  int64_t tile = tg;
-  if (tile < ntiles) {
-    xload(tile, xn, cn);
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-#pragma unroll
-      for (int ks = 0; ks < KX; ++ks) xf[tt][ks] = xn[tt][ks];
-      if constexpr (POS) xf[tt][KX] = pos_onehot(cn[tt], g);
-    }
-  }
-  __syncthreads();                                     // W slice visible; the only barrier of the kernel
-  // two alternating sets of store-data registers, kept formally alive over the whole tile loop: a set is rewritten two
-  // chunks after its stores were issued, and the compiler cannot recycle it for temporaries in between (either would
-  // make the wave wait for those stores: it protects the sources of a store in flight)
-  u32x4 oS[2][NTC / 2][TT];
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int h = 0; h < NTC / 2; ++h)
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) oS[c][h][tt] = u32x4{0u, 0u, 0u, 0u};
-
-#define TGR_CHUNK(c, ocur)                                                                                  \
-  {                                                                                                         \
-    f32x4 acc[NTC][TT];                                                                                     \
-    uint2 bcur[NTC];                                                                                        \
-    _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt) {                                                    \
-      bcur[nt] = *reinterpret_cast<const uint2*>(&bl[((c) * 64 + 4 * NTC * g + 4 * nt) * 2]);               \
-      _Pragma("unroll") for (int tt = 0; tt < TT; ++tt) acc[nt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};            \
-    }                                                                                                       \
-    /* W fragments one k-step ahead of the MFMAs that use them (LDS latency behind 8 MFMAs) */              \
-    u32x4 af[2][NTC];                                                                                       \
-    _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt)                                                      \
-      af[0][nt] = *reinterpret_cast<const u32x4*>(&wl[((c) * 64 + nt * 16 + i) * PITCH + g * 16]);          \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                     \
-      if (ks + 1 < KS) {                                                                                    \
-        _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt)                                                  \
-          af[(ks + 1) & 1][nt] =                                                                            \
-              *reinterpret_cast<const u32x4*>(&wl[((c) * 64 + nt * 16 + i) * PITCH + ((ks + 1) * 4 + g) * 16]); \
-      }                                                                                                     \
-      _Pragma("unroll") for (int nt = 0; nt < NTC; ++nt)                                                    \
-        _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                   \
-          acc[nt][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[ks & 1][nt]), \
-                                                                xf[tt][ks], acc[nt][tt], 0, 0, 0);          \
-    }                                                                                                       \
-    _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
-      _Pragma("unroll") for (int h = 0; h < NTC / 2; ++h) {                                                 \
-        unsigned w_[4];                                                                                     \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                     \
-          const int nt = 2 * h + q;                                                                         \
-          const f32x4 v_ = acc[nt][tt] + f32x4{__uint_as_float(bcur[nt].x << 16), __uint_as_float(bcur[nt].x & 0xFFFF0000u), \
-                                               __uint_as_float(bcur[nt].y << 16), __uint_as_float(bcur[nt].y & 0xFFFF0000u)}; \
-          w_[2 * q] = bf16_bits(v_[0]) | (bf16_bits(v_[1]) << 16);                                           \
-          w_[2 * q + 1] = bf16_bits(v_[2]) | (bf16_bits(v_[3]) << 16);                                       \
-        }                                                                                                   \
-        ocur[h][tt] = u32x4{w_[0], w_[1], w_[2], w_[3]};                                                    \
-      }                                                                                                     \
-    _Pragma("unroll") for (int tt = 0; tt < TT; ++tt)                                                       \
-      _Pragma("unroll") for (int h = 0; h < NTC / 2; ++h)                                                   \
-        __builtin_amdgcn_raw_buffer_store_b128(ocur[h][tt], yrsrc, voff[tt] + h * 16, (cg * NG + (c) * 64) * 2, TG_NT); \
-  }
-
-  for (; tile < ntiles; tile += ntg) {
-    const int64_t nxt = tile + ntg < ntiles ? tile + ntg : tile;     // past the end: re-load this tile (never used)
-    xload(nxt, xn, cn);
-    __builtin_amdgcn_sched_barrier(0);
-    int voff[TT];                                       // byte offset of (row, 16g) in y; >= ybytes drops the store
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-      const int64_t row = tile * 256 + w * 32 + tt * 16 + i;
-      voff[tt] = row < m ? (int)((row * ldy + 4 * NTC * g) * 2) : (int)ybytes;
-    }
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      TGR_CHUNK(c, oS[c & 1])
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int h = 0; h < NTC / 2; ++h)
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-          asm volatile("" ::"v"(oS[c][h][tt].x), "v"(oS[c][h][tt].y), "v"(oS[c][h][tt].z), "v"(oS[c][h][tt].w));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-#pragma unroll
-      for (int ks = 0; ks < KX; ++ks) xf[tt][ks] = xn[tt][ks];
-      if constexpr (POS) xf[tt][KX] = pos_onehot(cn[tt], g);
-    }
-  }
-#undef TGR_CHUNK
 }
 
 static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
@@ -423,27 +276,15 @@ static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const
 #define TG_LAUNCH_POS(KK, NCHT)                                                                                     \
   hipLaunchKernelGGL((token_gemm_kernel<KK, 2, 4, 4, 0, NCHT, true>), dim3(tmae_cdiv(m, 128)), dim3(256), 0, stream, \
                      TG_ARGS, (const __hip_bfloat16*)nullptr, (const uint8_t*)cells)
-  // 4 waves x 32 tokens, 64-column chunks; contraction 512: 16 tokens per wave (64 x registers) and 32-column chunks
-  // W-resident persistent kernel: contraction 256, 256-column groups, when there is at least one 256-token tile per CU
-  static const int res_off = [] { const char* e = getenv("TMAE_TG_RES"); return e && atoi(e) == 0; }();
-  if (!aux && !res_off && k == 256 && (n == 256 || n == 512 || (cells && n == 768)) && m >= 256 * 256) {
-    // column groups of 256; the workgroups of one token range sit on one XCD: 8 * ncg * (32 / ncg) workgroups
-    const int ncg = n / 256, grid = 8 * ncg * (32 / ncg);
-    const int lds = 256 * ((256 + (cells ? 32 : 0)) * 2 + 16) + 256 * 2;
-    static TmaeLdsAttr attr_plain, attr_pos;
-    if (int e_ = cells ? tmae_allow_lds(attr_pos, (const void*)token_gemm_res_kernel<256, 4, true>, lds)
-                       : tmae_allow_lds(attr_plain, (const void*)token_gemm_res_kernel<256, 4, false>, lds))
-      return e_;
-    if (cells)
-      hipLaunchKernelGGL((token_gemm_res_kernel<256, 4, true>), dim3(grid), dim3(512), lds, stream, (const __hip_bfloat16*)x,
-                         ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, (__hip_bfloat16*)y, ldy, m, ncg,
-                         (unsigned)ybytes, (const uint8_t*)cells);
-    else
-      hipLaunchKernelGGL((token_gemm_res_kernel<256, 4, false>), dim3(grid), dim3(512), lds, stream, (const __hip_bfloat16*)x,
-                         ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias, (__hip_bfloat16*)y, ldy, m, ncg,
-                         (unsigned)ybytes, (const uint8_t*)nullptr);
-    return tmae_launch_status();
+  // heavy shapes: the W-in-registers kernel of token_gemm_wreg.hip (x read once for all N columns, LDS-DMA ring)
+  {
+    const char* e = getenv("TMAE_TG_WREG");
+    if (!aux && !(e && atoi(e) == 0) && (k == 128 || k == 256) && m >= (n > 512 ? 65536 : 32768)) {
+      const int rc = tmae_token_gemm_wreg(x, ldx, m, k, w, n, bias, (const uint8_t*)cells, y, ldy, stream_);
+      if (rc != TMAE_EARG) return rc;
+    }
   }
+  // 4 waves x 32 tokens, 64-column chunks; contraction 512: 16 tokens per wave (64 x registers) and 32-column chunks
   // (the frequent widths run the fully unrolled chunk loop)
   if (cells) {
     if (k == 128) {
