@@ -60,7 +60,7 @@ def parse():
 
 
 def _pmc(key):
-    for name in ('round2_pmc.json', 'round1_pmc.json'):          # rocprofv3 --pmc passes of --probe-only (latest round first)
+    for name in ('round3_pmc.json', 'round2_pmc.json', 'round1_pmc.json'):          # rocprofv3 --pmc passes of --probe-only (latest round first)
         f = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(f):
             v = json.load(open(f)).get(key, {}).get('traffic_bytes_per_op')
@@ -83,12 +83,12 @@ def _stage2_tokens(model, batch):
 
 def token_gemm_roofline(model, batch, amp_dtype, iters=20):
     """`roofline`: the dominant hand-written kernel family of the step by GPU time (profiles/round1_g_kernel_stats.md):
-    the token GEMM of csrc/token_gemm.hip, here its W-resident persistent kernel token_gemm_res_kernel<256,4> on its
-    heaviest frequent shape -- the stage-2 FFN / q,k in-projection  Y[m,512] = X[m,256] W^T + b  over the token list of
-    both frames (bench batch).  One launch per op, timed with HIP events on the launch stream.  Algorithmic bytes: X read
-    once, Y written once, W and b read once.  The probe's launches are the last 23 launches of that
-    kernel in the process (3 warm-up + 20 timed): that is how the profile summaries tell them from the forward pass
-    that measures m."""
+    the token GEMM, here its W-in-registers kernel token_gemm_wreg_kernel<256,4,8> (csrc/token_gemm_wreg.hip, round 3;
+    rounds 1-2 priced the W-resident-in-LDS kernel on the same shape) on its heaviest frequent shape -- the stage-2 FFN /
+    q,k in-projection  Y[m,512] = X[m,256] W^T + b  over the token list of both frames (bench batch).  One launch per
+    op, timed with HIP events on the launch stream.  Algorithmic bytes: X read once, Y written once, W and b read once
+    (DESIGN.md section 4).  The probe's launches are the last 23 launches of that kernel in the process (3 warm-up + 20
+    timed): that is how the profile summaries tell them from the forward pass that measures m."""
     from tmae_amd._lib import lib, check
     m = _stage2_tokens(model, batch)
     n, k = 512, 256
@@ -114,11 +114,11 @@ def token_gemm_roofline(model, batch, amp_dtype, iters=20):
     ms = e0.elapsed_time(e1) / iters
     bytes_alg = m * (n + k) * 2 + (n * k + n) * 2
     achieved = bytes_alg / (ms * 1e-3) / 1e9
-    return {'kernel': 'token_gemm_res_kernel<256,4> (W-resident persistent token GEMM Y[m,512] = X[m,256] W^T + b of the stage-2 '
-                      'token list; one launch per op)', 'bound': 'hbm', 'achieved': round(achieved, 2),
+    return {'kernel': 'token_gemm_wreg_kernel<256,4,8> (W-in-registers persistent token GEMM Y[m,512] = X[m,256] W^T + b of the '
+                      'stage-2 token list; one launch per op)', 'bound': 'hbm', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
             'traffic': _pmc('token_gemm'),
-            'traffic_source': 'profiles/round2_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
+            'traffic_source': 'profiles/round3_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k}
 
 

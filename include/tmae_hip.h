@@ -344,6 +344,17 @@ int tmae_column_sums(const void* x, int dtype, int64_t rows, int c, float* out, 
  * 0), n | k << 32, index of the entry's first 32 x 32 tile -- entries ordered by that index; total_tiles = their sum. */
 int tmae_multi_cast_transpose(const void* table, int count, int64_t total_tiles, void* stream);
 
+/* The optimizer step of the recipe for ALL parameter tensors in one launch: decoupled weight decay p *= 1 - wd*lr for every
+ * entry (OptimWrapper.step, tools/train_utils/optimization/fastai_optim.py:139-150: true_wd, bn_wd), then torch.optim.Adam's
+ * update (fastai_optim.py:151 -> Adam.step; amsgrad / maximize off, weight_decay 0 inside Adam) for the entries that
+ * have a gradient.  table (device, 8-byte aligned): entries of six int64 -- p, grad (0: decay only), exp_avg, exp_avg_sq,
+ * the per-parameter step tensor (1 float on the device, receives `step`; 0: none), numel | first chunk << 40 -- where a
+ * chunk = 4096 elements and the entries are ordered by their first chunk; chunk_tensor (device int32 [total_chunks]) =
+ * the entry of every chunk.  step = this step's number (>= 1, after the increment); the bias corrections are taken in
+ * double on the host as torch does. */
+int tmae_adam_step(const void* table, const int32_t* chunk_tensor, int64_t total_chunks, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int64_t step, void* stream);
+
 /* Token-list Linear in bf16 (fp32 accumulate):  y[m,n] = x[m,k] . w[n,k]^T (+ bias[n]) -- the in-/out-projections
  * and FFN layers of EncoderLayer (sst_basic_block.py:45-83, F.linear) and, on w^T, their input gradients.
  * k in {128, 256, 512}, n a multiple of 64; ldx / ldy = row pitches in elements (column slices of packed buffers are
@@ -351,6 +362,13 @@ int tmae_multi_cast_transpose(const void* table, int count, int64_t total_tiles,
  * < 2^31 bytes.  x is read once, y written once. */
 int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
                     int64_t ldy, void* stream);
+/* In-place form  y[m,n] += x[m,k] . w[n,k]^T + bias[n]  -- torch.Tensor.addmm_ of the Linear input gradients whose input has
+ * a second consumer (ops.proj_fork: the FFN's first Linear, sst_basic_block.py:81-83, autograd's AccumulateGrad add in
+ * the reference).  Shapes: (k, n) = (512, 256) or (256, 128), m >= 32768; anything else returns TMAE_EARG and the
+ * caller keeps the library's addmm_.  Same pointer rules as tmae_token_gemm; y is read and written once. */
+int tmae_token_gemm_acc(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
+                        int64_t ldy, void* stream);
+
 /* Same GEMM with the backward of the exact (erf) GELU fused into the epilogue: y = (x . w^T + bias) * gelu'(aux),
  * aux [m,n] bf16 with y's pitch = the pre-activation saved by the forward (the FFN of EncoderLayer,
  * sst_basic_block.py:81: linear2(gelu(linear1(src))): dX of linear2 and GeluBackward in one pass). */

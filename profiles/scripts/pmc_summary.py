@@ -14,12 +14,13 @@ The training step itself is not run by --probe-only, so every launch of these ke
 import collections, csv, glob, json, sys
 
 out_dir = sys.argv[1]
-groups = {'token_gemm': ('token_gemm_res_kernel<256, 4, false>',),
+TG = 'token_gemm_wreg_kernel<256, 4, 8, false>'      # round 3 (rounds 1-2: 'token_gemm_res_kernel<256, 4, false>')
+groups = {'token_gemm': (TG,),
           'wgrad': ('wgrad256_kernel', 'wgrad_reduce_kernel'),
           'attention': ('win_attn_bwd_mfma_kernel<16',)}
 # the token GEMM also runs in the forward pass that measures the token count (same grid: the kernel is persistent, one
 # workgroup per CU): the probe's 3 warm-up + 20 timed launches are the LAST 23 dispatches of that kernel in the process
-LAST_N = {'token_gemm_res_kernel<256, 4, false>': 23}
+LAST_N = {TG: 23}
 raw = {}
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     f = glob.glob(f'{out_dir}/pmc_{c}/**/*counter_collection.csv', recursive=True)[0]

@@ -72,3 +72,28 @@ for (m, k, n, pos) in [(1000, 256, 512, False), (32768 + 37, 256, 512, False), (
         line += f" | old {res['0'][1]*1e3:7.1f} us {byts/res['0'][1]/1e6:6.0f} GB/s | new {res['1'][1]*1e3:7.1f} us {byts/res['1'][1]/1e6:6.0f} GB/s"
     print(line, flush=True)
     assert e1 <= max(2 * e0, 0.08), 'new kernel deviates'
+
+
+# ---- contraction 512 (FFN-2 forward) and the in-place accumulate form (FFN-1 input gradients) vs torch
+import torch.nn.functional as F
+for (m, k, n) in [(40001, 512, 256), (466268, 512, 256), (195000, 512, 256)]:
+    x = torch.randn(m, k, device=dev).bfloat16(); w = (torch.randn(n, k, device=dev) * 0.05).bfloat16(); b = torch.randn(n, device=dev).bfloat16()
+    ref = x.float() @ w.float().t() + b.float()
+    os.environ['TMAE_TG_WREG'] = '1'
+    y = ops.token_gemm(x, w, b)
+    err = (y.float() - ref).abs().max().item()
+    t_new = timeit(lambda: ops.token_gemm(x, w, b)); t_lib = timeit(lambda: F.linear(x, w, b))
+    byts = m * (k + n) * 2
+    print(f'm={m} k={k} n={n} | max|err| {err:.4f} | hipBLASLt {t_lib*1e3:7.1f} us | wreg {t_new*1e3:7.1f} us {byts/t_new/1e6:6.0f} GB/s', flush=True)
+    assert err <= 0.08
+for (m, n, k) in [(40001, 512, 256), (466268, 512, 256), (195000, 512, 256), (470000, 256, 128), (50001, 256, 128)]:
+    dy = torch.randn(m, n, device=dev).bfloat16(); w = (torch.randn(n, k, device=dev) * 0.05).bfloat16()
+    dx0 = torch.randn(m, k, device=dev).bfloat16()
+    ref = dx0.float() + dy.float() @ w.float()
+    dx = dx0.clone(); ops.addmm_inplace(dx, dy, w)
+    err = (dx.float() - ref).abs().max().item()
+    dx1 = dx0.clone(); dx2 = dx0.clone()
+    t_new = timeit(lambda: ops.addmm_inplace(dx1, dy, w)); t_lib = timeit(lambda: dx2.addmm_(dy, w))
+    byts = m * (n + 2 * k) * 2
+    print(f'acc m={m} {n}->{k} | max|err| {err:.4f} | addmm_ {t_lib*1e3:7.1f} us | wreg {t_new*1e3:7.1f} us {byts/t_new/1e6:6.0f} GB/s', flush=True)
+    assert err <= 0.1

@@ -265,4 +265,4 @@ int tmae_chamfer_bwd(const float* pred, const float* gt, const float* weights, c
   return tmae_launch_status();
 }
 
-int tmae_abi_version(void) { return 4; }
+int tmae_abi_version(void) { return 5; }

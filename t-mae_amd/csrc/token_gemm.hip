@@ -279,8 +279,8 @@ static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const
   // heavy shapes: the W-in-registers kernel of token_gemm_wreg.hip (x read once for all N columns, LDS-DMA ring)
   {
     const char* e = getenv("TMAE_TG_WREG");
-    if (!aux && !(e && atoi(e) == 0) && (k == 128 || k == 256) && m >= (n > 512 ? 65536 : 32768)) {
-      const int rc = tmae_token_gemm_wreg(x, ldx, m, k, w, n, bias, (const uint8_t*)cells, y, ldy, stream_);
+    if (!aux && !(e && atoi(e) == 0) && m >= (n > 512 ? 65536 : 32768)) {
+      const int rc = tmae_token_gemm_wreg(x, ldx, m, k, w, n, bias, (const uint8_t*)cells, y, ldy, 0, stream_);
       if (rc != TMAE_EARG) return rc;
     }
   }
@@ -310,6 +310,17 @@ int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w,
                     int64_t ldy, void* stream_) {
   (void)hipGetLastError();
   return token_gemm_launch(x, ldx, m, k, w, n, bias, y, ldy, nullptr, nullptr, stream_);
+}
+
+int tmae_token_gemm_acc(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
+                        int64_t ldy, void* stream_) {
+  (void)hipGetLastError();
+  if (m < 0) return TMAE_EARG;
+  if (m == 0) return TMAE_OK;
+  // the in-place form exists in the W-in-registers kernel only (the y tile travels through its LDS ring):
+  // [m, 256] += [m, 512] W^T and [m, 128] += [m, 256] W^T -- the FFN-1 input gradients of the d = 256 / d = 128 stages
+  if (m < 32768 || !((k == 512 && n == 256) || (k == 256 && n == 128))) return TMAE_EARG;
+  return tmae_token_gemm_wreg(x, ldx, m, k, w, n, bias, nullptr, y, ldy, 1, stream_);
 }
 
 int tmae_token_gemm_dgelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias,

@@ -41,7 +41,7 @@ __device__ __forceinline__ bf16x8 tgw_pos_onehot(unsigned cell, int g) {
 #define TGW_OOB 0x7FFFFFF0u          // voffset past every buffer: loads return zeros, stores are dropped
 #define TGW_NT 2                     // cache policy of the y stores (written once, streamed)
 
-template <int K, int NTC, int NWC, bool POS>
+template <int K, int NTC, int NWC, bool POS, bool ACC = false>
 __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfloat16* __restrict__ x, int ldx,
                                                                 const __hip_bfloat16* __restrict__ W,
                                                                 const __hip_bfloat16* __restrict__ bias,
@@ -49,15 +49,21 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
                                                                 unsigned xbytes, unsigned ybytes,
                                                                 const uint8_t* __restrict__ cells) {
   constexpr int TEAMS = 8 / NWC;                  // teams of NWC waves; a team covers all columns of the group
-  constexpr int STEP = K == 128 ? 128 : 64;       // tokens per ring slot (32 KB)
+  constexpr int STEP = 16384 / K;                 // tokens per ring slot (32 KB): 128 / 64 / 32 for K = 128 / 256 / 512
   constexpr int TGW = (STEP / 16) / TEAMS;        // 16-token groups per wave and step
   constexpr int KX = K / 32, KA = K + (POS ? 32 : 0), KS = KA / 32;
   constexpr int ROWB = K * 2;                     // bytes per x row
   constexpr int PPW = STEP * ROWB / 1024 / 8;     // 1-KiB DMA pieces per wave and step
   constexpr int CELLB = POS ? STEP * 4 : 0;       // one dword per token of the step (its window cell byte)
-  constexpr int SLOT = STEP * ROWB + CELLB;
-  constexpr int NS = 4;
-  constexpr int ND = PPW + (POS ? STEP / 64 : 0); // DMA instructions per wave and step
+  // ACC (y += x W^T, the in-place input gradient of a Linear whose input has a second consumer): the step's tile of y rides
+  // in the ring slot beside x (a register load of y in the epilogue would have to be waited for IN ORDER, i.e. together
+  // with the three steps of x prefetched before it) and the accumulators start from it
+  constexpr int YROWB = NWC * NTC * 32;           // bytes per row of the y tile (the group's columns)
+  constexpr int YB = ACC ? STEP * YROWB : 0, PPY = YB / 1024 / 8;
+  constexpr int SLOT = STEP * ROWB + CELLB + YB;
+  constexpr int NS = ACC ? 3 : 4;
+  constexpr int ND = PPW + (POS ? STEP / 64 : 0) + PPY; // DMA instructions per wave and step
+  static_assert(!ACC || YB % 8192 == 0, "y tile must divide into 1-KiB pieces per wave");
   constexpr int NST = TGW * (NTC / 2);            // 16-byte store instructions per wave and step
   constexpr int WAITN = (NS - 1) * NST + (NS - 2) * ND;
   static_assert(TGW >= 1 && (NTC == 2 || NTC == 4) && WAITN < 64 && ROWB <= 1024, "shape");
@@ -93,6 +99,18 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
       const unsigned vo = tok0 + drow[jj] < m ? tb + doff[jj] : TGW_OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(slot + (w * PPW + jj) * 1024),
                                                16, vo, 0, 0, 0);
+    }
+    if constexpr (ACC) {
+#pragma unroll
+      for (int jj = 0; jj < PPY; ++jj) {
+        const int lb = (w * PPY + jj) * 1024 + lane * 16;
+        const int R = lb / YROWB, cpos = (lb % YROWB) / 16;
+        const unsigned vo = tok0 + R < m ? (unsigned)(tok0 + R) * (unsigned)(ldy * 2) +
+                                               (unsigned)(cg * YROWB + ((cpos ^ (R & 15)) << 4)) : TGW_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (__attribute__((address_space(3))) void*)(slot + STEP * ROWB + CELLB +
+                                                                                                (w * PPY + jj) * 1024),
+                                                 16, vo, 0, 0, 0);
+      }
     }
     if constexpr (POS) {                           // every wave fetches the step's cell bytes (same values: benign)
 #pragma unroll
@@ -151,6 +169,27 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
       bf[0][t] = *reinterpret_cast<const u32x4*>(slot + ardr[0] + (tgi + t) * 16 * ROWB);
       if constexpr (POS) cellv[t] = *reinterpret_cast<const unsigned*>(slot + STEP * ROWB + ((tgi + t) * 16 + i) * 4);
     }
+    f32x4 c0[NTC][PT];                              // what the accumulators start from: the bias (+ the y tile)
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+#pragma unroll
+      for (int ct = 0; ct < NTC; ++ct) c0[ct][t] = bl[ct];
+      if constexpr (ACC) {                          // this lane's 4 NTC consecutive columns of token i: chunk index ^ i
+        const char* yt = slot + STEP * ROWB + CELLB + ((tgi + t) * 16 + i) * YROWB;
+#pragma unroll
+        for (int h = 0; h < NTC / 2; ++h) {
+          const int ch = wc * (NTC / 2) * 4 + (NTC / 2) * g + h;          // 16-byte chunk of the row
+          const u32x4 yv = *reinterpret_cast<const u32x4*>(yt + ((ch ^ i) << 4));
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2) {
+            c0[2 * h + q2][t][0] += __uint_as_float(yv[2 * q2] << 16);
+            c0[2 * h + q2][t][1] += __uint_as_float(yv[2 * q2] & 0xFFFF0000u);
+            c0[2 * h + q2][t][2] += __uint_as_float(yv[2 * q2 + 1] << 16);
+            c0[2 * h + q2][t][3] += __uint_as_float(yv[2 * q2 + 1] & 0xFFFF0000u);
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < KX; ++ks) {
       if (ks + 1 < KX) {
@@ -164,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
         for (int t = 0; t < PT; ++t)
           acc[ct][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ct][ks]),
                                                                __builtin_bit_cast(bf16x8, bf[ks & 1][t]),
-                                                               ks == 0 ? bl[ct] : acc[ct][t], 0, 0, 0);
+                                                               ks == 0 ? c0[ct][t] : acc[ct][t], 0, 0, 0);
     }
     if constexpr (POS) {
 #pragma unroll
@@ -218,18 +257,18 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may land after the workgroup has released its LDS
 }
 
-template <int K, int NTC, int NWC, bool POS>
+template <int K, int NTC, int NWC, bool POS, bool ACC = false>
 static int tgw_launch(const void* x, int64_t ldx, int64_t m, const void* w, int n, const void* bias, void* y, int64_t ldy,
                       const void* cells, hipStream_t stream) {
   constexpr int NG = NWC * NTC * 16;
-  constexpr int STEP = K == 128 ? 128 : 64;
-  constexpr int lds = 4 * (STEP * K * 2 + (POS ? STEP * 4 : 0)) + 8 * 16 * NTC * 32;
+  constexpr int STEP = 16384 / K;
+  constexpr int lds = (ACC ? 3 : 4) * (STEP * K * 2 + (POS ? STEP * 4 : 0) + (ACC ? STEP * NG * 2 : 0)) + 8 * 16 * NTC * 32;
   const int ncg = n / NG;
   static TmaeLdsAttr attr;
-  if (int e = tmae_allow_lds(attr, (const void*)token_gemm_wreg_kernel<K, NTC, NWC, POS>, lds)) return e;
+  if (int e = tmae_allow_lds(attr, (const void*)token_gemm_wreg_kernel<K, NTC, NWC, POS, ACC>, lds)) return e;
   const int64_t xbytes = ((m - 1) * ldx + K) * 2, ybytes = ((m - 1) * ldy + n) * 2;
   const int grid = 8 * ncg * (32 / ncg);
-  hipLaunchKernelGGL((token_gemm_wreg_kernel<K, NTC, NWC, POS>), dim3(grid), dim3(512), lds, stream,
+  hipLaunchKernelGGL((token_gemm_wreg_kernel<K, NTC, NWC, POS, ACC>), dim3(grid), dim3(512), lds, stream,
                      (const __hip_bfloat16*)x, (int)ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias,
                      (__hip_bfloat16*)y, (int)ldy, (int)m, ncg, (unsigned)xbytes, (unsigned)ybytes, (const uint8_t*)cells);
   return tmae_launch_status();
@@ -237,14 +276,23 @@ static int tgw_launch(const void* x, int64_t ldx, int64_t m, const void* w, int 
 
 // Returns TMAE_EARG for shapes this kernel does not cover (the caller falls back to csrc/token_gemm.hip's kernels).
 int tmae_token_gemm_wreg(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias,
-                         const uint8_t* cells, void* y, int64_t ldy, void* stream_) {
+                         const uint8_t* cells, void* y, int64_t ldy, int accumulate, void* stream_) {
   (void)hipGetLastError();
   hipStream_t stream = (hipStream_t)stream_;
   if (m <= 0 || !x || !w || !y || !bias || ldx < k || ldy < n || (ldx % 8) || (ldy % 8)) return TMAE_EARG;
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 1)) return TMAE_EARG;
   if (((m - 1) * ldx + k) * 2 >= (int64_t)TGW_OOB || ((m - 1) * ldy + n) * 2 >= (int64_t)TGW_OOB) return TMAE_EARG;
-  if (n % 128 || (k != 128 && k != 256) || (k == 256 && n % 256)) return TMAE_EARG;
-  // column blocks of 512 (8 waves x 64 columns), then one of 256 (2 teams of 4 waves) or 128 (4 teams of 2 waves, K = 128);
+  if (k == 512) {          // FFN-2 forward (sst_basic_block.py:82) and FFN-1's input gradient: 8 waves x 32 columns, W[256, 512]
+    if (n != 256 || cells) return TMAE_EARG;       // = 128 registers per lane
+    if (accumulate) return tgw_launch<512, 2, 8, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
+    return tgw_launch<512, 2, 8, false>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
+  }
+  if (accumulate) {        // the d = 128 FFN-1 input gradient [m, 128] += [m, 256] W
+    if (k != 256 || n != 128 || cells) return TMAE_EARG;
+    return tgw_launch<256, 4, 2, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
+  }
+  if (n % 128 || (k != 128 && k != 256)) return TMAE_EARG;
+  // column blocks of 512 (8 waves x 64 columns), then one of 256 (2 teams of 4 waves) or 128 (4 teams of 2 waves);
   // x is re-read per block (from the Infinity Cache where it fits): N = 768 = 512 + 256
   const int ka = k + (cells ? 32 : 0);
   for (int n0 = 0; n0 < n;) {
@@ -255,8 +303,8 @@ int tmae_token_gemm_wreg(const void* x, int64_t ldx, int64_t m, int k, const voi
     int rc;
 #define TGW_GO(KK, NWC, P) rc = tgw_launch<KK, 4, NWC, P>(x, ldx, m, wb, nb, bb, yb, ldy, cells, stream)
     if (k == 256) {
-      if (cells) { if (nb == 512) TGW_GO(256, 8, true); else TGW_GO(256, 4, true); }
-      else { if (nb == 512) TGW_GO(256, 8, false); else TGW_GO(256, 4, false); }
+      if (cells) { if (nb == 512) TGW_GO(256, 8, true); else if (nb == 256) TGW_GO(256, 4, true); else TGW_GO(256, 2, true); }
+      else { if (nb == 512) TGW_GO(256, 8, false); else if (nb == 256) TGW_GO(256, 4, false); else TGW_GO(256, 2, false); }
     } else {
       if (cells) { if (nb == 512) TGW_GO(128, 8, true); else if (nb == 256) TGW_GO(128, 4, true); else TGW_GO(128, 2, true); }
       else { if (nb == 512) TGW_GO(128, 8, false); else if (nb == 256) TGW_GO(128, 4, false); else TGW_GO(128, 2, false); }

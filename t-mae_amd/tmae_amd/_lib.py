@@ -81,6 +81,8 @@ SIGNATURES = {
     'tmae_frame_prepare': (I, [P, I, L, P, P, F, I, I, F, F, F, F, F, F, F, I, P, P, P, Z, P]),
     'tmae_token_gemm': (I, [P, L, L, I, P, I, P, P, L, P]),
     'tmae_multi_cast_transpose': (I, [P, I, L, P]),
+    'tmae_adam_step': (I, [P, P, L, F, F, F, F, F, L, P]),
+    'tmae_token_gemm_acc': (I, [P, L, L, I, P, I, P, P, L, P]),
     'tmae_token_gemm_dgelu': (I, [P, L, L, I, P, I, P, P, P, L, P]),
     'tmae_token_gemm_pos': (I, [P, L, L, I, P, I, P, P, P, L, P]),
     'tmae_window_cells': (I, [P, L, L, I, I, I, P, P, P]),
@@ -101,7 +103,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError('libtmae_hip.so ABI version mismatch; rebuild with t-mae_amd/build.py')
 

@@ -55,9 +55,11 @@ _TOKEN_GEMM_MIN_ROWS = 8192
 
 
 def _tg_ok(x, k, n):
-    # contraction 128 / 256: ahead of the library on every shape (profiles/scripts/gemm_probe.py).  Contraction 512 is
-    # supported by the kernel (16 tokens per wave: LDS-bound) but 10-15 % behind hipBLASLt: left to the library.
-    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[0] >= _TOKEN_GEMM_MIN_ROWS and k in (128, 256)
+    # contraction 128 / 256: ahead of the library on every shape (profiles/scripts/gemm_probe.py).  Contraction 512:
+    # the W-in-registers kernel (csrc/token_gemm_wreg.hip: n = 256, >= 64 k tokens) is ahead of hipBLASLt; the chunk-streaming
+    # kernel (16 tokens per wave: LDS-bound) is 10-15 % behind it on smaller token lists, which stay with the library.
+    return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[0] >= _TOKEN_GEMM_MIN_ROWS
+            and (k in (128, 256) or (k == 512 and n == 256 and x.shape[0] >= 65536))
             and n % 64 == 0 and x.shape[0] * n * 2 < 2 ** 31
             and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
 
@@ -89,6 +91,21 @@ def token_gemm(x, w, bias=None, force=False):
         check(lib.tmae_token_gemm(_p(x), x.stride(0), m, k, _p(w), n, _p(b), _p(y), n, _s()), 'tmae_token_gemm')
         return y
     return torch.nn.functional.linear(x, w, bias)
+
+
+def addmm_inplace(dx, dy, w):
+    """dx += dy @ w in place (w [n,k]: dx [m,k], dy [m,n]): the W-in-registers kernel's accumulate form on the shapes it
+    covers (tmae_token_gemm_acc: contraction 512 -> 256 and 256 -> 128, >= 32 k tokens), torch's addmm_ otherwise."""
+    n, k = w.shape
+    m = dx.shape[0]
+    if (m >= (65536 if n == 512 else 32768) and (n, k) in ((512, 256), (256, 128)) and dx.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
+            and w.dtype == torch.bfloat16 and dx.is_contiguous() and dy.stride(1) == 1 and dy.stride(0) % 8 == 0
+            and dy.data_ptr() % 16 == 0 and dx.data_ptr() % 16 == 0 and m * max(n, k) * 2 < 2 ** 31):
+        wt = _transposed(w)
+        check(lib.tmae_token_gemm_acc(_p(dy), dy.stride(0), m, n, _p(wt), k, _p(_zero_bias(k, dx.device)), _p(dx), k, _s()),
+              'tmae_token_gemm_acc')
+        return dx
+    return dx.addmm_(dy, w)
 
 
 def token_gemm_dx(dy, w, force=False):
@@ -370,17 +387,18 @@ class _ProjFork(torch.autograd.Function):
             dy = dy.to(x_c.dtype)
             if dy.stride(-1) != 1:
                 dy = dy.contiguous()
+            wseg = w_c if (r0 == 0 and r1 == rows) else w_c[r0:r1]     # the whole weight keeps its cached transpose
             if ctx.needs_input_grad[0]:
                 if dx is None:
-                    dx = token_gemm_dx(dy, w_c[r0:r1])
+                    dx = token_gemm_dx(dy, wseg)
                 elif ctx.inplace_dx:
                     # accumulate IN PLACE into the gradient that arrived through the alias (torch.addmm would first
                     # memcpy it into a new buffer).  Only on the caller's word (`inplace_dx`): the encoder layers
                     # guarantee that this buffer -- the dx of their add+LayerNorm backward -- has no reader left
                     # (its only other reader, the Linear on the norm's second input, is a younger node and has run).
-                    dx.addmm_(dy, w_c[r0:r1])
+                    addmm_inplace(dx, dy, wseg)
                 else:
-                    dx = torch.addmm(dx, dy, w_c[r0:r1])
+                    dx = torch.addmm(dx, dy, wseg)
             if dW is not None:
                 inp = xp if use_pos else x_c
                 if _wgrad_ok(dy, inp):          # straight into the rows of the packed gradient: no slice copies

@@ -1,8 +1,9 @@
 """adam_onecycle: Adam(beta2 0.99) with decoupled weight decay applied before the step and a one-cycle
 cosine schedule of lr and beta1 -- the update rule AND the parameter grouping of the reference's
 OptimWrapper / OneCycle (tools/train_utils/optimization/__init__.py:19-32, fastai_optim.py:16-27,99-152,
-learning_schedules_fastai.py:12-77), without the per-group Python loops: one foreach multiply for the decay
-and one fused Adam launch.
+learning_schedules_fastai.py:12-77), without the per-group Python loops: on the GPU the decay and the Adam update of
+ALL parameter tensors are ONE launch of the library's multi-tensor kernel (tmae_adam_step, csrc/optim.hip; torch's
+fused Adam + foreach multiply need ~36 launches for this model); CPU parameters (tests, small tools) take torch's Adam.
 
 Grouping (pinned by tests/golden/O1_optimizer.npz, generated from the reference's own classes):
 `flatten_model` keeps the LEAF modules of the model (modules without children) in depth-first order,
@@ -72,6 +73,12 @@ class AdamOneCycle:
                                     fused=fused)
         self.wd = wd
         self.lr, self.mom = lr, betas[0]
+        # GPU path: one multi-tensor launch (fp32 contiguous CUDA parameters on one device); torch.optim.Adam stays the
+        # owner of the state (exp_avg, exp_avg_sq, step) so that state_dict / load_state_dict keep the reference's format
+        self._native = fused and all(p.dtype == torch.float32 and p.is_contiguous() and p.device == self.decayed[0].device
+                                     for p in self.decayed)
+        self._steps = {}             # id(p) -> steps taken (host mirror of the state's step tensors)
+        self._table = None           # (key, device table, device chunk map, chunks)
 
     @property
     def lr(self):
@@ -118,9 +125,71 @@ class AdamOneCycle:
 
     @torch.no_grad()
     def step(self):
+        if self._native and self._native_step():
+            return
         if self.decayed and self.wd != 0.0:
             torch._foreach_mul_(self.decayed, 1.0 - self.wd * self._lr)
         self.opt.step()
+        for p in self.decayed:
+            if p.grad is not None:
+                self._steps[id(p)] = self._steps.get(id(p), 0) + 1
+
+    def _state_of(self, p):
+        st = self.opt.state[p]
+        if len(st) == 0:                      # torch.optim.Adam._init_group (fused: the step lives on the device)
+            st['step'] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            self._steps[id(p)] = 0
+        if id(p) not in self._steps:          # first use, or a state that load_state_dict brought in
+            self._steps[id(p)] = int(float(st['step']))
+        return st
+
+    def _native_step(self):
+        """Decay + Adam for every tensor in one launch.  Returns False (caller takes torch's path) when the tensors
+        with a gradient are not all at the same step count, which the kernel's scalar bias corrections assume."""
+        from .._lib import lib, check
+        rows, key, steps = [], [], set()
+        for p in self.decayed:
+            g = p.grad
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device):
+                return False
+            st = self._state_of(p) if g is not None else None
+            if g is not None:
+                steps.add(self._steps[id(p)])
+                if st['step'].device != p.device:
+                    st['step'] = st['step'].to(device=p.device, dtype=torch.float32)
+                key.append((p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(),
+                            st['step'].data_ptr(), p.numel()))
+            else:
+                key.append((p.data_ptr(), 0, 0, 0, 0, p.numel()))
+        if len(steps) > 1:
+            return False
+        if not steps and self.wd == 0.0:
+            return True
+        key = tuple(key)
+        if self._table is None or self._table[0] != key:
+            chunk, cmap = 0, []
+            for i, (pp, gp, mp, vp, sp, n) in enumerate(key):
+                nch = (n + 4095) // 4096
+                rows.append([pp, gp, mp, vp, sp, n | (chunk << 40)])
+                cmap += [i] * nch
+                chunk += nch
+            dev = self.decayed[0].device
+            self._table = (key, torch.tensor(rows, dtype=torch.int64, device=dev),
+                           torch.tensor(cmap, dtype=torch.int32, device=dev), chunk)
+        _, tab, cmap, chunks = self._table
+        step = (steps.pop() if steps else 0) + 1
+        g0 = self.opt.param_groups[0]
+        check(lib.tmae_adam_step(tab.data_ptr(), cmap.data_ptr(), chunks, self._lr, self._mom, g0['betas'][1], g0['eps'],
+                                 self.wd, step, torch.cuda.current_stream(tab.device).cuda_stream), 'tmae_adam_step')
+        for p in self.decayed:
+            if p.grad is not None:
+                self._steps[id(p)] = step
+        # the kernel wrote through raw pointers: tell autograd (the bf16 copies / folded weights of tmae_amd.ops are keyed
+        # on the parameters' version counters, exactly as an in-place torch op would have moved them)
+        torch.autograd.graph.increment_version(self.decayed)
+        return True
 
     def state_dict(self):
         return self.opt.state_dict()
@@ -136,6 +205,7 @@ class AdamOneCycle:
                              f'(non-BatchNorm / BatchNorm leaves, fastai_optim.py:16-27)')
         lr, mom = self._lr, self._mom
         self.opt.load_state_dict(sd)
+        self._steps, self._table = {}, None              # the host mirror of the step counts is re-read from the new state
         g0 = self.opt.param_groups[0]
         self._lr, self._mom = float(g0.get('lr', lr)), float(g0['betas'][0])
         for g in self.opt.param_groups:              # the reference leaves weight_decay 0 in the groups (true_wd)

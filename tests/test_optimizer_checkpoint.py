@@ -85,6 +85,80 @@ def test_trajectory_equals_the_reference_optimizer():
                                        err_msg=f'{n} step {it}')
 
 
+@pytest.mark.gpu
+def test_trajectory_equals_the_reference_optimizer_gpu():
+    """The same 20 steps on the GPU: the one-launch multi-tensor step (tmae_adam_step) for steps 0-7 (step 7 has a
+    parameter without a gradient: decay only), torch's Adam from step 8 on, where the step counts of the tensors differ."""
+    from tmae_amd.train import build_optimizer, build_scheduler
+    g = golden('O1_optimizer')
+    dev = torch.device('cuda', 0)
+    model = Tiny().to(dev)
+    with torch.no_grad():
+        for i, (n, p) in enumerate(model.named_parameters()):
+            p.copy_(torch.from_numpy(g[f'tiny_init_{i}']))
+    opt = build_optimizer(model, _optim_cfg())
+    assert opt._native
+    sched, _ = build_scheduler(opt, 10, 2, -1, _optim_cfg())
+    for it in range(20):
+        sched.step(it)
+        opt.zero_grad()
+        for i, (n, p) in enumerate(model.named_parameters()):
+            p.grad = None if (it == 7 and n == 'fc2.weight') else torch.from_numpy(g[f'tiny_grad_{i}'][it].copy()).to(dev)
+        opt.step()
+        for i, (n, p) in enumerate(model.named_parameters()):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), g[f'tiny_traj_{i}'][it], rtol=2e-6, atol=2e-7,
+                                       err_msg=f'{n} step {it}')
+    # the state is torch.optim.Adam's: step tensors on the device, equal to the number of gradients each tensor received
+    owned = {id(p) for p in opt.decayed}
+    for n, p in model.named_parameters():
+        if id(p) in owned:
+            st = opt.opt.state[p]
+            assert float(st['step']) == (19.0 if n == 'fc2.weight' else 20.0), (n, float(st['step']))
+
+
+@pytest.mark.gpu
+def test_multi_tensor_adam_step_equals_torch_adam():
+    """tmae_adam_step vs torch.optim.Adam (single-tensor formulas) + the decoupled decay on 40 tensors of odd sizes,
+    some gradients 4-byte aligned views into a flat buffer (DDP's gradient_as_bucket_view), over 5 steps with changing lr
+    and beta1."""
+    from tmae_amd.train.optim import AdamOneCycle
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    sizes = [(1,), (3,), (4097,), (128, 33), (256, 9, 17), (8191,), (4096,), (5, 7, 11)] * 5
+    ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in sizes]
+    ref = [p.detach().clone().double() for p in ps]
+    m = [torch.zeros_like(r) for r in ref]
+    v = [torch.zeros_like(r) for r in ref]
+    opt = AdamOneCycle(ps, lr=3e-3, wd=0.01, betas=(0.9, 0.99))
+    assert opt._native
+    flat = torch.zeros(sum(p.numel() for p in ps) + 1, device=dev)
+    for it in range(5):
+        versions = [p._version for p in ps]
+        opt.lr, opt.mom = 3e-3 * (1 + it), 0.95 - 0.02 * it
+        off = 1                                              # +1: the views start 4 bytes off a 16-byte boundary
+        for p in ps:
+            gview = flat[off:off + p.numel()].view_as(p)
+            gview.copy_(torch.randn_like(p) * (10.0 ** (it - 2)))
+            p.grad = gview if p.numel() % 2 else gview.clone()
+            off += p.numel()
+        opt.step()
+        b1, b2, lr, eps = opt.mom, 0.99, opt.lr, 1e-8
+        assert all(p._version > v0 for p, v0 in zip(ps, versions))    # caches keyed on the version see the update
+        for k, p in enumerate(ps):
+            gd = p.grad.double()
+            ref[k] *= 1 - 0.01 * lr
+            m[k] = m[k] + (gd - m[k]) * (1 - b1)
+            v[k] = b2 * v[k] + (1 - b2) * gd * gd
+            bc1, bc2 = 1 - b1 ** (it + 1), 1 - b2 ** (it + 1)
+            ref[k] -= lr / bc1 * m[k] / (v[k].sqrt() / bc2 ** 0.5 + eps)
+            err = (p.detach().double() - ref[k]).abs().max().item()
+            assert err <= 2e-6 * max(1.0, ref[k].abs().max().item()), (it, k, err)
+            st = opt.opt.state[p]
+            assert float(st['step']) == it + 1
+            assert (st['exp_avg'].double() - m[k]).abs().max().item() <= 5e-6 * max(1e-3, m[k].abs().max().item())
+    assert opt._table is not None
+
+
 def build_tiny_tmae(device='cpu'):
     """The small 1-stage model of the O2 fixture through the product's registry path (YAML edits only)."""
     from pcdet.models import build_network
