@@ -287,13 +287,22 @@ int tmae_spconv_wgrad(const void* dy, int64_t ldy, const void* feat, int64_t ldf
 /* Fused residual add + LayerNorm of the post-norm encoder layers (EncoderLayer.forward sst_basic_block.py:77-84,
  * wca_block.py:93-102): y = LN(a + b) * gamma + beta, eps inside the sqrt, biased variance (nn.LayerNorm).
  * a, b (b may be NULL), y, xsum [m,d] in `dtype`; d in {128, 256}; xsum (may be NULL) receives a + b for the
- * backward; mean / rstd [m] f32.  Statistics are taken in fp32 over the stored (rounded) sum. */
+ * backward; mean / rstd [m] f32.  Statistics are taken in fp32 over the stored (rounded) sum.
+ * bmask (may be NULL; [m] in `dtype`): row r of b is scaled by bmask[r] -- `src[keep_inds] += attn` of the cross layers
+ * (wca_block.py:93-96) as a 0/1 row weight.  post (may be NULL; [m,d] in `dtype`): y = LN(...) + post -- the block residual
+ * `x + encoder(x)` of SSTBlockV1.forward / WCABlock.forward (spt_backbone.py:342-353, SiamWCA.py:431-447) on the
+ * block's last norm. */
 int tmae_add_layernorm_fwd(const void* a, const void* b, int dtype, int64_t m, int d, const float* gamma,
-                           const float* beta, float eps, void* xsum, void* y, float* mean, float* rstd, void* stream);
-/* dx [m,d] = gradient wrt (a + b); dgamma / dbeta [d] f32 (two-stage fixed-order column sums). */
+                           const float* beta, float eps, void* xsum, void* y, float* mean, float* rstd,
+                           const void* bmask, const void* post, void* stream);
+/* dx [m,d] = gradient wrt (a + b); dgamma / dbeta [d] f32 (two-stage fixed-order column sums).  Optional pairs (both NULL or
+ * both given): skip / dx_skip: dx_skip = dx + skip (a gradient that reaches the first summand by another path, summed
+ * here instead of autograd's add); bmask / dx_b: dx_b = dx * bmask[row] (the gradient of the masked second summand).  dx
+ * itself may be NULL when nobody reads it. */
 size_t tmae_layernorm_bwd_workspace(int64_t m, int d);
 int tmae_layernorm_bwd(const void* dy, const void* x, int dtype, int64_t m, int d, const float* mean,
                        const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                       const void* skip, void* dx_skip, const void* bmask, void* dx_b,
                        void* ws, size_t ws_bytes, void* stream);
 
 /* BatchNorm1d with batch statistics (+ optional ReLU) over the rows of a token / point list -- the norm of
@@ -347,9 +356,10 @@ int tmae_multi_cast_transpose(const void* table, int count, int64_t total_tiles,
 /* The optimizer step of the recipe for ALL parameter tensors in one launch: decoupled weight decay p *= 1 - wd*lr for every
  * entry (OptimWrapper.step, tools/train_utils/optimization/fastai_optim.py:139-150: true_wd, bn_wd), then torch.optim.Adam's
  * update (fastai_optim.py:151 -> Adam.step; amsgrad / maximize off, weight_decay 0 inside Adam) for the entries that
- * have a gradient.  table (device, 8-byte aligned): entries of six int64 -- p, grad (0: decay only), exp_avg, exp_avg_sq,
- * the per-parameter step tensor (1 float on the device, receives `step`; 0: none), numel | first chunk << 40 -- where a
- * chunk = 4096 elements and the entries are ordered by their first chunk; chunk_tensor (device int32 [total_chunks]) =
+ * have a gradient.  table (device, 8-byte aligned): entries of seven int64 -- p, grad (0: decay only), exp_avg, exp_avg_sq,
+ * the per-parameter step tensor (1 float on the device, receives `step`; 0: none), numel | first chunk << 40, a bf16 copy
+ * of the parameter to refresh (what the autocast forward reads; 0: none) -- where a chunk = 4096 elements and the entries
+ * are ordered by their first chunk; chunk_tensor (device int32 [total_chunks]) =
  * the entry of every chunk.  step = this step's number (>= 1, after the increment); the bias corrections are taken in
  * double on the host as torch does. */
 int tmae_adam_step(const void* table, const int32_t* chunk_tensor, int64_t total_chunks, float lr, float beta1, float beta2,

@@ -9,12 +9,17 @@
 // VEC = D / 64 (2 or 4) is kept as the template parameter of the dispatch.
 
 // y = LN(a + b) * gamma + beta ; xsum (optional) = a + b in T ; mean/rstd per row (f32)
-template <class T, int VEC>
+// Round 3: bmask (optional, [m] in T) scales row r of b -- the cross layers add the attention update only to the query
+// rows whose window holds previous-frame tokens (wca_block.py:93-96) -- and post (optional, [m, D]) is added to the
+// normalised output: the block residual `x + encoder(x)` of SSTBlockV1 / WCABlock (spt_backbone.py:342-353) rides on
+// the last norm of the block instead of an elementwise pass of its own.
+template <class T, int VEC, bool EXTRA>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t m,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         T* __restrict__ xsum, T* __restrict__ y,
-                                                        float* __restrict__ mean, float* __restrict__ rstd) {
+                                                        float* __restrict__ mean, float* __restrict__ rstd,
+                                                        const T* __restrict__ bmask, const T* __restrict__ post) {
   constexpr int D = VEC * 64, LPR = D / 8, RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, sub = lane / LPR, cl = lane % LPR;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
@@ -23,7 +28,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ a
   for (int i = 0; i < 8; ++i) { g[i] = gamma[cl * 8 + i]; bt[i] = beta[cl * 8 + i]; }
   const T* __restrict__ bsrc = b ? b : a;           // no second summand: read (and ignore) a again, branch-free
   for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
-    float v[2][8], w[2][8];
+    float v[2][8], w[2][8], pz[2][8], bm[2];
     bool ok[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -33,13 +38,15 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ a
       ok[u] = r < m;
       load8<T>(a + rc * D + cl * 8, v[u]);
       load8<T>(bsrc + rc * D + cl * 8, w[u]);
+      if (EXTRA && post) load8<T>(post + rc * D + cl * 8, pz[u]);          // wave-uniform
+      bm[u] = (EXTRA && bmask) ? ld_f<T>(bmask + rc) : 1.0f;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int64_t r = r0 + u * RPW + sub;
       if (b) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[u][i] += w[u][i];
+        for (int i = 0; i < 8; ++i) v[u][i] += w[u][i] * bm[u];
       }
       if (xsum) {
 #pragma unroll
@@ -56,6 +63,10 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ a
       const float rs = rsqrtf(group_sum<LPR>(q) * (1.0f / D) + eps);
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[u][i] = (v[u][i] - mu) * rs * g[i] + bt[i];
+      if (EXTRA && post) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[u][i] += pz[u][i];
+      }
       if (ok[u]) {
         store8<T>(y + r * D + cl * 8, v[u]);
         if (cl == 0) { mean[r] = mu; rstd[r] = rs; }
@@ -65,11 +76,15 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ a
 }
 
 // dx = rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat)) ; partial dgamma/dbeta per workgroup
-template <class T, int VEC>
+// Round 3, all optional: dx_skip = dx + skip (the gradient that reaches the first summand through the block residual,
+// folded here instead of an AccumulateGrad add), dx_b = dx * bmask[row] (gradient of the masked second summand).
+template <class T, int VEC, bool EXTRA>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, int64_t m,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, T* __restrict__ dx,
-                                                    float* __restrict__ part /*[grid][2][D]*/) {
+                                                    float* __restrict__ part /*[grid][2][D]*/,
+                                                    const T* __restrict__ skip, T* __restrict__ dx_skip,
+                                                    const T* __restrict__ bmask, T* __restrict__ dx_b) {
   constexpr int D = VEC * 64, LPR = D / 8, RPW = 64 / LPR;
   __shared__ float red[4][2][D];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane / LPR, cl = lane % LPR;
@@ -78,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
   for (int i = 0; i < 8; ++i) { g[i] = gamma[cl * 8 + i]; dg[i] = 0.f; db[i] = 0.f; }
   for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
-    float v[2][8], d[2][8], mu[2], rs[2];
+    float v[2][8], d[2][8], sk[2][8], mu[2], rs[2], bm[2];
     bool ok[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -86,6 +101,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       ok[u] = r < m;
       load8<T>(x + rc * D + cl * 8, v[u]);                        // unconditional (clamped), dy masked below
       load8<T>(dy + rc * D + cl * 8, d[u]);
+      if (EXTRA && skip) load8<T>(skip + rc * D + cl * 8, sk[u]);          // wave-uniform
+      bm[u] = (EXTRA && bmask) ? ld_f<T>(bmask + rc) : 1.0f;
       mu[u] = mean[rc];
       rs[u] = rstd[rc];
 #pragma unroll
@@ -107,7 +124,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       s2 = group_sum<LPR>(s2) * (1.0f / D);
 #pragma unroll
       for (int i = 0; i < 8; ++i) d[u][i] = rs[u] * (d[u][i] - s1 - v[u][i] * s2);
-      if (ok[u]) store8<T>(dx + (r0 + u * RPW + sub) * D + cl * 8, d[u]);
+      const int64_t ro = (r0 + u * RPW + sub) * D + cl * 8;
+      if (ok[u] && (!EXTRA || dx)) store8<T>(dx + ro, d[u]);
+      if (EXTRA && dx_b) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[u][i] = d[u][i] * bm[u];
+        if (ok[u]) store8<T>(dx_b + ro, v[u]);
+      }
+      if (EXTRA && dx_skip) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[u][i] += sk[u][i];
+        if (ok[u]) store8<T>(dx_skip + ro, d[u]);
+      }
     }
   }
 #pragma unroll
@@ -161,16 +189,23 @@ static int ln_grid(int64_t m) {
 
 int tmae_add_layernorm_fwd(const void* a, const void* b, int dtype, int64_t m, int d, const float* gamma,
                            const float* beta, float eps, void* xsum, void* y, float* mean, float* rstd,
-                           void* stream_) {
+                           const void* bmask, const void* post, void* stream_) {
   (void)hipGetLastError();
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || (d != 128 && d != 256)) return TMAE_EARG;
   if (m == 0) return TMAE_OK;
   if (!a || !gamma || !beta || !y || !mean || !rstd) return TMAE_EARG;
   dim3 grid(ln_grid(m)), block(256);
+  const bool extra = (b && bmask) || post;      // the plain form keeps its lean instantiation
 #define FWD(T, V)                                                                                              \
-  hipLaunchKernelGGL((add_ln_fwd_kernel<T, V>), grid, block, 0, stream, (const T*)a, (const T*)b, m, gamma, beta, \
-                     eps, (T*)xsum, (T*)y, mean, rstd)
+  do {                                                                                                         \
+    if (extra)                                                                                                 \
+      hipLaunchKernelGGL((add_ln_fwd_kernel<T, V, true>), grid, block, 0, stream, (const T*)a, (const T*)b, m, gamma, beta, \
+                         eps, (T*)xsum, (T*)y, mean, rstd, (const T*)(b ? bmask : nullptr), (const T*)post);    \
+    else                                                                                                       \
+      hipLaunchKernelGGL((add_ln_fwd_kernel<T, V, false>), grid, block, 0, stream, (const T*)a, (const T*)b, m, gamma, beta, \
+                         eps, (T*)xsum, (T*)y, mean, rstd, (const T*)nullptr, (const T*)nullptr);              \
+  } while (0)
   if (dtype == TMAE_F32) { if (d == 128) FWD(float, 2); else FWD(float, 4); }
   else if (dtype == TMAE_BF16) { if (d == 128) FWD(__hip_bfloat16, 2); else FWD(__hip_bfloat16, 4); }
   else return TMAE_EDTYPE;
@@ -181,21 +216,30 @@ int tmae_add_layernorm_fwd(const void* a, const void* b, int dtype, int64_t m, i
 size_t tmae_layernorm_bwd_workspace(int64_t m, int d) { return (size_t)ln_grid(m) * 2 * d * 4 + 256; }
 
 int tmae_layernorm_bwd(const void* dy, const void* x, int dtype, int64_t m, int d, const float* mean,
-                       const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, void* wsp,
-                       size_t ws_bytes, void* stream_) {
+                       const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                       const void* skip, void* dx_skip, const void* bmask, void* dx_b, void* wsp, size_t ws_bytes,
+                       void* stream_) {
   (void)hipGetLastError();
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || (d != 128 && d != 256)) return TMAE_EARG;
   if (!dgamma || !dbeta || !gamma) return TMAE_EARG;
-  if (m > 0 && (!dy || !x || !mean || !rstd || !dx)) return TMAE_EARG;
+  if (m > 0 && (!dy || !x || !mean || !rstd || (!dx && !dx_skip && !dx_b))) return TMAE_EARG;
+  if ((skip == nullptr) != (dx_skip == nullptr) || (bmask == nullptr) != (dx_b == nullptr)) return TMAE_EARG;
   const int nb = ln_grid(m);
   WsCarver ws(wsp, ws_bytes);
   float* part = ws.take<float>((size_t)nb * 2 * d);
   if (!ws.ok) return TMAE_EWS;
   dim3 grid(nb), block(256);
+  const bool extra = skip || bmask;
 #define BWD(T, V)                                                                                                   \
-  hipLaunchKernelGGL((ln_bwd_kernel<T, V>), grid, block, 0, stream, (const T*)dy, (const T*)x, m, mean, rstd, gamma, \
-                     (T*)dx, part)
+  do {                                                                                                              \
+    if (extra)                                                                                                      \
+      hipLaunchKernelGGL((ln_bwd_kernel<T, V, true>), grid, block, 0, stream, (const T*)dy, (const T*)x, m, mean, rstd, gamma, \
+                         (T*)dx, part, (const T*)skip, (T*)dx_skip, (const T*)bmask, (T*)dx_b);                     \
+    else                                                                                                            \
+      hipLaunchKernelGGL((ln_bwd_kernel<T, V, false>), grid, block, 0, stream, (const T*)dy, (const T*)x, m, mean, rstd, gamma, \
+                         (T*)dx, part, (const T*)nullptr, (T*)nullptr, (const T*)nullptr, (T*)nullptr);           \
+  } while (0)
   if (dtype == TMAE_F32) { if (d == 128) BWD(float, 2); else BWD(float, 4); }
   else if (dtype == TMAE_BF16) { if (d == 128) BWD(__hip_bfloat16, 2); else BWD(__hip_bfloat16, 4); }
   else return TMAE_EDTYPE;

@@ -7,13 +7,14 @@
 // when all four pointers of the tensor are 16-byte aligned (gradients may be views into a DDP bucket).
 #include "common.h"
 
-struct AdamEntry {           // 6 x int64 in the host-built table
+struct AdamEntry {           // 7 x int64 in the host-built table
   float* p;                  // parameter (fp32), updated in place
   const float* g;            // gradient (fp32) or NULL: decay only (a parameter that received no gradient)
   float* m;                  // exp_avg
   float* v;                  // exp_avg_sq
   float* step;               // torch.optim.Adam's per-parameter step tensor (device, 1 float) or NULL
   int64_t numel_chunk0;      // numel | first chunk << 40
+  __hip_bfloat16* copy;      // bf16 copy of the updated parameter (what the autocast path reads) or NULL
 };
 
 #define ADAM_CHUNK 4096
@@ -28,8 +29,13 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamEntry* __restr
   const int n = left < ADAM_CHUNK ? (int)left : ADAM_CHUNK;
   if (base == 0 && threadIdx.x == 0 && e.step && e.g) *e.step = step_value;
   float* p = e.p + base;
+  __hip_bfloat16* cp = e.copy ? e.copy + base : nullptr;
   if (!e.g) {
-    for (int k = threadIdx.x; k < n; k += 256) p[k] *= decay;
+    for (int k = threadIdx.x; k < n; k += 256) {
+      const float pp = p[k] * decay;
+      p[k] = pp;
+      if (cp) cp[k] = __float2bfloat16(pp);
+    }
     return;
   }
   const float* g = e.g + base;
@@ -41,7 +47,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamEntry* __restr
     vv = b2 * vv + w2 * gg * gg;
     pp -= step_size * mm / (sqrtf(vv) * inv_bc2_sqrt + eps);
   };
-  const bool al = !(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15);
+  const bool al = !(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) && !((uintptr_t)cp & 7);
   if (al && n == ADAM_CHUNK) {
 #pragma unroll
     for (int r = 0; r < ADAM_CHUNK / 1024; ++r) {
@@ -50,12 +56,17 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamEntry* __restr
       const float4 gg = *reinterpret_cast<const float4*>(g + k);
       upd(pp.x, gg.x, mm.x, vv.x); upd(pp.y, gg.y, mm.y, vv.y); upd(pp.z, gg.z, mm.z, vv.z); upd(pp.w, gg.w, mm.w, vv.w);
       *reinterpret_cast<float4*>(p + k) = pp; *reinterpret_cast<float4*>(m + k) = mm; *reinterpret_cast<float4*>(v + k) = vv;
+      if (cp) {
+        __hip_bfloat16 t4[4] = {__float2bfloat16(pp.x), __float2bfloat16(pp.y), __float2bfloat16(pp.z), __float2bfloat16(pp.w)};
+        *reinterpret_cast<uint2*>(cp + k) = *reinterpret_cast<const uint2*>(t4);
+      }
     }
   } else {
     for (int k = threadIdx.x; k < n; k += 256) {
       float pp = p[k], mm = m[k], vv = v[k];
       upd(pp, g[k], mm, vv);
       p[k] = pp; m[k] = mm; v[k] = vv;
+      if (cp) cp[k] = __float2bfloat16(pp);
     }
   }
 }

@@ -57,9 +57,9 @@ SIGNATURES = {
     'tmae_dense_gather': (I, [P, I, I, I, I, I, P, L, P, P]),
     'tmae_chamfer_fwd': (I, [P, P, P, L, I, I, P, P, P, P]),
     'tmae_chamfer_bwd': (I, [P, P, P, P, P, P, L, I, I, P, P]),
-    'tmae_add_layernorm_fwd': (I, [P, P, I, L, I, P, P, F, P, P, P, P, P]),
+    'tmae_add_layernorm_fwd': (I, [P, P, I, L, I, P, P, F, P, P, P, P, P, P, P]),
     'tmae_layernorm_bwd_workspace': (Z, [L, I]),
-    'tmae_layernorm_bwd': (I, [P, P, I, L, I, P, P, P, P, P, P, P, Z, P]),
+    'tmae_layernorm_bwd': (I, [P, P, I, L, I, P, P, P, P, P, P, P, P, P, P, P, Z, P]),
     'tmae_bn_workspace': (Z, [L, I]),
     'tmae_bn_relu_fwd': (I, [P, I, L, I, P, P, F, I, P, P, P, P, P, Z, P]),
     'tmae_bn_relu_bwd': (I, [P, P, I, L, I, P, P, P, P, I, P, P, P, P, Z, P]),

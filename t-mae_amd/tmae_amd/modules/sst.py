@@ -171,16 +171,25 @@ class _EncoderTail(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.activation = _activation(activation)
 
-    def tail(self, src, attn):
-        """src = LN1(src + attn); src = LN2(src + linear2(act(linear1(src)))) -- both adds fused into the norms."""
-        src = ops.add_layer_norm(src, attn, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+    def tail(self, src, attn, bmask=None, passthrough=False, post=None):
+        """src = LN1(src + attn); src = LN2(src + linear2(act(linear1(src)))) -- both adds fused into the norms.
+        bmask: 0/1 row weights of attn (cross layers).  passthrough / post: the block residual (`x + encoder(x)`,
+        spt_backbone.py:342-353) -- the block's first layer hands out an alias of its input (passthrough: returns
+        (out, alias)), the last layer adds it to its output inside norm2 (post); see ops._AddLayerNorm."""
+        alias = None
+        if passthrough:
+            src, alias = ops.add_layer_norm(src, attn, self.norm1.weight, self.norm1.bias, self.norm1.eps, bmask=bmask,
+                                            passthrough=True)
+        else:
+            src = ops.add_layer_norm(src, attn, self.norm1.weight, self.norm1.bias, self.norm1.eps, bmask=bmask)
         h_pre, src_res = ops.proj_fork(src, self.linear1.weight, self.linear1.bias,
                                        ((0, self.linear1.out_features, False),), fork=True, inplace_dx=True)
         if self.activation is F.gelu:
             src2 = ops.gelu_linear(h_pre, self.linear2.weight, self.linear2.bias)     # GELU backward fused into the dX GEMM
         else:
             src2 = ops.linear(self.activation(h_pre), self.linear2.weight, self.linear2.bias)
-        return ops.add_layer_norm(src_res, src2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        out = ops.add_layer_norm(src_res, src2, self.norm2.weight, self.norm2.bias, self.norm2.eps, post=post)
+        return (out, alias) if passthrough else out
 
 
 class EncoderLayer(_EncoderTail):
@@ -189,9 +198,9 @@ class EncoderLayer(_EncoderTail):
     def __init__(self, d_model, nhead, dim_feedforward, dropout, activation, layer_cfg):
         super().__init__(WindowAttention(d_model, nhead, dropout, layer_cfg), d_model, dim_feedforward, activation)
 
-    def forward(self, src, plan, pos_table, window_shape, shift):
+    def forward(self, src, plan, pos_table, window_shape, shift, passthrough=False, post=None):
         attn, src_res = self.win_attn(src, plan, pos_table, window_shape, shift)
-        return self.tail(src_res, attn)
+        return self.tail(src_res, attn, passthrough=passthrough, post=post)
 
 
 class BasicShiftBlockV2(nn.Module):
@@ -202,10 +211,17 @@ class BasicShiftBlockV2(nn.Module):
         self.encoder_list = nn.ModuleList([EncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, layer_cfg)
                                            for _ in range(2)])
 
-    def forward(self, src, plan, pos_table, window_shape):
+    def forward(self, src, plan, pos_table, window_shape, tap=False, post=None):
+        """tap: the first layer also returns an alias of the block input (-> (out, alias)); post: added to the last
+        layer's output (the residual of the enclosing SSTBlockV1)."""
+        alias = None
         for i, layer in enumerate(self.encoder_list):
-            src = layer(src, plan, pos_table, window_shape, i == 1)
-        return src
+            last = i == len(self.encoder_list) - 1
+            if tap and i == 0:
+                src, alias = layer(src, plan, pos_table, window_shape, i == 1, passthrough=True)
+            else:
+                src = layer(src, plan, pos_table, window_shape, i == 1, post=post if last else None)
+        return (src, alias) if tap else src
 
 
 class WCAEncoderLayer(_EncoderTail):
@@ -214,13 +230,13 @@ class WCAEncoderLayer(_EncoderTail):
     def __init__(self, d_model, nhead, dim_feedforward, dropout, activation, layer_cfg):
         super().__init__(WindowCrossAttention(d_model, nhead, dropout, layer_cfg), d_model, dim_feedforward, activation)
 
-    def forward(self, src, plan, src_prv, plan_prv, pos_table, window_shape, shift, kept):
+    def forward(self, src, plan, src_prv, plan_prv, pos_table, window_shape, shift, kept, passthrough=False, post=None):
         a = self.win_attn.cross_attn
         o, src_res = self.win_attn(src, plan, src_prv, plan_prv, pos_table, window_shape, shift)
-        # src[keep] += out_proj(attn): kept = query rows whose window also holds previous-frame tokens
-        # (the out-proj bias must not reach the other rows)
-        upd = ops.linear(o, a.out_proj.weight, a.out_proj.bias) * kept
-        return self.tail(src_res, upd)
+        # src[keep] += out_proj(attn): kept = query rows whose window also holds previous-frame tokens (the out-proj
+        # bias must not reach the other rows): a 0/1 row weight of the update inside the fused add + norm
+        upd = ops.linear(o, a.out_proj.weight, a.out_proj.bias)
+        return self.tail(src_res, upd, bmask=kept, passthrough=passthrough, post=post)
 
 
 class BasicShiftBlock_WCA(nn.Module):
@@ -231,9 +247,17 @@ class BasicShiftBlock_WCA(nn.Module):
         self.encoder_list = nn.ModuleList([WCAEncoderLayer(d_model, nhead, dim_feedforward, dropout, activation,
                                                            layer_cfg) for _ in range(2)])
 
-    def forward(self, src, plan, src_prv, plan_prv, pos_table, window_shape, kept_list):
+    def forward(self, src, plan, src_prv, plan_prv, pos_table, window_shape, kept_list, residual=False):
+        """residual: returns src + layers(src) (WCABlock.forward's `x + res`), the sum taken inside the last norm."""
+        alias = None
         for i, layer in enumerate(self.encoder_list):
-            src = layer(src, plan, src_prv, plan_prv, pos_table, window_shape, i == 1, kept_list[i])
+            last = i == len(self.encoder_list) - 1
+            if residual and i == 0:
+                src, alias = layer(src, plan, src_prv, plan_prv, pos_table, window_shape, i == 1, kept_list[i],
+                                   passthrough=True)
+            else:
+                src = layer(src, plan, src_prv, plan_prv, pos_table, window_shape, i == 1, kept_list[i],
+                            post=alias if (residual and last) else None)
         return src
 
 
@@ -275,20 +299,32 @@ class SSTBlockV1(nn.Module):
         self.register_buffer('pos_table', pos_embed_table(d_model, self.window_shape,
                                                           model_cfg.PREPROCESS.POS_TEMPERATURE), persistent=False)
 
-    def encoder_forward(self, sp: SparseConvTensor):
-        """SSTBlockV1.encoder_forward (spt_backbone.py:314-340) on the ragged layout."""
+    def encoder_forward(self, sp: SparseConvTensor, residual=False):
+        """SSTBlockV1.encoder_forward (spt_backbone.py:314-340) on the ragged layout.  residual: returns
+        x + encoder(x) (the sum of forward(), spt_backbone.py:349-351), taken inside the last layer's norm."""
         plan = WindowPlan(sp)
         out = sp.features
-        for block in self.encoder_blocks:
-            out = block(out, plan, self.pos_table, self.window_shape)
+        alias = None
+        nb = len(self.encoder_blocks)
+        for j, block in enumerate(self.encoder_blocks):
+            tap, last = residual and j == 0, residual and j == nb - 1
+            if tap and last:                       # a single block: its first layer taps, its last layer adds
+                out, alias = block.encoder_list[0](out, plan, self.pos_table, self.window_shape, False, passthrough=True)
+                for i, layer in enumerate(block.encoder_list[1:], 1):
+                    out = layer(out, plan, self.pos_table, self.window_shape, i == 1,
+                                post=alias if i == len(block.encoder_list) - 1 else None)
+            elif tap:
+                out, alias = block(out, plan, self.pos_table, self.window_shape, tap=True)
+            else:
+                out = block(out, plan, self.pos_table, self.window_shape, post=alias if last else None)
         return out
 
     def forward(self, sp: SparseConvTensor):
         if self.conv_down is not None:
             sp = self.conv_down(sp)
         x = sp.features
-        out = self.encoder_forward(sp)
-        sp = sp.replace_feature(x + out.to(x.dtype))
+        out = self.encoder_forward(sp, residual=True)          # = x + encoder(x)
+        sp = sp.replace_feature(out.to(x.dtype))
         return self.conv_out(sp)
 
 
@@ -311,7 +347,7 @@ class WCABlock(nn.Module):
         self.register_buffer('pos_table', pos_embed_table(d_model, self.window_shape,
                                                           model_cfg.PREPROCESS.POS_TEMPERATURE), persistent=False)
 
-    def encoder_forward(self, sp: SparseConvTensor, sp_prev: SparseConvTensor):
+    def encoder_forward(self, sp: SparseConvTensor, sp_prev: SparseConvTensor, residual=False):
         """WCABlock.encoder_forward (SiamWCA.py:342-396): joint bucketing of the two frames, two cross layers."""
         plan_prv = WindowPlan(sp_prev)
         plan = WindowPlan(sp, other=plan_prv)
@@ -322,10 +358,11 @@ class WCABlock(nn.Module):
             wb = ops.window_bucket(plan.indices, plan.grid, plan_prv.grid, plan.batch, plan.ny, plan.nx,
                                    self.window_shape, shift, self.drop_info)
             kept.append(wb['keep'].view(-1, 1).to(x.dtype))
-        return self.encoder_blocks[0](x, plan, sp_prev.features, plan_prv, self.pos_table, self.window_shape, kept)
+        return self.encoder_blocks[0](x, plan, sp_prev.features, plan_prv, self.pos_table, self.window_shape, kept,
+                                      residual=residual)
 
     def forward(self, sp: SparseConvTensor, sp_prev: SparseConvTensor, dtime=0):
         x = sp.features
-        res = self.encoder_forward(sp, sp_prev)
-        sp = sp.replace_feature(x + res.to(x.dtype))
+        res = self.encoder_forward(sp, sp_prev, residual=True)      # = x + layers(x)
+        sp = sp.replace_feature(res.to(x.dtype))
         return self.conv_out(sp)

@@ -241,6 +241,34 @@ def refresh_param_copies(params, dtype=torch.bfloat16):
     _MCT_DONE.clear()
 
 
+def plain_copy_targets(params, dtype=torch.bfloat16):
+    """For the optimizer's one-launch step: per parameter the `dtype` copy it should write next to the update (created
+    here if missing), or None -- wrong dtype / device, or a matrix whose TRANSPOSED copy is in use (those are re-cast
+    and re-transposed together by refresh_param_copies' one-launch kernel)."""
+    out = []
+    for p in params:
+        if not (p.is_cuda and p.dtype == torch.float32 and dtype == torch.bfloat16 and p.is_contiguous()):
+            out.append(None)
+            continue
+        c = getattr(p, '_tmae_copy', None)
+        if c is None or c[2].dtype != dtype or c[2].shape != p.shape:
+            c = [0, 0, torch.empty_like(p, dtype=dtype)]
+            p._tmae_copy = c
+        out.append(None if (p.dim() == 2 and getattr(c[2], '_tmae_T', None) is not None) else c[2])
+    return out
+
+
+def mark_copies_written(params):
+    """The copies of `params` (plain_copy_targets) hold the parameters' current values: the bookkeeping of
+    refresh_param_copies for them."""
+    for p in params:
+        c = p._tmae_copy
+        c[0], c[1] = p._version, p.data_ptr()
+        c[2]._tmae_stamp = getattr(c[2], '_tmae_stamp', 0) + 1
+        if getattr(c[2], '_tmae_T', None) is not None:      # (not reached: such parameters are not handed out)
+            c[2]._tmae_T = None
+
+
 _MCT_TABLES = {}
 _MCT_DONE = set()
 
@@ -687,10 +715,14 @@ def linear(x, weight, bias=None):
 
 
 class _AddLayerNorm(torch.autograd.Function):
-    """y = LayerNorm(a + b): one fused pass forward, one backward (+ fixed-order gamma/beta sums)."""
+    """y = LayerNorm(a + b * bmask) + post: one fused pass forward, one backward (+ fixed-order gamma/beta sums).
+    bmask [m] (0/1 rows of b that count), post [m,d] (added after the norm) are optional.  passthrough: also returns an
+    alias of `a`; the gradient that arrives for the alias is summed into a's gradient INSIDE the backward kernel -- the
+    encoder blocks hand the block input to their last norm this way (post), so the block residual `x + encoder(x)`
+    costs no elementwise pass forward and no AccumulateGrad add backward."""
 
     @staticmethod
-    def forward(ctx, a, b, weight, bias, eps):
+    def forward(ctx, a, b, weight, bias, eps, bmask, post, passthrough):
         cdt = compute_dtype(a)
         a_c = a.to(cdt).contiguous()
         b_c = None if b is None else b.to(cdt).contiguous()
@@ -700,34 +732,60 @@ class _AddLayerNorm(torch.autograd.Function):
         mean = torch.empty((m,), dtype=torch.float32, device=a.device)
         rstd = torch.empty((m,), dtype=torch.float32, device=a.device)
         g32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        bm = None if (bmask is None or b_c is None) else bmask.to(cdt).reshape(-1).contiguous()
+        po = None if post is None else post.to(cdt).contiguous()
+        assert bm is None or bm.shape[0] == m
+        assert po is None or po.shape == a_c.shape
         check(lib.tmae_add_layernorm_fwd(_p(a_c), _p(b_c), _dt(a_c), m, d, _p(g32), _p(b32), float(eps), _p(xs), _p(y),
-                                         _p(mean), _p(rstd), _s()), 'tmae_add_layernorm_fwd')
-        ctx.save_for_backward(xs if xs is not None else a_c, mean, rstd, g32)
-        ctx.meta = (a.dtype, None if b is None else b.dtype, weight.dtype, bias.dtype)
+                                         _p(mean), _p(rstd), _p(bm), _p(po), _s()), 'tmae_add_layernorm_fwd')
+        ctx.save_for_backward(xs if xs is not None else a_c, mean, rstd, g32, bm)
+        ctx.meta = (a.dtype, None if b is None else b.dtype, weight.dtype, bias.dtype, None if post is None else post.dtype)
+        ctx.passthrough = bool(passthrough)
+        ctx.set_materialize_grads(False)
+        if passthrough:
+            return y, a.view_as(a)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
-        x, mean, rstd, g32 = ctx.saved_tensors
-        adt, bdt, wdt, btdt = ctx.meta
-        dy = dy.to(x.dtype).contiguous()
+    def backward(ctx, dy, dalias=None):
+        x, mean, rstd, g32, bm = ctx.saved_tensors
+        adt, bdt, wdt, btdt, pdt = ctx.meta
         m, d = x.shape
-        dx = torch.empty_like(x)
+        if dy is None:                        # only the alias was used downstream
+            z = None if dalias is None else dalias.to(adt)
+            return z, None, None, None, None, None, None, None
+        dy = dy.to(x.dtype).contiguous()
+        skip = None if dalias is None else dalias.to(x.dtype).contiguous()
+        need_b = bdt is not None
+        dx_skip = torch.empty_like(x) if skip is not None else None
+        dx_b = torch.empty_like(x) if (bm is not None and need_b) else None
+        need_dx = skip is None or (need_b and dx_b is None)
+        dx = torch.empty_like(x) if need_dx else None
         dg = torch.empty((d,), dtype=torch.float32, device=x.device)
         db = torch.empty((d,), dtype=torch.float32, device=x.device)
         wsb = lib.tmae_layernorm_bwd_workspace(m, d)
         ws = _ws(wsb, x.device)
         check(lib.tmae_layernorm_bwd(_p(dy), _p(x), _dt(x), m, d, _p(mean), _p(rstd), _p(g32), _p(dx), _p(dg), _p(db),
+                                     _p(skip), _p(dx_skip), _p(bm if dx_b is not None else None), _p(dx_b),
                                      _p(ws), wsb, _s()), 'tmae_layernorm_bwd')
-        return dx.to(adt), (None if bdt is None else dx.to(bdt)), dg.to(wdt), db.to(btdt), None
+        da = dx_skip if skip is not None else dx
+        dbb = None if not need_b else (dx_b if dx_b is not None else dx)
+        return (da.to(adt), None if dbb is None else dbb.to(bdt), dg.to(wdt), db.to(btdt), None, None,
+                None if pdt is None else dy.to(pdt), None)
 
 
-def add_layer_norm(a, b, weight, bias, eps=1e-5):
-    """LayerNorm(a + b) (b may be None) with nn.LayerNorm semantics; fused HIP kernel for d in {128, 256}."""
+def add_layer_norm(a, b, weight, bias, eps=1e-5, bmask=None, post=None, passthrough=False):
+    """LayerNorm(a + b) (b may be None) with nn.LayerNorm semantics; fused HIP kernel for d in {128, 256}.
+    bmask [m] or [m,1]: b's rows are scaled by it; post [m,d]: added to the result; passthrough: returns (y, alias of a)
+    -- see _AddLayerNorm."""
     if a.is_cuda and a.dim() == 2 and a.shape[1] in (128, 256):
-        return _AddLayerNorm.apply(a, b, weight, bias, eps)
-    x = a if b is None else a + b
-    return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+        return _AddLayerNorm.apply(a, b, weight, bias, eps, bmask, post, passthrough)
+    bb = b if (b is None or bmask is None) else b * bmask.reshape(-1, 1)
+    x = a if bb is None else a + bb
+    y = torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+    if post is not None:
+        y = y + post
+    return (y, a) if passthrough else y
 
 
 class _BatchNormReLU(torch.autograd.Function):

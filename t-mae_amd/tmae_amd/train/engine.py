@@ -38,7 +38,10 @@ def train_one_step(model, optimizer, scheduler, batch_dict, it, model_func, amp_
     loss.backward()
     if not use_amp and grad_norm_clip:
         torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm_clip)
-    optimizer.step()
+    if use_amp and hasattr(optimizer, '_native_step'):
+        optimizer.step(copy_dtype=amp_dtype)       # the one-launch step also refreshes the bf16 copies it can
+    else:
+        optimizer.step()
     if use_amp:
         from .. import ops
         ops.refresh_param_copies(optimizer.params if hasattr(optimizer, 'params') else model.parameters(), amp_dtype)

@@ -124,8 +124,11 @@ class AdamOneCycle:
                 p.grad.zero_()
 
     @torch.no_grad()
-    def step(self):
-        if self._native and self._native_step():
+    def step(self, copy_dtype=None):
+        """copy_dtype (torch.bfloat16 under autocast): the GPU kernel also refreshes the low-precision copies of the
+        parameters that tmae_amd.ops serves to the autocast forward (ops.cast_param), instead of multi-tensor copy
+        launches after the step; whatever it does not write, ops.refresh_param_copies still does."""
+        if self._native and self._native_step(copy_dtype):
             return
         if self.decayed and self.wd != 0.0:
             torch._foreach_mul_(self.decayed, 1.0 - self.wd * self._lr)
@@ -145,12 +148,17 @@ class AdamOneCycle:
             self._steps[id(p)] = int(float(st['step']))
         return st
 
-    def _native_step(self):
+    def _native_step(self, copy_dtype=None):
         """Decay + Adam for every tensor in one launch.  Returns False (caller takes torch's path) when the tensors
         with a gradient are not all at the same step count, which the kernel's scalar bias corrections assume."""
         from .._lib import lib, check
         rows, key, steps = [], [], set()
-        for p in self.decayed:
+        copies = [None] * len(self.decayed)
+        if copy_dtype == torch.bfloat16:
+            from .. import ops
+            copies = ops.plain_copy_targets(self.decayed, copy_dtype)
+        for p, cp in zip(self.decayed, copies):
+            cptr = 0 if cp is None else cp.data_ptr()
             g = p.grad
             if g is not None and (g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device):
                 return False
@@ -160,9 +168,9 @@ class AdamOneCycle:
                 if st['step'].device != p.device:
                     st['step'] = st['step'].to(device=p.device, dtype=torch.float32)
                 key.append((p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(),
-                            st['step'].data_ptr(), p.numel()))
+                            st['step'].data_ptr(), p.numel(), cptr))
             else:
-                key.append((p.data_ptr(), 0, 0, 0, 0, p.numel()))
+                key.append((p.data_ptr(), 0, 0, 0, 0, p.numel(), cptr))
         if len(steps) > 1:
             return False
         if not steps and self.wd == 0.0:
@@ -170,9 +178,9 @@ class AdamOneCycle:
         key = tuple(key)
         if self._table is None or self._table[0] != key:
             chunk, cmap = 0, []
-            for i, (pp, gp, mp, vp, sp, n) in enumerate(key):
+            for i, (pp, gp, mp, vp, sp, n, cp) in enumerate(key):
                 nch = (n + 4095) // 4096
-                rows.append([pp, gp, mp, vp, sp, n | (chunk << 40)])
+                rows.append([pp, gp, mp, vp, sp, n | (chunk << 40), cp])
                 cmap += [i] * nch
                 chunk += nch
             dev = self.decayed[0].device
@@ -189,6 +197,8 @@ class AdamOneCycle:
         # the kernel wrote through raw pointers: tell autograd (the bf16 copies / folded weights of tmae_amd.ops are keyed
         # on the parameters' version counters, exactly as an in-place torch op would have moved them)
         torch.autograd.graph.increment_version(self.decayed)
+        if copy_dtype == torch.bfloat16:
+            ops.mark_copies_written([p for p, cp in zip(self.decayed, copies) if cp is not None])
         return True
 
     def state_dict(self):

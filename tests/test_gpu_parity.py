@@ -738,6 +738,52 @@ def test_add_layernorm_kernel_vs_torch():
     assert (y - F.layer_norm(a, (256,), w, bb, 1e-5)).abs().max().item() < 2e-5
 
 
+def test_add_layernorm_residual_options_vs_torch():
+    """The round-3 options of the fused add + LayerNorm: a 0/1 row mask on the second summand (cross layers), an
+    alias of the first summand handed out (passthrough) and added to the output of a LATER norm (post) -- the block
+    residual x + encoder(x) -- against the same graph written with torch ops: outputs and every gradient."""
+    from tmae_amd import ops
+    torch.manual_seed(3)
+    for d in (128, 256):
+        for m in (5, 4099):
+            for dt, tol in ((torch.float32, 3e-5), (torch.bfloat16, 8e-2)):
+                a = torch.randn(m, d, device=dev()).to(dt)
+                b = (torch.randn(m, d, device=dev()) * 0.5).to(dt)
+                c = (torch.randn(m, d, device=dev()) * 0.5).to(dt)
+                keep = (torch.rand(m, 1, device=dev()) < 0.6).to(dt)
+                w1 = (1 + 0.1 * torch.randn(d, device=dev())).requires_grad_(True)
+                b1 = (0.1 * torch.randn(d, device=dev())).requires_grad_(True)
+                w2 = (1 + 0.1 * torch.randn(d, device=dev())).requires_grad_(True)
+                b2 = (0.1 * torch.randn(d, device=dev())).requires_grad_(True)
+                go = torch.randn(m, d, device=dev()).to(dt)
+
+                def run(mine):
+                    aa, bb_, cc = (t.clone().requires_grad_(True) for t in (a, b, c))
+                    if mine:
+                        h, alias = ops.add_layer_norm(aa, bb_, w1, b1, 1e-5, bmask=keep, passthrough=True)
+                        y = ops.add_layer_norm(h, cc, w2, b2, 1e-5, post=alias)
+                    else:
+                        af, bf, cf = aa.float(), bb_.float(), cc.float()
+                        x1 = af + bf * keep.float()
+                        x1 = x1 if dt == torch.float32 else x1.to(dt).float()
+                        h = F.layer_norm(x1, (d,), w1, b1, 1e-5)
+                        h = h if dt == torch.float32 else h.to(dt).float()
+                        x2 = h + cf
+                        x2 = x2 if dt == torch.float32 else x2.to(dt).float()
+                        y = F.layer_norm(x2, (d,), w2, b2, 1e-5) + af
+                    y.backward(go.to(y.dtype))
+                    out = (y.detach().float(), aa.grad.float(), bb_.grad.float(), cc.grad.float(), w1.grad.clone(),
+                           b1.grad.clone(), w2.grad.clone(), b2.grad.clone())
+                    w1.grad = b1.grad = w2.grad = b2.grad = None
+                    return out
+                got, ref = run(True), run(False)
+                for k, (x_, r_) in enumerate(zip(got, ref)):
+                    sc = max(1.0, float(r_.abs().max()))
+                    lim = tol * (4 if k in (1, 2, 3) else 1) * sc if k < 4 else (2e-3 if dt == torch.float32 else 5e-2) * sc * max(1, m ** 0.5 / 10)
+                    assert (x_ - r_).abs().max().item() <= lim, (d, m, dt, k, (x_ - r_).abs().max().item(), lim)
+                assert float((got[2] * (1 - keep.float())).abs().max()) == 0.0        # masked rows of b get no gradient
+
+
 def test_batchnorm_relu_kernel_vs_torch():
     from tmae_amd import ops
     torch.manual_seed(2)

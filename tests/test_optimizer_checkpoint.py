@@ -141,7 +141,12 @@ def test_multi_tensor_adam_step_equals_torch_adam():
             gview.copy_(torch.randn_like(p) * (10.0 ** (it - 2)))
             p.grad = gview if p.numel() % 2 else gview.clone()
             off += p.numel()
-        opt.step()
+        opt.step(copy_dtype=torch.bfloat16)            # also refreshes the bf16 copies the autocast path reads
+        from tmae_amd import ops
+        for p in ps:
+            c = p._tmae_copy
+            assert c[0] == p._version and torch.equal(c[2], p.detach().bfloat16())
+            assert ops.cast_param(p, torch.bfloat16) is c[2]
         b1, b2, lr, eps = opt.mom, 0.99, opt.lr, 1e-8
         assert all(p._version > v0 for p, v0 in zip(ps, versions))    # caches keyed on the version see the update
         for k, p in enumerate(ps):
