@@ -365,6 +365,15 @@ int tmae_multi_cast_transpose(const void* table, int count, int64_t total_tiles,
 int tmae_adam_step(const void* table, const int32_t* chunk_tensor, int64_t total_chunks, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int64_t step, void* stream);
 
+/* Running statistics of all BatchNorm layers of a forward pass in one launch (torch.nn.BatchNorm's training-mode update:
+ * running = (1 - momentum) * running + momentum * batch statistic, unbiased variance; num_batches_tracked += 1 -- the norms
+ * of network_utils.py:31, spconv_utils.py:50-54, SiamWCA_MAE.py:91-115).  bufs (device): nbufs entries of four int64 --
+ * running buffer (fp32), numel, index of its first update, number of its updates (applied in order: a module used twice);
+ * updates (device): entries of two int64 -- batch statistic (fp32 [numel]), float bits keep | scale << 32 (running =
+ * running * keep + statistic * scale); counters (device): ncounters pointers to int64 num_batches_tracked, each += 1. */
+int tmae_bn_running_update(const void* bufs, int nbufs, const void* updates, const void* counters, int ncounters,
+                           void* stream);
+
 /* Token-list Linear in bf16 (fp32 accumulate):  y[m,n] = x[m,k] . w[n,k]^T (+ bias[n]) -- the in-/out-projections
  * and FFN layers of EncoderLayer (sst_basic_block.py:45-83, F.linear) and, on w^T, their input gradients.
  * k in {128, 256, 512}, n a multiple of 64; ldx / ldy = row pitches in elements (column slices of packed buffers are

@@ -87,3 +87,47 @@ int tmae_adam_step(const void* table, const int32_t* chunk_tensor, int64_t total
                      (float)(1.0 - (double)beta2), (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps, (float)step);
   return tmae_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm running statistics of ALL norm layers of a forward pass in one launch (torch.nn.BatchNorm's update in
+// training mode, torch/nn/modules/batchnorm.py: running = (1 - momentum) * running + momentum * batch statistic, unbiased
+// variance; num_batches_tracked += 1).  The step has ~26 such updates (network_utils.py:31, spconv_utils.py:50-54,
+// SiamWCA_MAE.py:91-115); as torch._foreach calls they were ~14 multi-tensor launches.  One workgroup per BUFFER applies
+// that buffer's updates in order (the VFE norm runs once per frame: two updates of the same buffer).
+struct BnBuf {               // 4 x int64
+  float* running;            // running_mean or running_var
+  int64_t numel;
+  int64_t first, count;      // its updates in the update table
+};
+struct BnUpd {               // 2 x int64
+  const float* stat;         // batch mean / biased batch variance [numel]
+  int64_t keep_scale;        // float bits: keep (1 - momentum) | scale (momentum [* n / (n - 1)]) << 32
+};
+
+__global__ __launch_bounds__(128) void bn_running_update_kernel(const BnBuf* __restrict__ bufs, const BnUpd* __restrict__ upd,
+                                                              int64_t* const* __restrict__ counters, int ncounters) {
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < ncounters; c += 128)                           // num_batches_tracked: one entry per use
+      atomicAdd(reinterpret_cast<unsigned long long*>(counters[c]), 1ull);      // (a module used twice appears twice)
+  const BnBuf b = bufs[blockIdx.x];
+  for (int64_t e = threadIdx.x; e < b.numel; e += 128) {
+    float r = b.running[e];
+    for (int64_t u = 0; u < b.count; ++u) {
+      const BnUpd q = upd[b.first + u];
+      const float keep = __uint_as_float((unsigned)(q.keep_scale & 0xFFFFFFFF)), scale = __uint_as_float((unsigned)(q.keep_scale >> 32));
+      r = r * keep + q.stat[e] * scale;
+    }
+    b.running[e] = r;
+  }
+}
+
+int tmae_bn_running_update(const void* bufs, int nbufs, const void* updates, const void* counters, int ncounters,
+                           void* stream_) {
+  (void)hipGetLastError();
+  if (nbufs < 0 || ncounters < 0) return TMAE_EARG;
+  if (nbufs == 0) return TMAE_OK;
+  if (!bufs || !updates || (ncounters > 0 && !counters) || ((uintptr_t)bufs & 7) || ((uintptr_t)updates & 7)) return TMAE_EARG;
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(nbufs), dim3(128), 0, (hipStream_t)stream_, (const BnBuf*)bufs,
+                     (const BnUpd*)updates, (int64_t* const*)counters, ncounters);
+  return tmae_launch_status();
+}

@@ -82,6 +82,7 @@ SIGNATURES = {
     'tmae_token_gemm': (I, [P, L, L, I, P, I, P, P, L, P]),
     'tmae_multi_cast_transpose': (I, [P, I, L, P]),
     'tmae_adam_step': (I, [P, P, L, F, F, F, F, F, L, P]),
+    'tmae_bn_running_update': (I, [P, I, P, P, I, P]),
     'tmae_token_gemm_acc': (I, [P, L, L, I, P, I, P, P, L, P]),
     'tmae_token_gemm_dgelu': (I, [P, L, L, I, P, I, P, P, P, L, P]),
     'tmae_token_gemm_pos': (I, [P, L, L, I, P, I, P, P, P, L, P]),

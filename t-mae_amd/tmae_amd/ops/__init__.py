@@ -153,9 +153,49 @@ def _bn_running_update(bn, mean, var, count):
         bn.num_batches_tracked += 1
 
 
+def _bn_flush(pending):
+    """Apply the queued running-statistics updates: ONE launch of tmae_bn_running_update for fp32 CUDA buffers (a
+    workgroup per buffer applies that buffer's updates in order), torch ops otherwise."""
+    import struct
+    with torch.no_grad():
+        dev = pending[0][0].running_mean.device
+        ok = all(bn.running_mean.is_cuda and bn.running_mean.dtype == torch.float32 and mean.dtype == torch.float32
+                 and var.dtype == torch.float32 and mean.is_contiguous() and var.is_contiguous()
+                 and bn.running_mean.device == dev for bn, mean, var, _, _ in pending)
+        if not ok:
+            for bn, mean, var, mom, count in pending:
+                bn.running_mean.mul_(1 - mom).add_(mean.reshape(-1), alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(var.reshape(-1), alpha=mom * count / (count - 1))
+                bn.num_batches_tracked += 1
+            return
+        per_buf, order, counters = {}, [], []
+        for bn, mean, var, mom, count in pending:
+            for buf, stat, scale in ((bn.running_mean, mean, mom), (bn.running_var, var, mom * count / (count - 1.0))):
+                key = buf.data_ptr()
+                if key not in per_buf:
+                    per_buf[key] = (buf, [])
+                    order.append(key)
+                bits = struct.unpack('<q', struct.pack('<ff', 1.0 - mom, scale))[0]
+                per_buf[key][1].append((stat.data_ptr(), bits))
+            counters.append(bn.num_batches_tracked.data_ptr())
+        bufs, upds = [], []
+        for key in order:
+            buf, us = per_buf[key]
+            bufs.append([buf.data_ptr(), buf.numel(), len(upds), len(us)])
+            upds += [list(u) for u in us]
+        table = torch.tensor([v for row in bufs for v in row] + [v for row in upds for v in row] + counters,
+                             dtype=torch.int64, device=dev)
+        nb, nu = len(bufs), len(upds)
+        base = table.data_ptr()
+        check(lib.tmae_bn_running_update(base, nb, base + nb * 32, base + nb * 32 + nu * 16, len(counters), _s()),
+              'tmae_bn_running_update')
+        # keep the statistics tensors alive until the launch has read them (stream-ordered allocator reuse is safe: the
+        # next kernel that could reuse their memory is enqueued after this one on the same stream)
+
+
 class defer_bn_updates:
-    """Context manager: BatchNorm running-statistics updates made inside are applied at the exit, in order, with
-    torch._foreach kernels (one round per repeated use of a module, so the sequential semantics are kept)."""
+    """Context manager: BatchNorm running-statistics updates made inside are applied at the exit, in order, in one
+    launch (tmae_bn_running_update; a module used twice gets its two updates applied sequentially)."""
 
     def __enter__(self):
         global _BN_PENDING
@@ -169,23 +209,8 @@ class defer_bn_updates:
         if self.prev is not None:            # nested: the outermost context flushes
             return False
         pending, _BN_PENDING = _BN_PENDING, None
-        with torch.no_grad():
-            while pending:
-                seen, now, later = set(), [], []
-                for item in pending:
-                    (later if id(item[0]) in seen else now).append(item)
-                    seen.add(id(item[0]))
-                bufs, stats, keep, scale, nbt = [], [], [], [], []
-                for bn, mean, var, mom, count in now:
-                    bufs += [bn.running_mean, bn.running_var]
-                    stats += [mean, var]
-                    keep += [1.0 - mom, 1.0 - mom]
-                    scale += [mom, mom * count / (count - 1.0)]
-                    nbt.append(bn.num_batches_tracked)
-                torch._foreach_mul_(bufs, keep)
-                torch._foreach_add_(bufs, torch._foreach_mul(stats, scale))
-                torch._foreach_add_(nbt, 1)
-                pending = later
+        if pending:
+            _bn_flush(pending)
         return False
 
 
