@@ -2,7 +2,7 @@
 (the last 20 dispatches of every kernel = the timed probe launches).  usage: pmc_kernels.py <dir>"""
 import collections, csv, glob, os, re, sys
 root = sys.argv[1]
-want = ('win_attn_bwd_mfma_kernel', 'win_attn_fwd_mfma_kernel', 'token_gemm_res_kernel', 'wgrad256_kernel')
+want = ('win_attn_bwd_mfma_kernel', 'win_attn_fwd_mfma_kernel', 'token_gemm_res_kernel', 'token_gemm_wreg_kernel', 'wgrad256_kernel', 'wgrad_reduce')
 tab = collections.defaultdict(dict)
 for f in sorted(glob.glob(os.path.join(root, 'g*', '**', '*counter_collection.csv'), recursive=True)):
     rows = list(csv.DictReader(open(f)))

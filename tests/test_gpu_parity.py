@@ -579,6 +579,74 @@ def test_token_gemm_kernel_vs_torch():
     assert dx.shape == (40000, 512) and (dx.float() - ref).abs().max().item() <= 2e-2 * float(ref.abs().max())
 
 
+def test_token_gemm_wreg_kernel_every_instantiation_vs_torch():
+    """The W-in-registers token GEMM (csrc/token_gemm_wreg.hip, >= 32 k tokens): every (K, N, position, accumulate)
+    instantiation against fp32 matmul on the same bf16 inputs, on token counts that leave ragged last steps (a step =
+    128 / 64 / 32 tokens for K = 128 / 256 / 512), workgroups without work (32 769 tokens: fewer steps than CUs for
+    K = 128) and a strided x; the position columns against the one-hot formula; the in-place form against addmm."""
+    from tmae_amd import ops
+    from tmae_amd._lib import lib, check
+    torch.manual_seed(11)
+    st = torch.cuda.current_stream().cuda_stream
+    for (m, k, n, pos) in ((32769, 128, 128, False), (32769 + 77, 128, 256, False), (40003, 128, 384, True), (33001, 128, 128, True),
+                           (65537, 128, 256, True), (32768 + 63, 256, 128, False), (50001, 256, 256, False),
+                           (33333, 256, 512, False), (66001, 256, 768, True), (40001, 256, 512, True), (36001, 256, 256, True),
+                           (70001, 256, 1024, False), (65536 + 31, 512, 256, False), (100001, 512, 256, False)):
+        ka = k + (32 if pos else 0)
+        x = torch.randn(m, k, device=dev()).bfloat16()
+        w = (torch.randn(n, ka, device=dev()) * 0.1).bfloat16()
+        b = torch.randn(n, device=dev()).bfloat16()
+        y = torch.full((m, n), float('nan'), device=dev(), dtype=torch.bfloat16)
+        xf = x.float()
+        if pos:
+            cells = torch.randint(0, 64, (m,), device=dev(), dtype=torch.uint8)
+            check(lib.tmae_token_gemm_pos(x.data_ptr(), k, m, k, w.data_ptr(), n, b.data_ptr(), cells.data_ptr(),
+                                          y.data_ptr(), n, st), 'tmae_token_gemm_pos')
+            oh = torch.zeros(m, 32, device=dev())
+            xc, yc = (cells & 7).long(), (cells >> 3).long()
+            for gk in range(4):                       # hi / lo halves of the x-cell and y-cell tables
+                oh[torch.arange(m, device=dev()), gk * 8 + (yc if gk & 1 else xc)] = 1.0
+            xf = torch.cat([xf, oh], 1)
+        else:
+            check(lib.tmae_token_gemm(x.data_ptr(), k, m, k, w.data_ptr(), n, b.data_ptr(), y.data_ptr(), n, st),
+                  'tmae_token_gemm')
+        ref = xf @ w.float().t() + b.float()
+        err = (y.float() - ref).abs().max().item()          # (a NaN left in y fails the comparison)
+        assert err <= 2e-2 * max(1.0, float(ref.abs().max())), (m, k, n, pos, err)
+    big = torch.randn(80001, 384, device=dev()).bfloat16()   # x = a column slice of a packed buffer (pitch 384)
+    xs = big[:, 128:384]
+    w = (torch.randn(256, 256, device=dev()) * 0.1).bfloat16()
+    y = ops.token_gemm(xs, w, None, force=True)
+    ref = xs.float() @ w.float().t()
+    assert (y.float() - ref).abs().max().item() <= 2e-2 * float(ref.abs().max())
+    # y written into a column block of a wider buffer (ldy > n): the neighbours stay untouched
+    out = torch.full((40000, 768), 7.0, device=dev(), dtype=torch.bfloat16)
+    x = torch.randn(40000, 256, device=dev()).bfloat16()
+    w = (torch.randn(256, 256, device=dev()) * 0.1).bfloat16()
+    zb = torch.zeros(256, device=dev(), dtype=torch.bfloat16)
+    check(lib.tmae_token_gemm(x.data_ptr(), 256, 40000, 256, w.data_ptr(), 256, zb.data_ptr(), out[:, 256:].data_ptr(), 768, st),
+          'tmae_token_gemm')
+    assert float((out[:, :256].float() - 7).abs().max()) == 0 and float((out[:, 512:].float() - 7).abs().max()) == 0
+    ref = x.float() @ w.float().t()
+    assert (out[:, 256:512].float() - ref).abs().max().item() <= 2e-2 * float(ref.abs().max())
+    # in-place accumulate (FFN-1 input gradient): dx += dy @ w
+    for (m, n, k) in ((65536 + 33, 512, 256), (120001, 512, 256), (32768 + 5, 256, 128), (470001, 256, 128)):
+        dy = torch.randn(m, n, device=dev()).bfloat16()
+        w = (torch.randn(n, k, device=dev()) * 0.1).bfloat16()
+        dx0 = torch.randn(m, k, device=dev()).bfloat16()
+        dx = dx0.clone()
+        r = ops.addmm_inplace(dx, dy, w)
+        assert r.data_ptr() == dx.data_ptr()
+        ref = dx0.float() + dy.float() @ w.float()
+        assert (dx.float() - ref).abs().max().item() <= 2e-2 * max(1.0, float(ref.abs().max())), (m, n, k)
+    # shapes outside the kernel's table fall back to torch without touching anything else
+    dx = torch.randn(1000, 128, device=dev()).bfloat16()
+    dy, w = torch.randn(1000, 256, device=dev()).bfloat16(), (torch.randn(256, 128, device=dev()) * 0.1).bfloat16()
+    ref = dx.float() + dy.float() @ w.float()
+    ops.addmm_inplace(dx, dy, w)
+    assert (dx.float() - ref).abs().max().item() <= 4e-2 * float(ref.abs().max())
+
+
 def _pos_case(m, d, seed):
     """Random tokens on a 468 x 468 grid + the module's position table."""
     from tmae_amd.modules.sst import pos_embed_table
