@@ -14,6 +14,18 @@ from .sparse import SparseConvTensor
 from .sst import SSTBlockV1, WCABlock
 
 
+_SHIFTS = {}
+
+
+def _sample_shift(batch, device):
+    """[batch, 0, 0] int32 on `device` (the current frame's samples follow the previous frame's in the joint token list)."""
+    key = (int(batch), device)
+    t = _SHIFTS.get(key)
+    if t is None:
+        t = _SHIFTS[key] = torch.tensor([int(batch), 0, 0], dtype=torch.int32, device=device)
+    return t
+
+
 class SiamWCA_MAE(nn.Module):
     def __init__(self, model_cfg, input_channels, grid_size, voxel_size, point_cloud_range, **kwargs):
         super().__init__()
@@ -97,13 +109,13 @@ class SiamWCA_MAE(nn.Module):
         B = batch_size
         ind_p = coords_prev[:, [0, 2, 3]].int()
         ind_c = coords_cur[:, [0, 2, 3]].int()
-        ind_c = ind_c + torch.tensor([B, 0, 0], dtype=torch.int32, device=ind_c.device)
+        shift = _sample_shift(B, ind_c.device)       # cached: a torch.tensor(..., device=) per step is a synchronous copy
+        ind_c = ind_c + shift
         cdt = ops.compute_dtype(feats_prev)
         x = SparseConvTensor(torch.cat([feats_prev.to(cdt), feats_cur.to(cdt)], 0), torch.cat([ind_p, ind_c], 0),
                              self.sparse_shape, 2 * B, groups=((ind_p.shape[0], B), (ind_c.shape[0], B)))
         out_p, out_c, strides = {}, {}, {}
         self.last_pair_tokens, self.last_stage_indices = [], []
-        shift = torch.tensor([B, 0, 0], dtype=torch.int32, device=ind_c.device)
         for i, blk in enumerate(self.sst_blocks):
             x = blk(x)
             key = f'x_conv{i + 1}'

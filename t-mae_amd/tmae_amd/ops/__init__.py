@@ -153,6 +153,9 @@ def _bn_running_update(bn, mean, var, count):
         bn.num_batches_tracked += 1
 
 
+_BN_TABLES = {}
+
+
 def _bn_flush(pending):
     """Apply the queued running-statistics updates: ONE launch of tmae_bn_running_update for fp32 CUDA buffers (a
     workgroup per buffer applies that buffer's updates in order), torch ops otherwise."""
@@ -183,9 +186,19 @@ def _bn_flush(pending):
             buf, us = per_buf[key]
             bufs.append([buf.data_ptr(), buf.numel(), len(upds), len(us)])
             upds += [list(u) for u in us]
-        table = torch.tensor([v for row in bufs for v in row] + [v for row in upds for v in row] + counters,
-                             dtype=torch.int64, device=dev)
+        flat = [v for row in bufs for v in row] + [v for row in upds for v in row] + counters
         nb, nu = len(bufs), len(upds)
+        # sent from pinned memory with an asynchronous copy (a pageable torch.tensor(..., device=) copy is synchronous: the
+        # host would wait here for everything queued before); two staging buffers in turn
+        ent = _BN_TABLES.get((dev, len(flat)))
+        if ent is None:
+            ent = _BN_TABLES[(dev, len(flat))] = [[torch.empty(len(flat), dtype=torch.int64).pin_memory() for _ in range(2)], 0,
+                                                 torch.empty(len(flat), dtype=torch.int64, device=dev)]
+        host = ent[0][ent[1]]
+        ent[1] ^= 1
+        host.numpy()[:] = flat
+        table = ent[2]
+        table.copy_(host, non_blocking=True)
         base = table.data_ptr()
         check(lib.tmae_bn_running_update(base, nb, base + nb * 32, base + nb * 32 + nu * 16, len(counters), _s()),
               'tmae_bn_running_update')

@@ -17,6 +17,7 @@ The state_dict is torch.optim.Adam's with these two groups, so `optimizer_state`
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -152,7 +153,7 @@ class AdamOneCycle:
         """Decay + Adam for every tensor in one launch.  Returns False (caller takes torch's path) when the tensors
         with a gradient are not all at the same step count, which the kernel's scalar bias corrections assume."""
         from .._lib import lib, check
-        rows, key, steps = [], [], set()
+        key, steps = [], set()
         copies = [None] * len(self.decayed)
         if copy_dtype == torch.bfloat16:
             from .. import ops
@@ -177,15 +178,31 @@ class AdamOneCycle:
             return True
         key = tuple(key)
         if self._table is None or self._table[0] != key:
-            chunk, cmap = 0, []
-            for i, (pp, gp, mp, vp, sp, n, cp) in enumerate(key):
-                nch = (n + 4095) // 4096
-                rows.append([pp, gp, mp, vp, sp, n | (chunk << 40), cp])
-                cmap += [i] * nch
-                chunk += nch
+            # Gradients are fresh allocations every step, so some pointers usually move: the table is re-sent every
+            # step -- from PINNED memory with an asynchronous copy.  (torch.tensor(list, device=...) is a pageable,
+            # synchronous host-to-device copy: it made the host wait for the whole backward pass here, ~30 ms per step,
+            # and the next step's forward then started on an empty queue.)
             dev = self.decayed[0].device
-            self._table = (key, torch.tensor(rows, dtype=torch.int64, device=dev),
-                           torch.tensor(cmap, dtype=torch.int32, device=dev), chunk)
+            if self._table is None or self._table[1].shape[0] != len(key):
+                chunk, cmap = 0, []
+                for i, k_ in enumerate(key):
+                    nch = (k_[5] + 4095) // 4096
+                    cmap += [i] * nch
+                    chunk += nch
+                nchs = np.array([(k_[5] + 4095) // 4096 for k_ in key], dtype=np.int64)
+                self._chunk0 = np.concatenate([[0], np.cumsum(nchs)[:-1]]).astype(np.int64)
+                self._pinned = [torch.empty((len(key), 7), dtype=torch.int64).pin_memory() for _ in range(2)]
+                self._flip = 0
+                dev_tab = torch.empty((len(key), 7), dtype=torch.int64, device=dev)
+                dev_map = torch.tensor(cmap, dtype=torch.int32, device=dev)        # static (numels only): sent once
+                self._table = (None, dev_tab, dev_map, chunk)
+            host = self._pinned[self._flip]           # two buffers in turn: the previous step's copy may still be queued
+            self._flip ^= 1
+            rows = np.array(key, dtype=np.int64)
+            rows[:, 5] |= self._chunk0 << 40
+            host.numpy()[:] = rows
+            self._table[1].copy_(host, non_blocking=True)
+            self._table = (key,) + self._table[1:]
         _, tab, cmap, chunks = self._table
         step = (steps.pop() if steps else 0) + 1
         g0 = self.opt.param_groups[0]
