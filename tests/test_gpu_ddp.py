@@ -69,3 +69,60 @@ def test_two_ranks_full_model_ddp_step(shipped):
         assert finite and gn > 0
         assert same_g, 'DDP did not leave the same (averaged) gradient on both ranks'
         assert same_w, 'weights diverged after the optimizer step'
+
+
+def _rccl_worker(port, q):
+    """One rank on the `nccl` backend (= RCCL): process-group creation, DistributedDataParallel with bucket views over
+    RCCL's all-reduce (one rank: the collective runs, the result is the local gradient), the shipped step twice."""
+    for p in (os.path.join(ROOT, 't-mae_amd'), os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    import tmae_oracle as O
+    from conftest import build_product_model
+    from pcdet.models import model_fn_decorator
+    from tmae_amd.train import AdamOneCycle, OneCycle, train_one_step
+    dev = torch.device('cuda:0')
+    P = O.init_params(O.default_model_cfg(1), seed=3, pred_scale=0.1)
+    pts, prv = O.synth_frame_pair(3000, 2, seed=50)
+    vox = O.voxelize(pts, [-74.88, -74.88, -5, 74.88, 74.88, 3], [0.32, 0.32, 8], [468, 468, 1])
+    noise = torch.rand(100000, generator=torch.Generator().manual_seed(0))[:vox['voxel_coords'].shape[0]]
+    out = []
+    for use_ddp in (False, True):
+        model, cfg, _ = build_product_model(1, params=P, device=dev)
+        model.train()
+        net = model
+        if use_ddp:               # wrap_ddp's arguments (it returns the bare model for a world of one)
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=True,
+                                                            gradient_as_bucket_view=True, bucket_cap_mb=25)
+        opt = AdamOneCycle(model)
+        sch = OneCycle(opt, 10, 3e-3, [0.95, 0.85], 10, 0.4)
+        batch = {'points': torch.from_numpy(pts).to(dev), 'points_prev': torch.from_numpy(prv).to(dev), 'batch_size': 2,
+                 'mae_noise': noise.to(dev)}
+        losses = []
+        for it in range(2):
+            loss, _, _ = train_one_step(net, opt, sch, dict(batch), it, model_fn_decorator(), amp_dtype=torch.bfloat16)
+            losses.append(float(loss))
+        wts = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+        out.append((losses, wts))
+    t = torch.ones(1024, device=dev)
+    dist.all_reduce(t)
+    ok = bool((t == 1).all())
+    dist.barrier()
+    dist.destroy_process_group()
+    (l0, w0), (l1, w1) = out
+    q.put((l0, l1, float((w0 - w1).abs().max()), float(w0.abs().max()), ok))
+
+
+def test_single_rank_rccl_backend_runs_the_shipped_step():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(31700 + os.getpid() % 2000, q))
+    p.start()
+    l0, l1, dw, wmax, ok = q.get(timeout=500)
+    p.join(120)
+    assert ok, 'RCCL all_reduce on one rank changed the data'
+    assert all(abs(a - b) <= 2e-3 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)
+    assert dw <= 2e-2 * wmax, (dw, wmax)          # same two steps with and without DistributedDataParallel
