@@ -545,7 +545,7 @@ def test_token_gemm_kernel_vs_torch():
     strided input (column slice of a packed buffer), ragged token counts, and the dX use on W^T."""
     from tmae_amd import ops
     torch.manual_seed(3)
-    # (>= 65536 tokens with contraction 256 and 256 / 512 columns: the W-resident persistent kernel)
+    # (>= 32768 tokens: the W-in-registers kernel of csrc/token_gemm_wreg.hip; below: the chunk-streaming kernel)
     for (m, k, n) in ((8192, 128, 128), (50001, 128, 256), (33333, 256, 512), (20000, 256, 768), (9999, 256, 64),
                       (30001, 512, 256), (12000, 512, 64), (9000, 256, 2304), (70001, 256, 512), (150003, 256, 256),
                       (65536, 256, 512)):
@@ -566,7 +566,7 @@ def test_token_gemm_kernel_vs_torch():
     y = ops.token_gemm(xs, w, None, force=True)
     ref = xs.float() @ w.float().t()
     assert (y.float() - ref).abs().max().item() <= 2e-2 * float(ref.abs().max())
-    big = torch.randn(80001, 384, device=dev()).bfloat16()   # the same through the W-resident kernel
+    big = torch.randn(80001, 384, device=dev()).bfloat16()   # the same through the W-in-registers kernel
     xs = big[:, 128:384]
     w = (torch.randn(256, 256, device=dev()) * 0.1).bfloat16()
     y = ops.token_gemm(xs, w, None, force=True)
@@ -663,7 +663,7 @@ def test_pos_folded_in_projection_vs_materialised(shift):
     """tmae_token_gemm_pos (position embedding as a one-hot k-step of the in-projection GEMM) vs the fp32 formula
     (x + pos[cell]) W^T + b of WindowAttention.forward (sst_basic_block.py:45-52) on the same bf16 x / W: every
     width the layers use (d = 128: 128 / 256 / 384 rows; d = 256: 256 / 512 / 768 rows, chunk-streaming kernel below
-    65 536 tokens and the W-resident one above), v rows without position; then the backward of ops.pos_proj (dx
+    32 768 tokens and the W-in-registers one above), v rows without position; then the backward of ops.pos_proj (dx
     accumulated into the alias gradient, dW incl. the position part, db) vs autograd of the formula."""
     from tmae_amd import ops
     sh = 4 if shift else 8
