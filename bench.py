@@ -69,6 +69,18 @@ def _pmc(key):
     return None
 
 
+def _counters(*kernels):
+    """Matrix-core / vector-ALU utilisation of the named kernels from the committed counter passes
+    (profiles/round3_pmc_counters.json <- profiles/round3_pmc_kernels.md): fractions of all SIMD-cycles of a launch."""
+    f = os.path.join(ROOT, 'profiles', 'round3_pmc_counters.json')
+    if not os.path.exists(f):
+        return None
+    tab = json.load(open(f))['kernels']
+    out = {k: {q: tab[k][q] for q in ('mfma_busy', 'valu_busy', 'wave_wait_frac', 'wave_issue_stall_frac', 'l2_hit_rate')}
+           for k in kernels if k in tab}
+    return {'kernels': out, 'source': 'profiles/round3_pmc_counters.json (rocprofv3 --pmc, MI355X_MICROARCH.md units)'} if out else None
+
+
 _STAGE2_TOKENS = []
 
 
@@ -119,7 +131,8 @@ def token_gemm_roofline(model, batch, amp_dtype, iters=20):
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
             'traffic': _pmc('token_gemm'),
             'traffic_source': 'profiles/round3_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
-            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k}
+            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k,
+            'utilisation': _counters('token_gemm_wreg_kernel<256, 4, 8, false, false>')}
 
 
 def wgrad_roofline(model, batch, amp_dtype, iters=20):
@@ -150,8 +163,9 @@ def wgrad_roofline(model, batch, amp_dtype, iters=20):
                       'op = the kernel + its slab-reduction launch)', 'bound': 'hbm',
             'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': _pmc('wgrad'),
-            'traffic_source': 'profiles/round2_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
-            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k}
+            'traffic_source': 'profiles/round3_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
+            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k,
+            'utilisation': _counters('wgrad256_kernel<false, 1>', 'wgrad_reduce_kernel')}
 
 
 def attention_roofline(model, batch, amp_dtype, iters=20):
@@ -211,8 +225,10 @@ def attention_roofline(model, batch, amp_dtype, iters=20):
     return {'kernel': 'win_attn_bwd_mfma_kernel<16,NT> (stage-1 self-attention backward, previous frame; the op = its 3 '
                       'tile-class launches NT=1,2,4)', 'bound': 'hbm', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
-            'traffic_source': 'profiles/round2_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
-            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': int(m)}
+            'traffic_source': 'profiles/round3_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
+            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': int(m),
+            'utilisation': _counters('win_attn_bwd_mfma_kernel<16, 1, false>', 'win_attn_bwd_mfma_kernel<16, 1, true>',
+                                     'win_attn_bwd_mfma_kernel<16, 2, false>', 'win_attn_bwd_mfma_kernel<16, 4, false>')}
 
 
 def _host_cores():
