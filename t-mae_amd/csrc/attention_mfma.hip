@@ -132,22 +132,6 @@ __device__ __forceinline__ void split_frag(const float* f, typename Frag<FR * 4>
     lo[j] = f2bf(f[j] - bf2f(h));
   }
 }
-// The split only matters when the logits are divided by a small tau: a bf16 rounding of unit vectors moves a cosine
-// logit by <= ~2^-8, i.e. by 0.004 / tau.  For tau >= TAU_PRECISE (the module's tau is initialised to 1 and the reference's
-// optimizer never trains it: DESIGN.md section 2) that is below the bf16 rounding of the probabilities themselves, and the
-// kernels take the plain form: one MFMA per logit tile instead of three and no split arithmetic (these kernels are
-// VALU-bound: profiles/round3_pmc_counters.json).  `precise` is wave-uniform (a scalar load of tau).
-#define TAU_PRECISE 0.5f
-template <int FR>
-__device__ __forceinline__ void split_or_pack(bool precise, const float* f, typename Frag<FR * 4>::T& hi,
-                                              typename Frag<FR * 4>::T& lo) {
-  if (precise) {
-    split_frag<FR>(f, hi, lo);
-  } else {
-    hi = pack_frag<FR>(f);
-    lo = hi;                                    // never read on this path
-  }
-}
 
 
 // Row images whose transposed reads feed the SWAPPED products (rows = channels, columns = tokens): tile ct, position
@@ -386,8 +370,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
   }
   __syncthreads();
   const int nq = PAIR ? 1 : (Tq + 15) >> 4, nk = PAIR ? 1 : (Tk + 15) >> 4;
-  const float tau_f = fmaxf(tau[0], tau_min), inv_tau = 1.0f / tau_f;
-  const bool precise = tau_f < TAU_PRECISE;
+  const float inv_tau = 1.0f / fmaxf(tau[0], tau_min);
   // ---- all global row loads are issued here, one dependent round after the token ids
   frag_t kf[NT], kl[NT], qf[NT], ql[NT];
   typedef typename RawFrag<FR>::T raw_t;
@@ -409,7 +392,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
     if (t < nk) {                                   // wave-uniform
       unpack_row<FR>(rk[t], f);
       normalize_frag<FR>(f, 1.0f);
-      split_or_pack<FR>(precise, f, kf[t], kl[t]);
+      split_frag<FR>(f, kf[t], kl[t]);
       unpack_row<FR>(rv[t], f);
       store_img_frag<DH>(&vimg[w][slot * RB], g, pack_frag<FR>(f));
     } else {
@@ -423,7 +406,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
     if (t < nq) {
       unpack_row<FR>(rq[t], f);
       normalize_frag<FR>(f, inv_tau);
-      split_or_pack<FR>(precise, f, qf[t], ql[t]);
+      split_frag<FR>(f, qf[t], ql[t]);
     }
   }
   __syncthreads();
@@ -455,11 +438,9 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
       for (int kt = 0; kt < NT; ++kt) {
         if constexpr (KB) st[kt] = kbias[kt]; else st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (kt < nk) {
-          if (precise) {
-            st[kt] = mfma_s(kl[kt], qf[qt], st[kt]);
-            st[kt] = mfma_s(kf[kt], ql[qt], st[kt]);
-          }
-          st[kt] = mfma_s(kf[kt], qf[qt], st[kt]);                   // S^T tile: rows = keys 4g+r, col = query i
+          st[kt] = mfma_s(kl[kt], qf[qt], st[kt]);                   // S^T tile: rows = keys 4g+r, col = query i
+          st[kt] = mfma_s(kf[kt], ql[qt], st[kt]);
+          st[kt] = mfma_s(kf[kt], qf[qt], st[kt]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -616,7 +597,6 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
     return;
   }
   const float tau_c = fmaxf(tau[0], tau_min), inv_tau = 1.0f / tau_c;
-  const bool precise = tau_c < TAU_PRECISE;
   const __amdgpu_buffer_rsrc_t rsq = make_rsrc(q, nb.q), rsk = make_rsrc(k, nb.k), rsv = make_rsrc(v, nb.v),
                                rsg = make_rsrc(dout, nb.g), rsl = make_rsrc(lse, nb.lse), rsdq = make_rsrc(dq, nb.dq),
                                rsdk = make_rsrc(dk, nb.dk), rsdv = make_rsrc(dv, nb.dv);
@@ -649,7 +629,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
     if (t < nk) {                                    // wave-uniform
       unpack_row<FR>(rk[t], f);
       const float nrm = normalize_frag<FR>(f, 1.0f);
-      split_or_pack<FR>(precise, f, kf[t], kl[t]);
+      split_frag<FR>(f, kf[t], kl[t]);
       if (g == 0) knorm[w][slot] = nrm;
       unpack_row<FR>(rv[t], f);
       vr[t] = pack_frag<FR>(f);
@@ -662,7 +642,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
     if (t < nq) {
       unpack_row<FR>(rq[t], f);
       const float nrm = normalize_frag<FR>(f, inv_tau);
-      split_or_pack<FR>(precise, f, qf[t], ql[t]);
+      split_frag<FR>(f, qf[t], ql[t]);
       store_img_frag<DH>(&qimg[w][slot * RB], g, qf[t]);
       if (g == 0) qnorm[w][slot] = nrm;
       float gfl[FR];
@@ -715,11 +695,8 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
         if (kt < nk) {
           const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
           // swapped: rows = keys 4g+r of this tile, column = query i; masked keys / absent queries give p = 0
-          f32x4 sT = KB ? kbias[KB ? kt : 0] : z;
-          if (precise) {
-            sT = mfma_s(kl[kt], qf[qt], sT);
-            sT = mfma_s(kf[kt], ql[qt], sT);
-          }
+          f32x4 sT = mfma_s(kl[kt], qf[qt], KB ? kbias[KB ? kt : 0] : z);
+          sT = mfma_s(kf[kt], ql[qt], sT);
           sT = mfma_s(kf[kt], qf[qt], sT);
           const f32x4 dP = mfma_s(vr[kt], gf[qt], z);
           if constexpr (!RECOMP) { sTk[kt] = sT; dPk[kt] = dP; }
@@ -739,11 +716,8 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
           f32x4 sT, dP, pT;
           if constexpr (RECOMP) {
             const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-            sT = z;
-            if (precise) {
-              sT = mfma_s(kl[kt], qf[qt], sT);
-              sT = mfma_s(kf[kt], ql[qt], sT);
-            }
+            sT = mfma_s(kl[kt], qf[qt], z);
+            sT = mfma_s(kf[kt], ql[qt], sT);
             sT = mfma_s(kf[kt], qf[qt], sT);
             dP = mfma_s(vr[kt], gf[qt], z);
 #pragma unroll
