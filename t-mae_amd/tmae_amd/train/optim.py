@@ -80,6 +80,7 @@ class AdamOneCycle:
                                      for p in self.decayed)
         self._steps = {}             # id(p) -> steps taken (host mirror of the state's step tensors)
         self._table = None           # (key, device table, device chunk map, chunks)
+        self._pinned, self._flip, self._chunk0 = None, 0, None      # pinned staging buffers of the table (two, in turn)
 
     @property
     def lr(self):
@@ -145,8 +146,17 @@ class AdamOneCycle:
             st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
             self._steps[id(p)] = 0
-        if id(p) not in self._steps:          # first use, or a state that load_state_dict brought in
-            self._steps[id(p)] = int(float(st['step']))
+        if id(p) not in self._steps:          # a state that load_state_dict brought in: read every step count at once
+            ps = [q for q in self.decayed if id(q) not in self._steps and 'step' in self.opt.state.get(q, {})]
+            tens = [q for q in ps if torch.is_tensor(self.opt.state[q]['step'])]
+            if tens:
+                vals = torch.stack([self.opt.state[q]['step'].detach().reshape(()).float().to(p.device) for q in tens]).cpu().tolist()
+                for q, v in zip(tens, vals):
+                    self._steps[id(q)] = int(v)
+            for q in ps:
+                if id(q) not in self._steps:                  # a plain number (older checkpoints)
+                    self._steps[id(q)] = int(self.opt.state[q]['step'])
+                    self.opt.state[q]['step'] = torch.tensor(float(self._steps[id(q)]), dtype=torch.float32, device=q.device)
         return st
 
     def _native_step(self, copy_dtype=None):
