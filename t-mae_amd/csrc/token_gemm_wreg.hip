@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
   const int srow = lane / CPL, schunk = lane % CPL;
   const unsigned soff = (unsigned)((srow * ldy + colbase) * 2 + schunk * 16);
   // PT token groups (16 tokens each x this wave's 16 NTC columns) at a time: M = their MFMAs, E = their epilogue.
-  // (PT = 2 -- two groups share every W fragment register read -- and a half-step stagger of waves 4-7 against their
+  // (The non-temporal policy on the x DMA loads: 149 against 127-131 us on one box, not used.  PT = 2 -- two groups share every W fragment register read -- and a half-step stagger of waves 4-7 against their
   // SIMD partners were both measured: within the run-to-run noise of this HBM-bound kernel, and PT = 2 spills at KA = 288.)
   constexpr int PT = 1, NPR = TGW / PT;
   f32x4 acc[NTC][PT];
