@@ -164,6 +164,37 @@ def test_multi_tensor_adam_step_equals_torch_adam():
     assert opt._table is not None
 
 
+@pytest.mark.gpu
+def test_optimizer_step_does_not_wait_for_the_gpu():
+    """The one-launch step must ENQUEUE and return: its pointer table travels from pinned memory with an asynchronous
+    copy.  (A pageable torch.tensor(..., device=) copy made the host wait for everything queued before -- the whole
+    backward pass -- and the next forward then started on an empty queue.)  With ~100 ms of matmuls queued, step() has
+    to come back long before they finish."""
+    import time
+    from tmae_amd.train.optim import AdamOneCycle
+    dev = torch.device('cuda', 0)
+    ps = [torch.nn.Parameter(torch.randn(64, 64, device=dev)) for _ in range(50)]
+    opt = AdamOneCycle(ps, lr=1e-3, wd=0.01)
+    for it in range(2):                                   # first steps: state / table creation
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        opt.step(copy_dtype=torch.bfloat16)
+    a = torch.randn(8192, 8192, device=dev)
+    b = (a @ a) * 1e-4                                    # library warm-up outside the measurement
+    torch.cuda.synchronize()
+    for _ in range(16):
+        b = (b @ a) * 1e-4
+    for p in ps:
+        p.grad = torch.randn_like(p)                      # fresh gradient tensors: the table has to be re-sent
+    t1 = time.perf_counter()
+    opt.step(copy_dtype=torch.bfloat16)
+    t_step = time.perf_counter() - t1
+    torch.cuda.synchronize()
+    t_rest = time.perf_counter() - t1 - t_step
+    assert t_rest > 0.02, (t_step, t_rest)                # the GPU still had >= 20 ms of queued work when step() returned
+    assert t_step < 0.02, (t_step, t_rest)                # ... and step() did not wait for it
+
+
 def build_tiny_tmae(device='cpu'):
     """The small 1-stage model of the O2 fixture through the product's registry path (YAML edits only)."""
     from pcdet.models import build_network
