@@ -255,7 +255,7 @@ def _oracle_case(O, n_points, stages, iters, pred_scale=1.0):
         loss.backward()
         if i > 0:                           # iteration 0 = warm-up (allocator, thread pool, first-touch)
             times.append(time.perf_counter() - t0)
-    return times, float(loss), (cfg, pts, prv, noise)
+    return times, float(loss.detach()), (cfg, pts, prv, noise)
 
 
 def igemm_roofline(batch_per_gpu, iters=10):
