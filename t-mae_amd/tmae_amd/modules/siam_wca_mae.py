@@ -15,6 +15,18 @@ from .sst import SSTBlockV1, WCABlock
 
 
 _SHIFTS = {}
+_BYX = {}
+
+
+def _byx(coords):
+    """Columns (b, y, x) of [b, z, y, x] voxel coordinates as int32.  (`coords[:, [0, 2, 3]]` builds its index tensor
+    from the Python list with a pageable, SYNCHRONOUS host-to-device copy: near the end of forward() the host waited
+    ~10 ms there for the whole queued forward pass; the index is cached per device instead.)"""
+    idx = _BYX.get(coords.device)
+    if idx is None:
+        idx = _BYX[coords.device] = torch.tensor([0, 2, 3], dtype=torch.long, device=coords.device)
+    return coords.index_select(1, idx).int()
+
 
 
 def _sample_shift(batch, device):
@@ -92,7 +104,7 @@ class SiamWCA_MAE(nn.Module):
 
     # ------------------------------------------------------------------ encoder (SiamWCA_MAE.py:184-218)
     def sparse_encode(self, voxel_features, voxel_coords, batch_size, previous_sstblock=False):
-        x = SparseConvTensor(voxel_features, voxel_coords[:, [0, 2, 3]].int().contiguous(), self.sparse_shape,
+        x = SparseConvTensor(voxel_features, _byx(voxel_coords), self.sparse_shape,
                              batch_size)
         feats, strides = {}, {}
         for i, blk in enumerate(self.sst_blocks):                   # Siamese: the same weights for both frames
@@ -107,8 +119,8 @@ class SiamWCA_MAE(nn.Module):
         Attention and the sparse convs never mix samples, and BatchNorm keeps per-frame statistics (`groups`), so
         the results are those of the reference's two calls (SiamWCA_MAE.py:262-263, :289)."""
         B = batch_size
-        ind_p = coords_prev[:, [0, 2, 3]].int()
-        ind_c = coords_cur[:, [0, 2, 3]].int()
+        ind_p = _byx(coords_prev)
+        ind_c = _byx(coords_cur)
         shift = _sample_shift(B, ind_c.device)       # cached: a torch.tensor(..., device=) per step is a synchronous copy
         ind_c = ind_c + shift
         cdt = ops.compute_dtype(feats_prev)
@@ -207,7 +219,7 @@ class SiamWCA_MAE(nn.Module):
         batch_dict['spatial_features_stride'] = spatial_stride
         assert spatial.shape[0] == bs and spatial.shape[2] == self.grid_size[1] and spatial.shape[3] == self.grid_size[0]
 
-        all_ind = all_coords[:, [0, 2, 3]].int().contiguous()
+        all_ind = _byx(all_coords)
         grid_all = ops.index_grid(all_ind, bs, self.sparse_shape[0], self.sparse_shape[1])
         nhwc = spatial.permute(0, 2, 3, 1)
         pyramid = ops.dense_gather(nhwc, grid_all, all_ind)         # decoder feature at EVERY current voxel
