@@ -125,6 +125,16 @@ class CenterHead(nn.Module):
         out[:, :k] = comp[:, :k]
         return out * mask.unsqueeze(2).to(out.dtype)
 
+    def _code_weights(self, like, values):
+        """LOSS_WEIGHTS.code_weights as a tensor on `like`'s device, cached: new_tensor(list) is a pageable, synchronous
+        host-to-device copy -- once per head and step the host waited there for the whole forward pass."""
+        key = (like.device, like.dtype, tuple(float(v) for v in values))
+        cache = self.__dict__.setdefault('_cw_cache', {})
+        t = cache.get(key)
+        if t is None:
+            t = cache[key] = torch.tensor(key[2], dtype=like.dtype, device=like.device)
+        return t
+
     def get_loss(self):
         """center_head.py:237-262 (+ loss_utils FocalLossCenterNet / RegLossCenterNet)."""
         pred_dicts = self.forward_ret_dict['pred_dicts']
@@ -140,7 +150,7 @@ class CenterHead(nn.Module):
             feat = pred_boxes.permute(0, 2, 3, 1).reshape(B, -1, C)
             pred = feat.gather(1, ind.unsqueeze(2).expand(B, ind.shape[1], C))
             reg = _reg_loss(pred, target_dicts['target_boxes'][idx], target_dicts['masks'][idx])
-            loc_loss = (reg * reg.new_tensor(w['code_weights'])).sum() * w['loc_weight']
+            loc_loss = (reg * self._code_weights(reg, w['code_weights'])).sum() * w['loc_weight']
             loss = loss + hm_loss + loc_loss
             tb_dict['hm_loss_head_%d' % idx] = hm_loss.detach()        # tensors: no host sync (the reference calls .item())
             tb_dict['loc_loss_head_%d' % idx] = loc_loss.detach()

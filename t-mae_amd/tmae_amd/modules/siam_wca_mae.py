@@ -98,7 +98,8 @@ class SiamWCA_MAE(nn.Module):
         offs = np.concatenate([[0], np.cumsum(voxels_per_sample)]).astype(np.int32)
         keep_frac = 1 - self.mask_ratio
         n_vis = int(sum(int(L * keep_frac) for L in voxels_per_sample))        # known on the host: no sync
-        mask, vis_index, _ = ops.random_mask(noise, torch.from_numpy(offs).to(dev), batch_size, keep_frac)
+        offs_dev = torch.from_numpy(offs).pin_memory().to(dev, non_blocking=True)      # (a pageable copy is synchronous)
+        mask, vis_index, _ = ops.random_mask(noise, offs_dev, batch_size, keep_frac)
         vis = vis_index[:n_vis].long()
         return all_voxel_features[vis], all_voxel_coords[vis], mask
 
