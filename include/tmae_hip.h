@@ -356,14 +356,15 @@ int tmae_multi_cast_transpose(const void* table, int count, int64_t total_tiles,
 /* The optimizer step of the recipe for ALL parameter tensors in one launch: decoupled weight decay p *= 1 - wd*lr for every
  * entry (OptimWrapper.step, tools/train_utils/optimization/fastai_optim.py:139-150: true_wd, bn_wd), then torch.optim.Adam's
  * update (fastai_optim.py:151 -> Adam.step; amsgrad / maximize off, weight_decay 0 inside Adam) for the entries that
- * have a gradient.  table (device, 8-byte aligned): entries of seven int64 -- p, grad (0: decay only), exp_avg, exp_avg_sq,
- * the per-parameter step tensor (1 float on the device, receives `step`; 0: none), numel | first chunk << 40, a bf16 copy
- * of the parameter to refresh (what the autocast forward reads; 0: none) -- where a chunk = 4096 elements and the entries
- * are ordered by their first chunk; chunk_tensor (device int32 [total_chunks]) =
- * the entry of every chunk.  step = this step's number (>= 1, after the increment); the bias corrections are taken in
- * double on the host as torch does. */
+ * have a gradient.  table (device, 8-byte aligned): entries of EIGHT int64 -- p, grad (0: decay only), exp_avg, exp_avg_sq,
+ * the per-parameter step tensor (1 float on the device, receives the entry's step; 0: none), numel | first chunk << 40, a
+ * bf16 copy of the parameter to refresh (what the autocast forward reads; 0: none), the entry's step number after the
+ * increment (>= 1 for entries with a gradient; Adam keeps the step per parameter, so tensors that missed a gradient once
+ * lag behind) -- where a chunk = 4096 elements and the entries are ordered by their first chunk; chunk_tensor (device
+ * int32 [total_chunks]) = the entry of every chunk.  The bias corrections are taken in double per entry, as torch takes
+ * them on the host. */
 int tmae_adam_step(const void* table, const int32_t* chunk_tensor, int64_t total_chunks, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, int64_t step, void* stream);
+                   float eps, float weight_decay, void* stream);
 
 /* Running statistics of all BatchNorm layers of a forward pass in one launch (torch.nn.BatchNorm's training-mode update:
  * running = (1 - momentum) * running + momentum * batch statistic, unbiased variance; num_batches_tracked += 1 -- the norms

@@ -1,8 +1,11 @@
 #!/bin/bash
 # A/B of one environment switch on one box: kernel trace of 3 steps with VAR=A and VAR=B, kernels matching PATTERN listed.
 # bash profiles/scripts/ab_env.sh VAR A B PATTERN
+# The switches exist only in the -DTMAE_AB debug build (python t-mae_amd/build.py --ab, built here on the box if missing).
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
+[ -f t-mae_amd/build_ab/libtmae_ab.so ] || python3 t-mae_amd/build.py --ab || exit 1
+export TMAE_LIB_PATH="$GRAFT_REPO_ROOT/t-mae_amd/build_ab/libtmae_ab.so"
 VAR=$1; PAT=$4
 for val in "$2" "$3"; do
   export $VAR=$val

@@ -28,7 +28,16 @@ def _newer(src, dst, extra=()):
     return any(os.path.getmtime(s) > t for s in (src,) + tuple(extra))
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, ab=False):
+    """ab=True: the A/B debug build (-DTMAE_AB: environment switches and the retired kernel variants behind them, see
+    csrc/common.h) -> t-mae_amd/build_ab/libtmae_ab.so; load it with TMAE_LIB_PATH (profiles/scripts/ab_env.sh)."""
+    global OBJ, LIBDIR, LIB
+    flags = FLAGS
+    if ab:
+        OBJ = os.path.join(HERE, 'build_ab', 'obj')
+        LIBDIR = os.path.join(HERE, 'build_ab')
+        LIB = os.path.join(LIBDIR, 'libtmae_ab.so')
+        flags = FLAGS + ['-DTMAE_AB']
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
@@ -42,7 +51,7 @@ def build(force=False, verbose=False):
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        cmd = [HIPCC] + flags + ['-c', src, '-o', obj]
         if verbose:
             cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -70,5 +79,6 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--force', action='store_true')
     ap.add_argument('--verbose', action='store_true')
+    ap.add_argument('--ab', action='store_true', help='A/B debug build with -DTMAE_AB into t-mae_amd/build_ab/')
     a = ap.parse_args()
-    print(build(a.force, a.verbose))
+    print(build(a.force, a.verbose, a.ab))

@@ -296,13 +296,10 @@ int tmae_win_attn_bwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
                            int ny, int nx, int do_shift, const float* tau, float tau_min, void* dq, int64_t lddq,
                            void* dk, int64_t lddk, void* dv, int64_t lddv, float* dtau_partial,
                            const int32_t* worklist, hipStream_t stream);
+// bf16 inputs take the MFMA kernels; TMAE_ATTN_VALU=1 (debug build only, common.h) sends them to the fp32-style VALU kernels
 static bool use_mfma() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("TMAE_ATTN_IMPL");
-    v = (e && e[0] == 'v') ? 0 : 1;
-  }
-  return v == 1;
+  static const int valu = TMAE_AB_INT("TMAE_ATTN_VALU", 0);
+  return valu == 0;
 }
 
 static inline void attn_dims(int ny, int nx, int& Wy, int& Wx) {

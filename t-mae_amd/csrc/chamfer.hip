@@ -237,7 +237,7 @@ int tmae_chamfer_fwd(const float* pred, const float* gt, const float* weights, i
   if (m < 0 || np <= 0 || np > 64 || ng <= 0 || ng > 64) return TMAE_EARG;
   if (m == 0) return TMAE_OK;
   if (!pred || !gt || !weights || !per_voxel || !idx_x || !idx_y) return TMAE_EARG;
-  static const bool generic = [] { const char* e = getenv("TMAE_CHAMFER_GENERIC"); return e && atoi(e) != 0; }();
+  static const bool generic = TMAE_AB_INT("TMAE_CHAMFER_GENERIC", 0) != 0;
   if (np == 16 && ng == 64 && !generic)
     hipLaunchKernelGGL(chamfer_fwd_16x64_kernel, dim3(tmae_cdiv(m, 4)), dim3(256), 0, stream, pred, gt, weights, m,
                        per_voxel, idx_x, idx_y);
@@ -255,7 +255,7 @@ int tmae_chamfer_bwd(const float* pred, const float* gt, const float* weights, c
   if (m < 0 || np <= 0 || np > 64 || ng <= 0 || ng > 64) return TMAE_EARG;
   if (m == 0) return TMAE_OK;
   if (!pred || !gt || !weights || !idx_x || !idx_y || !scale || !dpred) return TMAE_EARG;
-  static const bool generic = [] { const char* e = getenv("TMAE_CHAMFER_GENERIC"); return e && atoi(e) != 0; }();
+  static const bool generic = TMAE_AB_INT("TMAE_CHAMFER_GENERIC", 0) != 0;
   if (np == 16 && ng == 64 && !generic)
     hipLaunchKernelGGL(chamfer_bwd_16x64_kernel, dim3(tmae_cdiv(m, 4)), dim3(256), 0, stream, pred, gt, weights, idx_x,
                        idx_y, scale, m, dpred);
@@ -265,4 +265,4 @@ int tmae_chamfer_bwd(const float* pred, const float* gt, const float* weights, c
   return tmae_launch_status();
 }
 
-int tmae_abi_version(void) { return 5; }
+int tmae_abi_version(void) { return 6; }

@@ -149,3 +149,15 @@ int tmae_token_gemm_wreg(const void* x, int64_t ldx, int64_t m, int k, const voi
 size_t tmae_scan_i32_workspace(int64_t n);
 int tmae_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total, void* ws, size_t ws_bytes,
                   hipStream_t stream);
+
+// ---- A/B switches ------------------------------------------------------------------------------
+// Only a debug build made with -DTMAE_AB (python t-mae_amd/build.py --ab -> t-mae_amd/build_ab/libtmae_ab.so, used by
+// profiles/scripts/ab_env.sh through TMAE_LIB_PATH) reads the environment, and only such a build carries the retired
+// kernel variants behind those switches.  The shipped libtmae_hip.so picks its kernels from its arguments alone: a C-ABI
+// library must not change behaviour with the caller's environment.
+#ifdef TMAE_AB
+#include <cstdlib>
+#define TMAE_AB_INT(name, dflt) ([]() -> int { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }())
+#else
+#define TMAE_AB_INT(name, dflt) (dflt)
+#endif

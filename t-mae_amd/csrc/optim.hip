@@ -7,7 +7,7 @@
 // when all four pointers of the tensor are 16-byte aligned (gradients may be views into a DDP bucket).
 #include "common.h"
 
-struct AdamEntry {           // 7 x int64 in the host-built table
+struct AdamEntry {           // 8 x int64 in the host-built table
   float* p;                  // parameter (fp32), updated in place
   const float* g;            // gradient (fp32) or NULL: decay only (a parameter that received no gradient)
   float* m;                  // exp_avg
@@ -15,14 +15,26 @@ struct AdamEntry {           // 7 x int64 in the host-built table
   float* step;               // torch.optim.Adam's per-parameter step tensor (device, 1 float) or NULL
   int64_t numel_chunk0;      // numel | first chunk << 40
   __hip_bfloat16* copy;      // bf16 copy of the updated parameter (what the autocast path reads) or NULL
+  int64_t step_no;           // THIS tensor's step number after the increment (>= 1 where g != NULL): tensors that missed a
+                             // gradient in some earlier step lag behind the others and keep their own bias corrections
 };
 
 #define ADAM_CHUNK 4096
 
 __global__ __launch_bounds__(256) void adam_step_kernel(const AdamEntry* __restrict__ tab, const int* __restrict__ chunk_tensor,
-                                                       float decay, float w1, float b2, float w2, float step_size,
-                                                       float inv_bc2_sqrt, float eps, float step_value) {
+                                                       float decay, float w1, float b2, float w2, double lr,
+                                                       double beta1, double beta2, float eps) {
   const AdamEntry e = tab[chunk_tensor[blockIdx.x]];
+  // the scalar factors in double, as torch.optim.Adam computes them on the host (python floats); per ENTRY: one thread,
+  // through LDS (a double pow is a few hundred instructions)
+  __shared__ float s_fac[2];
+  if (threadIdx.x == 0 && e.g) {
+    const double bc1 = 1.0 - pow(beta1, (double)e.step_no), bc2 = 1.0 - pow(beta2, (double)e.step_no);
+    s_fac[0] = (float)(lr / bc1);
+    s_fac[1] = (float)(1.0 / sqrt(bc2));
+  }
+  __syncthreads();
+  const float step_size = s_fac[0], inv_bc2_sqrt = s_fac[1], step_value = (float)e.step_no;
   const int64_t numel = e.numel_chunk0 & (((int64_t)1 << 40) - 1), chunk0 = e.numel_chunk0 >> 40;
   const int64_t base = ((int64_t)blockIdx.x - chunk0) * ADAM_CHUNK;
   const int64_t left = numel - base;
@@ -72,19 +84,17 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamEntry* __restr
 }
 
 int tmae_adam_step(const void* table, const int32_t* chunk_tensor, int64_t total_chunks, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, int64_t step, void* stream_) {
+                   float eps, float weight_decay, void* stream_) {
   (void)hipGetLastError();
-  if (total_chunks < 0 || total_chunks >= ((int64_t)1 << 31) || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) ||
+  if (total_chunks < 0 || total_chunks >= ((int64_t)1 << 31) || !(beta1 >= 0.f && beta1 < 1.f) ||
       !(beta2 >= 0.f && beta2 < 1.f))
     return TMAE_EARG;
   if (total_chunks == 0) return TMAE_OK;
   if (!table || !chunk_tensor || ((uintptr_t)table & 7)) return TMAE_EARG;
-  // the scalar factors in double, as torch.optim.Adam computes them on the host (python floats)
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const float decay = (float)(1.0 - (double)weight_decay * (double)lr);
   hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream_,
                      (const AdamEntry*)table, (const int*)chunk_tensor, decay, (float)(1.0 - (double)beta1), beta2,
-                     (float)(1.0 - (double)beta2), (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps, (float)step);
+                     (float)(1.0 - (double)beta2), (double)lr, (double)beta1, (double)beta2, eps);
   return tmae_launch_status();
 }
 

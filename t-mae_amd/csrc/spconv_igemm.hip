@@ -26,6 +26,7 @@ __device__ __forceinline__ unsigned ig_bf16_bits(float v) {
   return (unsigned)__builtin_bit_cast(unsigned short, __float2bfloat16(v));
 }
 
+#ifdef TMAE_AB   // the retired register-staged 128 x 128 kernel: only in the A/B debug build (common.h)
 template <int CIN>
 __global__ __launch_bounds__(256, 2) void spconv_igemm_kernel(const __hip_bfloat16* __restrict__ feat, int64_t ldf,
                                                              const int32_t* __restrict__ nbr, int64_t m_out,
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void spconv_igemm_kernel(const __hip_bfloat
   }
 }
 
+#endif
 // ------------------------------------------------------------------------------------------------
 // Ring variant (the one that runs): 256-row x 128-column tile, 8 waves, the slices travel global -> LDS by LDS-DMA
 // (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a 3-slot ring, two slices in flight behind a
@@ -307,10 +309,10 @@ static int igemm_launch(const void* feat, int64_t ldf, int64_t m_in, int cin, co
   if (!feat || !nbr || !w || !out || m_in == 0) return TMAE_EARG;
   if (((uintptr_t)feat & 15) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) return TMAE_EARG;
   const int nct = cout / IG_BN;
-  static const int impl = [] { const char* e = getenv("TMAE_IGEMM"); return e ? atoi(e) : 3; }();   // 2: register-staged 128x128
+  static const int impl = TMAE_AB_INT("TMAE_IGEMM", 3);   // 2 (debug build only): the retired register-staged 128x128 kernel
   if (impl == 3) {
     const int64_t rts = (m_out + IR_BM - 1) / IR_BM;
-    static const int wide_off = [] { const char* e = getenv("TMAE_IGEMM_BN256"); return e && atoi(e) == 0; }();
+    static const int wide_off = TMAE_AB_INT("TMAE_IGEMM_BN256", 1) == 0;
     const int bn = (cout % 256 == 0 && !wide_off) ? 256 : 128;
     const int nctr = cout / bn;
     const int64_t grid = ((rts + 7) / 8) * 8 * nctr;     // = 8 XCD residues x ceil(rts / 8) row tiles x column tiles
@@ -331,6 +333,7 @@ static int igemm_launch(const void* feat, int64_t ldf, int64_t m_in, int cin, co
 #undef IR_LAUNCH
     return tmae_launch_status();
   }
+#ifdef TMAE_AB
   const int64_t rts = (m_out + IG_BM - 1) / IG_BM;
   const int64_t grid = ((rts + 7) / 8) * 8 * nct;       // row tiles padded to a multiple of 8 (the XCD-aware id map)
   if (cin == 128)
@@ -343,6 +346,10 @@ static int igemm_launch(const void* feat, int64_t ldf, int64_t m_in, int cin, co
     hipLaunchKernelGGL((spconv_igemm_kernel<384>), dim3((unsigned)grid), dim3(256), 0, stream, (const __hip_bfloat16*)feat,
                        ldf, nbr, m_out, (const __hip_bfloat16*)w, cout, (__hip_bfloat16*)out, ldo);
   return tmae_launch_status();
+#else
+  (void)nct;
+  return TMAE_EARG;
+#endif
 }
 
 int tmae_spconv_fwd(const void* feat, int64_t ldf, int64_t m_in, int cin, const int32_t* nbr, int64_t m_out,

@@ -278,8 +278,8 @@ static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const
                      TG_ARGS, (const __hip_bfloat16*)nullptr, (const uint8_t*)cells)
   // heavy shapes: the W-in-registers kernel of token_gemm_wreg.hip (x read once for all N columns, LDS-DMA ring)
   {
-    const char* e = getenv("TMAE_TG_WREG");
-    if (!aux && !(e && atoi(e) == 0) && m >= (n > 512 ? 65536 : 32768)) {
+    static const int wreg = TMAE_AB_INT("TMAE_TG_WREG", 1);
+    if (!aux && wreg != 0 && m >= (n > 512 ? 65536 : 32768)) {
       const int rc = tmae_token_gemm_wreg(x, ldx, m, k, w, n, bias, (const uint8_t*)cells, y, ldy, 0, stream_);
       if (rc != TMAE_EARG) return rc;
     }

@@ -437,7 +437,7 @@ static void wgrad_plan(int64_t m, int n, int k, int& splits, int& rows_per_split
   const bool big = wgrad_big_tile(n, k);
   const int bt = big ? WG2_B : WG_BN;
   const int nb = ((n + bt - 1) / bt) * ((k + bt - 1) / bt);
-  static const int slots = [] { const char* e = getenv("TMAE_WGRAD_SLOTS"); return e ? atoi(e) : 0; }();
+  static const int slots = TMAE_AB_INT("TMAE_WGRAD_SLOTS", 0);
   const int per_xcd = slots > 0 ? slots : (big ? 32 : 64);
   int64_t c = per_xcd / nb;
   if (c < 1) c = 1;
@@ -500,8 +500,8 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
     if (nbr) hipLaunchKernelGGL((wgrad256_kernel<true>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
     else {
       // dY columns belong to one n-block each: with a single k-block nobody re-reads them; likewise X with one n-block
-      // (measured on the priced shape: -3 %; TMAE_WGRAD_NT=0 turns it off)
-      static const int ntl_env = [] { const char* e = getenv("TMAE_WGRAD_NT"); return e ? atoi(e) : 3; }();
+      // (measured on the priced shape: -3 %; TMAE_WGRAD_NT=0 in a -DTMAE_AB build turns it off)
+      static const int ntl_env = TMAE_AB_INT("TMAE_WGRAD_NT", 3);
       const int ntl = ntl_env & ((KB == 1 ? 1 : 0) | (NB == 1 ? 2 : 0));
       if (ntl == 1) hipLaunchKernelGGL((wgrad256_kernel<false, 1>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
       else if (ntl == 2) hipLaunchKernelGGL((wgrad256_kernel<false, 2>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);

@@ -81,7 +81,7 @@ SIGNATURES = {
     'tmae_frame_prepare': (I, [P, I, L, P, P, F, I, I, F, F, F, F, F, F, F, I, P, P, P, Z, P]),
     'tmae_token_gemm': (I, [P, L, L, I, P, I, P, P, L, P]),
     'tmae_multi_cast_transpose': (I, [P, I, L, P]),
-    'tmae_adam_step': (I, [P, P, L, F, F, F, F, F, L, P]),
+    'tmae_adam_step': (I, [P, P, L, F, F, F, F, F, P]),
     'tmae_bn_running_update': (I, [P, I, P, P, I, P]),
     'tmae_token_gemm_acc': (I, [P, L, L, I, P, I, P, P, L, P]),
     'tmae_token_gemm_dgelu': (I, [P, L, L, I, P, I, P, P, P, L, P]),
@@ -104,7 +104,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError('libtmae_hip.so ABI version mismatch; rebuild with t-mae_amd/build.py')
 
@@ -120,3 +120,32 @@ def check(rc, what):
     if rc != 0:
         msg = _ERR.get(rc, f'hipError_t {rc}' if rc > 0 else f'error {rc}')
         raise TmaeHipError(f'{what}: {msg}')
+
+
+class PinnedStager:
+    """Host -> device upload of a small int64 table through pinned staging buffers, asynchronously.
+
+    `upload(values, device_tensor)` writes `values` into the next of `depth` pinned buffers and enqueues the copy on
+    the current stream.  Every buffer carries the event recorded behind its last copy and is rewritten only after that
+    event has completed: a host running several steps ahead of the GPU (nothing else orders the two once the step's
+    host syncs are gone) would otherwise overwrite a table whose copy is still queued, and the launch behind that copy
+    would read pointers of a LATER step.  The wait is free in the steady state (the buffer's copy is `depth` uploads old).
+    """
+
+    def __init__(self, shape, depth=2):
+        self._bufs = [torch.empty(shape, dtype=torch.int64).pin_memory() for _ in range(depth)]
+        self._events = [None] * depth
+        self._next = 0
+
+    def upload(self, values, device_tensor):
+        i = self._next
+        self._next = (i + 1) % len(self._bufs)
+        ev = self._events[i]
+        if ev is not None:
+            ev.synchronize()                       # the previous copy out of this buffer has run
+        self._bufs[i].numpy()[...] = values
+        device_tensor.copy_(self._bufs[i], non_blocking=True)
+        if ev is None:
+            ev = self._events[i] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device_tensor.device))
+        return device_tensor

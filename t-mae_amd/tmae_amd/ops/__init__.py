@@ -7,7 +7,7 @@ No tensor math happens here besides allocation and dense GEMMs handed to hipBLAS
 import torch
 
 from .. import _lib
-from .._lib import lib, check
+from .._lib import lib, check, PinnedStager
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
@@ -162,9 +162,16 @@ def _bn_flush(pending):
     import struct
     with torch.no_grad():
         dev = pending[0][0].running_mean.device
-        ok = all(bn.running_mean.is_cuda and bn.running_mean.dtype == torch.float32 and mean.dtype == torch.float32
-                 and var.dtype == torch.float32 and mean.is_contiguous() and var.is_contiguous()
-                 and bn.running_mean.device == dev for bn, mean, var, _, _ in pending)
+        def _raw_ok(bn, mean, var):          # everything the kernel reads / writes through raw pointers
+            rm, rv, nbt = bn.running_mean, bn.running_var, bn.num_batches_tracked
+            n = rm.numel()
+            return (rm.is_cuda and rm.device == dev and rm.dtype == torch.float32 and rm.is_contiguous()
+                    and rv.device == dev and rv.dtype == torch.float32 and rv.is_contiguous() and rv.numel() == n
+                    and nbt.device == dev and nbt.dtype == torch.int64            # 64-bit atomic add in the kernel
+                    and mean.device == dev and var.device == dev and mean.dtype == torch.float32
+                    and var.dtype == torch.float32 and mean.is_contiguous() and var.is_contiguous()
+                    and mean.numel() == n and var.numel() == n)
+        ok = all(_raw_ok(bn, mean, var) for bn, mean, var, _, _ in pending)
         if not ok:
             for bn, mean, var, mom, count in pending:
                 bn.running_mean.mul_(1 - mom).add_(mean.reshape(-1), alpha=mom)
@@ -192,13 +199,8 @@ def _bn_flush(pending):
         # host would wait here for everything queued before); two staging buffers in turn
         ent = _BN_TABLES.get((dev, len(flat)))
         if ent is None:
-            ent = _BN_TABLES[(dev, len(flat))] = [[torch.empty(len(flat), dtype=torch.int64).pin_memory() for _ in range(2)], 0,
-                                                 torch.empty(len(flat), dtype=torch.int64, device=dev)]
-        host = ent[0][ent[1]]
-        ent[1] ^= 1
-        host.numpy()[:] = flat
-        table = ent[2]
-        table.copy_(host, non_blocking=True)
+            ent = _BN_TABLES[(dev, len(flat))] = (PinnedStager((len(flat),)), torch.empty(len(flat), dtype=torch.int64, device=dev))
+        table = ent[0].upload(flat, ent[1])      # event-guarded: never rewrites a buffer whose copy is still queued
         base = table.data_ptr()
         check(lib.tmae_bn_running_update(base, nb, base + nb * 32, base + nb * 32 + nu * 16, len(counters), _s()),
               'tmae_bn_running_update')

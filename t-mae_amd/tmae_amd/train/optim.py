@@ -79,8 +79,9 @@ class AdamOneCycle:
         self._native = fused and all(p.dtype == torch.float32 and p.is_contiguous() and p.device == self.decayed[0].device
                                      for p in self.decayed)
         self._steps = {}             # id(p) -> steps taken (host mirror of the state's step tensors)
-        self._table = None           # (key, device table, device chunk map, chunks)
-        self._pinned, self._flip, self._chunk0 = None, 0, None      # pinned staging buffers of the table (two, in turn)
+        self._table = None           # (device table, device chunk map, chunks)
+        self._pinned, self._chunk0 = None, None      # event-guarded pinned staging buffers of the table (_lib.PinnedStager)
+        self._warned = False
 
     @property
     def lr(self):
@@ -134,6 +135,9 @@ class AdamOneCycle:
             return
         if self.decayed and self.wd != 0.0:
             torch._foreach_mul_(self.decayed, 1.0 - self.wd * self._lr)
+        for p in self.decayed:               # host mirror of the step counts: read a loaded state BEFORE torch moves it
+            if p.grad is not None and id(p) not in self._steps and len(self.opt.state.get(p, {})):
+                self._state_of(p)
         self.opt.step()
         for p in self.decayed:
             if p.grad is not None:
@@ -160,67 +164,63 @@ class AdamOneCycle:
         return st
 
     def _native_step(self, copy_dtype=None):
-        """Decay + Adam for every tensor in one launch.  Returns False (caller takes torch's path) when the tensors
-        with a gradient are not all at the same step count, which the kernel's scalar bias corrections assume."""
-        from .._lib import lib, check
-        key, steps = [], set()
+        """Decay + Adam for every tensor in one launch; every table entry carries its own step number, so tensors that
+        missed a gradient in some earlier step (and lag behind, as in torch.optim.Adam) stay on this path.  Returns
+        False (caller takes torch's path) only for gradients the kernel cannot read (dtype / layout / device)."""
+        from .._lib import lib, check, PinnedStager
+        key, any_grad = [], False
         copies = [None] * len(self.decayed)
         if copy_dtype == torch.bfloat16:
             from .. import ops
             copies = ops.plain_copy_targets(self.decayed, copy_dtype)
+        for p in self.decayed:
+            g = p.grad
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device):
+                if not self._warned:
+                    self._warned = True
+                    import warnings
+                    warnings.warn('AdamOneCycle: a gradient is not fp32 / contiguous / on the parameter\'s device; '
+                                  'this step runs on torch.optim.Adam instead of tmae_adam_step')
+                return False
+        new_steps = {}
         for p, cp in zip(self.decayed, copies):
             cptr = 0 if cp is None else cp.data_ptr()
             g = p.grad
-            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device):
-                return False
-            st = self._state_of(p) if g is not None else None
             if g is not None:
-                steps.add(self._steps[id(p)])
+                st = self._state_of(p)
+                any_grad = True
                 if st['step'].device != p.device:
                     st['step'] = st['step'].to(device=p.device, dtype=torch.float32)
+                new_steps[id(p)] = self._steps[id(p)] + 1
                 key.append((p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(),
-                            st['step'].data_ptr(), p.numel(), cptr))
+                            st['step'].data_ptr(), p.numel(), cptr, new_steps[id(p)]))
             else:
-                key.append((p.data_ptr(), 0, 0, 0, 0, p.numel(), cptr))
-        if len(steps) > 1:
-            return False
-        if not steps and self.wd == 0.0:
+                key.append((p.data_ptr(), 0, 0, 0, 0, p.numel(), cptr, 0))
+        if not any_grad and self.wd == 0.0:
             return True
         key = tuple(key)
-        if self._table is None or self._table[0] != key:
-            # Gradients are fresh allocations every step, so some pointers usually move: the table is re-sent every
-            # step -- from PINNED memory with an asynchronous copy.  (torch.tensor(list, device=...) is a pageable,
-            # synchronous host-to-device copy: it made the host wait for the whole backward pass here, ~30 ms per step,
-            # and the next step's forward then started on an empty queue.)
-            dev = self.decayed[0].device
-            if self._table is None or self._table[1].shape[0] != len(key):
-                chunk, cmap = 0, []
-                for i, k_ in enumerate(key):
-                    nch = (k_[5] + 4095) // 4096
-                    cmap += [i] * nch
-                    chunk += nch
-                nchs = np.array([(k_[5] + 4095) // 4096 for k_ in key], dtype=np.int64)
-                self._chunk0 = np.concatenate([[0], np.cumsum(nchs)[:-1]]).astype(np.int64)
-                self._pinned = [torch.empty((len(key), 7), dtype=torch.int64).pin_memory() for _ in range(2)]
-                self._flip = 0
-                dev_tab = torch.empty((len(key), 7), dtype=torch.int64, device=dev)
-                dev_map = torch.tensor(cmap, dtype=torch.int32, device=dev)        # static (numels only): sent once
-                self._table = (None, dev_tab, dev_map, chunk)
-            host = self._pinned[self._flip]           # two buffers in turn: the previous step's copy may still be queued
-            self._flip ^= 1
-            rows = np.array(key, dtype=np.int64)
-            rows[:, 5] |= self._chunk0 << 40
-            host.numpy()[:] = rows
-            self._table[1].copy_(host, non_blocking=True)
-            self._table = (key,) + self._table[1:]
-        _, tab, cmap, chunks = self._table
-        step = (steps.pop() if steps else 0) + 1
+        # Gradients are fresh allocations every step and the step numbers move, so the table is re-sent every step --
+        # from PINNED memory with an asynchronous copy.  (torch.tensor(list, device=...) is a pageable, synchronous
+        # host-to-device copy: it made the host wait for the whole backward pass here, ~30 ms per step, and the next
+        # step's forward then started on an empty queue.)
+        dev = self.decayed[0].device
+        if self._table is None or self._table[0].shape[0] != len(key):
+            nchs = np.array([(k_[5] + 4095) // 4096 for k_ in key], dtype=np.int64)
+            cmap = np.repeat(np.arange(len(key), dtype=np.int32), nchs)
+            self._chunk0 = np.concatenate([[0], np.cumsum(nchs)[:-1]]).astype(np.int64)
+            self._pinned = PinnedStager((len(key), 8))
+            dev_tab = torch.empty((len(key), 8), dtype=torch.int64, device=dev)
+            dev_map = torch.from_numpy(cmap).to(dev)        # static (numels only): sent once
+            self._table = (dev_tab, dev_map, int(nchs.sum()))
+        rows = np.array(key, dtype=np.int64)
+        rows[:, 5] |= self._chunk0 << 40
+        # a staging buffer is rewritten only once the copy last queued out of it has run (the host may be steps ahead)
+        self._pinned.upload(rows, self._table[0])
+        tab, cmap, chunks = self._table
         g0 = self.opt.param_groups[0]
         check(lib.tmae_adam_step(tab.data_ptr(), cmap.data_ptr(), chunks, self._lr, self._mom, g0['betas'][1], g0['eps'],
-                                 self.wd, step, torch.cuda.current_stream(tab.device).cuda_stream), 'tmae_adam_step')
-        for p in self.decayed:
-            if p.grad is not None:
-                self._steps[id(p)] = step
+                                 self.wd, torch.cuda.current_stream(tab.device).cuda_stream), 'tmae_adam_step')
+        self._steps.update(new_steps)
         # the kernel wrote through raw pointers: tell autograd (the bf16 copies / folded weights of tmae_amd.ops are keyed
         # on the parameters' version counters, exactly as an in-place torch op would have moved them)
         torch.autograd.graph.increment_version(self.decayed)

@@ -87,8 +87,9 @@ def test_trajectory_equals_the_reference_optimizer():
 
 @pytest.mark.gpu
 def test_trajectory_equals_the_reference_optimizer_gpu():
-    """The same 20 steps on the GPU: the one-launch multi-tensor step (tmae_adam_step) for steps 0-7 (step 7 has a
-    parameter without a gradient: decay only), torch's Adam from step 8 on, where the step counts of the tensors differ."""
+    """The same 20 steps on the GPU, all on the one-launch multi-tensor step (tmae_adam_step): step 7 has a parameter
+    without a gradient (decay only), and from step 8 on that tensor's step count lags the others' -- every table entry
+    carries its own step number, as torch.optim.Adam keeps one per parameter."""
     from tmae_amd.train import build_optimizer, build_scheduler
     g = golden('O1_optimizer')
     dev = torch.device('cuda', 0)
@@ -104,7 +105,7 @@ def test_trajectory_equals_the_reference_optimizer_gpu():
         opt.zero_grad()
         for i, (n, p) in enumerate(model.named_parameters()):
             p.grad = None if (it == 7 and n == 'fc2.weight') else torch.from_numpy(g[f'tiny_grad_{i}'][it].copy()).to(dev)
-        opt.step()
+        assert opt._native_step() is True                   # (== opt.step(); mixed step counts stay on the one-launch path)
         for i, (n, p) in enumerate(model.named_parameters()):
             np.testing.assert_allclose(p.detach().cpu().numpy(), g[f'tiny_traj_{i}'][it], rtol=2e-6, atol=2e-7,
                                        err_msg=f'{n} step {it}')
@@ -193,6 +194,57 @@ def test_optimizer_step_does_not_wait_for_the_gpu():
     t_rest = time.perf_counter() - t1 - t_step
     assert t_rest > 0.02, (t_step, t_rest)                # the GPU still had >= 20 ms of queued work when step() returned
     assert t_step < 0.02, (t_step, t_rest)                # ... and step() did not wait for it
+
+
+@pytest.mark.gpu
+def test_optimizer_steps_queued_far_ahead_of_the_gpu_read_their_own_tables():
+    """Four optimizer steps (and four BatchNorm running-statistics flushes) enqueued back to back behind ~100 ms of
+    queued matmuls, no synchronisation in between: every step's pointer table travels through a pinned staging buffer,
+    and a buffer may be rewritten only after the copy last queued out of it has run (_lib.PinnedStager) -- otherwise an
+    earlier launch would read a later step's gradient / exp_avg pointers.  Result vs the same steps on torch.optim.Adam."""
+    from tmae_amd import ops
+    from tmae_amd.train.optim import AdamOneCycle
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(97, 33, device=dev)) for _ in range(30)]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    grads = [[torch.randn_like(p) for p in ps] for _ in range(5)]
+    opt = AdamOneCycle(ps, lr=2e-3, wd=0.01)
+    ropt = torch.optim.Adam(ref, lr=2e-3, betas=(0.9, 0.99))
+    bns = [torch.nn.BatchNorm1d(16).to(dev) for _ in range(3)]
+    rbn = [(b.running_mean.clone(), b.running_var.clone()) for b in bns]
+    stats = [[(torch.randn(16, device=dev), torch.rand(16, device=dev) + 0.5) for _ in bns] for _ in range(5)]
+
+    def one(it):
+        for p, gr in zip(ps, grads[it]):
+            p.grad = gr.clone()                               # fresh allocations: the table changes every step
+        opt.step()
+        with ops.defer_bn_updates():
+            for b, (mu, var) in zip(bns, stats[it]):
+                ops._bn_running_update(b, mu, var, 100.0)
+    one(0)                                                    # state / table creation
+    a = torch.randn(8192, 8192, device=dev)
+    b = (a @ a) * 1e-4
+    torch.cuda.synchronize()
+    for _ in range(16):
+        b = (b @ a) * 1e-4                                    # ~100 ms of queued work in front of the steps
+    for it in range(1, 5):
+        one(it)
+    torch.cuda.synchronize()
+    for it in range(5):
+        torch._foreach_mul_(ref, 1.0 - 0.01 * 2e-3)
+        for p, gr in zip(ref, grads[it]):
+            p.grad = gr
+        ropt.step()
+        for k, (mu, var) in enumerate(stats[it]):
+            rbn[k][0].mul_(0.9).add_(mu, alpha=0.1)
+            rbn[k][1].mul_(0.9).add_(var, alpha=0.1 * 100.0 / 99.0)
+    for p, r in zip(ps, ref):
+        assert (p - r).abs().max().item() <= 2e-6 * max(1.0, r.abs().max().item())
+    for b, (rm, rv) in zip(bns, rbn):
+        torch.testing.assert_close(b.running_mean, rm, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(b.running_var, rv, rtol=1e-6, atol=1e-6)
+        assert int(b.num_batches_tracked) == 5
 
 
 def build_tiny_tmae(device='cpu'):

@@ -36,7 +36,7 @@ def test_g2_losses(ft_oracle):
     rl = ft_oracle.reg_loss_centernet(pred_box, torch.from_numpy(g1['masks']), torch.from_numpy(g1['inds']),
                                       torch.from_numpy(g1['target_boxes']))
     (fl + rl.sum()).backward()
-    assert abs(float(fl) - float(g2['focal'])) <= 1e-5 * abs(float(g2['focal']))
+    assert abs(float(fl.detach()) - float(g2['focal'])) <= 1e-5 * abs(float(g2['focal']))
     np.testing.assert_allclose(rl.detach().numpy(), g2['reg'], atol=1e-6)
     np.testing.assert_allclose(pred_hm.grad.flatten()[torch.from_numpy(g2['grad_probe_index'])].numpy(), g2['grad_probe_hm'],
                                atol=1e-7)
