@@ -81,6 +81,50 @@ def _counters(*kernels):
     return {'kernels': out, 'source': 'profiles/round3_pmc_counters.json (rocprofv3 --pmc, MI355X_MICROARCH.md units)'} if out else None
 
 
+def box_peaks(dev, reps=5):
+    """What THIS box sustains: a 16-bytes-per-lane streaming copy of 1 GiB (HBM
+    bytes = read + write) and a register-resident bf16 MFMA loop on random operands, both library probes
+    (csrc/probe.hip), HIP events on the launch stream.  Every `roofline*` entry carries these as `peak_measured` next to
+    the spec `peak`; `frac_of_measured` is the fraction that is comparable across boxes."""
+    import ctypes as C
+    from tmae_amd._lib import lib, check
+    st = torch.cuda.current_stream().cuda_stream
+    nbytes = 1 << 30
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    flops = C.c_int64(0)
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms_copy = timed(lambda: check(lib.tmae_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, st), 'tmae_probe_copy'))
+    ms_mfma = timed(lambda: check(lib.tmae_probe_mfma(8192, sink.data_ptr(), C.addressof(flops), st), 'tmae_probe_mfma'))
+    del src, dst
+    return {'hbm_copy_gbs': round(2 * nbytes / (ms_copy * 1e-3) / 1e9, 1), 'hbm_copy_ms': round(ms_copy, 4),
+            'mfma_bf16_tflops': round(flops.value / (ms_mfma * 1e-3) / 1e12, 1), 'mfma_ms': round(ms_mfma, 4),
+            'how': '1 GiB float4 streaming copy (read + write bytes) and a 16x16x32 bf16 MFMA loop on random register '
+                   'operands, 512 threads per CU (csrc/probe.hip); mean of %d launches' % reps}
+
+
+def _with_measured(entry, peaks):
+    """peak_measured / frac_of_measured beside the spec-peak fraction of a roofline entry."""
+    if entry is None or peaks is None:
+        return entry
+    pm = peaks['hbm_copy_gbs'] if entry.get('bound') == 'hbm' else peaks['mfma_bf16_tflops']
+    entry['peak_measured'] = pm
+    entry['frac_of_measured'] = round(entry['achieved'] / pm, 5) if pm else None
+    return entry
+
+
 _STAGE2_TOKENS = []
 
 
@@ -362,6 +406,39 @@ def chamfer_parity(O, loss_default_cpu, case, dev):
                                  'chamfer_abs_err_bf16': round(abs(c16 - lc), 7), 'pred_scale': 0.1}}
 
 
+def training_curves(dev, steps=30, points=20000, batch=2, lr_steps=60):
+    """Does the bf16 step TRAIN like the fp32 step?  The same `steps` optimizer steps (full 3-stage model, B = `batch`
+    pairs of `points`-point scans, the recipe's Adam one-cycle, same initial weights, same batches, same masking noise:
+    torch.manual_seed before each run and the masking draws are the only device RNG calls) once in fp32 and once under bf16
+    autocast; returns both loss curves.  tests/test_gpu_parity.py::test_bf16_trains_like_fp32 asserts the band."""
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    from pcdet.models import model_fn_decorator
+    from tmae_amd.train import (SyntheticTemporalDataset, build_model_from_cfg, build_optimizer, build_scheduler,
+                                train_one_step)
+    cfg = cfg_from_yaml_file(os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae_ssl.yaml'), EasyDict())
+    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=points, batch_size=batch)
+    host = [ds.batch(i) for i in range(4)]
+    batches = [{'points': torch.from_numpy(b['points']).to(dev), 'points_prev': torch.from_numpy(b['points_prev']).to(dev),
+                'batch_size': b['batch_size']} for b in host]
+    curves = {}
+    for name, amp in (('fp32', None), ('bf16', torch.bfloat16)):
+        torch.manual_seed(1234)
+        model = build_model_from_cfg(cfg, ds).to(dev)
+        model.train()
+        opt = build_optimizer(model, cfg.OPTIMIZATION)
+        sched, _ = build_scheduler(opt, lr_steps, 1, -1, cfg.OPTIMIZATION)
+        mf = model_fn_decorator()
+        torch.manual_seed(99)                                           # the masking noise of every step
+        losses = [train_one_step(model, opt, sched, dict(batches[i % 4]), i, mf, amp_dtype=amp)[0].detach() for i in range(steps)]
+        curves[name] = [round(float(v), 5) for v in torch.stack(losses).cpu()]
+    a, b = np.array(curves['fp32']), np.array(curves['bf16'])
+    return {'config': f'{steps} optimizer steps, B = {batch} x {points}-pt pairs (4 batches cycled), full model, Adam one-cycle '
+                      f'over {lr_steps} steps, same init / batches / masking noise', 'fp32': curves['fp32'], 'bf16': curves['bf16'],
+            'max_rel_gap': round(float(np.max(np.abs(a - b) / np.abs(a))), 5),
+            'fp32_first5_last5': [round(float(a[:5].mean()), 5), round(float(a[-5:].mean()), 5)],
+            'bf16_first5_last5': [round(float(b[:5].mean()), 5), round(float(b[-5:].mean()), 5)]}
+
+
 def step_flops(model, batch, amp):
     """Algorithmic FLOPs of ONE training step on `batch` from SURVEY.md 8(d)'s formulas, evaluated on the batch's REAL
     token / window / kernel-pair counts (one extra no-grad forward pass collects the index sets): forward, and 3x that
@@ -478,10 +555,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # TEST-ONLY (tests/test_gpu_ddp.py): TMAE_BENCH_SHARED_GPU=1 puts every rank on GPU 0 and swaps RCCL for gloo (two
+    # ranks cannot share one GPU under RCCL), so that the launcher, the rank bookkeeping and the JSON relay of an N > 1
+    # run can be rehearsed on a one-GPU box.  Such a line says so in `collective_backend` and is not a measurement.
+    shared_gpu = world > 1 and os.environ.get('TMAE_BENCH_SHARED_GPU') == '1'
+    dev_index = 0 if shared_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group('nccl')          # RCCL over xGMI
+        dist.init_process_group('gloo' if shared_gpu else 'nccl')          # nccl = RCCL over xGMI
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from pcdet.config import EasyDict, cfg_from_yaml_file
@@ -506,7 +588,7 @@ def main():
     if args.skip_unread_gradients:
         cfg.OPTIMIZATION.SKIP_UNREAD_GRADIENTS = True
     opt = build_optimizer(model, cfg.OPTIMIZATION)      # before the DDP wrap: it fixes the set of reduced parameters
-    ddp = wrap_ddp(model, local_rank)
+    ddp = wrap_ddp(model, dev_index)
     sched, _ = build_scheduler(opt, 1000, cfg.OPTIMIZATION.NUM_EPOCHS, -1, cfg.OPTIMIZATION)
     model_func = model_fn_decorator()
     amp = torch.bfloat16 if args.dtype == 'bf16' else None
@@ -525,7 +607,8 @@ def main():
         return train_one_step(ddp, opt, sched, dict(batches[i % nb]), i, model_func, amp_dtype=amp)[0]
 
     if args.probe_only:
-        print(json.dumps({'roofline': token_gemm_roofline(model, dict(batches[0]), amp),
+        print(json.dumps({'box_peaks': box_peaks(dev),
+                          'roofline': token_gemm_roofline(model, dict(batches[0]), amp),
                           'roofline_wgrad': wgrad_roofline(model, dict(batches[0]), amp),
                           'roofline_attention': attention_roofline(model, dict(batches[0]), amp),
                           'roofline_igemm': igemm_roofline(args.batch_per_gpu)}), flush=True)
@@ -585,7 +668,8 @@ def main():
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                        **({'variant': 'skip_unread_gradients (not the reference step: see DESIGN.md)'}
                           if args.skip_unread_gradients else {})},
-            'ranks': ranks_seen, 'collective_backend': 'nccl (RCCL)' if world > 1 else None,
+            'ranks': ranks_seen,
+            'collective_backend': ('gloo, all ranks on GPU 0: REHEARSAL, not a measurement' if shared_gpu else 'nccl (RCCL)') if world > 1 else None,
             'rank_ms_per_step': {'min': round(1e3 * min(per_rank) / args.steps, 3),
                                  'max': round(1e3 * max(per_rank) / args.steps, 3)},
         }
@@ -601,12 +685,16 @@ def main():
                 'note': 'algorithmic FLOPs of SURVEY.md 8(d) on the real token / window / kernel-pair counts of batch 0 '
                         '(forward x 3 for forward + backward) / measured step time / dense bf16 MFMA peak'}
         log(f'timed region done: {1e3 * elapsed / args.steps:.1f} ms/step; timing the dominant kernel ...')
-        line['roofline'] = token_gemm_roofline(model, dict(batches[0]), amp)
+        peaks = box_peaks(dev)
+        line['box_peaks'] = peaks
+        if 'roofline_step' in line:
+            _with_measured(line['roofline_step'], peaks)
+        line['roofline'] = _with_measured(token_gemm_roofline(model, dict(batches[0]), amp), peaks)
         # round-1 history: the two kernels that led the profile before this one, still priced the same way
-        line['roofline_wgrad'] = wgrad_roofline(model, dict(batches[0]), amp)
-        line['roofline_attention'] = attention_roofline(model, dict(batches[0]), amp)
+        line['roofline_wgrad'] = _with_measured(wgrad_roofline(model, dict(batches[0]), amp), peaks)
+        line['roofline_attention'] = _with_measured(attention_roofline(model, dict(batches[0]), amp), peaks)
         if args.task == 'pretrain' and amp is not None:
-            line['roofline_igemm'] = igemm_roofline(args.batch_per_gpu)
+            line['roofline_igemm'] = _with_measured(igemm_roofline(args.batch_per_gpu), peaks)
         if world == 1 and not args.no_cpu_baseline:
             log('timing the CPU oracle (cpu_baseline: warm-up + 3 iterations at C2 and C1) ...')
             line['cpu_baseline'], (O, loss_cpu, case) = cpu_baseline(args.cpu_points)
@@ -615,6 +703,8 @@ def main():
                 line['parity'] = chamfer_parity(O, loss_cpu, case, dev)
                 line['chamfer_abs_err_fp32'] = line['parity']['default_head']['chamfer_abs_err_fp32']
                 line['chamfer_abs_err_bf16'] = line['parity']['default_head']['chamfer_abs_err_bf16']
+                log('30 training steps in fp32 and in bf16 (same init, batches, masking noise) ...')
+                line['parity']['training_curves'] = training_curves(dev)
         if (world == 1 and not args.no_secondary and not args.no_cpu_baseline and args.task == 'pretrain'
                 and args.shape == 'once' and not args.skip_unread_gradients):
             line['secondary'] = secondary_runs(args, log)

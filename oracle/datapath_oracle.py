@@ -84,7 +84,8 @@ def augment(points, params):
     return p
 
 
-def prepare_pair(points, points_prev, pose_cur, pose_prev, params, perm, pc_range, ego_radius=2.0, align=True):
+def prepare_pair(points, points_prev, pose_cur, pose_prev, params, perm, pc_range, ego_radius=2.0, align=True,
+                 augment_points=True):
     """One sample: remove ego points, align the previous frame, joint augmentation, range crop on x / y
     (common_utils.mask_points_by_range), shuffle of the combined array with `perm` (an index permutation of the kept
     points, previous frame first), split.  Returns (points_prev [n0,4], points [n1,4]) float32."""
@@ -93,7 +94,8 @@ def prepare_pair(points, points_prev, pose_cur, pose_prev, params, perm, pc_rang
     if align:
         prv = convert_prv_frame_to_cur(prv, pose_prev, pose_cur)
     both = np.vstack((np.hstack((prv, np.zeros((prv.shape[0], 1)))), np.hstack((cur, np.ones((cur.shape[0], 1))))))
-    both = augment(both, params)                                       # the group-id column rides along untouched
+    if augment_points:             # training; the test-mode path (_combine_two_pcs, once_temporal_dataset.py:214-218) has none
+        both = augment(both, params)                                   # the group-id column rides along untouched
     m = (both[:, 0] >= pc_range[0]) & (both[:, 0] <= pc_range[3]) & (both[:, 1] >= pc_range[1]) & (both[:, 1] <= pc_range[4])
     both = both[m]
     if perm is not None:
@@ -109,3 +111,132 @@ def collate(samples):
                                    for i, s in enumerate(samples)], axis=0)
     out['batch_size'] = len(samples)
     return out
+
+
+# ----------------------------------------------------------------------------------------------- labels (fine-tune)
+
+def limit_period(val, offset=0.5, period=np.pi):
+    """common_utils.limit_period (common_utils.py:85-88): fp32 (check_numpy_to_torch casts to float)."""
+    v = torch.from_numpy(np.asarray(val)).float()
+    return (v - torch.floor(v / period + offset) * period).numpy()
+
+
+def rotate_z_fp32(xyz, angle):
+    """common_utils.rotate_points_along_z on one batch of [n, 3] rows: fp32 matmul with (cos, sin; -sin, cos)."""
+    t = torch.from_numpy(np.asarray(xyz)).float()
+    ang = torch.from_numpy(np.array([angle])).float()
+    c, s = torch.cos(ang), torch.sin(ang)
+    z, o = ang.new_zeros(1), ang.new_ones(1)
+    rm = torch.stack((c, s, z, -s, c, z, z, z, o), dim=1).view(-1, 3, 3).float()
+    return torch.matmul(t[None, :, 0:3], rm)[0].numpy()
+
+
+def augment_boxes(gt_boxes, params):
+    """gt_boxes [n, 7] (x, y, z, dx, dy, dz, heading) through random_world_flip / rotation / scaling
+    (data_augmentor.py:55-142), in the array's own dtype (the reference edits annos['boxes_3d'] in place; the rotated
+    centres come back from an fp32 matmul)."""
+    b = np.array(gt_boxes, copy=True)
+    for axis in params['flips']:
+        if axis == 'x':
+            b[:, 1] = -b[:, 1]
+            b[:, 6] = -b[:, 6]
+        else:
+            b[:, 0] = -b[:, 0]
+            b[:, 6] = -(b[:, 6] + np.pi)
+    b[:, 0:3] = rotate_z_fp32(b[:, 0:3], params['rot'])
+    b[:, 6] += params['rot']
+    b[:, :6] *= params['scale']
+    return b
+
+
+def boxes_to_corners_3d(boxes):
+    """box_utils.boxes_to_corners_3d (box_utils.py:28-53), fp32."""
+    b = torch.from_numpy(np.asarray(boxes)).float()
+    template = b.new_tensor(([1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1],
+                             [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1])) / 2
+    corners = b[:, None, 3:6].repeat(1, 8, 1) * template[None, :, :]
+    c, s = torch.cos(b[:, 6]), torch.sin(b[:, 6])
+    z, o = b.new_zeros(b.shape[0]), b.new_ones(b.shape[0])
+    rm = torch.stack((c, s, z, -s, c, z, z, z, o), dim=1).view(-1, 3, 3)
+    corners = torch.matmul(corners, rm) + b[:, None, 0:3]
+    return corners.numpy()
+
+
+def mask_boxes_outside_range(boxes, limit_range, min_num_corners=1):
+    """box_utils.mask_boxes_outside_range_numpy (box_utils.py:56-72)."""
+    limit_range = np.asarray(limit_range, dtype=np.float32)
+    corners = boxes_to_corners_3d(np.asarray(boxes)[:, 0:7])
+    mask = ((corners >= limit_range[0:3]) & (corners <= limit_range[3:6])).all(axis=2)
+    return mask.sum(axis=1) >= min_num_corners
+
+
+def prepare_labels(gt_boxes, gt_names, class_names, params, pc_range, training=True, remove_outside=True):
+    """The label side of ONCETemporalDataset.prepare_data (once_temporal_dataset.py:246-330) without gt_sampling:
+    world augmentation of the boxes (training), heading wrapped to [-pi, pi) (DataAugmentor.forward,
+    data_augmentor.py:243-246), boxes of classes outside `class_names` dropped (gt_boxes_mask / keep_arrays_by_name),
+    class index appended as an 8th column, boxes with no corner inside the range removed (training,
+    data_processor.py:85-89).  Returns gt_boxes [k, 8] (None: the sample has no box left and the reference draws
+    another index, once_temporal_dataset.py:199-202)."""
+    b = np.array(gt_boxes, copy=True)
+    names = np.asarray(gt_names)
+    if training:
+        keep = np.array([n in class_names for n in names], dtype=np.bool_)
+        b = augment_boxes(b, params)
+        b[:, 6] = limit_period(b[:, 6], offset=0.5, period=2 * np.pi)
+        b, names = b[keep], names[keep]
+    sel = np.array([i for i, n in enumerate(names) if n in class_names], dtype=np.int64)
+    b, names = b[sel], names[sel]
+    cls = np.array([class_names.index(n) + 1 for n in names], dtype=np.int32)
+    b = np.concatenate((b, cls.reshape(-1, 1).astype(np.float32)), axis=1)
+    if training and remove_outside:
+        b = b[mask_boxes_outside_range(b, pc_range, 1)] if len(b) else b
+    if training and len(b) == 0:
+        return None
+    return b
+
+
+def collate_boxes(box_list):
+    """DatasetTemplate.collate_batch for gt_boxes (dataset.py:208-213): zero-padded [B, max_n, 8] float32."""
+    mx = max(len(x) for x in box_list)
+    out = np.zeros((len(box_list), mx, box_list[0].shape[-1]), dtype=np.float32)
+    for k, x in enumerate(box_list):
+        out[k, :len(x), :] = x
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- sample index logic
+
+def generate_intervals(start_id, end_id, max_interval):
+    """DatasetTemplate._generate_intervals (dataset.py:240-252): (first, last-exclusive) per frame of a sequence."""
+    return [(max(start_id, last - max_interval), last) for last in range(start_id + 1, end_id + 1)]
+
+
+def build_intervals(infos, scan_window, split):
+    """ONCETemporalDataset.include_once_data (once_temporal_dataset.py:72-108), including its boundary behaviour: a
+    sequence's intervals are emitted when the NEXT sequence starts (or at the last info), the frame at index i then
+    opens the next run, and the very last info closes the last run one frame early."""
+    intervals, seq_id, start_id = [], '', 0
+    for i, info in enumerate(infos):
+        if seq_id != info['sequence_id'] or i == len(infos) - 1:
+            seq_id = info['sequence_id']
+            intervals.extend(generate_intervals(start_id, i, scan_window))
+            start_id = i
+    if split in ('train', 'val'):
+        intervals = [iv for iv in intervals if 'annos' in infos[iv[1] - 1]]
+    return intervals
+
+
+def pick_pair(interval, scan_window, fixed_gap=-1):
+    """(idx, idx_prev) of ONCETemporalDataset.__getitem__ (once_temporal_dataset.py:142-156); draws from np.random
+    exactly when the reference does."""
+    num_frames = interval[1] - interval[0]
+    idx = interval[1] - 1
+    sampling_window = int(np.floor(scan_window / 3))
+    if fixed_gap == -1:
+        if num_frames == 1:
+            idx_prev = idx
+        else:
+            idx_prev = np.random.choice(np.arange(interval[0], interval[0] + sampling_window), 1)[0]
+    else:
+        idx_prev = max(interval[0], idx - fixed_gap)
+    return idx, int(idx_prev)

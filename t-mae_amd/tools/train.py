@@ -1,7 +1,9 @@
-"""Pre-training driver with the reference's CLI surface (tools/train.py:35-149: --cfg_file --batch_size --epochs
---launcher --amp --set --ckpt --extra_tag ...) for MODEL.NAME == TMAE.  One process per GPU; `--launcher pytorch`
-reads the torchrun environment and uses RCCL ('nccl') for the gradient all-reduce.  The real ONCE loader is out
-of scope: `--synthetic` feeds deterministic ONCE-shape frame pairs."""
+"""Training driver with the reference's CLI surface (tools/train.py:35-149: --cfg_file --batch_size --epochs
+--launcher --amp --set --ckpt --extra_tag ...) for MODEL.NAME == TMAE (pre-training) and CenterPoint (fine-tuning).
+One process per GPU; `--launcher pytorch` reads the torchrun environment and uses RCCL ('nccl') for the gradient
+all-reduce.  Data: a directory laid out like ONCE under DATA_CONFIG.DATA_PATH (or --data_path) through
+pcdet.datasets.build_dataloader (tmae_amd.data: .bin reader threads + the on-device two-frame pipeline), or
+`--synthetic`: deterministic ONCE-shape frame pairs generated on the fly."""
 import argparse
 import os
 import sys
@@ -14,6 +16,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from pcdet.config import cfg, cfg_from_list, cfg_from_yaml_file, log_config_to_file  # noqa: E402
+from pcdet.datasets import build_dataloader  # noqa: E402
 from pcdet.models import build_network, model_fn_decorator  # noqa: E402
 from pcdet.utils import common_utils  # noqa: E402
 from tmae_amd.train import (SyntheticTemporalDataset, build_optimizer, build_scheduler, train_one_step,  # noqa: E402
@@ -40,6 +43,9 @@ def parse_config():
     p.add_argument('--synthetic_points', type=int, default=120000)
     p.add_argument('--iters_per_epoch', type=int, default=100)
     p.add_argument('--output_dir', type=str, default=None)
+    p.add_argument('--data_path', type=str, default=None, help='ONCE root (default: DATA_CONFIG.DATA_PATH)')
+    p.add_argument('--reference_rng_order', action='store_true',
+                   help='np.random stream of a single-process reference run (one host sync per sample, --workers 0)')
     # the rest of the reference's command line (tools/train.py:37-131, tools/scripts/once_train.sh): accepted so that its
     # launch lines run unchanged; what has no meaning here says so when it is used
     p.add_argument('--tcp_port', type=int, default=18888, help='unused: the rendezvous comes from the launcher environment')
@@ -85,8 +91,18 @@ def _ckpt_epoch(p):
 
 def list_checkpoints(ckpt_dir):
     """checkpoint_epoch_<N>.pth of `ckpt_dir`, ascending in N (epoch numbers, not mtimes: every rank and every file
-    system orders them the same way)."""
+    system orders them the same way).  Used for evaluation lists; pruning goes by age (prune_checkpoints)."""
     return sorted((p for p in Path(ckpt_dir).glob('checkpoint_epoch_*.pth') if _ckpt_epoch(p) >= 0), key=_ckpt_epoch)
+
+
+def prune_checkpoints(ckpt_dir, max_ckpt_save_num):
+    """Make room BEFORE the next save, oldest files (mtime) first, so that at most max_ckpt_save_num remain afterwards --
+    the reference's rule (train_utils.py:219-228).  The file about to be written is never a candidate, whatever stale
+    higher-epoch files an earlier run left in the directory."""
+    files = sorted(Path(ckpt_dir).glob('checkpoint_epoch_*.pth'), key=os.path.getmtime)
+    if len(files) >= max_ckpt_save_num:
+        for old in files[:len(files) - max_ckpt_save_num + 1]:
+            old.unlink()
 
 
 def main():
@@ -105,46 +121,69 @@ def main():
     (out / 'ckpt').mkdir(parents=True, exist_ok=True)
     logger = common_utils.create_logger(out / f'log_train_{time.strftime("%Y%m%d-%H%M%S")}.txt', rank=rank)
     log_config_to_file(cfg, logger=logger)
-    if not args.synthetic:
-        raise NotImplementedError('the ONCE two-frame dataloader is outside this hot path (SURVEY 8f-2); use --synthetic')
-    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=args.synthetic_points, batch_size=bs, rank=rank,
-                                  n_boxes=40 if cfg.MODEL.get('DENSE_HEAD', None) is not None else 0)   # labels for the fine-tune config
+    train_loader = train_sampler = None
+    if args.synthetic:
+        ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=args.synthetic_points, batch_size=bs, rank=rank,
+                                      n_boxes=40 if cfg.MODEL.get('DENSE_HEAD', None) is not None else 0)   # labels for the fine-tune config
+        iters_per_epoch = args.iters_per_epoch
+    else:
+        ds, train_loader, train_sampler = build_dataloader(
+            cfg.DATA_CONFIG, cfg.CLASS_NAMES, bs, dist=world > 1, root_path=args.data_path, workers=args.workers, logger=logger,
+            training=True, total_epochs=epochs, device=torch.device('cuda', torch.cuda.current_device()))
+        train_loader.pipeline.reference_rng_order = bool(args.reference_rng_order)
+        iters_per_epoch = len(train_loader)
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds, logger).cuda()
     opt = build_optimizer(model, cfg.OPTIMIZATION)
     start_epoch = it = 0
     if args.pretrained_model:
         model.load_params_from_file(args.pretrained_model, logger=logger)
-    if args.ckpt:
+    ckpt_dir = out / 'ckpt'
+    resume = args.ckpt
+    if resume is None:
+        # resume from the newest checkpoint of the output directory, as the reference does (tools/train.py:268-280)
+        found = sorted(ckpt_dir.glob('*checkpoint_epoch_*.pth'), key=os.path.getmtime)
+        if found:
+            resume = str(found[-1])
+            logger.info(f'resuming from {resume} (newest checkpoint in {ckpt_dir})')
+    if resume:
         # the stored 'epoch' counts trained epochs (the reference saves cur_epoch + 1): resume AT it
-        it, start_epoch = model.load_params_with_optimizer(args.ckpt, optimizer=opt, logger=logger)
+        it, start_epoch = model.load_params_with_optimizer(resume, optimizer=opt, logger=logger)
         start_epoch = max(int(start_epoch), 0)
+    stale = [p_.name for p_ in list_checkpoints(ckpt_dir) if _ckpt_epoch(p_) > start_epoch]
+    if stale and rank == 0:
+        logger.warning(f'{ckpt_dir} holds checkpoints of later epochs than the starting epoch {start_epoch}: {stale}; '
+                       f'they count towards --max_ckpt_save_num and are pruned by age like any other')
     model.train()
     ddp = wrap_ddp(model, local_rank)
-    sched, _ = build_scheduler(opt, args.iters_per_epoch, epochs, -1, cfg.OPTIMIZATION)
+    sched, _ = build_scheduler(opt, iters_per_epoch, epochs, -1, cfg.OPTIMIZATION)
     model_func = model_fn_decorator()
     amp = torch.bfloat16 if args.amp else None
     for epoch in range(start_epoch, epochs):
         t0 = time.time()
-        for i in range(args.iters_per_epoch):
-            batch = ds.batch(epoch * args.iters_per_epoch + i)
+        if train_sampler is not None:
+            train_sampler.set_epoch(epoch)
+            ds.set_epoch(epoch)
+        batches = (ds.batch(epoch * iters_per_epoch + i) for i in range(iters_per_epoch)) if train_loader is None else train_loader
+        for i, batch in enumerate(batches):
             loss, tb, _ = train_one_step(ddp, opt, sched, batch, it, model_func, amp_dtype=amp,
                                          grad_norm_clip=cfg.OPTIMIZATION.get('GRAD_NORM_CLIP', None))
             it += 1
-            if rank == 0 and (i % 10 == 0 or i == args.iters_per_epoch - 1):
-                logger.info(f'epoch {epoch} it {i}/{args.iters_per_epoch} loss {float(loss):.5f} lr {opt.lr:.2e}')
+            if rank == 0 and (i % 10 == 0 or i == iters_per_epoch - 1):
+                logger.info(f'epoch {epoch} it {i}/{iters_per_epoch} loss {float(loss):.5f} lr {opt.lr:.2e}')
         if rank == 0:
             logger.info(f'epoch {epoch} done in {time.time() - t0:.1f} s '
-                        f'({bs * world * args.iters_per_epoch / (time.time() - t0):.1f} frame-pairs/s incl. data gen)')
+                        f'({bs * world * iters_per_epoch / (time.time() - t0):.1f} frame-pairs/s incl. the data path)')
             if (epoch + 1) % args.ckpt_save_interval == 0:
-                save_checkpoint(ddp, opt, epoch + 1, it, out / 'ckpt' / f'checkpoint_epoch_{epoch + 1}.pth')
-                # keep the newest --max_ckpt_save_num checkpoints (train_utils.py:217-232)
-                kept = list_checkpoints(out / 'ckpt')
-                for old_ckpt in kept[:max(len(kept) - args.max_ckpt_save_num, 0)]:
-                    old_ckpt.unlink()
+                prune_checkpoints(ckpt_dir, args.max_ckpt_save_num)           # before the save, by age: never the new file
+                save_checkpoint(ddp, opt, epoch + 1, it, ckpt_dir / f'checkpoint_epoch_{epoch + 1}.pth')
     # --num_epochs_to_eval N (tools/train.py:335-372 -> repeat_eval_ckpt): evaluate the last N checkpoints of a detector
     if args.num_epochs_to_eval > 0 and cfg.MODEL.get('DENSE_HEAD', None) is not None:
         from tmae_amd.eval import eval_one_epoch
         from tmae_amd.train import SyntheticEvalLoader
+        test_loader = None
+        if not args.synthetic:
+            _, test_loader, _ = build_dataloader(cfg.DATA_CONFIG, cfg.CLASS_NAMES, bs, dist=world > 1, root_path=args.data_path,
+                                                 workers=args.workers, logger=logger, training=False)
         cfg.LOCAL_RANK = local_rank
         # rank 0 has finished writing / pruning before anybody lists the directory, and every rank evaluates the list rank 0
         # saw (a rank that globbed by itself could see a file about to be pruned: mismatched all_gather_object calls)
@@ -154,7 +193,7 @@ def main():
             dist.broadcast_object_list(names, src=0)
         for ck in map(Path, names[0]):
             model.load_params_from_file(str(ck), logger=logger)
-            loader = SyntheticEvalLoader(ds, 4 * bs, bs, rank=rank, world=world)
+            loader = test_loader if test_loader is not None else SyntheticEvalLoader(ds, 4 * bs, bs, rank=rank, world=world)
             ret = eval_one_epoch(cfg, model, loader, ck.stem, logger, dist_test=world > 1, result_dir=out / 'eval' / ck.stem,
                                  amp_dtype=amp)
             if rank == 0:

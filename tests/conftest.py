@@ -86,3 +86,33 @@ def ft_oracle():
 def dp_oracle():
     import datapath_oracle
     return datapath_oracle
+
+
+def write_once_directory(root, g):
+    """A directory laid out like ONCE (ImageSets/<split>.txt, once_infos_<split>.pkl, data/<seq>/lidar_roof/<frame>.bin)
+    rebuilt from the raw inputs stored in the D2 fixture.  Returns the info list."""
+    import pickle
+    from pathlib import Path
+    root = Path(root)
+    infos = []
+    for i in range(int(g['n_infos'])):
+        info = {'sequence_id': str(g[f'info_seq_{i}']), 'frame_id': str(g[f'info_frame_{i}']), 'pose': np.array(g[f'info_pose_{i}'])}
+        if int(g[f'has_annos_{i}']):
+            info['annos'] = {'name': np.array([str(n) for n in g[f'names_{i}']]), 'boxes_3d': np.array(g[f'boxes_{i}'])}
+        d = root / 'data' / info['sequence_id'] / 'lidar_roof'
+        d.mkdir(parents=True, exist_ok=True)
+        np.asarray(g[f'scan_{i}'], np.float32).tofile(d / f"{info['frame_id']}.bin")
+        infos.append(info)
+    (root / 'ImageSets').mkdir(parents=True, exist_ok=True)
+    seqs = list(dict.fromkeys(info['sequence_id'] for info in infos))
+    for split in ('train', 'val'):
+        (root / 'ImageSets' / f'{split}.txt').write_text('\n'.join(seqs) + '\n')
+        with open(root / f'once_infos_{split}.pkl', 'wb') as fh:
+            pickle.dump(infos, fh)
+    return infos
+
+
+def finetune_data_cfg():
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    cfg = cfg_from_yaml_file(os.path.join(os.path.dirname(CFG_YAML), 't_mae.yaml'), EasyDict())
+    return cfg

@@ -126,3 +126,28 @@ def test_single_rank_rccl_backend_runs_the_shipped_step():
     assert ok, 'RCCL all_reduce on one rank changed the data'
     assert all(abs(a - b) <= 2e-3 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)
     assert dw <= 2e-2 * wmax, (dw, wmax)          # same two steps with and without DistributedDataParallel
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` end to end -- its own torch.distributed.run launch, rank bookkeeping, barriers, the
+    MAX-over-ranks clock, the per-rank skew fields and rank 0's ONE JSON line -- with the test-only switch
+    TMAE_BENCH_SHARED_GPU=1 (both ranks on GPU 0, gloo instead of RCCL: two ranks cannot share a GPU under RCCL).  The
+    8-GPU run is the driver's; this is the part of it that must not fail on its first execution."""
+    import json
+    import subprocess
+    env = dict(os.environ, TMAE_BENCH_SHARED_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+           '--no-secondary', '--batch-per-gpu', '4', '--points', '40000']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, lines                                     # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['ranks'] == 2 and d['config']['global_batch'] == 8 and d['config']['parallelism'] == 'dp2'
+    assert d['steps'] == 3 and d['scaling'] == 'weak' and 'REHEARSAL' in d['collective_backend']
+    assert 0 < d['rank_ms_per_step']['min'] <= d['rank_ms_per_step']['max'] <= d['ms_per_step'] * 1.001
+    assert abs(d['value'] - 8 * 3 / (d['ms_per_step'] * 3e-3)) <= 1e-2 * d['value']
+    for key in ('roofline', 'roofline_wgrad', 'roofline_attention', 'roofline_step', 'box_peaks'):
+        assert key in d, key
+    assert d['roofline']['peak_measured'] == d['box_peaks']['hbm_copy_gbs'] > 1000
+    assert d['roofline_step']['peak_measured'] == d['box_peaks']['mfma_bf16_tflops'] > 100

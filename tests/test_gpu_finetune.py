@@ -373,3 +373,107 @@ def test_train_cli_accepts_the_reference_launch_line(tmp_path):
            '--synthetic_points', '20000', '--synthetic_samples', '4', '--batch_size', '2', '--output_dir', str(out / 'test')]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_once_loader_golden_and_real_data_cli(tmp_path):
+    """The ONCE-format reader + on-device pipeline against what the reference's own ONCETemporalDataset returned on the
+    same tiny ONCE-layout directory (fixture D2): same points kept in the same order (coordinates <= 2 ulp: the reference
+    rotates with an fp32 BLAS matmul), gt_boxes bit for bit; then the loader as tools/train.py / tools/test.py use it
+    (reader threads, resampling, evaluation split) and both tools WITHOUT --synthetic."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT, finetune_data_cfg, write_once_directory
+    from tmae_amd.data import ONCETemporalDataset, TemporalPairPipeline, build_dataloader
+    g = golden('D2_once_dataset')
+    root = tmp_path / 'once'
+    write_once_directory(root, g)
+    cfg = finetune_data_cfg()
+    ds = ONCETemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True, root_path=root)
+    pipe = TemporalPairPipeline(cfg.DATA_CONFIG, training=True, class_names=cfg.CLASS_NAMES, reference_rng_order=True)
+
+    def lazy(i):                                             # the fixture seeded np.random per sample
+        def read():
+            np.random.seed(500 + i)
+            return ds.raw_sample(i)
+        return read
+    n = len(ds)
+    out = pipe([lazy(i) for i in range(n)], dev())           # its OWN draws, in the reference's per-sample order
+    for key in ('points', 'points_prev'):
+        got, ref = out[key].cpu().numpy(), g[key]
+        assert got.shape == ref.shape, (key, got.shape, ref.shape)
+        assert np.array_equal(got[:, 0], ref[:, 0]) and np.array_equal(got[:, 4], ref[:, 4])
+        np.testing.assert_allclose(got[:, 1:4], ref[:, 1:4], rtol=3e-7, atol=2e-5)
+    assert np.array_equal(out['gt_boxes'], g['gt_boxes'])
+    assert [str(f) for f in out['frame_id']] == [str(g[f'info_frame_{int(p[0])}']) for p in g['picks']]
+    # evaluation mode (no augmentation, no shuffle) on sample 2
+    pipe_t = TemporalPairPipeline(cfg.DATA_CONFIG, training=False, class_names=cfg.CLASS_NAMES)
+    ds_t = ONCETemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=False, root_path=root)
+    np.random.seed(77)
+    o2 = pipe_t([ds_t.raw_sample(2)], dev())
+    for key, ref in (('points', g['test_points']), ('points_prev', g['test_points_prev'])):
+        got = o2[key].cpu().numpy()[:, 1:]
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, rtol=3e-7, atol=2e-5)
+    assert np.array_equal(o2['gt_boxes'][0], g['test_gt_boxes'].astype(np.float32))
+    # the loader: reader threads, every sample once per epoch, a different order in the next epoch
+    _, loader, sampler = build_dataloader(cfg.DATA_CONFIG, cfg.CLASS_NAMES, 3, dist=False, root_path=root, workers=2,
+                                          training=True, device=dev())
+    seen = []
+    for ep in range(2):
+        sampler.set_epoch(ep)
+        frames = []
+        for batch in loader:
+            assert batch['points'].is_cuda and batch['points'].shape[1] == 5 and batch['batch_size'] in (2, 3)
+            assert batch['gt_boxes'].shape[0] == batch['batch_size'] and batch['gt_boxes'].shape[2] == 8
+            cls = batch['gt_boxes'][..., 7]
+            assert ((cls >= 0) & (cls <= 5)).all() and (np.abs(batch['gt_boxes'][..., 6]) <= np.pi + 1e-6).all()
+            frames += [str(f) for f in batch['frame_id']]
+        assert len(frames) == n and len(set(frames)) == n
+        seen.append(frames)
+    assert seen[0] != seen[1]
+    # a sample that loses every box is replaced by another one (once_temporal_dataset.py:199-202)
+    calls = []
+    s_bad = dict(ds.raw_sample(0), gt_names=np.array(['Tricycle'] * len(ds.raw_sample(0)['gt_names'])))
+    b = TemporalPairPipeline(cfg.DATA_CONFIG, training=True, class_names=cfg.CLASS_NAMES)(
+        [s_bad, ds.raw_sample(1)], dev(), resample=lambda: (calls.append(1), ds.raw_sample(3))[1])
+    assert calls == [1] and b['batch_size'] == 2 and b['gt_boxes'].shape[0] == 2
+    # tools/train.py and tools/test.py on the directory, no --synthetic (the reference's launch line otherwise)
+    out_dir = tmp_path / 'run'
+    yaml_ft = os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae.yaml')
+    cmd = [sys.executable, os.path.join(ROOT, 't-mae_amd', 'tools', 'train.py'), '--cfg_file', yaml_ft, '--workers', '2',
+           '--extra_tag', 't', '--max_ckpt_save_num', '1', '--num_epochs_to_eval', '1', '--amp', '--epochs', '2', '--batch_size', '2',
+           '--data_path', str(root), '--output_dir', str(out_dir)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert sorted(p.name for p in (out_dir / 'ckpt').glob('*.pth')) == ['checkpoint_epoch_2.pth']
+    assert 'Total samples for ONCE dataset: %d' % n in (r.stdout + r.stderr)
+    # stale higher-epoch checkpoints of an earlier run never cost the one just written (pruned by age, before the save)
+    import shutil
+    import time as _time
+    for e in (7, 8):
+        shutil.copy(out_dir / 'ckpt' / 'checkpoint_epoch_2.pth', out_dir / 'ckpt' / f'checkpoint_epoch_{e}.pth')
+    old = _time.time() - 1000
+    for e in (2, 7, 8):
+        os.utime(out_dir / 'ckpt' / f'checkpoint_epoch_{e}.pth', (old + e, old + e))
+    cmd2 = cmd[:cmd.index('--epochs') + 1] + ['4'] + cmd[cmd.index('--epochs') + 2:]
+    cmd2[cmd2.index('--max_ckpt_save_num') + 1] = '3'
+    cmd2 += ['--ckpt', str(out_dir / 'ckpt' / 'checkpoint_epoch_2.pth')]
+    r = subprocess.run(cmd2, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    left = sorted(p.name for p in (out_dir / 'ckpt').glob('*.pth'))
+    assert 'checkpoint_epoch_3.pth' in left and 'checkpoint_epoch_4.pth' in left and len(left) == 3, left
+    cmd = [sys.executable, os.path.join(ROOT, 't-mae_amd', 'tools', 'test.py'), '--cfg_file', yaml_ft, '--workers', '2',
+           '--ckpt', str(out_dir / 'ckpt' / 'checkpoint_epoch_4.pth'), '--batch_size', '2', '--data_path', str(root),
+           '--output_dir', str(out_dir / 'test')]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'AP' in (r.stdout + r.stderr)
+    # pre-training on the same directory (t_mae_ssl.yaml trains on the raw_large split: point it at the tiny train split)
+    yaml_ssl = os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae_ssl.yaml')
+    cmd = [sys.executable, os.path.join(ROOT, 't-mae_amd', 'tools', 'train.py'), '--cfg_file', yaml_ssl, '--workers', '2', '--amp',
+           '--epochs', '1', '--batch_size', '2', '--data_path', str(root), '--output_dir', str(tmp_path / 'ssl'),
+           '--set', 'DATA_CONFIG.DATA_SPLIT.train', 'train']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert (tmp_path / 'ssl' / 'ckpt' / 'checkpoint_epoch_1.pth').exists()
