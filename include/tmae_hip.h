@@ -456,10 +456,10 @@ int tmae_frame_prepare(const float* points, int row, int64_t n, const double* r1
 
 /* ---- box calibration probes (bench.py `peak_measured`; SURVEY.md section 7: measured achievable peaks on the box next
  * to the spec peaks -- no reference counterpart).  tmae_probe_copy: a 16-bytes-per-lane streaming copy of `bytes` (a
- * multiple of 16) from src to dst: HBM bytes moved = 2 x bytes.  tmae_probe_mfma: `iters` x 16 back-to-back
+ * multiple of 16) from src to dst (nontemporal != 0: nt loads and stores): HBM bytes moved = 2 x bytes.  tmae_probe_mfma: `iters` x 16 back-to-back
  * v_mfma_f32_16x16x32_bf16 per wave on random register operands, one 512-thread workgroup per CU; *flops (host, optional)
  * receives the FLOPs of the launch; sink = 1 float on the device (never written in practice). */
-int tmae_probe_copy(const void* src, void* dst, int64_t bytes, void* stream);
+int tmae_probe_copy(const void* src, void* dst, int64_t bytes, int nontemporal, void* stream);
 int tmae_probe_mfma(int iters, float* sink, int64_t* flops, void* stream);
 
 #ifdef __cplusplus

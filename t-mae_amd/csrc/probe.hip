@@ -12,6 +12,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+template <bool NT>
 __global__ __launch_bounds__(256) void probe_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int64_t n16) {
   // full tiles of 1024 x 16 bytes: four unconditional loads in flight per lane, then four stores (a load under a
   // predicate is waited for before the next one is issued); the tail tile clamps its loads and predicates its stores
@@ -21,9 +22,12 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const u32x4* __restrict
     u32x4 v[4];
     if (t * 1024 + 1024 <= n16) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = __builtin_nontemporal_load(src + i + 256 * j);
+      for (int j = 0; j < 4; ++j) v[j] = NT ? __builtin_nontemporal_load(src + i + 256 * j) : src[i + 256 * j];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(v[j], dst + i + 256 * j);
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (NT) __builtin_nontemporal_store(v[j], dst + i + 256 * j);
+        else dst[i + 256 * j] = v[j];
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = src[i + 256 * j < n16 ? i + 256 * j : n16 - 1];
@@ -34,13 +38,16 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const u32x4* __restrict
   }
 }
 
-int tmae_probe_copy(const void* src, void* dst, int64_t bytes, void* stream_) {
+int tmae_probe_copy(const void* src, void* dst, int64_t bytes, int nontemporal, void* stream_) {
   (void)hipGetLastError();
   if (!src || !dst || bytes <= 0 || (bytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return TMAE_EARG;
   const int64_t n16 = bytes / 16;
   const int64_t want = (n16 + 1023) / 1024;
   const unsigned grid = (unsigned)(want < 256 * 16 ? want : 256 * 16);       // 16 workgroups per CU, grid-stride beyond that
-  hipLaunchKernelGGL(probe_copy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const u32x4*)src, (u32x4*)dst, n16);
+  if (nontemporal)
+    hipLaunchKernelGGL(probe_copy_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const u32x4*)src, (u32x4*)dst, n16);
+  else
+    hipLaunchKernelGGL(probe_copy_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const u32x4*)src, (u32x4*)dst, n16);
   return tmae_launch_status();
 }
 

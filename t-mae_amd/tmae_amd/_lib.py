@@ -91,7 +91,7 @@ SIGNATURES = {
     'tmae_linear_wgrad': (I, [P, L, P, L, L, I, I, P, P, P, Z, P]),
     'tmae_linear_wgrad_cells': (I, [P, L, P, L, L, I, I, P, I, P, P, P, P, Z, P]),
     'tmae_spconv_wgrad': (I, [P, L, P, L, P, L, I, I, P, P, Z, P]),
-    'tmae_probe_copy': (I, [P, P, L, P]),
+    'tmae_probe_copy': (I, [P, P, L, I, P]),
     'tmae_probe_mfma': (I, [I, P, P, P]),
 }
 

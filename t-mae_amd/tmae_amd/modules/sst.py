@@ -215,6 +215,8 @@ class BasicShiftBlockV2(nn.Module):
         """tap: the first layer also returns an alias of the block input (-> (out, alias)); post: added to the last
         layer's output (the residual of the enclosing SSTBlockV1)."""
         alias = None
+        # the block residual is folded into the norms of the FIRST (tap) and LAST (post) layer: they must be two layers
+        assert len(self.encoder_list) >= 2 or (not tap and post is None), 'residual folding needs >= 2 encoder layers'
         for i, layer in enumerate(self.encoder_list):
             last = i == len(self.encoder_list) - 1
             if tap and i == 0:
@@ -250,6 +252,7 @@ class BasicShiftBlock_WCA(nn.Module):
     def forward(self, src, plan, src_prv, plan_prv, pos_table, window_shape, kept_list, residual=False):
         """residual: returns src + layers(src) (WCABlock.forward's `x + res`), the sum taken inside the last norm."""
         alias = None
+        assert len(self.encoder_list) >= 2 or not residual, 'residual folding needs >= 2 cross layers'
         for i, layer in enumerate(self.encoder_list):
             last = i == len(self.encoder_list) - 1
             if residual and i == 0:
@@ -306,9 +309,13 @@ class SSTBlockV1(nn.Module):
         out = sp.features
         alias = None
         nb = len(self.encoder_blocks)
+        if nb == 0:                                # NUM_BLOCKS: 0 -- the reference's x + encoder(x) with encoder = identity
+            return out + out if residual else out
         for j, block in enumerate(self.encoder_blocks):
             tap, last = residual and j == 0, residual and j == nb - 1
             if tap and last:                       # a single block: its first layer taps, its last layer adds
+                assert len(block.encoder_list) >= 2, 'residual folding needs >= 2 encoder layers'
+
                 out, alias = block.encoder_list[0](out, plan, self.pos_table, self.window_shape, False, passthrough=True)
                 for i, layer in enumerate(block.encoder_list[1:], 1):
                     out = layer(out, plan, self.pos_table, self.window_shape, i == 1,

@@ -167,7 +167,9 @@ def test_finetune_bf16_step_runs_and_is_close(ft_oracle):
         ret, _, _ = model(bd)
     ret['loss'].backward()
     assert torch.isfinite(ret['loss'])
-    assert abs(float(ret['loss']) - float(g['loss'])) <= 0.05 * abs(float(g['loss']))
+    rel = abs(float(ret['loss'].detach()) - float(g['loss'])) / abs(float(g['loss']))
+    print(f'finetune bf16 loss vs fp32 reference: rel {rel:.2e}')
+    assert rel <= 0.05
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 
@@ -424,7 +426,7 @@ def test_once_loader_golden_and_real_data_cli(tmp_path):
         sampler.set_epoch(ep)
         frames = []
         for batch in loader:
-            assert batch['points'].is_cuda and batch['points'].shape[1] == 5 and batch['batch_size'] in (2, 3)
+            assert batch['points'].is_cuda and batch['points'].shape[1] == 5 and batch['batch_size'] in (1, 2, 3)
             assert batch['gt_boxes'].shape[0] == batch['batch_size'] and batch['gt_boxes'].shape[2] == 8
             cls = batch['gt_boxes'][..., 7]
             assert ((cls >= 0) & (cls <= 5)).all() and (np.abs(batch['gt_boxes'][..., 6]) <= np.pi + 1e-6).all()

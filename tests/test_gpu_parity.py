@@ -1455,9 +1455,8 @@ def test_bf16_trains_like_fp32():
     """The benched dtype must TRAIN like fp32, not only agree on one forward pass: 30 optimizer steps of the full model
     (B = 2 x 20 k-point pairs, the recipe's Adam one-cycle) from the same initial weights on the same batches with the
     same masking noise, once in fp32 and once under bf16 autocast (bench.training_curves, also printed in the bench
-    line's `parity`).  Both curves must fall, and stay within a stated band of each other: the per-step gap is bounded
-    by 8 % (chaotic divergence of two trajectories that start 1e-4 apart, through the 75 % random masking) and the
-    means over the last ten steps by 3 %."""
+    line's `parity`).  Both curves must fall (3.77 -> 0.88 here) and stay within a stated band of each other: every step
+    within 2 % (measured: 0.5 % at worst, step 25), the means over the last ten steps within 1 %."""
     import bench
     c = bench.training_curves(dev())
     a, b = np.array(c['fp32']), np.array(c['bf16'])
@@ -1466,5 +1465,5 @@ def test_bf16_trains_like_fp32():
     assert np.isfinite(a).all() and np.isfinite(b).all()
     assert a[-5:].mean() < 0.9 * a[:5].mean() and b[-5:].mean() < 0.9 * b[:5].mean(), (c['fp32_first5_last5'], c['bf16_first5_last5'])
     assert abs(a[0] - b[0]) <= 2e-3 * abs(a[0])                          # the first step: same weights, bf16 forward error only
-    assert c['max_rel_gap'] <= 0.08, c['max_rel_gap']
-    assert abs(a[-10:].mean() - b[-10:].mean()) <= 0.03 * a[-10:].mean()
+    assert c['max_rel_gap'] <= 0.02, c['max_rel_gap']
+    assert abs(a[-10:].mean() - b[-10:].mean()) <= 0.01 * a[-10:].mean()

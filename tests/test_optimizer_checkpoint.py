@@ -232,7 +232,8 @@ def test_optimizer_steps_queued_far_ahead_of_the_gpu_read_their_own_tables():
         one(it)
     torch.cuda.synchronize()
     for it in range(5):
-        torch._foreach_mul_(ref, 1.0 - 0.01 * 2e-3)
+        with torch.no_grad():
+            torch._foreach_mul_(ref, 1.0 - 0.01 * 2e-3)
         for p, gr in zip(ref, grads[it]):
             p.grad = gr
         ropt.step()
