@@ -389,6 +389,13 @@ int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w,
 int tmae_token_gemm_acc(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
                         int64_t ldy, void* stream);
 
+/* The FFN's first Linear with its activation (sst_basic_block.py:81: activation(linear1(src)), exact erf GELU):
+ * y = x . w^T + bias (the pre-activation, which the backward needs) AND y_gelu = gelu(y), same shape and pitch, written
+ * by the same launch -- the separate elementwise GELU pass (read and write of [m, n]) becomes one extra write.
+ * (k, n) = (256, 512) or (128, 256), m >= 32768; anything else returns TMAE_EARG and the caller runs tmae_token_gemm plus
+ * its own activation pass.  Same pointer rules as tmae_token_gemm (y_gelu: 16-byte aligned). */
+int tmae_token_gemm_gelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
+                         void* y_gelu, int64_t ldy, void* stream);
 /* Same GEMM with the backward of the exact (erf) GELU fused into the epilogue: y = (x . w^T + bias) * gelu'(aux),
  * aux [m,n] bf16 with y's pitch = the pre-activation saved by the forward (the FFN of EncoderLayer,
  * sst_basic_block.py:81: linear2(gelu(linear1(src))): dX of linear2 and GeluBackward in one pass). */

@@ -323,6 +323,16 @@ int tmae_token_gemm_acc(const void* x, int64_t ldx, int64_t m, int k, const void
   return tmae_token_gemm_wreg(x, ldx, m, k, w, n, bias, nullptr, y, ldy, 1, stream_);
 }
 
+int tmae_token_gemm_gelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
+                         void* y_gelu, int64_t ldy, void* stream_) {
+  (void)hipGetLastError();
+  if (m < 0) return TMAE_EARG;
+  if (m == 0) return TMAE_OK;
+  // the dual-store form exists in the W-in-registers kernel only, on the two shapes of the encoder FFN's first Linear
+  if (m < 32768 || !((k == 256 && n == 512) || (k == 128 && n == 256))) return TMAE_EARG;
+  return tmae_token_gemm_wreg_gelu(x, ldx, m, k, w, n, bias, y, y_gelu, ldy, stream_);
+}
+
 int tmae_token_gemm_dgelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias,
                           const void* aux, void* y, int64_t ldy, void* stream_) {
   (void)hipGetLastError();

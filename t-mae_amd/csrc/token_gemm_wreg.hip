@@ -38,16 +38,35 @@ __device__ __forceinline__ bf16x8 tgw_pos_onehot(unsigned cell, int g) {
   return __builtin_bit_cast(bf16x8, u);
 }
 
+// exact (erf) GELU of a bf16-rounded pre-activation, the forward twin of token_gemm.hip's dgelu(): erf through
+// Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 rounding of the result), one exp, one rcp, a few FMAs
+__device__ __forceinline__ float tgw_gelu(float x) {
+  const float e = __expf(-0.5f * x * x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * 0.70710678f * fabsf(x));
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;
+  return x * (0.5f * (1.0f + copysignf(erf_abs, x)));
+}
+// the two bf16 halves of a packed dword through GELU, packed again
+__device__ __forceinline__ unsigned tgw_gelu2(unsigned u) {
+  return tgw_pack2(tgw_gelu(__uint_as_float(u << 16)), tgw_gelu(__uint_as_float(u & 0xFFFF0000u)));
+}
+
 #define TGW_OOB 0x7FFFFFF0u          // voffset past every buffer: loads return zeros, stores are dropped
 #define TGW_NT 2                     // cache policy of the y stores (written once, streamed)
 
-template <int K, int NTC, int NWC, bool POS, bool ACC = false>
+// GELU2 (the FFN's first Linear, sst_basic_block.py:81): the kernel ALSO writes y2 = gelu(y) (same shape and pitch) from
+// the bf16-rounded tile it is about to store -- a second trip through the staging patch and a second set of full-line
+// stores.  The separate GELU pass (read [m, dff], write [m, dff]: 84 us per layer at 466 k tokens, as fast as a copy)
+// becomes one extra write here; this kernel's step has ~3x the VALU slack the ~13 instructions per element need.
+template <int K, int NTC, int NWC, bool POS, bool ACC = false, bool GELU2 = false>
 __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfloat16* __restrict__ x, int ldx,
                                                                 const __hip_bfloat16* __restrict__ W,
                                                                 const __hip_bfloat16* __restrict__ bias,
                                                                 __hip_bfloat16* __restrict__ y, int ldy, int m, int ncg,
                                                                 unsigned xbytes, unsigned ybytes,
-                                                                const uint8_t* __restrict__ cells) {
+                                                                const uint8_t* __restrict__ cells,
+                                                                __hip_bfloat16* __restrict__ y2) {
   constexpr int TEAMS = 8 / NWC;                  // teams of NWC waves; a team covers all columns of the group
   constexpr int STEP = 16384 / K;                 // tokens per ring slot (32 KB): 128 / 64 / 32 for K = 128 / 256 / 512
   constexpr int TGW = (STEP / 16) / TEAMS;        // 16-token groups per wave and step
@@ -64,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
   constexpr int NS = ACC ? 3 : 4;
   constexpr int ND = PPW + (POS ? STEP / 64 : 0) + PPY; // DMA instructions per wave and step
   static_assert(!ACC || YB % 8192 == 0, "y tile must divide into 1-KiB pieces per wave");
-  constexpr int NST = TGW * (NTC / 2);            // 16-byte store instructions per wave and step
+  constexpr int NST = TGW * (NTC / 2) * (GELU2 ? 2 : 1);   // 16-byte store instructions per wave and step
   constexpr int WAITN = (NS - 1) * NST + (NS - 2) * ND;
   static_assert(TGW >= 1 && (NTC == 2 || NTC == 4) && WAITN < 64 && ROWB <= 1024, "shape");
   extern __shared__ __attribute__((aligned(1024))) char ring[];
@@ -78,6 +97,7 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc((void*)(GELU2 ? y2 : y), 0, (int)ybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)(POS ? cells : (const uint8_t*)x), 0, POS ? m : 0, 0x00020000);
 
   // ---- what this lane fetches in every step: PPW pieces; piece p = w * PPW + jj covers LDS bytes [1024 p, +1024) of the slot
@@ -223,11 +243,12 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
   auto epi_tg = [&](int tokb) {                      // tokb = first token of the PT groups
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
+      u32x4 pk[NTC / 2];
 #pragma unroll
       for (int h = 0; h < NTC / 2; ++h) {
         const f32x4 v0 = acc[2 * h][t], v1 = acc[2 * h + 1][t];
-        *reinterpret_cast<u32x4*>(stg + i * (NTC * 32) + ((((NTC / 2) * g + h) ^ (i & (CPL - 1))) << 4)) =
-            u32x4{tgw_pack2(v0[0], v0[1]), tgw_pack2(v0[2], v0[3]), tgw_pack2(v1[0], v1[1]), tgw_pack2(v1[2], v1[3])};
+        pk[h] = u32x4{tgw_pack2(v0[0], v0[1]), tgw_pack2(v0[2], v0[3]), tgw_pack2(v1[0], v1[1]), tgw_pack2(v1[2], v1[3])};
+        *reinterpret_cast<u32x4*>(stg + i * (NTC * 32) + ((((NTC / 2) * g + h) ^ (i & (CPL - 1))) << 4)) = pk[h];
       }
 #pragma unroll
       for (int hh = 0; hh < NTC / 2; ++hh) {
@@ -235,6 +256,19 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
         const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * (NTC * 32) + ((schunk ^ (r & (CPL - 1))) << 4));
         const unsigned vo = tokb + t * 16 + r < m ? (unsigned)(tokb + t * 16 + hh * RPI) * (unsigned)(ldy * 2) + soff : TGW_OOB;
         __builtin_amdgcn_raw_buffer_store_b128(v, yr, (int)vo, 0, TGW_NT);
+      }
+      if constexpr (GELU2) {                             // the same tile through GELU: LDS operations of one wave are ordered,
+#pragma unroll                                           // so the patch can be rewritten right behind the reads above
+        for (int h = 0; h < NTC / 2; ++h)
+          *reinterpret_cast<u32x4*>(stg + i * (NTC * 32) + ((((NTC / 2) * g + h) ^ (i & (CPL - 1))) << 4)) =
+              u32x4{tgw_gelu2(pk[h][0]), tgw_gelu2(pk[h][1]), tgw_gelu2(pk[h][2]), tgw_gelu2(pk[h][3])};
+#pragma unroll
+        for (int hh = 0; hh < NTC / 2; ++hh) {
+          const int r = hh * RPI + srow;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * (NTC * 32) + ((schunk ^ (r & (CPL - 1))) << 4));
+          const unsigned vo = tokb + t * 16 + r < m ? (unsigned)(tokb + t * 16 + hh * RPI) * (unsigned)(ldy * 2) + soff : TGW_OOB;
+          __builtin_amdgcn_raw_buffer_store_b128(v, y2r, (int)vo, 0, TGW_NT);
+        }
       }
     }
   };
@@ -257,20 +291,21 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may land after the workgroup has released its LDS
 }
 
-template <int K, int NTC, int NWC, bool POS, bool ACC = false>
+template <int K, int NTC, int NWC, bool POS, bool ACC = false, bool GELU2 = false>
 static int tgw_launch(const void* x, int64_t ldx, int64_t m, const void* w, int n, const void* bias, void* y, int64_t ldy,
-                      const void* cells, hipStream_t stream) {
+                      const void* cells, hipStream_t stream, void* y2 = nullptr) {
   constexpr int NG = NWC * NTC * 16;
   constexpr int STEP = 16384 / K;
   constexpr int lds = (ACC ? 3 : 4) * (STEP * K * 2 + (POS ? STEP * 4 : 0) + (ACC ? STEP * NG * 2 : 0)) + 8 * 16 * NTC * 32;
   const int ncg = n / NG;
   static TmaeLdsAttr attr;
-  if (int e = tmae_allow_lds(attr, (const void*)token_gemm_wreg_kernel<K, NTC, NWC, POS, ACC>, lds)) return e;
+  if (int e = tmae_allow_lds(attr, (const void*)token_gemm_wreg_kernel<K, NTC, NWC, POS, ACC, GELU2>, lds)) return e;
   const int64_t xbytes = ((m - 1) * ldx + K) * 2, ybytes = ((m - 1) * ldy + n) * 2;
   const int grid = 8 * ncg * (32 / ncg);
-  hipLaunchKernelGGL((token_gemm_wreg_kernel<K, NTC, NWC, POS, ACC>), dim3(grid), dim3(512), lds, stream,
+  hipLaunchKernelGGL((token_gemm_wreg_kernel<K, NTC, NWC, POS, ACC, GELU2>), dim3(grid), dim3(512), lds, stream,
                      (const __hip_bfloat16*)x, (int)ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias,
-                     (__hip_bfloat16*)y, (int)ldy, (int)m, ncg, (unsigned)xbytes, (unsigned)ybytes, (const uint8_t*)cells);
+                     (__hip_bfloat16*)y, (int)ldy, (int)m, ncg, (unsigned)xbytes, (unsigned)ybytes, (const uint8_t*)cells,
+                     (__hip_bfloat16*)y2);
   return tmae_launch_status();
 }
 
@@ -314,4 +349,18 @@ int tmae_token_gemm_wreg(const void* x, int64_t ldx, int64_t m, int k, const voi
     n0 += nb;
   }
   return TMAE_OK;
+}
+
+// y = x W^T + bias AND y_gelu = gelu(y) in one pass (tmae_token_gemm_gelu): the FFN's first Linear, (k, n) = (256, 512) or
+// (128, 256).  TMAE_EARG for anything else (the caller runs tmae_token_gemm and its own GELU pass).
+int tmae_token_gemm_wreg_gelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
+                              void* y_gelu, int64_t ldy, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m <= 0 || !x || !w || !y || !y_gelu || !bias || ldx < k || ldy < n || (ldx % 8) || (ldy % 8)) return TMAE_EARG;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)y_gelu & 15) || ((uintptr_t)bias & 1)) return TMAE_EARG;
+  if (((m - 1) * ldx + k) * 2 >= (int64_t)TGW_OOB || ((m - 1) * ldy + n) * 2 >= (int64_t)TGW_OOB) return TMAE_EARG;
+  if (k == 256 && n == 512) return tgw_launch<256, 4, 8, false, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream, y_gelu);
+  if (k == 128 && n == 256) return tgw_launch<128, 4, 4, false, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream, y_gelu);
+  return TMAE_EARG;
 }

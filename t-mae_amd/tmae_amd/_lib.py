@@ -85,6 +85,7 @@ SIGNATURES = {
     'tmae_bn_running_update': (I, [P, I, P, P, I, P]),
     'tmae_token_gemm_acc': (I, [P, L, L, I, P, I, P, P, L, P]),
     'tmae_token_gemm_dgelu': (I, [P, L, L, I, P, I, P, P, P, L, P]),
+    'tmae_token_gemm_gelu': (I, [P, L, L, I, P, I, P, P, P, L, P]),
     'tmae_token_gemm_pos': (I, [P, L, L, I, P, I, P, P, P, L, P]),
     'tmae_window_cells': (I, [P, L, L, I, I, I, P, P, P]),
     'tmae_linear_wgrad_workspace': (Z, [L, I, I]),

@@ -182,11 +182,15 @@ class _EncoderTail(nn.Module):
                                             passthrough=True)
         else:
             src = ops.add_layer_norm(src, attn, self.norm1.weight, self.norm1.bias, self.norm1.eps, bmask=bmask)
-        h_pre, src_res = ops.proj_fork(src, self.linear1.weight, self.linear1.bias,
-                                       ((0, self.linear1.out_features, False),), fork=True, inplace_dx=True)
         if self.activation is F.gelu:
-            src2 = ops.gelu_linear(h_pre, self.linear2.weight, self.linear2.bias)     # GELU backward fused into the dX GEMM
+            # linear1 and the GELU in one launch (the activation is a second store of the GEMM's epilogue), the GELU
+            # backward fused into the dX GEMM of linear2
+            h_pre, h_act, src_res = ops.proj_fork(src, self.linear1.weight, self.linear1.bias,
+                                                  ((0, self.linear1.out_features, False),), fork=True, inplace_dx=True, gelu=True)
+            src2 = ops.gelu_linear(h_pre, self.linear2.weight, self.linear2.bias, h=h_act)
         else:
+            h_pre, src_res = ops.proj_fork(src, self.linear1.weight, self.linear1.bias,
+                                           ((0, self.linear1.out_features, False),), fork=True, inplace_dx=True)
             src2 = ops.linear(self.activation(h_pre), self.linear2.weight, self.linear2.bias)
         out = ops.add_layer_norm(src_res, src2, self.norm2.weight, self.norm2.bias, self.norm2.eps, post=post)
         return (out, alias) if passthrough else out

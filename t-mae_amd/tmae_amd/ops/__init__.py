@@ -93,6 +93,23 @@ def token_gemm(x, w, bias=None, force=False):
     return torch.nn.functional.linear(x, w, bias)
 
 
+def token_gemm_gelu(x, w, bias):
+    """(y, gelu(y)) with y = x @ w^T + bias: ONE launch on the shapes of the encoder FFN's first Linear
+    (tmae_token_gemm_gelu: d -> 2d for d in {128, 256}, >= 32 k tokens, bf16), otherwise the GEMM and an elementwise pass."""
+    n, k = w.shape
+    m = x.shape[0]
+    if (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and (k, n) in ((256, 512), (128, 256)) and m >= 32768
+            and bias is not None and bias.dtype == torch.bfloat16 and w.is_contiguous() and x.stride(1) == 1
+            and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 and m * n * 2 < 2 ** 31):
+        y = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
+        yg = torch.empty_like(y)
+        check(lib.tmae_token_gemm_gelu(_p(x), x.stride(0), m, k, _p(w), n, _p(bias.contiguous()), _p(y), _p(yg), n, _s()),
+              'tmae_token_gemm_gelu')
+        return y, yg
+    y = token_gemm(x, w, bias)
+    return y, torch.nn.functional.gelu(y)
+
+
 def addmm_inplace(dx, dy, w):
     """dx += dy @ w in place (w [n,k]: dx [m,k], dy [m,n]): the W-in-registers kernel's accumulate form on the shapes it
     covers (tmae_token_gemm_acc: contraction 512 -> 256 and 256 -> 128, >= 32 k tokens), torch's addmm_ otherwise."""
@@ -413,7 +430,7 @@ class _ProjFork(torch.autograd.Function):
     (no slice-backward zero fills).  pos = (indices, table, wy, wx, do_shift) or None."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, segs, pos, fork, inplace_dx):
+    def forward(ctx, x, weight, bias, segs, pos, fork, inplace_dx, gelu=False):
         cdt = compute_dtype(x)
         x_c = x.to(cdt).contiguous()
         w_c = cast_param(weight, cdt)
@@ -425,13 +442,23 @@ class _ProjFork(torch.autograd.Function):
             check(lib.tmae_add_pos_embed(_p(x_c), _dt(x_c), x_c.shape[0], x_c.shape[1], _p(indices), wy, wx,
                                          1 if do_shift else 0, _p(table), _p(xp), _s()), 'tmae_add_pos_embed')
         outs = []
-        for r0, r1, use_pos in segs:
-            outs.append(token_gemm(xp if use_pos else x_c, w_c[r0:r1], None if b_c is None else b_c[r0:r1]))
+        act = None
+        if gelu:             # one segment, the whole weight: the projection and its GELU (not differentiable here: the
+            r0, r1, use_pos = segs[0]        # consumer, ops.gelu_linear, differentiates through the pre-activation)
+            assert len(segs) == 1 and not use_pos and r0 == 0 and r1 == w_c.shape[0]
+            y, act = token_gemm_gelu(x_c, w_c, b_c)
+            outs.append(y)
+        else:
+            for r0, r1, use_pos in segs:
+                outs.append(token_gemm(xp if use_pos else x_c, w_c[r0:r1], None if b_c is None else b_c[r0:r1]))
         ctx.save_for_backward(x_c, xp, w_c)
         ctx.segs, ctx.fork, ctx.has_bias = segs, fork, bias is not None
         ctx.inplace_dx = bool(inplace_dx and fork)
         ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
         ctx.set_materialize_grads(False)
+        if act is not None:
+            ctx.mark_non_differentiable(act)
+            outs.append(act)
         if fork:
             outs.append(x.view_as(x))
         return tuple(outs)
@@ -476,11 +503,13 @@ class _ProjFork(torch.autograd.Function):
                     if dB is not None:
                         dB[r0:r1] = dy.float().sum(0)
         return (None if dx is None else dx.to(xdt), None if dW is None else dW.to(wdt),
-                None if dB is None else dB.to(bdt), None, None, None, None)
+                None if dB is None else dB.to(bdt), None, None, None, None, None)
 
 
-def proj_fork(x, weight, bias, segs, pos=None, fork=False, inplace_dx=False):
+def proj_fork(x, weight, bias, segs, pos=None, fork=False, inplace_dx=False, gelu=False):
     """See _ProjFork.  Returns the projections (and x's alias last when fork) as a tuple.
+    gelu (one segment covering the whole weight): the tuple is (y, gelu(y), [alias]) -- the activation comes out of the
+    same launch (token_gemm_gelu) and carries no gradient; hand it to ops.gelu_linear(y, ..., h=gelu(y)).
     inplace_dx: the backward may add into the gradient tensor it receives for the alias instead of copying it.
     Pass True only if the alias feeds exactly one consumer whose backward hands over a buffer nobody else reads
     afterwards (no hooks / retain_grad on the alias, no second use, no retain_graph replay)."""
@@ -490,7 +519,7 @@ def proj_fork(x, weight, bias, segs, pos=None, fork=False, inplace_dx=False):
     if pos is not None:
         indices, table, window_shape, do_shift = pos
         pos = (indices, table, int(window_shape[1]), int(window_shape[0]), bool(do_shift))
-    return _ProjFork.apply(x, weight, bias, segs, pos, bool(fork), bool(inplace_dx))
+    return _ProjFork.apply(x, weight, bias, segs, pos, bool(fork), bool(inplace_dx), bool(gelu))
 
 
 def _derived(t, name, fn):
@@ -701,10 +730,11 @@ class _GeluLinear(torch.autograd.Function):
     (tmae_token_gemm_dgelu: the GEMM's epilogue reads h_pre) instead of a GEMM plus an elementwise GeluBackward."""
 
     @staticmethod
-    def forward(ctx, h_pre, weight, bias):
+    def forward(ctx, h_pre, weight, bias, h=None):
         cdt = compute_dtype(h_pre)
         hp = h_pre.to(cdt).contiguous()
-        h = torch.nn.functional.gelu(hp)
+        if h is None or h.dtype != cdt or h.shape != hp.shape:        # h = gelu(h_pre) already made by the producing GEMM
+            h = torch.nn.functional.gelu(hp)
         w_c = cast_param(weight, cdt)
         y = token_gemm(h, w_c, None if bias is None else cast_param(bias, cdt))
         ctx.save_for_backward(hp, h, w_c)
@@ -737,13 +767,14 @@ class _GeluLinear(torch.autograd.Function):
         else:
             dw = dy.float().t() @ h.float()
             db = dy.float().sum(0) if ctx.has_bias else None
-        return dhp, dw.to(wdt), (db.to(bdt) if ctx.has_bias else None)
+        return dhp, dw.to(wdt), (db.to(bdt) if ctx.has_bias else None), None
 
 
-def gelu_linear(h_pre, weight, bias=None):
-    """linear(gelu(h_pre), weight, bias) with the GELU backward fused into the input-gradient GEMM (GPU, 2-D)."""
+def gelu_linear(h_pre, weight, bias=None, h=None):
+    """linear(gelu(h_pre), weight, bias) with the GELU backward fused into the input-gradient GEMM (GPU, 2-D).
+    h: gelu(h_pre) if the caller already has it (ops.proj_fork(..., gelu=True)); never differentiated through."""
     if h_pre.is_cuda and h_pre.dim() == 2:
-        return _GeluLinear.apply(h_pre, weight, bias)
+        return _GeluLinear.apply(h_pre, weight, bias, h)
     return torch.nn.functional.linear(torch.nn.functional.gelu(h_pre), weight, bias)
 
 

@@ -1456,7 +1456,10 @@ def test_bf16_trains_like_fp32():
     (B = 2 x 20 k-point pairs, the recipe's Adam one-cycle) from the same initial weights on the same batches with the
     same masking noise, once in fp32 and once under bf16 autocast (bench.training_curves, also printed in the bench
     line's `parity`).  Both curves must fall (3.77 -> 0.88 here) and stay within a stated band of each other: every step
-    within 2 % (measured: 0.5 % at worst, step 25), the means over the last ten steps within 1 %."""
+    within 8 %, the means over the last ten steps within 3 %.  What was measured: the bf16 curve repeats bit for bit from
+    run to run; the fp32 curve does not (library reductions on the fp32 path), and from step ~20 on its own runs differ by
+    up to 6 % at single steps (0.888 / 0.939 at step 27 in two runs) -- the two dtypes were within 0.5 % of each other in
+    one run and 5.7 % in another, i.e. inside fp32's own run-to-run spread."""
     import bench
     c = bench.training_curves(dev())
     a, b = np.array(c['fp32']), np.array(c['bf16'])
@@ -1465,5 +1468,62 @@ def test_bf16_trains_like_fp32():
     assert np.isfinite(a).all() and np.isfinite(b).all()
     assert a[-5:].mean() < 0.9 * a[:5].mean() and b[-5:].mean() < 0.9 * b[:5].mean(), (c['fp32_first5_last5'], c['bf16_first5_last5'])
     assert abs(a[0] - b[0]) <= 2e-3 * abs(a[0])                          # the first step: same weights, bf16 forward error only
-    assert c['max_rel_gap'] <= 0.02, c['max_rel_gap']
-    assert abs(a[-10:].mean() - b[-10:].mean()) <= 0.01 * a[-10:].mean()
+    assert c['max_rel_gap'] <= 0.08, c['max_rel_gap']
+    assert abs(a[-10:].mean() - b[-10:].mean()) <= 0.03 * a[-10:].mean()
+
+
+def test_token_gemm_gelu_dual_store_vs_torch():
+    """tmae_token_gemm_gelu (the FFN's first Linear + its exact GELU in one launch, csrc/token_gemm_wreg.hip GELU2): both
+    shapes, ragged token counts, a strided x.  y against fp32 matmul on the same bf16 inputs; y_gelu against torch's erf
+    GELU of the KERNEL's own y (the activation is taken from the bf16-rounded pre-activation, as F.gelu(y) would): at
+    most one bf16 ulp (Abramowitz-Stegun erf, |error| < 1.5e-7, then one rounding).  Then the encoder tail that uses it
+    (ops.proj_fork(gelu=True) -> ops.gelu_linear(h=...)) against the two-pass form: identical outputs and gradients."""
+    from tmae_amd import ops
+    from tmae_amd._lib import lib, check
+    torch.manual_seed(5)
+    st = torch.cuda.current_stream().cuda_stream
+    for (m, k, n) in ((32768 + 17, 256, 512), (70001, 256, 512), (32769, 128, 256), (100003, 128, 256)):
+        big = torch.randn(m, k + 64, device=dev()).bfloat16()
+        x = big[:, 32:32 + k]                                                   # pitch k + 64
+        w = (torch.randn(n, k, device=dev()) * 0.1).bfloat16()
+        b = torch.randn(n, device=dev()).bfloat16()
+        y = torch.full((m, n), float('nan'), device=dev(), dtype=torch.bfloat16)
+        yg = torch.full((m, n), float('nan'), device=dev(), dtype=torch.bfloat16)
+        check(lib.tmae_token_gemm_gelu(x.data_ptr(), x.stride(0), m, k, w.data_ptr(), n, b.data_ptr(), y.data_ptr(), yg.data_ptr(), n,
+                                       st), 'tmae_token_gemm_gelu')
+        ref = x.float() @ w.float().t() + b.float()
+        assert (y.float() - ref).abs().max().item() <= 2e-2 * max(1.0, float(ref.abs().max())), (m, k, n)
+        y_plain = ops.token_gemm(x, w, b, force=True)
+        assert torch.equal(y, y_plain), 'the pre-activation must not depend on the second store'
+        want = F.gelu(y.float())
+        ulp = torch.maximum(want.abs(), torch.full_like(want, 2.0 ** -100)) * 2.0 ** -8
+        assert bool(((yg.float() - want).abs() <= ulp + 1e-30).all()), (m, k, n, float(((yg.float() - want).abs() / ulp).max()))
+        assert float((yg.float() != want.bfloat16().float()).float().mean()) < 2e-3        # almost always the same rounding
+    # refused shapes: the caller falls back (ops.token_gemm_gelu does)
+    x = torch.randn(1000, 256, device=dev()).bfloat16()
+    w = torch.randn(512, 256, device=dev()).bfloat16()
+    b = torch.zeros(512, device=dev()).bfloat16()
+    y = torch.empty(1000, 512, device=dev(), dtype=torch.bfloat16)
+    assert lib.tmae_token_gemm_gelu(x.data_ptr(), 256, 1000, 256, w.data_ptr(), 512, b.data_ptr(), y.data_ptr(), y.data_ptr(), 512, st) == -1
+    y2, g2 = ops.token_gemm_gelu(x, w, b)
+    assert torch.equal(g2, F.gelu(y2))
+    # the encoder tail: fused vs two-pass, forward and every gradient
+    m, d = 40000, 256
+    xin = torch.randn(m, d, device=dev()).bfloat16()
+    lin1, lin2 = torch.nn.Linear(d, 2 * d).to(dev()), torch.nn.Linear(2 * d, d).to(dev())
+    outs = []
+    for fused in (True, False):
+        xi = xin.clone().requires_grad_(True)
+        for p in list(lin1.parameters()) + list(lin2.parameters()):
+            p.grad = None
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            if fused:
+                h_pre, h_act, alias = ops.proj_fork(xi, lin1.weight, lin1.bias, ((0, 2 * d, False),), fork=True, gelu=True)
+                out = ops.gelu_linear(h_pre, lin2.weight, lin2.bias, h=h_act) + alias
+            else:
+                h_pre, alias = ops.proj_fork(xi, lin1.weight, lin1.bias, ((0, 2 * d, False),), fork=True)
+                out = ops.gelu_linear(h_pre, lin2.weight, lin2.bias) + alias
+        out.float().square().mean().backward()
+        outs.append((out.detach().float(), xi.grad.float(), lin1.weight.grad.clone(), lin2.weight.grad.clone(), lin1.bias.grad.clone()))
+    for a, b_ in zip(*outs):
+        assert (a - b_).abs().max().item() <= 4e-3 * max(1e-6, float(b_.abs().max())), float((a - b_).abs().max())
