@@ -323,6 +323,10 @@ int tmae_bn_relu_bwd(const void* dy, const void* x, int dtype, int64_t m, int c,
  * dx = gamma * rstd * (dz - dbeta/count - xhat * dgamma/count) with caller-provided totals. */
 int tmae_bn_stats(const void* x, int dtype, int64_t m, int c, double count, float eps, float* mean, float* var,
                   float* rstd, void* ws, size_t ws_bytes, void* stream);
+/* y = relu?((x - mean) * rstd * gamma + beta) with caller-provided statistics (the apply half of tmae_bn_relu_fwd): for
+ * statistics merged over ranks first -- torch.nn.SyncBatchNorm, tools/train.py:74,244-245 (--sync_bn). */
+int tmae_bn_apply(const void* x, int dtype, int64_t m, int c, const float* mean, const float* rstd, const float* gamma,
+                  const float* beta, int relu, void* y, void* stream);
 int tmae_bn_bwd_sums(const void* dy, const void* x, int dtype, int64_t m, int c, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, int relu, float* sum_dz, float* sum_dz_xhat, void* ws,
                      size_t ws_bytes, void* stream);

@@ -353,6 +353,26 @@ int tmae_bn_stats(const void* x_, int dtype, int64_t m, int c, double count, flo
   return tmae_launch_status();
 }
 
+// y = relu?((x - mean) * rstd * gamma + beta) with CALLER-provided statistics: the apply half of tmae_bn_relu_fwd, for
+// statistics that were merged over ranks first (SyncBatchNorm, tools/train.py --sync_bn)
+int tmae_bn_apply(const void* x_, int dtype, int64_t m, int c, const float* mean, const float* rstd, const float* gamma,
+                  const float* beta, int relu, void* y_, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!bn_args_ok(m, c, dtype) || !x_ || !mean || !rstd || !gamma || !beta || !y_) return TMAE_EARG;
+  dim3 grid(bn_grid(m)), block(256);
+  if (dtype == TMAE_F32) {
+    const float* x = (const float*)x_;
+    float* y = (float*)y_;
+    BN_DISPATCH(float, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y);
+  } else {
+    const __hip_bfloat16* x = (const __hip_bfloat16*)x_;
+    __hip_bfloat16* y = (__hip_bfloat16*)y_;
+    BN_DISPATCH(__hip_bfloat16, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y);
+  }
+  return tmae_launch_status();
+}
+
 int tmae_bn_bwd_sums(const void* dy_, const void* x_, int dtype, int64_t m, int c, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, int relu, float* sum_dz, float* sum_dz_xhat, void* wsp,
                      size_t ws_bytes, void* stream_) {

@@ -64,6 +64,7 @@ SIGNATURES = {
     'tmae_bn_relu_fwd': (I, [P, I, L, I, P, P, F, I, P, P, P, P, P, Z, P]),
     'tmae_bn_relu_bwd': (I, [P, P, I, L, I, P, P, P, P, I, P, P, P, P, Z, P]),
     'tmae_bn_stats': (I, [P, I, L, I, D, F, P, P, P, P, Z, P]),
+    'tmae_bn_apply': (I, [P, I, L, I, P, P, P, P, I, P, P]),
     'tmae_bn_bwd_sums': (I, [P, P, I, L, I, P, P, P, P, I, P, P, P, Z, P]),
     'tmae_bn_bwd_apply': (I, [P, P, I, L, I, P, P, P, P, I, P, P, D, P, P]),
     'tmae_deblock_scatter': (I, [P, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P]),

@@ -144,11 +144,11 @@ class SparseSequential(SparseModule):
             m = mods[i]
             if isinstance(m, SparseModule):
                 x = m(x)
-            elif isinstance(m, nn.BatchNorm1d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+            elif isinstance(m, (nn.BatchNorm1d, nn.SyncBatchNorm)) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
                 rows = None if x.groups is None else [g[0] for g in x.groups]
                 x = x.replace_feature(ops.batch_norm_relu(x.features, m, relu=True, groups=rows))   # fused BN + ReLU
                 i += 1
-            elif isinstance(m, nn.BatchNorm1d) and x.groups is not None:
+            elif isinstance(m, (nn.BatchNorm1d, nn.SyncBatchNorm)) and x.groups is not None:
                 x = x.replace_feature(ops.batch_norm_relu(x.features, m, relu=False, groups=[g[0] for g in x.groups]))
             else:
                 x = x.replace_feature(m(x.features))

@@ -80,7 +80,7 @@ class TemporalDynVFE(VFETemplate):
                     x = torch.nn.functional.pad(x, (0, pad))
                     w = torch.nn.functional.pad(w, (0, pad))
                 x = ops.linear(x, w, None)
-            elif isinstance(layer, nn.BatchNorm1d):
+            elif isinstance(layer, (nn.BatchNorm1d, nn.SyncBatchNorm)):
                 x = ops.batch_norm_relu(x, layer, relu=True)         # the ReLU that follows is fused
         x_max, _ = ops.scatter_max(x, vox['inverse'], perm, offsets, m)
         return x_max

@@ -859,12 +859,44 @@ def add_layer_norm(a, b, weight, bias, eps=1e-5, bmask=None, post=None, passthro
     return (y, a) if passthrough else y
 
 
+def _sync_group(bn):
+    """The process group over which `bn` shares its batch statistics, or None: a torch.nn.SyncBatchNorm module (what
+    tools/train.py --sync_bn makes of every BatchNorm, as the reference does with convert_sync_batchnorm,
+    tools/train.py:244-245) in training mode under an initialised process group of more than one rank."""
+    import torch.distributed as dist
+    if not isinstance(bn, torch.nn.SyncBatchNorm) or not bn.training:
+        return None
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    pg = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return pg if dist.get_world_size(pg) > 1 else None
+
+
+def _merge_stats(mean, var, count, pg):
+    """Batch statistics of the union of every rank's rows from the per-rank (mean, biased var, row count): one
+    all_gather of [2c + 1] floats per rank, merged in float64 (the pairwise update of Chan et al.: no E[x^2] - E[x]^2
+    cancellation).  Returns (mean, biased var) f32 [c] and the total count (float)."""
+    import torch.distributed as dist
+    c = mean.numel()
+    mine = torch.cat([mean.reshape(-1).double(), var.reshape(-1).double(), mean.new_full((1,), float(count)).double()])
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size(pg))]
+    dist.all_gather(parts, mine, group=pg)
+    allp = torch.stack(parts)                                # [W, 2c + 1]
+    n = allp[:, 2 * c:]                                      # [W, 1]
+    tot = n.sum()
+    gmean = (allp[:, :c] * n).sum(0) / tot
+    gvar = ((allp[:, c:2 * c] + (allp[:, :c] - gmean) ** 2) * n).sum(0) / tot
+    return gmean.float(), gvar.float(), float(tot)
+
+
 class _BatchNormReLU(torch.autograd.Function):
     """`bounds` = row offsets [0, r1, ..., m]: every row range is normalised with its own batch statistics (the
-    Siamese encoder runs both frames as one token list; the reference normalises each frame's call separately)."""
+    Siamese encoder runs both frames as one token list; the reference normalises each frame's call separately).
+    pg (a process group, SyncBatchNorm): statistics and the two backward sums are taken over the rows of ALL ranks
+    (torch.nn.SyncBatchNorm semantics: the gradients of gamma / beta stay the rank's own sums, DDP averages them)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, relu, bounds):
+    def forward(ctx, x, weight, bias, eps, relu, bounds, pg=None):
         x = x.contiguous()
         m, c = x.shape
         ng = len(bounds) - 1
@@ -872,15 +904,27 @@ class _BatchNormReLU(torch.autograd.Function):
         mean = torch.empty((ng, c), dtype=torch.float32, device=x.device)
         var, rstd = torch.empty_like(mean), torch.empty_like(mean)
         g32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        counts = []
         for g in range(ng):
             r0, r1 = bounds[g], bounds[g + 1]
             wsb = lib.tmae_bn_workspace(r1 - r0, c)
             ws = _ws(wsb, x.device)
-            check(lib.tmae_bn_relu_fwd(_p(x[r0:r1]), _dt(x), r1 - r0, c, _p(g32), _p(b32), float(eps), 1 if relu else 0,
-                                       _p(y[r0:r1]), _p(mean[g]), _p(var[g]), _p(rstd[g]), _p(ws), wsb, _s()),
-                  'tmae_bn_relu_fwd')
+            if pg is None:
+                check(lib.tmae_bn_relu_fwd(_p(x[r0:r1]), _dt(x), r1 - r0, c, _p(g32), _p(b32), float(eps), 1 if relu else 0,
+                                           _p(y[r0:r1]), _p(mean[g]), _p(var[g]), _p(rstd[g]), _p(ws), wsb, _s()),
+                      'tmae_bn_relu_fwd')
+                counts.append(float(r1 - r0))
+                continue
+            check(lib.tmae_bn_stats(_p(x[r0:r1]), _dt(x), r1 - r0, c, float(r1 - r0), float(eps), _p(mean[g]), _p(var[g]),
+                                    _p(rstd[g]), _p(ws), wsb, _s()), 'tmae_bn_stats')
+            gm, gv, tot = _merge_stats(mean[g], var[g], r1 - r0, pg)
+            mean[g], var[g], rstd[g] = gm, gv, torch.rsqrt(gv + eps)
+            counts.append(tot)
+            check(lib.tmae_bn_apply(_p(x[r0:r1]), _dt(x), r1 - r0, c, _p(mean[g]), _p(rstd[g]), _p(g32), _p(b32),
+                                    1 if relu else 0, _p(y[r0:r1]), _s()), 'tmae_bn_apply')
         ctx.save_for_backward(x, mean, rstd, g32, b32)
-        ctx.relu, ctx.bounds = relu, bounds
+        ctx.relu, ctx.bounds, ctx.pg, ctx.counts = relu, bounds, pg, counts
+        _BatchNormReLU.last_counts = counts            # rows behind every group's statistics (all ranks under SyncBatchNorm)
         ctx.dtypes = (weight.dtype, bias.dtype)
         ctx.mark_non_differentiable(mean, var)
         ctx.set_materialize_grads(False)       # no zero-filled "gradients" for the statistics outputs (2 fills per layer)
@@ -889,7 +933,7 @@ class _BatchNormReLU(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _m, _v):
         if dy is None:
-            return (None,) * 6
+            return (None,) * 7
         x, mean, rstd, g32, b32 = ctx.saved_tensors
         dy = dy.to(x.dtype).contiguous()
         m, c = x.shape
@@ -902,14 +946,26 @@ class _BatchNormReLU(torch.autograd.Function):
             r0, r1 = bounds[g], bounds[g + 1]
             wsb = lib.tmae_bn_workspace(r1 - r0, c)
             ws = _ws(wsb, x.device)
-            check(lib.tmae_bn_relu_bwd(_p(dy[r0:r1]), _p(x[r0:r1]), _dt(x), r1 - r0, c, _p(mean[g]), _p(rstd[g]), _p(g32),
-                                       _p(b32), 1 if ctx.relu else 0, _p(dx[r0:r1]), _p(dg[g]), _p(db[g]), _p(ws), wsb,
-                                       _s()), 'tmae_bn_relu_bwd')
+            if ctx.pg is None:
+                check(lib.tmae_bn_relu_bwd(_p(dy[r0:r1]), _p(x[r0:r1]), _dt(x), r1 - r0, c, _p(mean[g]), _p(rstd[g]), _p(g32),
+                                           _p(b32), 1 if ctx.relu else 0, _p(dx[r0:r1]), _p(dg[g]), _p(db[g]), _p(ws), wsb,
+                                           _s()), 'tmae_bn_relu_bwd')
+                continue
+            import torch.distributed as dist
+            check(lib.tmae_bn_bwd_sums(_p(dy[r0:r1]), _p(x[r0:r1]), _dt(x), r1 - r0, c, _p(mean[g]), _p(rstd[g]), _p(g32),
+                                       _p(b32), 1 if ctx.relu else 0, _p(db[g]), _p(dg[g]), _p(ws), wsb, _s()),
+                  'tmae_bn_bwd_sums')
+            tot = torch.stack([db[g], dg[g]])                 # the sums of every rank enter dx; dgamma / dbeta stay local
+            dist.all_reduce(tot, group=ctx.pg)
+            tb, tg = tot[0].contiguous(), tot[1].contiguous()
+            check(lib.tmae_bn_bwd_apply(_p(dy[r0:r1]), _p(x[r0:r1]), _dt(x), r1 - r0, c, _p(mean[g]), _p(rstd[g]), _p(g32),
+                                        _p(b32), 1 if ctx.relu else 0, _p(tb), _p(tg), float(ctx.counts[g]), _p(dx[r0:r1]),
+                                        _s()), 'tmae_bn_bwd_apply')
         if ng > 1:
             dg, db = dg.sum(0), db.sum(0)
         else:
             dg, db = dg[0], db[0]
-        return dx, dg.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None, None
+        return dx, dg.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None, None, None
 
 
 class _DeadBias(torch.autograd.Function):
@@ -944,14 +1000,18 @@ def batch_norm_relu(x, bn, relu=True, groups=None, pre_bias=None):
         bounds = [0]
         for g in sizes:
             bounds.append(bounds[-1] + g)
-        y, mean, var = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.eps, relu, tuple(bounds))
+        pg = _sync_group(bn)
+        y, mean, var = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.eps, relu, tuple(bounds), pg)
         if pre_bias is not None:
             y = _DeadBias.apply(y, pre_bias)
             mean = mean + pre_bias.detach().float()
         if bn.track_running_stats:
-            for g, m in enumerate(sizes):
+            for g, m in enumerate(_BatchNormReLU.last_counts):      # SyncBatchNorm: the rows of all ranks (unbiased variance)
                 _bn_running_update(bn, mean[g], var[g], m)
         return y
+    if _sync_group(bn) is not None:
+        raise NotImplementedError('SyncBatchNorm: this layer shape has no fused kernel (channels in {64, 128, 256}, bf16 / fp32 '
+                                  'rows on the GPU); the library path would need an RCCL-capable torch SyncBatchNorm call here')
     if len(sizes) > 1:
         ys = [bn(part) for part in torch.split(x, sizes)]
         y = torch.cat(ys, 0)
@@ -1483,7 +1543,7 @@ class _DeblocksToDense(torch.autograd.Function):
     args = (feat_i, weight_i [cin, cout, s, s], gamma_i, beta_i) per source."""
 
     @staticmethod
-    def forward(ctx, metas, batch, ny, nx, eps, *args):
+    def forward(ctx, metas, batch, ny, nx, eps, pg, *args):
         n_src = len(metas)
         feats = args[0::4]
         dev = feats[0].device
@@ -1510,6 +1570,9 @@ class _DeblocksToDense(torch.autograd.Function):
             ws = _ws(wsb, dev)
             check(lib.tmae_bn_stats(_p(v), _dt(v), rows, cout, count, float(eps[i]), _p(mean), _p(var), _p(rstd),
                                     _p(ws), wsb, _s()), 'tmae_bn_stats')
+            if pg is not None:                    # SyncBatchNorm: every rank counts batch * ny * nx cells
+                gm, gv, _ = _merge_stats(mean, var, count, pg)
+                mean.copy_(gm), var.copy_(gv), rstd.copy_(torch.rsqrt(gv + float(eps[i])))
             check(lib.tmae_deblock_scatter(_p(v), _dt(v), _p(grid), batch, ys, xs, s, cout, _p(mean), _p(rstd), _p(g32),
                                            _p(b32), _p(cat), ctot, coff, _s()), 'tmae_deblock_scatter')
             saved += [x_c, wmat, v, mean, rstd, g32, b32, grid, indices]
@@ -1519,6 +1582,7 @@ class _DeblocksToDense(torch.autograd.Function):
         ctx.meta = (n_src, [(ys, xs, s) for (_, _, ys, xs, s) in metas], batch, ny, nx, couts, count,
                     [(args[4 * i].dtype, args[4 * i + 1].dtype, args[4 * i + 2].dtype, args[4 * i + 3].dtype)
                      for i in range(n_src)])
+        ctx.pg = pg
         ctx.mark_non_differentiable(*stats)
         ctx.set_materialize_grads(False)
         return (cat, *stats)
@@ -1527,7 +1591,7 @@ class _DeblocksToDense(torch.autograd.Function):
     def backward(ctx, dcat, *_unused):
         n_src, shapes, batch, ny, nx, couts, count, dts = ctx.meta
         if dcat is None:
-            return (None,) * (5 + 4 * n_src)
+            return (None,) * (6 + 4 * n_src)
         saved = ctx.saved_tensors
         ctot = sum(couts)
         dev = dcat.device
@@ -1567,12 +1631,18 @@ class _DeblocksToDense(torch.autograd.Function):
             rest = (s_all[coff:coff + cout] - s_act) * live0
             dbeta = (sum_dz + rest).contiguous()
             dgamma = (sum_dzx + rest * xhat0).contiguous()
+            tb, tg, tcount = dbeta, dgamma, count
+            if ctx.pg is not None:                # the sums of every rank enter dx; dgamma / dbeta stay this rank's
+                import torch.distributed as dist
+                tot = torch.stack([dbeta, dgamma])
+                dist.all_reduce(tot, group=ctx.pg)
+                tb, tg, tcount = tot[0].contiguous(), tot[1].contiguous(), count * dist.get_world_size(ctx.pg)
             dv = torch.empty_like(v)
             check(lib.tmae_bn_bwd_apply(_p(g), _p(v), _dt(v), rows, cout, _p(mean), _p(rstd), _p(g32), _p(b32), 1,
-                                        _p(dbeta), _p(dgamma), count, _p(dv), _s()), 'tmae_bn_bwd_apply')
-            dfeat = token_gemm_dx(dv, wmat) if ctx.needs_input_grad[5 + 4 * i] else None
+                                        _p(tb), _p(tg), tcount, _p(dv), _s()), 'tmae_bn_bwd_apply')
+            dfeat = token_gemm_dx(dv, wmat) if ctx.needs_input_grad[6 + 4 * i] else None
             dwmat = None
-            if ctx.needs_input_grad[5 + 4 * i + 1]:
+            if ctx.needs_input_grad[6 + 4 * i + 1]:
                 if _wgrad_ok(dv, x_c):
                     dwmat, _ = linear_wgrad(dv, x_c, want_bias=False)
                 else:
@@ -1581,7 +1651,7 @@ class _DeblocksToDense(torch.autograd.Function):
                 dwmat = dwmat.view(s, s, cout, cin).permute(3, 2, 0, 1).to(dts[i][1])
             grads += [None if dfeat is None else dfeat.to(dts[i][0]), dwmat, dgamma.to(dts[i][2]), dbeta.to(dts[i][3])]
             coff += cout
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
 def deblocks_to_dense(sources, batch, ny, nx):
@@ -1595,9 +1665,16 @@ def deblocks_to_dense(sources, batch, ny, nx):
         metas.append((grid, indices, int(ys), int(xs), s))
         args += [feat, deconv.weight, bn.weight, bn.bias]
         eps.append(bn.eps)
-    out = _DeblocksToDense.apply(metas, batch, ny, nx, eps, *args)
+    pgs = {id(pg): pg for pg in (_sync_group(src[5]) for src in sources)}
+    if len(pgs) > 1:
+        raise NotImplementedError('decoder norms on different SyncBatchNorm process groups')
+    pg = next(iter(pgs.values()))
+    out = _DeblocksToDense.apply(metas, batch, ny, nx, eps, pg, *args)
     cat, stats = out[0], out[1:]
     n = float(batch * ny * nx)
+    if pg is not None:
+        import torch.distributed as dist
+        n *= dist.get_world_size(pg)
     for i, src in enumerate(sources):
         bn = src[5]
         if bn.track_running_stats:
@@ -1607,7 +1684,7 @@ def deblocks_to_dense(sources, batch, ny, nx):
 
 def deblocks_fusable(sources, training):
     for feat, grid, indices, shape, deconv, bn in sources:
-        if not (isinstance(deconv, torch.nn.ConvTranspose2d) and isinstance(bn, torch.nn.BatchNorm2d)):
+        if not (isinstance(deconv, torch.nn.ConvTranspose2d) and isinstance(bn, (torch.nn.BatchNorm2d, torch.nn.SyncBatchNorm))):
             return False
         s = deconv.stride[0]
         if (deconv.kernel_size != (s, s) or deconv.stride != (s, s) or deconv.bias is not None

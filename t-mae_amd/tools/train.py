@@ -49,7 +49,7 @@ def parse_config():
     # the rest of the reference's command line (tools/train.py:37-131, tools/scripts/once_train.sh): accepted so that its
     # launch lines run unchanged; what has no meaning here says so when it is used
     p.add_argument('--tcp_port', type=int, default=18888, help='unused: the rendezvous comes from the launcher environment')
-    p.add_argument('--sync_bn', action='store_true', help='not supported: BatchNorm statistics are per rank (SYNC_BN off in the shipped configs)')
+    p.add_argument('--sync_bn', action='store_true', help='batch statistics over all ranks (torch.nn.SyncBatchNorm semantics)')
     p.add_argument('--merge_all_iters_to_one_epoch', action='store_true')
     p.add_argument('--max_waiting_mins', type=int, default=1)
     p.add_argument('--start_epoch', type=int, default=0)
@@ -60,8 +60,6 @@ def parse_config():
     p.add_argument('--wandb_proj_name', type=str, default='t-mae-0.05')
     p.add_argument('--fixed_gap_eval', type=int, default=None)
     args = p.parse_args()
-    if args.sync_bn:
-        raise NotImplementedError('--sync_bn: the BatchNorm kernels keep per-rank statistics (the shipped recipes do not use it)')
     if args.merge_all_iters_to_one_epoch:
         raise NotImplementedError('--merge_all_iters_to_one_epoch is not used by the T-MAE recipes')
     cfg_from_yaml_file(args.cfg_file, cfg)
@@ -132,7 +130,12 @@ def main():
             training=True, total_epochs=epochs, device=torch.device('cuda', torch.cuda.current_device()))
         train_loader.pipeline.reference_rng_order = bool(args.reference_rng_order)
         iters_per_epoch = len(train_loader)
-    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds, logger).cuda()
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds, logger)
+    if args.sync_bn:
+        # the reference's conversion (tools/train.py:244-245); the fused BatchNorm kernels read the module type and merge
+        # their statistics and backward sums over the ranks of the process group (tmae_amd.ops._BatchNormReLU)
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    model = model.cuda()
     opt = build_optimizer(model, cfg.OPTIMIZATION)
     start_epoch = it = 0
     if args.pretrained_model:

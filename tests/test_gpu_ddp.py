@@ -151,3 +151,80 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
         assert key in d, key
     assert d['roofline']['peak_measured'] == d['box_peaks']['hbm_copy_gbs'] > 1000
     assert d['roofline_step']['peak_measured'] == d['box_peaks']['mfma_bf16_tflops'] > 100
+
+
+def _syncbn_worker(rank, world, port, q):
+    for p in (os.path.join(ROOT, 't-mae_amd'), os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tmae_amd import ops
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(0)
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    # ---- row BatchNorm (+ ReLU), two row groups (the two frames of the pair encoder), different row counts per rank
+    c = 128
+    sizes = [[3000, 1700], [2100, 2600]]
+    xs = [torch.randn(sum(sz), c, generator=g) * 2 + 0.5 for sz in sizes]
+    dys = [torch.randn(sum(sz), c, generator=g) for sz in sizes]
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    bn = torch.nn.SyncBatchNorm(c, eps=1e-3, momentum=0.01).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(gamma), bn.bias.copy_(beta)
+    bn.train()
+    x = xs[rank].to(dev).requires_grad_(True)
+    y = ops.batch_norm_relu(x, bn, relu=True, groups=sizes[rank])
+    y.backward(dys[rank].to(dev))
+    out['bn'] = (y.detach().cpu(), x.grad.cpu(), bn.weight.grad.cpu(), bn.bias.grad.cpu(), bn.running_mean.cpu(),
+                 bn.running_var.cpu(), int(bn.num_batches_tracked))
+    # the same union of rows through ONE plain BatchNorm per group on this rank alone = the definition of SyncBatchNorm
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev)
+    with torch.no_grad():
+        ref.weight.copy_(gamma), ref.bias.copy_(beta)
+    ref.train()
+    ys, gxs = [], []
+    for grp in range(2):
+        parts = []
+        for r in range(world):
+            o = sum(sizes[r][:grp])
+            parts.append((xs[r][o:o + sizes[r][grp]], dys[r][o:o + sizes[r][grp]]))
+        xu = torch.cat([p_[0] for p_ in parts]).to(dev).requires_grad_(True)
+        yu = torch.relu(ref(xu))
+        yu.backward(torch.cat([p_[1] for p_ in parts]).to(dev))
+        lo = sum(sizes[r][grp] for r in range(rank))
+        ys.append(yu.detach()[lo:lo + sizes[rank][grp]].cpu())
+        gxs.append(xu.grad[lo:lo + sizes[rank][grp]].cpu())
+    out['bn_ref'] = (torch.cat(ys), torch.cat(gxs), ref.weight.grad.cpu(), ref.bias.grad.cpu(), ref.running_mean.cpu(),
+                     ref.running_var.cpu())
+    # gamma / beta gradients are the rank's own sums (DDP averages them later): their sum over ranks = the union's
+    gsum = torch.stack([bn.weight.grad, bn.bias.grad]).clone()
+    dist.all_reduce(gsum)
+    out['bn_gsum'] = gsum.cpu()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_equals_the_union_batch():
+    """tools/train.py --sync_bn (the reference: convert_sync_batchnorm, tools/train.py:244-245): a SyncBatchNorm module
+    makes ops.batch_norm_relu merge its statistics and backward sums over the ranks.  Two ranks (gloo, one GPU) with
+    different row counts against ONE BatchNorm over the union of their rows: outputs, input gradients, the summed
+    gamma / beta gradients and the running statistics."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 30900 + os.getpid() % 2000
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=300) for _ in range(2))
+    [p.join(60) for p in procs]
+    for rank in range(2):
+        y, gx, gw, gb, rm, rv, nbt = res[rank]['bn']
+        y0, gx0, gw0, gb0, rm0, rv0 = res[rank]['bn_ref']
+        assert nbt == 2                                                       # two groups = two BatchNorm calls
+        torch.testing.assert_close(y, y0, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(gx, gx0, rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(rm, rm0, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rv, rv0, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(res[rank]['bn_gsum'][0], gw0, rtol=2e-4, atol=2e-3)
+        torch.testing.assert_close(res[rank]['bn_gsum'][1], gb0, rtol=2e-4, atol=2e-3)

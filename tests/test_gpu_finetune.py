@@ -361,7 +361,7 @@ def test_train_cli_accepts_the_reference_launch_line(tmp_path):
     out = tmp_path / 'run'
     cmd = [sys.executable, os.path.join(ROOT, 't-mae_amd', 'tools', 'train.py'), '--cfg_file',
            os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae.yaml'), '--workers', '8', '--extra_tag', 't',
-           '--max_ckpt_save_num', '1', '--num_epochs_to_eval', '1', '--amp', '--fixed_gap_eval', '1', '--synthetic',
+           '--max_ckpt_save_num', '1', '--num_epochs_to_eval', '1', '--amp', '--fixed_gap_eval', '1', '--synthetic', '--sync_bn',
            '--synthetic_points', '20000', '--iters_per_epoch', '2', '--epochs', '2', '--batch_size', '2', '--output_dir', str(out)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1475,8 +1475,10 @@ def test_bf16_trains_like_fp32():
 def test_token_gemm_gelu_dual_store_vs_torch():
     """tmae_token_gemm_gelu (the FFN's first Linear + its exact GELU in one launch, csrc/token_gemm_wreg.hip GELU2): both
     shapes, ragged token counts, a strided x.  y against fp32 matmul on the same bf16 inputs; y_gelu against torch's erf
-    GELU of the KERNEL's own y (the activation is taken from the bf16-rounded pre-activation, as F.gelu(y) would): at
-    most one bf16 ulp (Abramowitz-Stegun erf, |error| < 1.5e-7, then one rounding).  Then the encoder tail that uses it
+    GELU of the KERNEL's own y (the activation is taken from the bf16-rounded pre-activation, as F.gelu(y) would): one
+    bf16 rounding (relative 2^-8) plus the Abramowitz-Stegun erf's absolute error (< 1.5e-7 in erf, i.e. < 1e-7 |y| in
+    the result -- visible only in the far negative tail, where gelu itself is ~1e-6; the backward's gelu' has used the
+    same formula since round 1).  Then the encoder tail that uses it
     (ops.proj_fork(gelu=True) -> ops.gelu_linear(h=...)) against the two-pass form: identical outputs and gradients."""
     from tmae_amd import ops
     from tmae_amd._lib import lib, check
@@ -1496,8 +1498,8 @@ def test_token_gemm_gelu_dual_store_vs_torch():
         y_plain = ops.token_gemm(x, w, b, force=True)
         assert torch.equal(y, y_plain), 'the pre-activation must not depend on the second store'
         want = F.gelu(y.float())
-        ulp = torch.maximum(want.abs(), torch.full_like(want, 2.0 ** -100)) * 2.0 ** -8
-        assert bool(((yg.float() - want).abs() <= ulp + 1e-30).all()), (m, k, n, float(((yg.float() - want).abs() / ulp).max()))
+        bound = want.abs() * 2.0 ** -8 + 2e-7 * y.float().abs() + 1e-30
+        assert bool(((yg.float() - want).abs() <= bound).all()), (m, k, n, float(((yg.float() - want).abs() / bound).max()))
         assert float((yg.float() != want.bfloat16().float()).float().mean()) < 2e-3        # almost always the same rounding
     # refused shapes: the caller falls back (ops.token_gemm_gelu does)
     x = torch.randn(1000, 256, device=dev()).bfloat16()
