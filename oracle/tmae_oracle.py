@@ -443,14 +443,18 @@ def sst_encoder(x, coords, grid_xyz, p, prefix, stage, cfg, capture=None):
     NUM_BLOCKS x BasicShiftBlockV2 (layer 0 on shift 0, layer 1 on shift 1,
     sst_basic_block.py:100-114)."""
     info = sst_input_layer(coords, grid_xyz, cfg)
-    assert info['voxel_keep_inds'].shape[0] == coords.shape[0]      # SURVEY A-6: nothing dropped
+    # Voxels whose in-window rank reaches their level's max_tokens are dropped from the encoder (spt_backbone.py:47-135)
+    # and come back as zero rows (:347-349: voxel_features_unshuffle[voxel_shuffle_inds] = ...), i.e. they keep only the
+    # block's residual.  With the shipped DROP_INFO (8 x 8 windows, top level 64 tokens) nobody is dropped (SURVEY A-6).
+    keep = torch.from_numpy(info['voxel_keep_inds'])
+    xk = x if keep.numel() == x.shape[0] else x[keep]
     d = x.shape[1]
     per_shift = []
     for i in range(2):
         f2w = info[f'flat2win_inds_shift{i}']
         pos = pos_embed(info[f'coors_in_win_shift{i}'], d, cfg['window_shape'], cfg['pos_temperature'])
-        per_shift.append((pos, f2w, key_padding_mask(f2w, cfg['drop_info'], x.shape[0])))
-    out = x
+        per_shift.append((pos, f2w, key_padding_mask(f2w, cfg['drop_info'], xk.shape[0])))
+    out = xk
     for blk in range(stage['num_blocks']):
         for i in range(2):
             pos, f2w, kpm = per_shift[i]
@@ -458,6 +462,8 @@ def sst_encoder(x, coords, grid_xyz, p, prefix, stage, cfg, capture=None):
                                 f'{prefix}encoder_blocks.{blk}.encoder_list.{i}.', stage['nhead'], cfg)
     if capture is not None:
         capture['input_layer'] = info
+    if keep.numel() != x.shape[0]:
+        out = torch.zeros_like(x).index_copy(0, keep, out)
     return out
 
 

@@ -68,11 +68,24 @@ class WindowPlan:
         self.key_grid = self.grid if other is None else other.grid
         self._wl = {}
         self._cells = {}
+        self._shift_grids = {}           # shift -> (query grid, key grid) with dropped tokens masked out (token dropping)
+
+    def set_shift_grids(self, shift, grid_q, grid_k):
+        """Attention of `shift` sees these grids instead of the stage's: a token whose cell reads -1 does not exist for
+        it (DROP_INFO with max_tokens below the window's voxel count: per-shift keep sets, SiamWCA.py:141-215)."""
+        self._shift_grids[bool(shift)] = (grid_q, grid_k)
+        self._wl.pop(bool(shift), None)
+
+    def grid_q(self, shift):
+        return self._shift_grids.get(bool(shift), (self.grid, self.key_grid))[0]
+
+    def grid_k(self, shift):
+        return self._shift_grids.get(bool(shift), (self.grid, self.key_grid))[1]
 
     def worklist(self, shift):
         shift = bool(shift)
         if shift not in self._wl:
-            self._wl[shift] = ops.window_worklist(self.grid, self.key_grid, self.batch, self.ny, self.nx, shift)
+            self._wl[shift] = ops.window_worklist(self.grid_q(shift), self.grid_k(shift), self.batch, self.ny, self.nx, shift)
         return self._wl[shift]
 
     def cells(self, shift, window_shape):
@@ -137,14 +150,14 @@ class WindowCrossAttention(nn.Module):
             E = ops.pos_axes(pos_table, window_shape)
             q, kv, x_res = ops.pos_proj_cross(x, x_prv, w, b, plan.cells(shift, window_shape),
                                               plan_prv.cells(shift, window_shape), E, inplace_dx=True)
-            o = ops.win_attn(q, kv, 'kv', a.tau, plan.grid, plan_prv.grid, self.nhead, plan.batch, plan.ny, plan.nx,
-                             shift, a.tau_min, worklist=plan.worklist(shift))
+            o = ops.win_attn(q, kv, 'kv', a.tau, plan.grid_q(shift), plan.grid_k(shift), self.nhead, plan.batch, plan.ny,
+                             plan.nx, shift, a.tau_min, worklist=plan.worklist(shift))
             return o, x_res
         q, x_res = ops.proj_fork(x, w, b, ((0, d, True),), pos=(plan.indices, pos_table, window_shape, shift), fork=True,
                                  inplace_dx=True)
         k, v = ops.proj_fork(x_prv, w, b, ((d, 2 * d, True), (2 * d, 3 * d, False)),
                              pos=(plan_prv.indices, pos_table, window_shape, shift))
-        o = ops.win_attn(q, k, v, a.tau, plan.grid, plan_prv.grid, self.nhead, plan.batch, plan.ny, plan.nx,
+        o = ops.win_attn(q, k, v, a.tau, plan.grid_q(shift), plan.grid_k(shift), self.nhead, plan.batch, plan.ny, plan.nx,
                          shift, a.tau_min, worklist=plan.worklist(shift))
         return o, x_res
 
@@ -276,10 +289,28 @@ def _check_preprocess(pre):
         raise NotImplementedError('SHUFFLE_VOXELS is False in the T-MAE configs')
     if pre.get('NORMALIZE_POS', False):
         raise NotImplementedError('NORMALIZE_POS is False in the T-MAE configs')
-    top = max(int(v['max_tokens']) for v in pre.DROP_INFO['train'].values())
-    if top < ws[0] * ws[1]:
-        # SURVEY A-6: with max_tokens >= window cells no voxel is ever dropped and the ragged kernel is exact
-        raise NotImplementedError('DROP_INFO must keep every token of a window (max_tokens >= 64)')
+    if max(int(v['max_tokens']) for v in pre.DROP_INFO['train'].values()) > ws[0] * ws[1]:
+        raise NotImplementedError('DROP_INFO max_tokens above the 64 cells of a window')
+
+
+def _drop_info(pre):
+    """(drop_info dict, can_drop): DROP_INFO['train'] -- the reference reads `self.training` at construction time, when it
+    is still True (spt_backbone.py:32, SURVEY A-6) -- and whether any window can lose tokens at all: only if some level
+    admits more voxels than its max_tokens.  With the shipped levels (16 / 32 / 64 for < 16 / < 32 / the rest, 64 cells
+    per window) nobody is ever dropped and the token-dropping code below is never entered."""
+    di = {int(k): dict(v) for k, v in pre.DROP_INFO['train'].items()}
+    cells = int(pre.WINDOW_SHAPE[0]) * int(pre.WINDOW_SHAPE[1])
+    can = any(min(int(v['drop_range'][1]) - 1, cells) > int(v['max_tokens']) for v in di.values())
+    return di, can
+
+
+def _mask_grid(plan, keep):
+    """The plan's dense row-index grid with the cells of the tokens with keep == 0 set to -1 (no host sync)."""
+    ind = plan.indices.long()
+    cell = (ind[:, 0] * plan.ny + ind[:, 1]) * plan.nx + ind[:, 2]
+    rows = torch.arange(ind.shape[0], device=ind.device, dtype=torch.int32)
+    g = torch.full_like(plan.grid, -1)
+    return g.scatter_(0, cell, torch.where(keep.bool(), rows, torch.full_like(rows, -1)))
 
 
 class SSTBlockV1(nn.Module):
@@ -299,6 +330,7 @@ class SSTBlockV1(nn.Module):
                                             indice_key=f'{indice_key}_spconv', conv_type='spconv', dim=2)
         _check_preprocess(model_cfg.PREPROCESS)
         self.window_shape = list(model_cfg.PREPROCESS.WINDOW_SHAPE)
+        self.drop_info, self.can_drop = _drop_info(model_cfg.PREPROCESS)
         self.encoder_blocks = nn.ModuleList([
             BasicShiftBlockV2(d_model, enc.NHEAD, enc.DIM_FEEDFORWARD, enc.DROPOUT, enc.ACTIVATION, enc.LAYER_CFG)
             for _ in range(enc.NUM_BLOCKS)])
@@ -306,9 +338,35 @@ class SSTBlockV1(nn.Module):
         self.register_buffer('pos_table', pos_embed_table(d_model, self.window_shape,
                                                           model_cfg.PREPROCESS.POS_TEMPERATURE), persistent=False)
 
+    def kept_rows(self, sp: SparseConvTensor):
+        """Rows that survive SSTInputLayer.drop_voxel (spt_backbone.py:73-135): in shift 0 a voxel whose in-window rank
+        (ascending row index = cell order, SURVEY A-5) reaches its level's max_tokens goes; the survivors are bucketed again
+        under shift 1 and dropped by the same rule.  None when everybody stays.  Two host syncs (the survivor counts):
+        only configurations that can drop at all come here."""
+        ny, nx = sp.spatial_shape
+        wb0 = ops.window_bucket(sp.indices, sp.grid, None, sp.batch_size, ny, nx, self.window_shape, False, self.drop_info)
+        idx0 = wb0['keep'].bool().nonzero().squeeze(1)
+        ind1 = sp.indices[idx0].contiguous()
+        grid1 = ops.index_grid(ind1, sp.batch_size, ny, nx)
+        wb1 = ops.window_bucket(ind1, grid1, None, sp.batch_size, ny, nx, self.window_shape, True, self.drop_info)
+        kept = idx0[wb1['keep'].bool().nonzero().squeeze(1)]
+        return None if kept.shape[0] == sp.indices.shape[0] else kept
+
     def encoder_forward(self, sp: SparseConvTensor, residual=False):
         """SSTBlockV1.encoder_forward (spt_backbone.py:314-340) on the ragged layout.  residual: returns
         x + encoder(x) (the sum of forward(), spt_backbone.py:349-351), taken inside the last layer's norm."""
+        if self.can_drop:
+            kept = self.kept_rows(sp)
+            if kept is not None:
+                # dropped voxels skip the encoder and come back as zero rows (spt_backbone.py:347-349): the layers run
+                # on the compacted survivors, their output is added into the survivors' rows of x
+                sub = SparseConvTensor(sp.features[kept], sp.indices[kept], sp.spatial_shape, sp.batch_size)
+                enc = self._encoder_forward(sub, residual=False)
+                full = torch.zeros_like(sp.features).index_add(0, kept, enc.to(sp.features.dtype))
+                return sp.features + full if residual else full
+        return self._encoder_forward(sp, residual)
+
+    def _encoder_forward(self, sp: SparseConvTensor, residual=False):
         plan = WindowPlan(sp)
         out = sp.features
         alias = None
@@ -351,7 +409,7 @@ class WCABlock(nn.Module):
         norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
         _check_preprocess(model_cfg.PREPROCESS)
         self.window_shape = list(model_cfg.PREPROCESS.WINDOW_SHAPE)
-        self.drop_info = {int(k): dict(v) for k, v in model_cfg.PREPROCESS.DROP_INFO['train'].items()}
+        self.drop_info, self.can_drop = _drop_info(model_cfg.PREPROCESS)
         self.encoder_blocks = nn.ModuleList([
             BasicShiftBlock_WCA(d_model, enc.NHEAD, enc.DIM_FEEDFORWARD, enc.DROPOUT, enc.ACTIVATION, enc.LAYER_CFG)])
         self.conv_out = post_act_block(d_model, d_model, 3, norm_fn=norm_fn, indice_key=f'{indice_key}_subm', dim=2)
@@ -369,6 +427,13 @@ class WCABlock(nn.Module):
             wb = ops.window_bucket(plan.indices, plan.grid, plan_prv.grid, plan.batch, plan.ny, plan.nx,
                                    self.window_shape, shift, self.drop_info)
             kept.append(wb['keep'].view(-1, 1).to(x.dtype))
+            if self.can_drop:
+                # per-shift keep sets of BOTH frames (drop_single_shift_ref_to_prv, SiamWCA.py:65-140): dropped queries
+                # get no update (bmask above), dropped previous-frame tokens are no keys -- both vanish from the grids
+                # this shift's attention reads
+                wbp = ops.window_bucket(plan_prv.indices, plan_prv.grid, plan.grid, plan.batch, plan.ny, plan.nx,
+                                        self.window_shape, shift, self.drop_info)
+                plan.set_shift_grids(shift, _mask_grid(plan, wb['keep']), _mask_grid(plan_prv, wbp['keep']))
         return self.encoder_blocks[0](x, plan, sp_prev.features, plan_prv, self.pos_table, self.window_shape, kept,
                                       residual=residual)
 

@@ -4,6 +4,7 @@ ranks must end with identical weights and the averaged gradient of the two shard
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -201,6 +202,9 @@ def _syncbn_worker(rank, world, port, q):
     gsum = torch.stack([bn.weight.grad, bn.bias.grad]).clone()
     dist.all_reduce(gsum)
     out['bn_gsum'] = gsum.cpu()
+    # numpy, not tensors: a tensor travels through the queue as a file descriptor of a process that may be gone
+    out = {k: tuple(v.numpy() if torch.is_tensor(v) else v for v in val) if isinstance(val, tuple) else val.numpy()
+           for k, val in out.items()}
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -219,12 +223,13 @@ def test_sync_batchnorm_two_ranks_equals_the_union_batch():
     res = dict(q.get(timeout=300) for _ in range(2))
     [p.join(60) for p in procs]
     for rank in range(2):
-        y, gx, gw, gb, rm, rv, nbt = res[rank]['bn']
-        y0, gx0, gw0, gb0, rm0, rv0 = res[rank]['bn_ref']
+        y, gx, gw, gb, rm, rv, nbt = (torch.from_numpy(v) if isinstance(v, np.ndarray) else v for v in res[rank]['bn'])
+        y0, gx0, gw0, gb0, rm0, rv0 = (torch.from_numpy(v) for v in res[rank]['bn_ref'])
+        gsum = torch.from_numpy(res[rank]['bn_gsum'])
         assert nbt == 2                                                       # two groups = two BatchNorm calls
         torch.testing.assert_close(y, y0, rtol=2e-5, atol=2e-5)
         torch.testing.assert_close(gx, gx0, rtol=2e-4, atol=2e-5)
         torch.testing.assert_close(rm, rm0, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(rv, rv0, rtol=1e-5, atol=1e-6)
-        torch.testing.assert_close(res[rank]['bn_gsum'][0], gw0, rtol=2e-4, atol=2e-3)
-        torch.testing.assert_close(res[rank]['bn_gsum'][1], gb0, rtol=2e-4, atol=2e-3)
+        torch.testing.assert_close(gsum[0], gw0, rtol=2e-4, atol=2e-3)
+        torch.testing.assert_close(gsum[1], gb0, rtol=2e-4, atol=2e-3)

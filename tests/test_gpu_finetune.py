@@ -169,7 +169,7 @@ def test_finetune_bf16_step_runs_and_is_close(ft_oracle):
     assert torch.isfinite(ret['loss'])
     rel = abs(float(ret['loss'].detach()) - float(g['loss'])) / abs(float(g['loss']))
     print(f'finetune bf16 loss vs fp32 reference: rel {rel:.2e}')
-    assert rel <= 0.05
+    assert rel <= 0.01                                   # measured 3.9e-3 (round 4); the bar was 5 % until round 3
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 

@@ -1529,3 +1529,53 @@ def test_token_gemm_gelu_dual_store_vs_torch():
         outs.append((out.detach().float(), xi.grad.float(), lin1.weight.grad.clone(), lin2.weight.grad.clone(), lin1.bias.grad.clone()))
     for a, b_ in zip(*outs):
         assert (a - b_).abs().max().item() <= 4e-3 * max(1e-6, float(b_.abs().max())), float((a - b_).abs().max())
+
+
+def test_e2e_token_dropping_vs_reference(oracle):
+    """DROP_INFO that really drops tokens (max_tokens 4 / 8 / 12: a pure YAML edit the reference accepts; the shipped
+    levels never drop, SURVEY A-6) on a dense cloud: half of the stage-1 voxels skip the encoder of their SST block
+    (spt_backbone.py:47-135,347-349) and the window cross-attention sees per-shift keep sets of both frames
+    (SiamWCA.py:65-215).  Whole step in fp32 against the reference's captured loss / mask / predictions / gradient
+    norms (fixture F13, oracle/gen_golden_dropping.py) and, per parameter, against the oracle's gradients."""
+    g = golden('F13_e2e_dropping')
+    nst, bs = int(g['num_stages']), int(g['batch_size'])
+    drop = {i: dict(max_tokens=int(t), drop_range=(int(lo), int(hi)))
+            for i, (t, lo, hi) in enumerate(zip(g['drop_max_tokens'], g['drop_lower'], g['drop_upper']))}
+    cfg = oracle.default_model_cfg(nst)
+    cfg['drop_info'] = drop
+    P = oracle.init_params(cfg, seed=int(g['param_seed']), tau=float(g['tau']), pred_scale=float(g['pred_scale']))
+    from pcdet.models import build_network
+    from tmae_amd.train import SyntheticTemporalDataset
+    ycfg = load_cfg(nst)
+    for blk in ycfg.MODEL.BACKBONE_3D.SST_BLOCK_LIST:
+        for mode in ('train', 'test'):
+            blk.PREPROCESS.DROP_INFO[mode] = {str(k): {'max_tokens': v['max_tokens'], 'drop_range': list(v['drop_range'])}
+                                              for k, v in drop.items()}
+    ds = SyntheticTemporalDataset(ycfg.DATA_CONFIG, ycfg.CLASS_NAMES, n_points=1000, batch_size=bs)
+    model = build_network(ycfg.MODEL, len(ycfg.CLASS_NAMES), ds)
+    res = model.load_state_dict(P, strict=False)
+    assert not res.unexpected_keys
+    model = model.to(dev()).train()
+    assert all(b.can_drop for b in model.backbone_3d.sst_blocks) and all(b.can_drop for b in model.backbone_3d.wca_blocks)
+    loss, bd = _run_product(model, g['points'], g['points_prev'], g['noise'], bs)
+    assert abs(float(loss) - float(g['loss'])) < 1e-4, (float(loss), float(g['loss']))
+    assert np.array_equal(bd['voxel_mae_mask'].cpu().numpy(), g['mask'])
+    pred = model.backbone_3d.forward_ret_dict['pred_points']
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g['pred_points'], atol=2e-3)
+    sf = bd['spatial_features'].detach().double()
+    assert float(sf.abs().sum()) == pytest.approx(float(g['spatial_abs_checksum']), rel=1e-4)
+    grads = dict(model.named_parameters())
+    for n, gn in zip([str(n) for n in g['grad_names']], g['grad_norms']):
+        assert abs(float(grads[n].grad.norm()) - gn) <= 5e-3 * max(1.0, gn), n
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lo = oracle.forward_loss(Pg, g['points'], g['points_prev'], g['noise'], bs, cfg)
+    lo.backward()
+    for n in [str(n) for n in g['grad_names']]:
+        a, b = grads[n].grad.cpu(), Pg[n].grad
+        assert (a - b).abs().max().item() <= 5e-3 * max(1.0, b.abs().max().item()), n
+    # bf16 autocast: the same keep sets, loss within the bf16 bar of the other e2e tests
+    l16, _ = _run_product(model, g['points'], g['points_prev'], g['noise'], bs, amp=True)
+    assert abs(float(l16) - float(g['loss'])) < 3e-3
+    # the shipped levels never enter the dropping code
+    m3, _, _ = build_product_model(1, device=dev())
+    assert not any(b.can_drop for b in m3.backbone_3d.sst_blocks) and not any(b.can_drop for b in m3.backbone_3d.wca_blocks)

@@ -209,3 +209,19 @@ def test_chamfer_against_kdtree_nearest_neighbours(oracle):
     want = num / float(w.sum())
     got = float(O.chamfer_distance(torch.from_numpy(pred), torch.from_numpy(gt), torch.from_numpy(w)))
     assert abs(got - want) <= 2e-6 * max(1.0, abs(want)), (got, want)
+
+
+def test_f13_e2e_token_dropping(oracle):
+    """The oracle with a DROP_INFO that really drops tokens against what the reference computed (F13)."""
+    g = golden('F13_e2e_dropping')
+    nst, bs = int(g['num_stages']), int(g['batch_size'])
+    cfg = oracle.default_model_cfg(nst)
+    cfg['drop_info'] = {i: dict(max_tokens=int(t), drop_range=(int(lo), int(hi)))
+                        for i, (t, lo, hi) in enumerate(zip(g['drop_max_tokens'], g['drop_lower'], g['drop_upper']))}
+    P = oracle.init_params(cfg, seed=int(g['param_seed']), tau=float(g['tau']), pred_scale=float(g['pred_scale']))
+    cap = {}
+    with torch.no_grad():
+        lo = oracle.forward_loss(P, g['points'], g['points_prev'], g['noise'], bs, cfg, cap)
+    assert abs(float(lo) - float(g['loss'])) < 1e-5
+    assert np.array_equal(cap['mask'], g['mask'])
+    assert int(g['dropped_stage1_unmasked']) > 1000
