@@ -1335,8 +1335,9 @@ class _WinAttn(torch.autograd.Function):
         tau32 = tau.detach().reshape(-1).float().contiguous()
         if a.dtype != torch.bfloat16:
             worklist = None                                  # the fp32 kernels walk the dense windows
-        # with a work list, tokens of windows in no list are not written: start from zeros in cross mode
-        alloc = torch.zeros if (worklist is not None and cross) else torch.empty
+        # cross mode starts from zeros: with a work list, tokens of windows in no list are not written; and under token
+        # dropping (modules/sst.py: per-shift grids with the dropped tokens masked out) a token may be in no window at all
+        alloc = torch.zeros if cross else torch.empty
         out = alloc((mq, d), dtype=a.dtype, device=a.device)
         lse = alloc((mq, nhead), dtype=torch.float32, device=a.device)
         check(lib.tmae_win_attn_fwd(q, ldq, k, ldk, v, ldv, _dt(a), mq, mk, nhead, dh, _p(grid_q), _p(grid_k),
@@ -1363,7 +1364,7 @@ class _WinAttn(torch.autograd.Function):
         if not ctx.has_wl:
             worklist = None
         dout = dout.contiguous()
-        alloc = torch.zeros_like if (worklist is not None and ctx.cross) else torch.empty_like
+        alloc = torch.zeros_like if ctx.cross else torch.empty_like
         da = alloc(a)
         db = alloc(b) if b is not None else None
         dc = alloc(c) if torch.is_tensor(c) else c

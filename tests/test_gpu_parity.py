@@ -1546,6 +1546,7 @@ def test_e2e_token_dropping_vs_reference(oracle):
     P = oracle.init_params(cfg, seed=int(g['param_seed']), tau=float(g['tau']), pred_scale=float(g['pred_scale']))
     from pcdet.models import build_network
     from tmae_amd.train import SyntheticTemporalDataset
+    from conftest import load_cfg
     ycfg = load_cfg(nst)
     for blk in ycfg.MODEL.BACKBONE_3D.SST_BLOCK_LIST:
         for mode in ('train', 'test'):
@@ -1558,15 +1559,16 @@ def test_e2e_token_dropping_vs_reference(oracle):
     model = model.to(dev()).train()
     assert all(b.can_drop for b in model.backbone_3d.sst_blocks) and all(b.can_drop for b in model.backbone_3d.wca_blocks)
     loss, bd = _run_product(model, g['points'], g['points_prev'], g['noise'], bs)
-    assert abs(float(loss) - float(g['loss'])) < 1e-4, (float(loss), float(g['loss']))
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-4, (float(loss.detach()), float(g['loss']))
     assert np.array_equal(bd['voxel_mae_mask'].cpu().numpy(), g['mask'])
     pred = model.backbone_3d.forward_ret_dict['pred_points']
     np.testing.assert_allclose(pred.detach().cpu().numpy(), g['pred_points'], atol=2e-3)
     sf = bd['spatial_features'].detach().double()
     assert float(sf.abs().sum()) == pytest.approx(float(g['spatial_abs_checksum']), rel=1e-4)
     grads = dict(model.named_parameters())
-    for n, gn in zip([str(n) for n in g['grad_names']], g['grad_norms']):
-        assert abs(float(grads[n].grad.norm()) - gn) <= 5e-3 * max(1.0, gn), n
+    bad = [(n, float(grads[n].grad.norm()), float(gn)) for n, gn in zip([str(n) for n in g['grad_names']], g['grad_norms'])
+           if not abs(float(grads[n].grad.norm()) - gn) <= 5e-3 * max(1.0, gn)]
+    assert not bad, bad[-6:]
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     lo = oracle.forward_loss(Pg, g['points'], g['points_prev'], g['noise'], bs, cfg)
     lo.backward()
@@ -1575,7 +1577,7 @@ def test_e2e_token_dropping_vs_reference(oracle):
         assert (a - b).abs().max().item() <= 5e-3 * max(1.0, b.abs().max().item()), n
     # bf16 autocast: the same keep sets, loss within the bf16 bar of the other e2e tests
     l16, _ = _run_product(model, g['points'], g['points_prev'], g['noise'], bs, amp=True)
-    assert abs(float(l16) - float(g['loss'])) < 3e-3
+    assert abs(float(l16.detach()) - float(g['loss'])) < 3e-3
     # the shipped levels never enter the dropping code
     m3, _, _ = build_product_model(1, device=dev())
     assert not any(b.can_drop for b in m3.backbone_3d.sst_blocks) and not any(b.can_drop for b in m3.backbone_3d.wca_blocks)
