@@ -59,8 +59,15 @@ def parse():
     return ap.parse_args()
 
 
+def _pmc_source():
+    for name in ('round4_pmc.json', 'round3_pmc.json', 'round2_pmc.json', 'round1_pmc.json'):
+        if os.path.exists(os.path.join(ROOT, 'profiles', name)):
+            return f'profiles/{name} (FETCH_SIZE x2 + WRITE_SIZE, bytes per op; a committed counter pass of `bench.py --probe-only`, not measured in this run)'
+    return None
+
+
 def _pmc(key):
-    for name in ('round3_pmc.json', 'round2_pmc.json', 'round1_pmc.json'):          # rocprofv3 --pmc passes of --probe-only (latest round first)
+    for name in ('round4_pmc.json', 'round3_pmc.json', 'round2_pmc.json', 'round1_pmc.json'):          # rocprofv3 --pmc passes of --probe-only (latest round first)
         f = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(f):
             v = json.load(open(f)).get(key, {}).get('traffic_bytes_per_op')
@@ -114,6 +121,21 @@ def box_peaks(dev, reps=5):
             'mfma_bf16_tflops': round(flops.value / (ms_mfma * 1e-3) / 1e12, 1), 'mfma_ms': round(ms_mfma, 4),
             'how': '1 GiB float4 streaming copy (read + write bytes) and a 16x16x32 bf16 MFMA loop on random register '
                    'operands, 512 threads per CU (csrc/probe.hip); mean of %d launches' % reps}
+
+
+def _step_bytes():
+    """Whole-step HBM traffic of the committed counter pass (profiles/scripts/pmc_step.sh: FETCH_SIZE x2 + WRITE_SIZE of every
+    kernel of three timed steps of this configuration), newest round first."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_step_bytes.json')), reverse=True):
+        try:
+            d = json.load(open(f))
+            return {'bytes': d['step_hbm_bytes'], 'read': d['step_fetch_bytes'], 'written': d['step_write_bytes'],
+                    'families_gb': {k: round(v['bytes'] / 1e9, 2) for k, v in sorted(d['families'].items(), key=lambda kv: -kv[1]['bytes'])},
+                    'source': 'profiles/' + os.path.basename(f) + ' (a committed rocprofv3 --pmc pass of `bench.py --steps 3 --warmup 2`, not measured in this run)'}
+        except Exception:
+            continue
+    return None
 
 
 def _with_measured(entry, peaks):
@@ -175,7 +197,7 @@ def token_gemm_roofline(model, batch, amp_dtype, iters=20):
                       'stage-2 token list; one launch per op)', 'bound': 'hbm', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
             'traffic': _pmc('token_gemm'),
-            'traffic_source': 'profiles/round3_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
+            'traffic_source': _pmc_source(),
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k,
             'utilisation': _counters('token_gemm_wreg_kernel<256, 4, 8, false, false>')}
 
@@ -208,7 +230,7 @@ def wgrad_roofline(model, batch, amp_dtype, iters=20):
                       'op = the kernel + its slab-reduction launch)', 'bound': 'hbm',
             'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': _pmc('wgrad'),
-            'traffic_source': 'profiles/round3_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
+            'traffic_source': _pmc_source(),
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k,
             'utilisation': _counters('wgrad256_kernel<false, 1>', 'wgrad_reduce_kernel')}
 
@@ -270,7 +292,7 @@ def attention_roofline(model, batch, amp_dtype, iters=20):
     return {'kernel': 'win_attn_bwd_mfma_kernel<16,NT> (stage-1 self-attention backward, previous frame; the op = its 3 '
                       'tile-class launches NT=1,2,4)', 'bound': 'hbm', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
-            'traffic_source': 'profiles/round3_pmc.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per op)',
+            'traffic_source': _pmc_source(),
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': int(m),
             'utilisation': _counters('win_attn_bwd_mfma_kernel<16, 1, false>', 'win_attn_bwd_mfma_kernel<16, 1, true>',
                                      'win_attn_bwd_mfma_kernel<16, 2, false>', 'win_attn_bwd_mfma_kernel<16, 4, false>')}
@@ -690,6 +712,15 @@ def main():
         line['box_peaks'] = peaks
         if 'roofline_step' in line:
             _with_measured(line['roofline_step'], peaks)
+            sb = _step_bytes() if (args.shape == 'once' and args.points == 120000 and args.batch_per_gpu == 8) else None
+            if sb is not None:
+                # the step as a byte stream: what the present op decomposition moves, and how long that takes at the rate
+                # this box's float4 copy sustains -- the floor of the decomposition, next to the measured step
+                line['roofline_step'].update({
+                    'hbm_bytes': sb['bytes'], 'hbm_read_bytes': sb['read'], 'hbm_written_bytes': sb['written'],
+                    'hbm_gbs_achieved': round(sb['bytes'] / (elapsed / args.steps) / 1e9, 1),
+                    'hbm_floor_ms_at_measured_copy_rate': round(sb['bytes'] / (peaks['hbm_copy_gbs'] * 1e9) * 1e3, 2),
+                    'hbm_families_gb': sb['families_gb'], 'hbm_source': sb['source']})
         line['roofline'] = _with_measured(token_gemm_roofline(model, dict(batches[0]), amp), peaks)
         # round-1 history: the two kernels that led the profile before this one, still priced the same way
         line['roofline_wgrad'] = _with_measured(wgrad_roofline(model, dict(batches[0]), amp), peaks)

@@ -14,7 +14,7 @@ The training step itself is not run by --probe-only, so every launch of these ke
 import collections, csv, glob, json, sys
 
 out_dir = sys.argv[1]
-TG = 'token_gemm_wreg_kernel<256, 4, 8, false, false>'      # round 3 (rounds 1-2: 'token_gemm_res_kernel<256, 4, false>')
+TG = 'token_gemm_wreg_kernel<256, 4, 8, false, false, false>'      # round 4 (round 3: five template arguments; rounds 1-2: 'token_gemm_res_kernel<256, 4, false>')
 groups = {'token_gemm': (TG,),
           'wgrad': ('wgrad256_kernel', 'wgrad_reduce_kernel'),
           'attention': ('win_attn_bwd_mfma_kernel<16',)}

@@ -31,7 +31,7 @@ def grid_of(r):
     return r.get('Grid_Size_X', r.get('Grid_Size', ''))
 
 
-for title, pats in (('token GEMM op (one launch)', ('token_gemm_wreg_kernel<256, 4, 8, false, false>', 'token_gemm_res_kernel<256, 4>')),
+for title, pats in (('token GEMM op (one launch)', ('token_gemm_wreg_kernel<256, 4, 8, false, false, false>', 'token_gemm_wreg_kernel<256, 4, 8, false, false>', 'token_gemm_res_kernel<256, 4>')),
                     ('wgrad256 op (kernel + slab reduction)', ('wgrad256_kernel', 'wgrad_reduce_kernel')),
                     ('stage-1 attention backward op (3 tile classes)', ('win_attn_bwd_mfma_kernel<16',))):
     probe = [r for r in tail if any(p in r['Kernel_Name'] for p in pats)]

@@ -98,6 +98,8 @@ class WindowPlan:
 
 # TMAE_POS_FOLD=0: the in-projections run on a materialised x + pos (two GEMMs) instead of the position-folded GEMM
 _POS_FOLD = os.environ.get('TMAE_POS_FOLD', '1') != '0'
+# TMAE_FFN_GELU=pass: linear1 and the GELU as two launches (A/B of the dual-store epilogue, profiles/scripts/ab_gelu.sh)
+_FFN_GELU_FUSED = os.environ.get('TMAE_FFN_GELU', 'fused') != 'pass'
 
 
 class WindowAttention(nn.Module):
@@ -195,7 +197,7 @@ class _EncoderTail(nn.Module):
                                             passthrough=True)
         else:
             src = ops.add_layer_norm(src, attn, self.norm1.weight, self.norm1.bias, self.norm1.eps, bmask=bmask)
-        if self.activation is F.gelu:
+        if self.activation is F.gelu and _FFN_GELU_FUSED:
             # linear1 and the GELU in one launch (the activation is a second store of the GEMM's epilogue), the GELU
             # backward fused into the dX GEMM of linear2
             h_pre, h_act, src_res = ops.proj_fork(src, self.linear1.weight, self.linear1.bias,
@@ -204,7 +206,10 @@ class _EncoderTail(nn.Module):
         else:
             h_pre, src_res = ops.proj_fork(src, self.linear1.weight, self.linear1.bias,
                                            ((0, self.linear1.out_features, False),), fork=True, inplace_dx=True)
-            src2 = ops.linear(self.activation(h_pre), self.linear2.weight, self.linear2.bias)
+            if self.activation is F.gelu:
+                src2 = ops.gelu_linear(h_pre, self.linear2.weight, self.linear2.bias)
+            else:
+                src2 = ops.linear(self.activation(h_pre), self.linear2.weight, self.linear2.bias)
         out = ops.add_layer_norm(src_res, src2, self.norm2.weight, self.norm2.bias, self.norm2.eps, post=post)
         return (out, alias) if passthrough else out
 
