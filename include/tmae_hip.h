@@ -464,6 +464,14 @@ size_t tmae_frame_prepare_workspace(int64_t n);
 int tmae_frame_prepare(const float* points, int row, int64_t n, const double* r1t1, const double* m2, float ego_radius,
                        int flip_x, int flip_y, float cosa, float sina, float scale, float xmin, float ymin, float xmax,
                        float ymax, int batch_idx, float* out, int32_t* count, void* ws, size_t ws_bytes, void* stream);
+/* The same with gt_sampling's point removal (database_sampler.py:201-205: remove_points_in_boxes3d with REMOVE_EXTRA_WIDTH ->
+ * roiaware_pool3d.cpp:119-140): points that lie, AFTER the alignment and BEFORE the augmentation, inside one of n_boxes <= 64
+ * boxes are dropped.  remove_boxes (device, [n_boxes, 8] float64, prepared by the host): cx, cy, cz, (float)cos(-heading),
+ * (float)sin(-heading), dz / 2, dx / 2 + 1e-2f, dy / 2 + 1e-2f -- the reference's fp32 rotation and double thresholds. */
+int tmae_frame_prepare_boxes(const float* points, int row, int64_t n, const double* r1t1, const double* m2, float ego_radius,
+                             int flip_x, int flip_y, float cosa, float sina, float scale, float xmin, float ymin, float xmax,
+                             float ymax, int batch_idx, const double* remove_boxes, int n_boxes, float* out, int32_t* count,
+                             void* ws, size_t ws_bytes, void* stream);
 
 /* ---- box calibration probes (bench.py `peak_measured`; SURVEY.md section 7: measured achievable peaks on the box next
  * to the spec peaks -- no reference counterpart).  tmae_probe_copy: a 16-bytes-per-lane streaming copy of `bytes` (a

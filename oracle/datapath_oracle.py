@@ -240,3 +240,178 @@ def pick_pair(interval, scan_window, fixed_gap=-1):
     else:
         idx_prev = max(interval[0], idx - fixed_gap)
     return idx, int(idx_prev)
+
+
+# ----------------------------------------------------------------------------------------------- gt_sampling
+# DataBaseSampler (pcdet/datasets/augmentor/database_sampler.py) in front of the world augmentations of the fine-tune
+# config.  The Python logic is the reference's (pinned by tests/golden/D3_gt_sampling.npz, produced by the reference's own
+# DataBaseSampler / ONCETemporalDataset run with stand-ins for its two COMPILED geometry helpers); those two helpers --
+# iou3d_nms_cuda.boxes_iou_bev_cpu and roiaware_pool3d_cuda.points_in_boxes_cpu -- are restated here from their sources
+# (roiaware_pool3d.cpp:119-140 is in the reference tree; iou3d_cpu.cpp includes cuda.h and cannot be built here):
+# PARITY UNPINNED for the two helpers themselves.  The sampler only asks whether two boxes overlap at all (iou == 0).
+
+def points_in_boxes_cpu(points_xyz, boxes):
+    """roiaware_pool3d.cpp:119-168 (check_pt_in_box3d_cpu): [nb, n] int mask.  fp32 point / box values; cos / sin of the
+    double angle rounded to fp32; the products in fp32; the three comparisons in double, MARGIN = (float)1e-2."""
+    p = np.asarray(points_xyz, np.float32)
+    b = np.asarray(boxes, np.float32)
+    out = np.zeros((b.shape[0], p.shape[0]), np.int32)
+    margin = np.float64(np.float32(1e-2))
+    for i in range(b.shape[0]):
+        cx, cy, cz, dx, dy, dz, rz = (b[i, k] for k in range(7))
+        zin = ~(np.abs(p[:, 2] - cz).astype(np.float64) > np.float64(dz) / 2.0)
+        ca, sa = np.float32(np.cos(-np.float64(rz))), np.float32(np.sin(-np.float64(rz)))
+        sx, sy = p[:, 0] - cx, p[:, 1] - cy
+        lx = sx * ca + sy * (-sa)
+        ly = sx * sa + sy * ca
+        inside = (np.abs(lx).astype(np.float64) < np.float64(dx) / 2.0 + margin) & \
+                 (np.abs(ly).astype(np.float64) < np.float64(dy) / 2.0 + margin)
+        out[i] = (zin & inside).astype(np.int32)
+    return out
+
+
+def boxes_overlap_bev(boxes_a, boxes_b):
+    """[na, nb] bool: do the two rotated BEV rectangles overlap with positive area (separating-axis test, float64)?
+    Stands where boxes_bev_iou_cpu(...) != 0 stands in DataBaseSampler.__call__ (database_sampler.py:240-244)."""
+    def corners(b):
+        b = np.asarray(b, np.float64)
+        c, s = np.cos(b[:, 6]), np.sin(b[:, 6])
+        hx, hy = b[:, 3] / 2, b[:, 4] / 2
+        loc = np.array([[1, 1], [1, -1], [-1, -1], [-1, 1]], np.float64)
+        x = b[:, None, 0] + loc[None, :, 0] * hx[:, None] * c[:, None] - loc[None, :, 1] * hy[:, None] * s[:, None]
+        y = b[:, None, 1] + loc[None, :, 0] * hx[:, None] * s[:, None] + loc[None, :, 1] * hy[:, None] * c[:, None]
+        axes = np.stack([np.stack([c, s], -1), np.stack([-s, c], -1)], 1)          # [n, 2 axes, 2]
+        return np.stack([x, y], -1), axes
+    ca, axa = corners(boxes_a)
+    cb, axb = corners(boxes_b)
+    na, nb = ca.shape[0], cb.shape[0]
+    over = np.ones((na, nb), bool)
+    for axes, own_a in ((axa, True), (axb, False)):
+        for k in range(2):
+            ax = axes[:, k]                                                         # [n, 2]
+            if own_a:
+                pa = np.einsum('ipc,ic->ip', ca, ax)[:, None, :].repeat(nb, 1)      # [na, nb, 4]
+                pb = np.einsum('jpc,ic->ijp', cb, ax)
+            else:
+                pa = np.einsum('ipc,jc->ijp', ca, ax)
+                pb = np.einsum('jpc,jc->jp', cb, ax)[None, :, :].repeat(na, 0)
+            over &= (pa.max(-1) > pb.min(-1) + 1e-9) & (pb.max(-1) > pa.min(-1) + 1e-9)
+    return over
+
+
+class DataBaseSamplerOracle:
+    """DataBaseSampler.__init__ / sample_with_fixed_number / __call__ / add_sampled_boxes_to_scene
+    (database_sampler.py:13-259) without shared memory, road planes or fake-lidar boxes (the ONCE config has none)."""
+
+    def __init__(self, db_infos, cfg, class_names, read_points):
+        self.class_names = list(class_names)
+        self.cfg = cfg
+        self.read_points = read_points                       # info -> [n, NUM_POINT_FEATURES] float32 (the .bin crop)
+        self.db_infos = {c: list(db_infos.get(c, [])) for c in class_names}
+        for name_num in cfg.get('filter_by_min_points', []):
+            name, mn = name_num.split(':')
+            if int(mn) > 0 and name in self.db_infos:
+                self.db_infos[name] = [i for i in self.db_infos[name] if i['num_points_in_gt'] >= int(mn)]
+        self.limit_whole_scene = bool(cfg.get('limit_whole_scene', False))
+        self.fade_epoch = int(cfg.get('fade_epoch', 0))
+        self.sample_groups, self.sample_class_num = {}, {}
+        for x in cfg['sample_groups']:
+            name, num = x.split(':')
+            if name not in class_names:
+                continue
+            self.sample_class_num[name] = num
+            self.sample_groups[name] = {'sample_num': num, 'pointer': len(self.db_infos[name]),
+                                        'indices': np.arange(len(self.db_infos[name]))}
+
+    def _sample(self, name, grp):
+        num, pointer, indices = int(grp['sample_num']), grp['pointer'], grp['indices']
+        if pointer >= len(self.db_infos[name]):
+            indices = np.random.permutation(len(self.db_infos[name]))
+            pointer = 0
+        out = [self.db_infos[name][i] for i in indices[pointer:pointer + num]]
+        grp['pointer'], grp['indices'] = pointer + num, indices
+        return out
+
+    def __call__(self, gt_boxes, gt_names, cur_epoch=0, total_epochs=1):
+        """Returns (sampled_boxes [k, 7] float32, sampled infos) -- what __call__ appends to the scene."""
+        if total_epochs < self.fade_epoch + cur_epoch + 1:
+            return np.zeros((0, 7), np.float32), []
+        existed = np.asarray(gt_boxes)
+        names = np.asarray(gt_names).astype(str)
+        n0 = existed.shape[0]
+        chosen = []
+        for name, grp in self.sample_groups.items():
+            if self.limit_whole_scene:
+                grp['sample_num'] = str(int(self.sample_class_num[name]) - int(np.sum(name == names)))
+            if int(grp['sample_num']) > 0:
+                cand = self._sample(name, grp)
+                sb = np.stack([c['box3d_lidar'] for c in cand], 0).astype(np.float32)
+                o1 = boxes_overlap_bev(sb[:, :7], existed[:, :7]) if existed.shape[0] > 0 else None
+                o2 = boxes_overlap_bev(sb[:, :7], sb[:, :7])
+                o2[np.arange(len(sb)), np.arange(len(sb))] = False
+                if o1 is None:
+                    o1 = o2
+                valid = np.nonzero(~(o1.any(1) | o2.any(1)))[0]
+                chosen += [cand[i] for i in valid]
+                existed = np.concatenate((existed, sb[valid]), axis=0)
+        return existed[n0:, :], chosen
+
+    def object_points(self, infos):
+        pts = []
+        for info in infos:
+            p = np.array(self.read_points(info), np.float32, copy=True)
+            p[:, :3] += info['box3d_lidar'][:3]
+            pts.append(p)
+        return np.concatenate(pts, 0) if pts else None
+
+
+def prepare_pair_sampled(points, points_prev, pose_cur, pose_prev, gt_boxes, gt_names, class_names, sampler, draw, pc_range,
+                         extra_width=(0.0, 0.0, 0.0), ego_radius=2.0, align=True, shuffle=True):
+    """One training sample with gt_sampling at the head of the augmentor queue (prepare_data, once_temporal_dataset.py:246-330;
+    DataAugmentor.forward; _combine_two_pcs_with_delimiter / _attach_group_ids :225-244): returns (points_prev, points,
+    gt_boxes [k, 8]) or None (no box left).  `draw()` = the world-augmentation draws, called AFTER the sampler's own
+    np.random use, `shuffle`: np.random.permutation over the kept rows."""
+    cur = remove_ego_points(points, ego_radius)
+    prv = remove_ego_points(points_prev, ego_radius)
+    if align:
+        prv = convert_prv_frame_to_cur(prv, pose_prev, pose_cur)
+    boxes = np.array(gt_boxes, copy=True)
+    names = np.asarray(gt_names)
+    mask = np.array([n in class_names for n in names], dtype=np.bool_)
+    sboxes, infos = sampler(boxes, names)
+    added = None
+    if len(infos) > 0:
+        obj = sampler.object_points(infos)
+        large = np.array(sboxes[:, 0:7], np.float32, copy=True)
+        large[:, 3:6] += np.asarray(extra_width, np.float32)[None, :]
+        keep_p = points_in_boxes_cpu(np.asarray(prv, np.float32)[:, :3], large).sum(0) == 0
+        keep_c = points_in_boxes_cpu(np.asarray(cur, np.float32)[:, :3], large).sum(0) == 0
+        prv, cur = np.asarray(prv, np.float32)[keep_p], np.asarray(cur, np.float32)[keep_c]     # remove_points_in_boxes3d: fp32 from here
+        added = obj
+        boxes = np.concatenate([boxes[mask], sboxes], 0)
+        names = np.concatenate([names[mask], np.array([i['name'] for i in infos])], 0)
+        mask = np.ones(len(boxes), np.bool_)
+    params = draw()
+    # combined order after _attach_group_ids: [added (group 1), added (group 0), prev (0), cur (1)]
+    parts = []
+    if added is not None:
+        parts += [np.hstack((added, np.ones((len(added), 1)))), np.hstack((added, np.zeros((len(added), 1))))]
+    parts += [np.hstack((prv, np.zeros((prv.shape[0], 1)))), np.hstack((cur, np.ones((cur.shape[0], 1))))]
+    both = augment(np.vstack(parts), params)
+    m = (both[:, 0] >= pc_range[0]) & (both[:, 0] <= pc_range[3]) & (both[:, 1] >= pc_range[1]) & (both[:, 1] <= pc_range[4])
+    both = both[m]
+    # labels: everything already class-filtered when boxes were pasted (gt_boxes_mask was consumed by the sampler)
+    b = augment_boxes(boxes, params)
+    b[:, 6] = limit_period(b[:, 6], offset=0.5, period=2 * np.pi)
+    if len(infos) == 0:
+        b, names = b[mask], names[mask]
+    sel = np.array([i for i, n in enumerate(names) if n in class_names], dtype=np.int64)
+    b, names = b[sel], names[sel]
+    cls = np.array([class_names.index(n) + 1 for n in names], dtype=np.int32)
+    b = np.concatenate((b, cls.reshape(-1, 1).astype(np.float32)), axis=1)
+    b = b[mask_boxes_outside_range(b, pc_range, 1)] if len(b) else b
+    if shuffle:
+        both = both[np.random.permutation(both.shape[0])]
+    if len(b) == 0:
+        return None
+    return both[both[:, -1] == 0, :-1], both[both[:, -1] == 1, :-1], b

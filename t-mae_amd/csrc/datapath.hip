@@ -15,8 +15,18 @@ struct FrameXform {
   int flip_x, flip_y;
 };
 
+// Removal of the scene points inside the (enlarged) boxes that gt_sampling pastes (database_sampler.py:201-205 ->
+// box_utils.remove_points_in_boxes3d -> roiaware_pool3d.cpp:119-140 check_pt_in_box3d_cpu): the test runs on the ALIGNED,
+// not yet augmented point in fp32 -- |z - cz| > dz / 2 rejects; (x - cx, y - cy) rotated by -heading in fp32 with
+// (float)cos / (float)sin of the double angle; inside iff |lx| < dx / 2 + 1e-2f and |ly| < dy / 2 + 1e-2f, the thresholds in double.
+// rb [nb, 8] doubles prepared by the host: cx, cy, cz, cosa, sina (float values), dz / 2, dx / 2 + margin, dy / 2 + margin.
+#define FRAME_MAX_RB 64
 __global__ __launch_bounds__(256) void frame_xform_kernel(const float* __restrict__ in, int row, int64_t n, FrameXform f,
-                                                         float* __restrict__ xyz /* [n,3] */, int32_t* __restrict__ flag) {
+                                                         float* __restrict__ xyz /* [n,3] */, int32_t* __restrict__ flag,
+                                                         const double* __restrict__ rb, int nb) {
+  __shared__ double srb[FRAME_MAX_RB * 8];
+  for (int t = threadIdx.x; t < nb * 8; t += 256) srb[t] = rb[t];
+  if (nb > 0) __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float* p = in + i * row;
@@ -35,6 +45,17 @@ __global__ __launch_bounds__(256) void frame_xform_kernel(const float* __restric
     gy = ax * f.m2[4] + ay * f.m2[5] + az * f.m2[6] + f.m2[7];
     gz = ax * f.m2[8] + ay * f.m2[9] + az * f.m2[10] + f.m2[11];
   }
+  bool boxed = false;
+  {
+    const float px = (float)gx, py = (float)gy, pz = (float)gz;
+    for (int b = 0; b < nb; ++b) {
+      const double* q = srb + b * 8;
+      if ((double)fabsf(sub_rn(pz, (float)q[2])) > q[5]) continue;
+      const float sx = sub_rn(px, (float)q[0]), sy = sub_rn(py, (float)q[1]), ca = (float)q[3], sa = (float)q[4];
+      const float lx = add_rn(mul_rn(sx, ca), mul_rn(sy, -sa)), ly = add_rn(mul_rn(sx, sa), mul_rn(sy, ca));
+      boxed |= ((double)fabsf(lx) < q[6]) & ((double)fabsf(ly) < q[7]);
+    }
+  }
   if (f.flip_x) gy = -gy;                       // 'x': mirror about the x axis, data_augmentor.py:69-70
   if (f.flip_y) gx = -gx;
   const float x = (float)gx, y = (float)gy, z = (float)gz;
@@ -45,7 +66,7 @@ __global__ __launch_bounds__(256) void frame_xform_kernel(const float* __restric
   yr = mul_rn(yr, f.scale);
   const float zr = mul_rn(z, f.scale);
   xyz[i * 3] = xr; xyz[i * 3 + 1] = yr; xyz[i * 3 + 2] = zr;
-  flag[i] = (!ego && xr >= f.xmin && xr <= f.xmax && yr >= f.ymin && yr <= f.ymax) ? 1 : 0;
+  flag[i] = (!ego && !boxed && xr >= f.xmin && xr <= f.xmax && yr >= f.ymin && yr <= f.ymax) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void frame_emit_kernel(const float* __restrict__ in, int row, int64_t n,
@@ -68,9 +89,17 @@ int tmae_frame_prepare(const float* points, int row, int64_t n, const double* r1
                        const double* m2 /* 12 or null */, float ego_radius, int flip_x, int flip_y, float cosa, float sina,
                        float scale, float xmin, float ymin, float xmax, float ymax, int batch_idx, float* out,
                        int32_t* count, void* wsp, size_t ws_bytes, void* stream_) {
+  return tmae_frame_prepare_boxes(points, row, n, r1t1, m2, ego_radius, flip_x, flip_y, cosa, sina, scale, xmin, ymin, xmax,
+                                  ymax, batch_idx, nullptr, 0, out, count, wsp, ws_bytes, stream_);
+}
+
+int tmae_frame_prepare_boxes(const float* points, int row, int64_t n, const double* r1t1, const double* m2, float ego_radius,
+                             int flip_x, int flip_y, float cosa, float sina, float scale, float xmin, float ymin, float xmax,
+                             float ymax, int batch_idx, const double* remove_boxes /* device [n_boxes, 8] or null */,
+                             int n_boxes, float* out, int32_t* count, void* wsp, size_t ws_bytes, void* stream_) {
   (void)hipGetLastError();
   hipStream_t stream = (hipStream_t)stream_;
-  if (n < 0 || row < 4 || !count) return TMAE_EARG;
+  if (n < 0 || row < 4 || !count || n_boxes < 0 || n_boxes > FRAME_MAX_RB || (n_boxes > 0 && !remove_boxes)) return TMAE_EARG;
   if (n == 0) return (int)hipMemsetAsync(count, 0, 4, stream);
   if (!points || !out) return TMAE_EARG;
   FrameXform f;
@@ -89,7 +118,7 @@ int tmae_frame_prepare(const float* points, int row, int64_t n, const double* r1
   void* scanws = ws.take<char>(sb);
   if (!ws.ok) return TMAE_EWS;
   const dim3 grid(tmae_cdiv(n, 256)), block(256);
-  hipLaunchKernelGGL(frame_xform_kernel, grid, block, 0, stream, points, row, n, f, xyz, flag);
+  hipLaunchKernelGGL(frame_xform_kernel, grid, block, 0, stream, points, row, n, f, xyz, flag, remove_boxes, n_boxes);
   const int r = tmae_scan_i32(flag, pos, n, count, scanws, sb, stream);
   if (r) return r;
   hipLaunchKernelGGL(frame_emit_kernel, grid, block, 0, stream, points, row, n, xyz, flag, pos, (float)batch_idx, out);

@@ -80,6 +80,7 @@ SIGNATURES = {
     'tmae_nms_bev': (I, [P, I, F, P, P, P, Z, P]),
     'tmae_frame_prepare_workspace': (Z, [L]),
     'tmae_frame_prepare': (I, [P, I, L, P, P, F, I, I, F, F, F, F, F, F, F, I, P, P, P, Z, P]),
+    'tmae_frame_prepare_boxes': (I, [P, I, L, P, P, F, I, I, F, F, F, F, F, F, F, I, P, I, P, P, P, Z, P]),
     'tmae_token_gemm': (I, [P, L, L, I, P, I, P, P, L, P]),
     'tmae_multi_cast_transpose': (I, [P, I, L, P]),
     'tmae_adam_step': (I, [P, P, L, F, F, F, F, F, P]),

@@ -217,6 +217,7 @@ class DeviceBatchLoader:
 
     def __iter__(self):
         order = list(self.sampler)
+        self.pipeline.cur_epoch = self.dataset.cur_epoch                 # gt_sampling's FADE_EPOCH rule
         chunks = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
         if self.drop_last and chunks and len(chunks[-1]) < self.batch_size:
             chunks.pop()
@@ -262,6 +263,8 @@ def build_dataloader(dataset_cfg, class_names, batch_size, dist, root_path=None,
     sampler = EpochSampler(len(dataset), rank, world, shuffle=training, seed=seed)
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device())
-    pipeline = TemporalPairPipeline(dataset_cfg, training=training, class_names=class_names, logger=logger)
+    pipeline = TemporalPairPipeline(dataset_cfg, training=training, class_names=class_names, logger=logger,
+                                    root_path=dataset.root_path)
+    pipeline.total_epochs = total_epochs if total_epochs else pipeline.total_epochs
     loader = DeviceBatchLoader(dataset, batch_size, sampler, pipeline, device, workers=workers, drop_last=drop_last)
     return dataset, loader, sampler

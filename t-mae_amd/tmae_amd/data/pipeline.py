@@ -61,7 +61,7 @@ class TemporalPairPipeline:
     permutations after the batch's one sync."""
 
     def __init__(self, dataset_cfg, training=True, ego_radius=2.0, class_names=None, logger=None,
-                 reference_rng_order=False):
+                 reference_rng_order=False, root_path=None):
         self.pc_range = [float(v) for v in dataset_cfg.POINT_CLOUD_RANGE]
         self.align = bool(dataset_cfg.get('ALIGN_TWO_FRAMES', True))
         self.training = training
@@ -74,7 +74,8 @@ class TemporalPairPipeline:
         aug = dataset_cfg.get('DATA_AUGMENTOR', None)
         disabled = set(aug.get('DISABLE_AUG_LIST', [])) if aug is not None else set()
         self.aug_order = []
-        for c in (aug.AUG_CONFIG_LIST if (aug is not None and training) else []):
+        self.sampler, self.cur_epoch, self.total_epochs = None, 0, 1 << 30
+        for pos_, c in enumerate(aug.AUG_CONFIG_LIST if (aug is not None and training) else []):
             if c.NAME in disabled:
                 continue
             if c.NAME == 'random_world_flip':
@@ -84,8 +85,16 @@ class TemporalPairPipeline:
             elif c.NAME == 'random_world_scaling':
                 self.scale_prob, self.scale_range = float(c.PROBABILITY), [float(v) for v in c.WORLD_SCALE_RANGE]
             elif c.NAME == 'gt_sampling':
-                if logger is not None:                    # label-database pasting (database_sampler.py): not built
-                    logger.warning('DATA_AUGMENTOR gt_sampling is configured but not built: samples keep their own boxes only')
+                # label-database pasting (database_sampler.py), the head of the fine-tune recipe's augmentor queue; it needs
+                # the data root (database infos + object crops): without one -- synthetic scans -- it is skipped, loudly
+                if self.aug_order:
+                    raise NotImplementedError('gt_sampling behind another augmentation (the recipes put it first)')
+                if root_path is None or self.class_names is None:
+                    if logger is not None:
+                        logger.warning('DATA_AUGMENTOR gt_sampling needs a data root with its label database: skipped')
+                    continue
+                from .database_sampler import DataBaseSampler
+                self.sampler = DataBaseSampler(root_path, c, self.class_names, logger)
                 continue
             else:
                 raise NotImplementedError(f'augmentation {c.NAME}')
@@ -157,17 +166,26 @@ class TemporalPairPipeline:
         return b
 
     # ------------------------------------------------------------------ one batch
-    def _launch(self, s, par, b, device):
+    def _launch(self, s, par, b, device, paste=None):
+        """Frames of one sample on the device: [previous, current(, pasted object points)] as (rows, count) pairs.
+        paste = (object points [n, 4] host, removal table [nb, 8] float64 host or None): gt_sampling."""
         ang = torch.tensor([par['rot']], dtype=torch.float64).float()             # rotate_points_along_z: fp32 angle
         cosa, sina = float(torch.cos(ang)), float(torch.sin(ang))
         r1t1 = m2 = None
         if self.align and 'pose' in s and 'pose_prev' in s:
             r1t1, m2 = prev_to_cur_transform(s['pose_prev'], s['pose'])
+        rb = None
+        if paste is not None and paste[1] is not None:
+            rb = torch.from_numpy(paste[1]).to(device, non_blocking=True)
         frames = []
         for key, xf in (('points_prev', (r1t1, m2)), ('points', (None, None))):
             pts = torch.as_tensor(s[key], dtype=torch.float32).to(device, non_blocking=True)
             frames.append(ops.frame_prepare(pts, xf[0], xf[1], self.ego_radius, 'x' in par['flips'], 'y' in par['flips'],
-                                            cosa, sina, np.float32(par['scale']), self.pc_range, b))
+                                            cosa, sina, np.float32(par['scale']), self.pc_range, b, remove_boxes=rb))
+        if paste is not None:
+            obj = torch.as_tensor(paste[0], dtype=torch.float32).to(device, non_blocking=True)
+            frames.append(ops.frame_prepare(obj, None, None, 0.0, 'x' in par['flips'], 'y' in par['flips'], cosa, sina,
+                                            np.float32(par['scale']), self.pc_range, b))
         return frames
 
     def __call__(self, samples, device, params=None, perms=None, resample=None):
@@ -182,18 +200,31 @@ class TemporalPairPipeline:
             while True:
                 if callable(s):
                     s = s()
+                gt_boxes, gt_names, paste = s.get('gt_boxes', None), s.get('gt_names', None), None
+                if self.sampler is not None and gt_boxes is not None:
+                    # gt_sampling first (its np.random use precedes the world-augmentation draws): candidates that collide
+                    # with no box of the scene, their points in front of both frames, the scene points inside them removed
+                    sboxes, infos = self.sampler.sample(gt_boxes, gt_names, self.cur_epoch, self.total_epochs)
+                    if infos:
+                        known = np.array([str(n) in self.class_names for n in np.asarray(gt_names)], dtype=np.bool_)
+                        gt_boxes = np.concatenate([np.asarray(gt_boxes)[known][:, :7], sboxes], 0)
+                        gt_names = np.concatenate([np.asarray(gt_names)[known], np.array([i['name'] for i in infos])], 0)
+                        from .database_sampler import removal_table
+                        paste = (self.sampler.object_points(infos),
+                                 removal_table(sboxes, self.sampler.extra_width) if self.sampler.remove_points else None)
                 par = params[b] if params is not None else self.draw()
                 boxes = None
-                if s.get('gt_boxes', None) is not None:
-                    boxes = self.prepare_labels(s['gt_boxes'], s['gt_names'], par)
-                frames = self._launch(s, par, b, device)
+                if gt_boxes is not None:
+                    boxes = self.prepare_labels(gt_boxes, gt_names, par)
+                frames = self._launch(s, par, b, device, paste)
                 if self.reference_rng_order:                     # per-sample sync: the permutation is this sample's last draw
-                    n0, n1 = (int(v) for v in torch.stack([frames[0][1], frames[1][1]]).cpu().view(-1).tolist())
+                    cnt = [int(v) for v in torch.stack([f[1] for f in frames]).cpu().view(-1).tolist()]
+                    n0, n1, na = cnt[0], cnt[1], (cnt[2] if len(cnt) > 2 else 0)
                     perm = None
                     if self.shuffle:
-                        perm = perms[b] if perms is not None else np.random.permutation(n0 + n1)
-                    strict_counts.append((n0, n1, perm))
-                if s.get('gt_boxes', None) is not None and boxes is None:
+                        perm = perms[b] if perms is not None else np.random.permutation(n0 + n1 + 2 * na)
+                    strict_counts.append((n0, n1, na, perm))
+                if gt_boxes is not None and boxes is None:
                     if resample is None:
                         raise ValueError(f'sample {b} has no gt box left after class / range filtering and no resample() was given')
                     if self.reference_rng_order:
@@ -207,19 +238,29 @@ class TemporalPairPipeline:
             if 'frame_id' in s:
                 frame_ids.append(s['frame_id'])
         if self.reference_rng_order:
-            counts = [(n0, n1) for n0, n1, _ in strict_counts]
+            counts = [(n0, n1, na) for n0, n1, na, _ in strict_counts]
         else:
-            counts = torch.stack([f[1] for fr in launched for f in fr]).cpu().view(-1, 2).tolist()     # the one host sync
+            zero = torch.zeros((1,), dtype=torch.int32, device=device)
+            flat = torch.stack([(fr[i][1] if i < len(fr) else zero) for fr in launched for i in range(3)])
+            counts = flat.cpu().view(-1, 3).tolist()                                          # the one host sync
         outs = {'points_prev': [], 'points': []}
-        for b, (fr, (n0, n1)) in enumerate(zip(launched, counts)):
+        for b, (fr, (n0, n1, na)) in enumerate(zip(launched, counts)):
             prv, cur = fr[0][0][:n0], fr[1][0][:n1]
+            if na > 0:
+                # the pasted points stand in front of BOTH frames (_attach_group_ids): combined order of the reference's
+                # array = [pasted (current copy), pasted (previous copy), previous, current]
+                obj = fr[2][0][:na]
+                prv, cur = torch.cat([obj, prv], 0), torch.cat([obj, cur], 0)
             if self.shuffle:
                 if self.reference_rng_order:
-                    perm = strict_counts[b][2]
+                    perm = strict_counts[b][3]
                 else:
-                    perm = perms[b] if perms is not None else np.random.permutation(n0 + n1)   # data_processor.py:92-96
+                    perm = perms[b] if perms is not None else np.random.permutation(n0 + n1 + 2 * na)   # data_processor.py:92-96
                 perm = torch.as_tensor(perm, dtype=torch.long, device=device)
-                sel_prv, sel_cur = perm[perm < n0], perm[perm >= n0] - n0                 # order inside the shuffled array
+                in_prev = (perm >= na) & (perm < 2 * na + n0)
+                sel_prv = perm[in_prev] - na                                                  # -> [pasted | previous]
+                pc = perm[~in_prev]
+                sel_cur = torch.where(pc < na, pc, pc - (na + n0))                            # -> [pasted | current]
                 prv, cur = prv[sel_prv], cur[sel_cur]
             outs['points_prev'].append(prv)
             outs['points'].append(cur)

@@ -1995,9 +1995,10 @@ def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
 
 # ----------------------------------------------------------------------------- data path (frame preparation)
 
-def frame_prepare(points, r1t1, m2, ego_radius, flip_x, flip_y, cosa, sina, scale, pc_range, batch_idx):
+def frame_prepare(points, r1t1, m2, ego_radius, flip_x, flip_y, cosa, sina, scale, pc_range, batch_idx, remove_boxes=None):
     """One frame of one sample through tmae_frame_prepare: returns (rows [n, row+1] worst case, count [1] i32 on the
-    device); the caller slices after its one sync.  r1t1 / m2: float64 host arrays of 12 or None."""
+    device); the caller slices after its one sync.  r1t1 / m2: float64 host arrays of 12 or None.
+    remove_boxes: device [nb, 8] float64 (tmae_frame_prepare_boxes: gt_sampling's point removal) or None."""
     import ctypes as C
     _need_cuda(points)
     pts = points.contiguous().float()
@@ -2014,7 +2015,9 @@ def frame_prepare(points, r1t1, m2, ego_radius, flip_x, flip_y, cosa, sina, scal
         return arr, C.cast(arr, C.c_void_p)
     k1, p1 = dptr(r1t1)
     k2, p2 = dptr(m2)
-    check(lib.tmae_frame_prepare(_p(pts), row, n, p1, p2, float(ego_radius), int(bool(flip_x)), int(bool(flip_y)), float(cosa),
-                                 float(sina), float(scale), float(pc_range[0]), float(pc_range[1]), float(pc_range[3]),
-                                 float(pc_range[4]), int(batch_idx), _p(out), _p(cnt), _p(ws), wsb, _s()), 'tmae_frame_prepare')
+    nb = 0 if remove_boxes is None else int(remove_boxes.shape[0])
+    check(lib.tmae_frame_prepare_boxes(_p(pts), row, n, p1, p2, float(ego_radius), int(bool(flip_x)), int(bool(flip_y)), float(cosa),
+                                       float(sina), float(scale), float(pc_range[0]), float(pc_range[1]), float(pc_range[3]),
+                                       float(pc_range[4]), int(batch_idx), _p(remove_boxes) if nb else None, nb, _p(out),
+                                       _p(cnt), _p(ws), wsb, _s()), 'tmae_frame_prepare_boxes')
     return out, cnt

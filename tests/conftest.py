@@ -103,6 +103,17 @@ def write_once_directory(root, g):
         d.mkdir(parents=True, exist_ok=True)
         np.asarray(g[f'scan_{i}'], np.float32).tofile(d / f"{info['frame_id']}.bin")
         infos.append(info)
+    if 'n_db' in g.files:                    # gt_sampling's label database: once_dbinfos_train.pkl + gt_database/*.bin crops
+        db = {}
+        for k in range(int(g['n_db'])):
+            rel = str(g[f'db_path_{k}'])
+            (root / rel).parent.mkdir(parents=True, exist_ok=True)
+            np.asarray(g[f'db_crop_{k}'], np.float32).tofile(root / rel)
+            db.setdefault(str(g[f'db_name_{k}']), []).append(
+                {'name': str(g[f'db_name_{k}']), 'path': rel, 'box3d_lidar': np.array(g[f'db_box_{k}']),
+                 'num_points_in_gt': int(g[f'db_npts_{k}']), 'difficulty': 0})
+        with open(root / 'once_dbinfos_train.pkl', 'wb') as fh:
+            pickle.dump(db, fh)
     (root / 'ImageSets').mkdir(parents=True, exist_ok=True)
     seqs = list(dict.fromkeys(info['sequence_id'] for info in infos))
     for split in ('train', 'val'):
@@ -112,7 +123,16 @@ def write_once_directory(root, g):
     return infos
 
 
-def finetune_data_cfg():
+def finetune_data_cfg(gt_sampling=False):
+    """t_mae.yaml; gt_sampling=True: with the reference recipe's label-database pasting at the head of the augmentor queue
+    (the values of the reference's t_mae.yaml DATA_AUGMENTOR.AUG_CONFIG_LIST[0])."""
     from pcdet.config import EasyDict, cfg_from_yaml_file
     cfg = cfg_from_yaml_file(os.path.join(os.path.dirname(CFG_YAML), 't_mae.yaml'), EasyDict())
+    if gt_sampling:
+        gs = EasyDict(dict(NAME='gt_sampling', BACKEND=EasyDict(dict(NAME='HardDiskBackend')), USE_ROAD_PLANE=False,
+                           DB_INFO_PATH=['once_dbinfos_train.pkl'],
+                           PREPARE=EasyDict(dict(filter_by_min_points=['Car:5', 'Bus:5', 'Truck:5', 'Pedestrian:5', 'Cyclist:5'])),
+                           SAMPLE_GROUPS=['Car:1', 'Bus:4', 'Truck:3', 'Pedestrian:2', 'Cyclist:2'], NUM_POINT_FEATURES=4,
+                           REMOVE_EXTRA_WIDTH=[0.0, 0.0, 0.0], LIMIT_WHOLE_SCENE=True))
+        cfg.DATA_CONFIG.DATA_AUGMENTOR.AUG_CONFIG_LIST = [gs] + list(cfg.DATA_CONFIG.DATA_AUGMENTOR.AUG_CONFIG_LIST)
     return cfg

@@ -479,3 +479,62 @@ def test_once_loader_golden_and_real_data_cli(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (tmp_path / 'ssl' / 'ckpt' / 'checkpoint_epoch_1.pth').exists()
+
+
+def test_gt_sampling_device_path_golden(tmp_path):
+    """gt_sampling end to end on the device against what the reference's DataBaseSampler + ONCETemporalDataset returned on
+    the same tiny directory and label database (fixture D3): scene points inside the pasted boxes removed from BOTH frames
+    (tmae_frame_prepare_boxes), the pasted points in front of both frames and through the same augmentation, the shuffle
+    over [pasted (current) | pasted (previous) | previous | current] -- same points in the same order (<= 2 ulp), boxes bit
+    for bit.  Then the loader and tools/train.py with the fine-tune recipe's full augmentor queue."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT, finetune_data_cfg, write_once_directory
+    from tmae_amd.data import ONCETemporalDataset, TemporalPairPipeline, build_dataloader
+    g = golden('D3_gt_sampling')
+    root = tmp_path / 'once'
+    write_once_directory(root, g)
+    cfg = finetune_data_cfg(gt_sampling=True)
+    ds = ONCETemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True, root_path=root)
+    pipe = TemporalPairPipeline(cfg.DATA_CONFIG, training=True, class_names=cfg.CLASS_NAMES, reference_rng_order=True,
+                                root_path=root)
+    pipe.total_epochs = 1
+
+    def lazy(i):
+        def read():
+            np.random.seed(int(g['seed_base']) + i)
+            return ds.raw_sample(i)
+        return read
+    n = len(ds)
+    out = pipe([lazy(i) for i in range(n)], dev())
+    for key in ('points', 'points_prev'):
+        got, ref = out[key].cpu().numpy(), g[key]
+        assert got.shape == ref.shape, (key, got.shape, ref.shape)          # same points removed, pasted and kept
+        assert np.array_equal(got[:, 0], ref[:, 0]) and np.array_equal(got[:, 4], ref[:, 4])
+        np.testing.assert_allclose(got[:, 1:4], ref[:, 1:4], rtol=3e-7, atol=2e-5)
+    assert np.array_equal(out['gt_boxes'], g['gt_boxes'])
+    # the loader with the database, then the tool
+    _, loader, sampler = build_dataloader(cfg.DATA_CONFIG, cfg.CLASS_NAMES, 3, dist=False, root_path=root, workers=2,
+                                          training=True, total_epochs=2, device=dev())
+    assert loader.pipeline.sampler is not None
+    nb = sum(int((b['gt_boxes'][..., 7] > 0).sum()) for b in loader)
+    own = sum(int(sum(str(x) in cfg.CLASS_NAMES for x in info['annos']['name'])) for info in ds.once_infos if 'annos' in info)
+    assert nb > 0.8 * own
+    yaml_ft = os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae.yaml')
+    import yaml as _yaml
+    y = _yaml.safe_load(open(yaml_ft))
+    y['DATA_CONFIG']['_BASE_CONFIG_'] = os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'dataset_configs', 'once_temporal_dataset.yaml')
+    gs = dict(NAME='gt_sampling', BACKEND=dict(NAME='HardDiskBackend'), USE_ROAD_PLANE=False, DB_INFO_PATH=['once_dbinfos_train.pkl'],
+              PREPARE=dict(filter_by_min_points=['Car:5', 'Bus:5', 'Truck:5', 'Pedestrian:5', 'Cyclist:5']),
+              SAMPLE_GROUPS=['Car:1', 'Bus:4', 'Truck:3', 'Pedestrian:2', 'Cyclist:2'], NUM_POINT_FEATURES=4,
+              REMOVE_EXTRA_WIDTH=[0.0, 0.0, 0.0], LIMIT_WHOLE_SCENE=True)
+    y['DATA_CONFIG']['DATA_AUGMENTOR']['AUG_CONFIG_LIST'] = [gs] + y['DATA_CONFIG']['DATA_AUGMENTOR']['AUG_CONFIG_LIST']
+    yml = tmp_path / 't_mae_gt.yaml'
+    yml.write_text(_yaml.safe_dump(y))
+    cmd = [sys.executable, os.path.join(ROOT, 't-mae_amd', 'tools', 'train.py'), '--cfg_file', str(yml), '--workers', '2', '--amp',
+           '--epochs', '1', '--batch_size', '2', '--data_path', str(root), '--output_dir', str(tmp_path / 'run')]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'Database filter by min points' in (r.stdout + r.stderr)
+    assert (tmp_path / 'run' / 'ckpt' / 'checkpoint_epoch_1.pth').exists()

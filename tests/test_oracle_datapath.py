@@ -117,3 +117,44 @@ def test_d2_product_labels_and_index_logic_host_side():
             mine.set_epoch(4)
             assert list(mine) == list(ref) and len(mine) == len(ref)
     assert list(EpochSampler(7, 1, 2, shuffle=False)) == [1, 3, 5, 0]
+
+
+def test_d3_gt_sampling_host_logic():
+    """gt_sampling (label-database pasting, database_sampler.py) of the product -- sampling order / pointers / permutations,
+    LIMIT_WHOLE_SCENE, the collision rule, the box list after the world augmentation -- against what the reference's own
+    DataBaseSampler + ONCETemporalDataset returned (fixture D3; the two compiled geometry helpers of the reference were
+    stand-ins there: parity unpinned for those).  Host side only: the pasted / removed POINTS are the GPU test's."""
+    import tempfile
+    from conftest import write_once_directory, finetune_data_cfg
+    from tmae_amd.data import ONCETemporalDataset, TemporalPairPipeline
+    g = golden('D3_gt_sampling')
+    cfg = finetune_data_cfg(gt_sampling=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        write_once_directory(tmp, g)
+        ds = ONCETemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True, root_path=tmp)
+        pipe = TemporalPairPipeline(cfg.DATA_CONFIG, training=True, class_names=cfg.CLASS_NAMES, root_path=tmp)
+        assert pipe.sampler is not None and pipe.aug_order == ['random_world_flip', 'random_world_rotation', 'random_world_scaling']
+        pipe.total_epochs = 1
+        n_own = n_all = 0
+        for i in range(len(ds)):
+            np.random.seed(int(g['seed_base']) + i)
+            s = ds.raw_sample(i)
+            sboxes, infos = pipe.sampler.sample(s['gt_boxes'], s['gt_names'], 0, 1)
+            known = np.array([str(n) in cfg.CLASS_NAMES for n in s['gt_names']])
+            boxes = np.concatenate([s['gt_boxes'][known][:, :7], sboxes], 0) if infos else s['gt_boxes']
+            names = np.concatenate([s['gt_names'][known], np.array([x['name'] for x in infos])], 0) if infos else s['gt_names']
+            got = pipe.prepare_labels(boxes, names, pipe.draw())
+            assert np.array_equal(got, g[f'gt_boxes_{i}']), i
+            n_own += int(known.sum())
+            n_all += len(got)
+        assert n_all > n_own                                       # boxes were really pasted
+        # the fade-out rule (database_sampler.py:218-219): no pasting once total_epochs < FADE_EPOCH + cur_epoch + 1
+        assert pipe.sampler.sample(s['gt_boxes'], s['gt_names'], cur_epoch=1, total_epochs=1)[1] == []
+    # the overlap test behind the collision rule: touching is not overlapping, rotation counts
+    from tmae_amd.data.database_sampler import bev_rectangles_overlap
+    a = np.array([[0, 0, 0, 4, 2, 1, 0.0]])
+    assert bev_rectangles_overlap(a, np.array([[3.9, 0, 0, 4, 2, 1, 0.0]]))[0, 0]
+    assert not bev_rectangles_overlap(a, np.array([[4.0, 0, 0, 4, 2, 1, 0.0]]))[0, 0]
+    assert not bev_rectangles_overlap(a, np.array([[3.3, 0.0, 0, 2, 2, 1, 0.0]]))[0, 0]            # x in [2.3, 4.3]
+    assert bev_rectangles_overlap(a, np.array([[3.3, 0.0, 0, 2, 2, 1, np.pi / 4]]))[0, 0]          # its corner reaches x = 1.886
+    assert not bev_rectangles_overlap(a, np.array([[3.2, 1.8, 0, 2, 2, 1, np.pi / 4]]))[0, 0]      # diamond edge x + y = 3.586 > 3
