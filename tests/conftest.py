@@ -124,15 +124,11 @@ def write_once_directory(root, g):
 
 
 def finetune_data_cfg(gt_sampling=False):
-    """t_mae.yaml; gt_sampling=True: with the reference recipe's label-database pasting at the head of the augmentor queue
-    (the values of the reference's t_mae.yaml DATA_AUGMENTOR.AUG_CONFIG_LIST[0])."""
+    """t_mae.yaml (its DATA_CONFIG carries the reference recipe's augmentor queue, gt_sampling first); gt_sampling=False:
+    with the label-database pasting disabled through DISABLE_AUG_LIST (the D2 fixture's configuration)."""
     from pcdet.config import EasyDict, cfg_from_yaml_file
     cfg = cfg_from_yaml_file(os.path.join(os.path.dirname(CFG_YAML), 't_mae.yaml'), EasyDict())
-    if gt_sampling:
-        gs = EasyDict(dict(NAME='gt_sampling', BACKEND=EasyDict(dict(NAME='HardDiskBackend')), USE_ROAD_PLANE=False,
-                           DB_INFO_PATH=['once_dbinfos_train.pkl'],
-                           PREPARE=EasyDict(dict(filter_by_min_points=['Car:5', 'Bus:5', 'Truck:5', 'Pedestrian:5', 'Cyclist:5'])),
-                           SAMPLE_GROUPS=['Car:1', 'Bus:4', 'Truck:3', 'Pedestrian:2', 'Cyclist:2'], NUM_POINT_FEATURES=4,
-                           REMOVE_EXTRA_WIDTH=[0.0, 0.0, 0.0], LIMIT_WHOLE_SCENE=True))
-        cfg.DATA_CONFIG.DATA_AUGMENTOR.AUG_CONFIG_LIST = [gs] + list(cfg.DATA_CONFIG.DATA_AUGMENTOR.AUG_CONFIG_LIST)
+    assert cfg.DATA_CONFIG.DATA_AUGMENTOR.AUG_CONFIG_LIST[0].NAME == 'gt_sampling'
+    if not gt_sampling:
+        cfg.DATA_CONFIG.DATA_AUGMENTOR.DISABLE_AUG_LIST = ['gt_sampling']
     return cfg

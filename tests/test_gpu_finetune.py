@@ -445,7 +445,8 @@ def test_once_loader_golden_and_real_data_cli(tmp_path):
     yaml_ft = os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae.yaml')
     cmd = [sys.executable, os.path.join(ROOT, 't-mae_amd', 'tools', 'train.py'), '--cfg_file', yaml_ft, '--workers', '2',
            '--extra_tag', 't', '--max_ckpt_save_num', '1', '--num_epochs_to_eval', '1', '--amp', '--epochs', '2', '--batch_size', '2',
-           '--data_path', str(root), '--output_dir', str(out_dir)]
+           '--data_path', str(root), '--output_dir', str(out_dir),
+           '--set', 'DATA_CONFIG.DATA_AUGMENTOR.DISABLE_AUG_LIST', 'gt_sampling']       # this directory has no label database
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert sorted(p.name for p in (out_dir / 'ckpt').glob('*.pth')) == ['checkpoint_epoch_2.pth']
@@ -460,7 +461,8 @@ def test_once_loader_golden_and_real_data_cli(tmp_path):
         os.utime(out_dir / 'ckpt' / f'checkpoint_epoch_{e}.pth', (old + e, old + e))
     cmd2 = cmd[:cmd.index('--epochs') + 1] + ['4'] + cmd[cmd.index('--epochs') + 2:]
     cmd2[cmd2.index('--max_ckpt_save_num') + 1] = '3'
-    cmd2 += ['--ckpt', str(out_dir / 'ckpt' / 'checkpoint_epoch_2.pth')]
+    k = cmd2.index('--set')                                               # --set takes the REMAINDER of the line: keep it last
+    cmd2 = cmd2[:k] + ['--ckpt', str(out_dir / 'ckpt' / 'checkpoint_epoch_2.pth')] + cmd2[k:]
     r = subprocess.run(cmd2, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     left = sorted(p.name for p in (out_dir / 'ckpt').glob('*.pth'))
@@ -521,17 +523,7 @@ def test_gt_sampling_device_path_golden(tmp_path):
     nb = sum(int((b['gt_boxes'][..., 7] > 0).sum()) for b in loader)
     own = sum(int(sum(str(x) in cfg.CLASS_NAMES for x in info['annos']['name'])) for info in ds.once_infos if 'annos' in info)
     assert nb > 0.8 * own
-    yaml_ft = os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae.yaml')
-    import yaml as _yaml
-    y = _yaml.safe_load(open(yaml_ft))
-    y['DATA_CONFIG']['_BASE_CONFIG_'] = os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'dataset_configs', 'once_temporal_dataset.yaml')
-    gs = dict(NAME='gt_sampling', BACKEND=dict(NAME='HardDiskBackend'), USE_ROAD_PLANE=False, DB_INFO_PATH=['once_dbinfos_train.pkl'],
-              PREPARE=dict(filter_by_min_points=['Car:5', 'Bus:5', 'Truck:5', 'Pedestrian:5', 'Cyclist:5']),
-              SAMPLE_GROUPS=['Car:1', 'Bus:4', 'Truck:3', 'Pedestrian:2', 'Cyclist:2'], NUM_POINT_FEATURES=4,
-              REMOVE_EXTRA_WIDTH=[0.0, 0.0, 0.0], LIMIT_WHOLE_SCENE=True)
-    y['DATA_CONFIG']['DATA_AUGMENTOR']['AUG_CONFIG_LIST'] = [gs] + y['DATA_CONFIG']['DATA_AUGMENTOR']['AUG_CONFIG_LIST']
-    yml = tmp_path / 't_mae_gt.yaml'
-    yml.write_text(_yaml.safe_dump(y))
+    yml = os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae.yaml')      # gt_sampling is in the shipped recipe
     cmd = [sys.executable, os.path.join(ROOT, 't-mae_amd', 'tools', 'train.py'), '--cfg_file', str(yml), '--workers', '2', '--amp',
            '--epochs', '1', '--batch_size', '2', '--data_path', str(root), '--output_dir', str(tmp_path / 'run')]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
