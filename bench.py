@@ -66,6 +66,27 @@ def _pmc_source():
     return None
 
 
+_PMC_FILES = {'token_gemm': 'token_gemm_wreg.hip', 'wgrad': 'wgrad.hip', 'attention': 'attention_mfma.hip'}
+
+
+def _pmc_current(key):
+    """Is the committed counter pass still about THIS kernel source?  (sha256 of the .hip file at measurement time, written by
+    profiles/scripts/pmc_summary.py, against the file in this tree; None for passes of earlier rounds that carry no hash.)"""
+    import hashlib
+    for name in ('round4_pmc.json', 'round3_pmc.json', 'round2_pmc.json', 'round1_pmc.json'):
+        f = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(f):
+            d = json.load(open(f))
+            if d.get(key, {}).get('traffic_bytes_per_op') is None:
+                continue
+            want = d.get('source_sha16', {}).get(_PMC_FILES[key])
+            if want is None:
+                return None
+            src = os.path.join(ROOT, 't-mae_amd', 'csrc', _PMC_FILES[key])
+            return hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16] == want
+    return None
+
+
 def _pmc(key):
     for name in ('round4_pmc.json', 'round3_pmc.json', 'round2_pmc.json', 'round1_pmc.json'):          # rocprofv3 --pmc passes of --probe-only (latest round first)
         f = os.path.join(ROOT, 'profiles', name)
@@ -196,7 +217,7 @@ def token_gemm_roofline(model, batch, amp_dtype, iters=20):
     return {'kernel': 'token_gemm_wreg_kernel<256,4,8> (W-in-registers persistent token GEMM Y[m,512] = X[m,256] W^T + b of the '
                       'stage-2 token list; one launch per op)', 'bound': 'hbm', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
-            'traffic': _pmc('token_gemm'),
+            'traffic': _pmc('token_gemm'), 'traffic_is_of_this_source': _pmc_current('token_gemm'),
             'traffic_source': _pmc_source(),
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k,
             'utilisation': _counters('token_gemm_wreg_kernel<256, 4, 8, false, false>')}
@@ -229,7 +250,7 @@ def wgrad_roofline(model, batch, amp_dtype, iters=20):
     return {'kernel': 'wgrad256_kernel (token-split weight gradient dW[512,256] = dY^T X of the stage-2 token list; the '
                       'op = the kernel + its slab-reduction launch)', 'bound': 'hbm',
             'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': _pmc('wgrad'),
+            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': _pmc('wgrad'), 'traffic_is_of_this_source': _pmc_current('wgrad'),
             'traffic_source': _pmc_source(),
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k,
             'utilisation': _counters('wgrad256_kernel<false, 1>', 'wgrad_reduce_kernel')}
@@ -292,6 +313,7 @@ def attention_roofline(model, batch, amp_dtype, iters=20):
     return {'kernel': 'win_attn_bwd_mfma_kernel<16,NT> (stage-1 self-attention backward, previous frame; the op = its 3 '
                       'tile-class launches NT=1,2,4)', 'bound': 'hbm', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+            'traffic_is_of_this_source': _pmc_current('attention') if code == 1 else None,
             'traffic_source': _pmc_source(),
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': int(m),
             'utilisation': _counters('win_attn_bwd_mfma_kernel<16, 1, false>', 'win_attn_bwd_mfma_kernel<16, 1, true>',

@@ -50,4 +50,9 @@ for g, pats in groups.items():
     res[g] = {'FETCH_SIZE_KB_per_launch': fk, 'WRITE_SIZE_KB_per_launch': wk, 'fetch_bytes_raw': fetch_raw,
               'fetch_bytes_corrected': 2 * fetch_raw, 'write_bytes': write,
               'traffic_bytes_per_op': 2 * fetch_raw + write}
+# what the priced kernels' sources looked like when the counters were read: bench.py compares these with the tree it runs from
+import hashlib, os
+_csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 't-mae_amd', 'csrc')
+res['source_sha16'] = {f: hashlib.sha256(open(os.path.join(_csrc, f), 'rb').read()).hexdigest()[:16]
+                       for f in ('token_gemm_wreg.hip', 'wgrad.hip', 'attention_mfma.hip')}
 print(json.dumps(res, indent=1))
