@@ -223,6 +223,42 @@ def token_gemm_roofline(model, batch, amp_dtype, iters=20):
             'utilisation': _counters('token_gemm_wreg_kernel<256, 4, 8, false, false>')}
 
 
+def gelu_gemm_roofline(model, batch, amp_dtype, iters=20):
+    """`roofline_gemm_gelu` (round 4): the FFN's first Linear with its exact GELU as a second store of the epilogue
+    (token_gemm_wreg_kernel<256,4,8,...,GELU2>, csrc/token_gemm_wreg.hip) on the token-GEMM probe's shape: x read once, the
+    pre-activation AND the activation written once each -- algorithmic bytes M (K + 2N) 2 + W."""
+    from tmae_amd._lib import lib, check
+    m = _stage2_tokens(model, batch)
+    n, k = 512, 256
+    dev = next(model.parameters()).device
+    x = torch.randn(m, k, device=dev).bfloat16()
+    w = (torch.randn(n, k, device=dev) * 0.05).bfloat16()
+    b = torch.randn(n, device=dev).bfloat16()
+    y = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+    yg = torch.empty_like(y)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        check(lib.tmae_token_gemm_gelu(x.data_ptr(), k, m, k, w.data_ptr(), n, b.data_ptr(), y.data_ptr(), yg.data_ptr(), n, st),
+              'tmae_token_gemm_gelu')
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    bytes_alg = m * (2 * n + k) * 2 + (n * k + n) * 2
+    achieved = bytes_alg / (ms * 1e-3) / 1e9
+    return {'kernel': 'token_gemm_wreg_kernel<256,4,8,..,GELU2> (Y = X W^T + b and gelu(Y) in one launch, stage-2 token list)',
+            'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None, 'ms_per_launch': round(ms, 4),
+            'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k}
+
+
 def wgrad_roofline(model, batch, amp_dtype, iters=20):
     """`roofline_wgrad` (the step's dominant kernel until its loads were made branch-free): the token-split weight
     gradient of the d = 256 stages, wgrad256_kernel (csrc/wgrad.hip), on its most frequent heavy shape -- the
@@ -654,6 +690,7 @@ def main():
     if args.probe_only:
         print(json.dumps({'box_peaks': box_peaks(dev),
                           'roofline': token_gemm_roofline(model, dict(batches[0]), amp),
+                          'roofline_gemm_gelu': gelu_gemm_roofline(model, dict(batches[0]), amp),
                           'roofline_wgrad': wgrad_roofline(model, dict(batches[0]), amp),
                           'roofline_attention': attention_roofline(model, dict(batches[0]), amp),
                           'roofline_igemm': igemm_roofline(args.batch_per_gpu)}), flush=True)
@@ -744,6 +781,8 @@ def main():
                     'hbm_floor_ms_at_measured_copy_rate': round(sb['bytes'] / (peaks['hbm_copy_gbs'] * 1e9) * 1e3, 2),
                     'hbm_families_gb': sb['families_gb'], 'hbm_source': sb['source']})
         line['roofline'] = _with_measured(token_gemm_roofline(model, dict(batches[0]), amp), peaks)
+        if amp is not None:
+            line['roofline_gemm_gelu'] = _with_measured(gelu_gemm_roofline(model, dict(batches[0]), amp), peaks)
         # round-1 history: the two kernels that led the profile before this one, still priced the same way
         line['roofline_wgrad'] = _with_measured(wgrad_roofline(model, dict(batches[0]), amp), peaks)
         line['roofline_attention'] = _with_measured(attention_roofline(model, dict(batches[0]), amp), peaks)
