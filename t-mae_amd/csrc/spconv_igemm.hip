@@ -12,6 +12,7 @@
 // 64-byte segment per token (no holes inside a line: csrc/token_gemm.hip, csrc/token_gemm_wreg.hip).  The input gradient is the same kernel on the transposed rulebook and the transposed weight.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void spconv_igemm_kernel(const __hip_bfloat
 // layout).  The gather is the per-lane source address of the DMA; an absent neighbour fetches a row of zeros.
 // ------------------------------------------------------------------------------------------------
 #define IR_BM 256
-__device__ __attribute__((aligned(256))) unsigned ig_zero_row[64];   // 256 bytes of zeros (static storage: zero-initialised)
+__device__ __attribute__((aligned(256))) unsigned ig_zero_row[256];  // 1 KB of zeros (static storage: zero-initialised)
 
 __device__ __forceinline__ void ig_glds16(const void* g, char* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -387,14 +388,13 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
                                                                    int X, const __hip_bfloat16* __restrict__ W, int cout,
                                                                    __hip_bfloat16* __restrict__ out) {
   constexpr int KC = CIN / 64;
-  constexpr int STEPS = 9 * KC;
   constexpr int HW = HaloGeom<DIL>::HW, NH = HaloGeom<DIL>::NH, NP = HaloGeom<DIL>::NP, HC_ABYTES = HaloGeom<DIL>::ABYTES;
-  static_assert(NP <= 72, "a channel slice has 9 x 8 halo transfers");
+  static_assert(NP <= 64, "the piece issued in the last tap step of a slice must be a dummy (it may still be in flight)");
+  static_assert(KC * 128 + 128 <= (int)sizeof(ig_zero_row), "zero-row sources advance with the channel slice");
   extern __shared__ __attribute__((aligned(1024))) char lds[];
-  char* aimg = lds;                                    // 2 halo images (channel slices kc, kc+1)
-  char* bring = lds + 2 * HC_ABYTES;                   // 3 weight slots of 16 KB
-  char* scratch = bring + 3 * (IG_BN * 128);           // 1 KB sink of the dummy transfers
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15;
+  constexpr int BRING = 2 * HC_ABYTES;                 // 2 halo images (channel slices kc, kc+1), then 3 weight slots of 16 KB
+  constexpr int SCRATCH = BRING + 3 * (IG_BN * 128);   // 1 KB sink of the dummy transfers
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, i = lane & 15;
   const int nct = cout / IG_BN;
   const int bx = (X + 15) / 16, by = (Y + 15) / 16;
   int bid = blockIdx.x;
@@ -403,84 +403,133 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   const int ty = bid % by;
   const int b = bid / by;
   const int y0 = ty * 16, x0 = tx * 16, n0 = ct * IG_BN;
-  const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
-  // this lane's halo source per piece index p = step-in-slice * 8 + w: halo row h = 8 p + r8 -> cell (y0-1+h/18, x0-1+h%18)
-  const char* zrow = reinterpret_cast<const char*>(ig_zero_row) + chunk * 16;
-  const char* wsrc[2];
+  const int r8 = lane >> 3, slot8 = lane & 7;
+  // All addresses of the main loop are set up here (the loop itself then spends ~10 VALU instructions per 32 MFMAs; computed
+  // in the loop they were 77 -- 3.6 VALU per MFMA, as much SIMD time as the MFMAs themselves: profiles/round4_pmc_counters).
+  // Halo image: row h = hy * HW + hx of the (16 + 2 DIL)^2 halo, 128 bytes; the 16-byte chunk c of a row sits at chunk
+  // position c ^ (hx & 7) -- a swizzle by the COLUMN only, so that a tap shift (ky, kx) of a reader is an immediate offset
+  // plus one of three per-lane bases.  Piece p = t * 8 + w (tap step t, wave w) = halo rows 8 p .. 8 p + 7.
+  const uintptr_t zlane = (uintptr_t)ig_zero_row + slot8 * 16;
+  uintptr_t hsrc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int p = t * 8 + w, h = 8 * p + r8;
+    const int hy = h / HW, hx = h - hy * HW;
+    const int y = y0 - DIL + hy, x = x0 - DIL + hx;
+    const bool ok = p < NP && h < NH && y >= 0 && y < Y && x >= 0 && x < X;
+    hsrc[t] = ok ? (uintptr_t)in + ((uintptr_t)(((int64_t)b * Y + y) * X + x) * CIN) * 2 + ((slot8 ^ (hx & 7)) << 4) : zlane;
+  }
+  uintptr_t wk[2];                                     // weight rows of this lane, tap 0 of the current channel slice
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int L = w * 16 + j * 8 + r8, s64 = L & 63;
     const int n = (L & ~63) + 32 * (s64 >> 5) + 8 * ((s64 >> 2) & 3) + 4 * ((s64 >> 4) & 1) + (s64 & 3);
-    wsrc[j] = reinterpret_cast<const char*>(W + (int64_t)(n0 + n) * (9 * CIN)) + chunk * 16;
+    wk[j] = (uintptr_t)(W + (int64_t)(n0 + n) * (9 * CIN)) + ((slot8 ^ r8) << 4);
   }
-  auto issue_halo = [&](int kc, int p) {              // piece p (0..71; >= NP: dummy) of channel slice kc
-    const int h = 8 * p + r8;
-    const int hy = h / HW, hx = h - hy * HW;
-    const int y = y0 - DIL + hy, x = x0 - DIL + hx;
-    const bool ok = p < NP && h < NH && y >= 0 && y < Y && x >= 0 && x < X && kc < KC;
-    const uintptr_t pa = (uintptr_t)in + ((uintptr_t)(((int64_t)b * Y + (ok ? y : 0)) * X + (ok ? x : 0)) * CIN + kc * 64) * 2 + chunk * 16;
-    const uintptr_t src = ok ? pa : (uintptr_t)zrow;
-    char* dst = p < NP ? aimg + (kc & 1) * HC_ABYTES + p * 1024 : scratch;
-    ig_glds16(reinterpret_cast<const void*>(src), dst);
-  };
-  auto issue_w = [&](int step) {
-    const int kc = step / 9, t = step - kc * 9;
-    char* sb = bring + (step % 3) * (IG_BN * 128);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) ig_glds16(wsrc[j] + (t * CIN + kc * 64) * 2, sb + (w * 16 + 8 * j) * 128);
-  };
-  // prologue: the whole halo of slice 0 (NP pieces: waves take PQ each, dummies past the end) and two weight slices
-#pragma unroll
-  for (int q = 0; q < HaloGeom<DIL>::PQ; ++q) issue_halo(0, q * 8 + w);
-  issue_w(0);
-  issue_w(1);
   const int wm = w & 3, wn = w >> 2;
+  int vB[3][2], vA[2];                                 // LDS byte offsets of this lane's operand reads (image 0, slot 0)
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    vA[ks] = BRING + (wn * 64 + i) * 128 + (((ks * 4 + g) ^ (i & 7)) << 4);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+      vB[kx][ks] = (4 * wm * HW + i + kx * DIL) * 128 + (((ks * 4 + g) ^ ((i + kx * DIL) & 7)) << 4);
+  }
+  // every tap step issues exactly 3 transfers per wave (2 weight pieces of step + 2, 1 halo piece of the next channel slice;
+  // dummies into the scratch KB where there is nothing to fetch), so one counted wait serves all steps
+  const int wdst = (w * 16) * 128;
+  auto issue_halo = [&](int t, int img, bool real) {
+    const int p = t * 8 + w;
+    ig_glds16(reinterpret_cast<const void*>(real ? hsrc[t] : zlane), lds + (p < NP ? img + p * 1024 : SCRATCH));
+  };
+  auto issue_w = [&](int t, int extra, bool real) {    // tap t of the slice `extra` bytes further
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      ig_glds16(reinterpret_cast<const void*>(wk[j] + (real ? t * CIN * 2 + extra : 0)),
+                lds + (real ? BRING + (t % 3) * (IG_BN * 128) + wdst + 8 * j * 128 : SCRATCH));
+  };
+#pragma unroll
+  for (int q = 0; q < HaloGeom<DIL>::PQ; ++q) issue_halo(q, 0, true);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) hsrc[t] += 128;
+  issue_w(0, 0, true);
+  issue_w(1, 0, true);
+  ig_glds16(reinterpret_cast<const void*>(zlane), lds + SCRATCH);
   f32x4 acc[4][4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int step = 0; step < STEPS; ++step) {
-    const int kc = step / 9, t = step - kc * 9, ky = t / 3, kx = t - ky * 3;
-    // weight slice `step` has landed once everything older than the newest transfers has: in flight stay the 3 issued
-    // during the previous step (weight slice step+1 + one halo piece); before step 0 only weight slice 1 (2 transfers)
-    if (step == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (step + 1 < STEPS) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const char* sa = aimg + (kc & 1) * HC_ABYTES;
-    const char* sb = bring + (step % 3) * (IG_BN * 128);
+  // Operand registers are double-buffered: the reads of a half step (32 channels of a tap) are issued one half step ahead
+  // and land under the 16 MFMAs of the current one.  One barrier per tap step, in its MIDDLE: after the first half's MFMAs
+  // a wave drains its LDS reads (issued a half step ago: done), issues the step's 3 transfers, waits until everything older
+  // than those has landed (= the next step's weight slice, issued a step ago) and meets the others; the next step's first
+  // half is read right behind the barrier.  Write-after-read: slot (s+2)%3 and the other halo image were last read by
+  // reads that every wave drained before the PREVIOUS barrier.
+  // The reads are inline asm with hand-counted waits: left to the compiler, every MFMA group waited for lgkmcnt(0), i.e. also
+  // for the reads issued just before it for the NEXT group.
+  u32x4 af[2][4], bfr[2][4];
+  // operand reads of tap T (a constant expression), channel half ks, halo image at byte offset `img` -> register buffer buf
+#define HC_LOAD_OPS(buf, T, ks, img)                                                                                   \
+  do {                                                                                                                 \
+    constexpr int ky_ = (T) / 3, kx_ = (T) - ky_ * 3, so_ = ((T) % 3) * (IG_BN * 128), ro_ = ky_ * DIL * HW * 128;       \
+    const unsigned aa_ = (unsigned)vA[ks], ab_ = (unsigned)(vB[kx_][ks] + (img));                                      \
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"                                 \
+                 "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"                                      \
+                 : "=&v"(af[buf][0]), "=&v"(af[buf][1]), "=&v"(af[buf][2]), "=&v"(af[buf][3])                           \
+                 : "v"(aa_), "n"(so_), "n"(so_ + 2048), "n"(so_ + 4096), "n"(so_ + 6144) : "memory");                   \
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"                                 \
+                 "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"                                      \
+                 : "=&v"(bfr[buf][0]), "=&v"(bfr[buf][1]), "=&v"(bfr[buf][2]), "=&v"(bfr[buf][3])                       \
+                 : "v"(ab_), "n"(ro_), "n"(ro_ + HW * 128), "n"(ro_ + 2 * HW * 128), "n"(ro_ + 3 * HW * 128) : "memory"); \
+  } while (0)
+  // wait until at most N LDS reads are outstanding; the operand registers of buffer `buf` pass through the statement so
+  // that no MFMA on them can be scheduled above it
+#define HC_WAIT_OPS(buf, N)                                                                                            \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                             \
+               : "+v"(af[buf][0]), "+v"(af[buf][1]), "+v"(af[buf][2]), "+v"(af[buf][3]), "+v"(bfr[buf][0]),            \
+                 "+v"(bfr[buf][1]), "+v"(bfr[buf][2]), "+v"(bfr[buf][3])::"memory")
+  auto mfmas = [&](int buf) {
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (ks == 1 && step + 2 < STEPS) {
-        __builtin_amdgcn_sched_barrier(0);
-        issue_w(step + 2);                             // slot (step+2)%3: last read in step-1, finished before this barrier
-        issue_halo(kc + 1, t * 8 + w);                 // the other halo image: last read in slice kc-1
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      bf16x8 af[4], bfr[4];
-      const int c = ks * 4 + g;
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int L = wn * 64 + nt * 16 + i;
-        af[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sb + L * 128 + ((c ^ (L & 7)) << 4)));
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const int R = (4 * wm + mt + ky * DIL) * HW + i + kx * DIL;
-        bfr[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sa + R * 128 + ((c ^ (R & 7)) << 4)));
-      }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[mt], acc[nt][mt], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int mt = 0; mt < 4; ++mt)
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[buf][nt]),
+                                                              __builtin_bit_cast(bf16x8, bfr[buf][mt]), acc[nt][mt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define HC_STEP(T)                                                                                                     \
+  do {                                                                                                                 \
+    HC_LOAD_OPS(1, T, 1, img);                                                                                         \
+    HC_WAIT_OPS(0, 8);                                                                                                 \
+    mfmas(0);                                                                                                          \
+    HC_WAIT_OPS(1, 0);                                                                                                 \
+    if ((T) < 7) issue_w((T) + 2, 0, true); else issue_w((T) - 7, 128, more);                                          \
+    issue_halo(T, img ^ HC_ABYTES, more);                                                                              \
+    hsrc[T] += 128;                                                                                                    \
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    asm volatile("" ::: "memory");                                                                                     \
+    HC_LOAD_OPS(0, ((T) + 1) % 9, 0, (T) < 8 ? img : img ^ HC_ABYTES);                                                 \
+    mfmas(1);                                                                                                          \
+  } while (0)
+  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // the halo of slice 0 and weight slice 0
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  int img = 0;
+  HC_LOAD_OPS(0, 0, 0, img);
+  for (int kc = 0; kc < KC; ++kc) {
+    const bool more = kc + 1 < KC;
+    HC_STEP(0); HC_STEP(1); HC_STEP(2); HC_STEP(3); HC_STEP(4); HC_STEP(5); HC_STEP(6); HC_STEP(7); HC_STEP(8);
+    img ^= HC_ABYTES;
+    wk[0] += 128;
+    wk[1] += 128;
   }
+#undef HC_STEP
+#undef HC_WAIT_OPS
+#undef HC_LOAD_OPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the dummy transfers of the last steps
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int y = y0 + 4 * wm + mt, x = x0 + i;
