@@ -435,26 +435,29 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
     for (int kx = 0; kx < 3; ++kx)
       vB[kx][ks] = (4 * wm * HW + i + kx * DIL) * 128 + (((ks * 4 + g) ^ ((i + kx * DIL) & 7)) << 4);
   }
-  // every tap step issues exactly 3 transfers per wave (2 weight pieces of step + 2, 1 halo piece of the next channel slice;
-  // dummies into the scratch KB where there is nothing to fetch), so one counted wait serves all steps
+  // every tap step issues exactly 3 transfers per wave (weight piece j = 1 of step + 2, one halo piece of the next channel
+  // slice, weight piece j = 0 of step + 3; dummies into the scratch KB where there is nothing to fetch), so one counted wait
+  // serves all steps.  They are spread over the MFMAs of the step (see HC_STEP): issued back to back they stall the wave
+  // for several hundred cycles in which its SIMD partner, at the same point behind the same barrier, does the same.
   const int wdst = (w * 16) * 128;
   auto issue_halo = [&](int t, int img, bool real) {
     const int p = t * 8 + w;
     ig_glds16(reinterpret_cast<const void*>(real ? hsrc[t] : zlane), lds + (p < NP ? img + p * 1024 : SCRATCH));
   };
-  auto issue_w = [&](int t, int extra, bool real) {    // tap t of the slice `extra` bytes further
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      ig_glds16(reinterpret_cast<const void*>(wk[j] + (real ? t * CIN * 2 + extra : 0)),
-                lds + (real ? BRING + (t % 3) * (IG_BN * 128) + wdst + 8 * j * 128 : SCRATCH));
+  auto issue_w = [&](int j, int t, int extra, bool real) {    // piece j of tap t of the slice `extra` bytes further
+    ig_glds16(reinterpret_cast<const void*>(wk[j] + (real ? t * CIN * 2 + extra : 0)),
+              lds + (real ? BRING + (t % 3) * (IG_BN * 128) + wdst + 8 * j * 128 : SCRATCH));
   };
 #pragma unroll
   for (int q = 0; q < HaloGeom<DIL>::PQ; ++q) issue_halo(q, 0, true);
 #pragma unroll
   for (int t = 0; t < 9; ++t) hsrc[t] += 128;
-  issue_w(0, 0, true);
-  issue_w(1, 0, true);
+  issue_w(0, 0, 0, true);
+  issue_w(1, 0, 0, true);
+  issue_w(0, 1, 0, true);
+  issue_w(1, 1, 0, true);
   ig_glds16(reinterpret_cast<const void*>(zlane), lds + SCRATCH);
+  issue_w(0, 2, 0, true);
   f32x4 acc[4][4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
@@ -489,32 +492,35 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                             \
                : "+v"(af[buf][0]), "+v"(af[buf][1]), "+v"(af[buf][2]), "+v"(af[buf][3]), "+v"(bfr[buf][0]),            \
                  "+v"(bfr[buf][1]), "+v"(bfr[buf][2]), "+v"(bfr[buf][3])::"memory")
-  auto mfmas = [&](int buf) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[buf][nt]),
-                                                              __builtin_bit_cast(bf16x8, bfr[buf][mt]), acc[nt][mt], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
+  // 16 MFMAs of operand buffer `buf`; `mid` runs after the 5th and `late` after the 11th (a transfer each)
+#define HC_MFMAS(buf, mid, late)                                                                                       \
+  do {                                                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                     \
+    _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                                \
+      const int nt_ = e_ >> 2, mt_ = e_ & 3;                                                                           \
+      acc[nt_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[buf][nt_]),                \
+                                                              __builtin_bit_cast(bf16x8, bfr[buf][mt_]), acc[nt_][mt_], 0, 0, 0); \
+      if (e_ == 4) { __builtin_amdgcn_sched_barrier(0); mid; __builtin_amdgcn_sched_barrier(0); }                     \
+      if (e_ == 10) { __builtin_amdgcn_sched_barrier(0); late; __builtin_amdgcn_sched_barrier(0); }                   \
+    }                                                                                                                  \
+    __builtin_amdgcn_s_setprio(0);                                                                                     \
+  } while (0)
+  // slot (s+2)%3 [(s+3)%3] was last read by reads that every wave drained before the barrier of step s-1 [s]; the other
+  // halo image in the previous slice
 #define HC_STEP(T)                                                                                                     \
   do {                                                                                                                 \
     HC_LOAD_OPS(1, T, 1, img);                                                                                         \
     HC_WAIT_OPS(0, 8);                                                                                                 \
-    mfmas(0);                                                                                                          \
+    HC_MFMAS(0, issue_w(1, ((T) + 2) % 9, (T) < 7 ? 0 : 128, (T) < 7 || more),                                         \
+             (issue_halo(T, img ^ HC_ABYTES, more), hsrc[T] += 128));                                                  \
     HC_WAIT_OPS(1, 0);                                                                                                 \
-    if ((T) < 7) issue_w((T) + 2, 0, true); else issue_w((T) - 7, 128, more);                                          \
-    issue_halo(T, img ^ HC_ABYTES, more);                                                                              \
-    hsrc[T] += 128;                                                                                                    \
-    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                                   \
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                                   \
     __builtin_amdgcn_s_barrier();                                                                                      \
     asm volatile("" ::: "memory");                                                                                     \
     HC_LOAD_OPS(0, ((T) + 1) % 9, 0, (T) < 8 ? img : img ^ HC_ABYTES);                                                 \
-    mfmas(1);                                                                                                          \
+    HC_MFMAS(1, (void)0, issue_w(0, ((T) + 3) % 9, (T) < 6 ? 0 : 128, (T) < 6 || more));                               \
   } while (0)
-  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");       // the halo of slice 0 and weight slice 0
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // the halo of slice 0 and weight slice 0
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   int img = 0;
@@ -526,6 +532,7 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
     wk[0] += 128;
     wk[1] += 128;
   }
+#undef HC_MFMAS
 #undef HC_STEP
 #undef HC_WAIT_OPS
 #undef HC_LOAD_OPS
