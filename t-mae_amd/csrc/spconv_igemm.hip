@@ -299,6 +299,182 @@ __global__ __launch_bounds__(512, 1) void spconv_igemm_ring_kernel(const __hip_b
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The 256-column form (the d = 256 stages: cout = 256), second generation.  Same tile (256 rows x 256 columns, 8 waves,
+// wave tile 64 x 128), same LDS image and swizzle as spconv_igemm_ring_kernel<CIN, 256>, two slots of 64 KB; what changed
+// is everything around the MFMAs (the first generation spent 1.1 VALU instructions per MFMA on addresses and waited for
+// every operand read right before its use; MFMA busy 0.44):
+//  * transfers are `buffer_load_dwordx4 ... lds` with a 32-bit per-lane offset and a SCALAR slice offset: the rulebook tile in
+//    LDS holds byte offsets (row * pitch; an absent neighbour = an offset past the buffer, which the range check turns
+//    into zeros), a gathered piece costs one v_add, a weight piece nothing;
+//  * the step loop is unrolled over the two slots, so every LDS operand address is a per-lane base + an immediate;
+//  * operand reads are inline asm, issued one 16-MFMA group ahead into alternating register sets, with counted waits;
+//  * one barrier per step, placed before the step's LAST MFMA group: a wave drains its reads of the slot, waits for the next
+//    slice (issued a whole step earlier), meets the others, issues the slice after next into the slot just drained and the
+//    first reads of the next step, then runs the last group.
+// ------------------------------------------------------------------------------------------------
+#define IR2_OOB 0x7FFFFFF0u
+template <int CIN>
+__global__ __launch_bounds__(512, 1) void spconv_igemm_ring256_kernel(const __hip_bfloat16* __restrict__ feat, int64_t ldf,
+                                                                     unsigned fbytes, const int32_t* __restrict__ nbr,
+                                                                     int64_t m_out, const __hip_bfloat16* __restrict__ W,
+                                                                     int cout, __hip_bfloat16* __restrict__ out, int64_t ldo) {
+  constexpr int KC = CIN / IG_BK, STEPS = 9 * KC, BN = 256;
+  // LDS: gathered rows of slot 0, of slot 1, weight rows of slot 0, of slot 1 (32 KB each), then the rulebook tile: the two
+  // slots of an operand lie 32 KB apart, within the 16-bit offset field of a DS instruction
+  constexpr int HALF = IR_BM * 128, BOFF = 2 * HALF;
+  static_assert(STEPS % 2 == 0, "the step loop is unrolled over the two slots");
+  extern __shared__ __attribute__((aligned(1024))) char ring[];
+  unsigned* nb = reinterpret_cast<unsigned*>(ring + 4 * HALF);           // [9][256] byte offsets of the neighbour rows
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, i = lane & 15;
+  const int nct = cout / BN;
+  const int64_t bid = blockIdx.x;
+  const int64_t per_xcd = (int64_t)gridDim.x / (8 * nct);               // XCD-contiguous row tiles (see the kernel above)
+  const int64_t rt = (bid & 7) * per_xcd + (bid >> 3) / nct;
+  const int ct = (int)((bid >> 3) % nct);
+  const int64_t row0 = rt * IR_BM;
+  if (row0 >= m_out) return;
+  const int n0 = ct * BN;
+  const unsigned pitch = (unsigned)ldf * 2u;
+  for (int e = tid; e < IR_BM * 9; e += 512) {
+    const int64_t r = row0 + e / 9;
+    const int v = r < m_out ? nbr[r * 9 + (e % 9)] : -1;
+    nb[(e % 9) * IR_BM + e / 9] = v < 0 ? IR2_OOB : (unsigned)v * pitch;
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)fbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (int64_t)n0 * (9 * CIN)), 0,
+                                                                      BN * 9 * CIN * 2, 0x00020000);
+  const int r8 = lane >> 3, chunk16 = ((lane & 7) ^ r8) << 4;
+  // weight row of this lane's piece j: LDS row L = 32 w + 8 j + r8 holds column n(L) (the permutation of the kernel above);
+  // n(32 w + 8 j + r8) = n(32 w + r8) + {0, 16, 4, 20}[j], so one per-lane offset serves the four pieces
+  unsigned woff;
+  {
+    const int L = w * 32 + r8, s64 = L & 63;
+    const int n = (L & ~63) + 32 * (s64 >> 5) + 8 * ((s64 >> 2) & 3) + 4 * ((s64 >> 4) & 1) + (s64 & 3);
+    woff = (unsigned)n * (9 * CIN * 2) + chunk16;
+  }
+  const unsigned* nbl = nb + w * 32 + r8;                                // gathered row of piece j: 32 w + r8 + 8 j
+  unsigned goff[4];
+  auto fetch_goff = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) goff[j] = nbl[t * IR_BM + 8 * j] + chunk16;
+  };
+  auto issue = [&](int slot, int t, int kc) {                            // uses goff (of tap t)
+    char* sa = ring + slot * HALF + (w * 32) * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(fr, (__attribute__((address_space(3))) void*)(sa + 8 * j * 128), 16, goff[j],
+                                               kc * 128, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(sa + BOFF + 8 * j * 128), 16,
+                                               woff, (t * CIN + kc * IG_BK) * 2 + (16 * (j & 1) + 4 * (j >> 1)) * (9 * CIN * 2),
+                                               0, 0);
+  };
+  const int wm = w & 3, wn = w >> 2;                   // wave tile: rows wm*64.., columns wn*128..
+  unsigned vA[2], vB[2];                               // LDS byte addresses of the operand reads (slot 0) per channel half
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int sw = ((ks * 4 + g) ^ (i & 7)) << 4;
+    vB[ks] = (unsigned)((wm * 64 + i) * 128 + sw);
+    vA[ks] = (unsigned)(BOFF + (wn * 128 + i) * 128 + sw);
+  }
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 af[2][4], bfr[2][4];
+  // 4 reads of 16-byte fragments, rows 16 apart (2048 bytes), from `addr` + OFF into registers R[0..3]
+#define IR2_READ4(R, addr, OFF)                                                                                        \
+  asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"                                    \
+               "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"                                        \
+               : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3])                                                    \
+               : "v"(addr), "n"(OFF), "n"((OFF) + 2048), "n"((OFF) + 4096), "n"((OFF) + 6144) : "memory")
+#define IR2_WAIT(N, RA, RB)                                                                                            \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                             \
+               : "+v"(RA[0]), "+v"(RA[1]), "+v"(RA[2]), "+v"(RA[3]), "+v"(RB[0]), "+v"(RB[1]), "+v"(RB[2]), "+v"(RB[3])  \
+               ::"memory")
+#define IR2_MFMAS(NH, RA, RB)                                                                                          \
+  do {                                                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                     \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                                   \
+      _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_)                                                              \
+        acc[(NH) * 4 + q_][mt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, RA[q_]),          \
+                                                                          __builtin_bit_cast(bf16x8, RB[mt_]),         \
+                                                                          acc[(NH) * 4 + q_][mt_], 0, 0, 0);           \
+    __builtin_amdgcn_s_setprio(0);                                                                                     \
+  } while (0)
+  // one step on slot SL; on entry the reads of its first group (bfr[0], af[0]) are in flight.  (tq, kq) = the slice that the
+  // transfer issued in this step fetches (step + 2).
+#define IR2_STEP(SL)                                                                                                   \
+  do {                                                                                                                 \
+    IR2_READ4(af[1], vA[0], (SL) * HALF + 8192);                                  /* columns 64..127 of the wave, channels 0..31 */  \
+    IR2_WAIT(4, af[0], bfr[0]);                                                                                        \
+    IR2_MFMAS(0, af[0], bfr[0]);                                                                                       \
+    IR2_READ4(bfr[1], vB[1], (SL) * HALF);                                                                            \
+    IR2_READ4(af[0], vA[1], (SL) * HALF);                                                                             \
+    IR2_WAIT(8, af[1], bfr[0]);                                                                                        \
+    IR2_MFMAS(1, af[1], bfr[0]);                                                                                       \
+    IR2_READ4(af[1], vA[1], (SL) * HALF + 8192);                                                                      \
+    IR2_WAIT(4, af[0], bfr[1]);                                                                                        \
+    IR2_MFMAS(0, af[0], bfr[1]);                                                                                       \
+    IR2_WAIT(0, af[1], bfr[1]);                                         /* all reads of this slot are done */              \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    /* the next slice (issued a step ago) landed */   \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    asm volatile("" ::: "memory");                                                                                     \
+    if (tq < 9) {                                                                                                      \
+      issue(SL, tq, kq);                                                                                               \
+      if (++kq == KC) { kq = 0; if (++tq < 9) fetch_goff(tq); }                                                       \
+    }                                                                                                                  \
+    IR2_READ4(bfr[0], vB[0], (1 - (SL)) * HALF);                                                                      \
+    IR2_READ4(af[0], vA[0], (1 - (SL)) * HALF);                                                                       \
+    IR2_MFMAS(1, af[1], bfr[1]);                                                                                       \
+  } while (0)
+  int tq = 0, kq = 0;
+  fetch_goff(0);
+  issue(0, 0, 0);
+  if (++kq == KC) { kq = 0; ++tq; fetch_goff(tq); }
+  issue(1, tq, kq);
+  if (++kq == KC) { kq = 0; ++tq; fetch_goff(tq); }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                       // slice 0 (slice 1's 8 transfers may be in flight)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  IR2_READ4(bfr[0], vB[0], 0);
+  IR2_READ4(af[0], vA[0], 0);
+  for (int step = 0; step < STEPS; step += 2) {
+    IR2_STEP(0);
+    IR2_STEP(1);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef IR2_STEP
+#undef IR2_MFMAS
+#undef IR2_WAIT
+#undef IR2_READ4
+  // rows 4g + r of column tile nt = output channels (slab nt/4) * 64 + 32 ((nt%4) / 2) + 8g + 4 (nt % 2) + r; column i = token
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int64_t r = row0 + wm * 64 + mt * 16 + i;
+    if (r < m_out) {
+#pragma unroll
+      for (int sbk = 0; sbk < 2; ++sbk) {
+        __hip_bfloat16* p = out + r * ldo + n0 + wn * 128 + sbk * 64 + 8 * g;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int t0 = sbk * 4 + 2 * h;
+          u32x4 v;
+          v[0] = ig_bf16_bits(acc[t0][mt][0]) | (ig_bf16_bits(acc[t0][mt][1]) << 16);
+          v[1] = ig_bf16_bits(acc[t0][mt][2]) | (ig_bf16_bits(acc[t0][mt][3]) << 16);
+          v[2] = ig_bf16_bits(acc[t0 + 1][mt][0]) | (ig_bf16_bits(acc[t0 + 1][mt][1]) << 16);
+          v[3] = ig_bf16_bits(acc[t0 + 1][mt][2]) | (ig_bf16_bits(acc[t0 + 1][mt][3]) << 16);
+          *reinterpret_cast<u32x4*>(p + 32 * h) = v;
+        }
+      }
+    }
+  }
+}
+
 // out [m_out, cout] bf16 = sparse conv of feat [m_in, cin] bf16 through the rulebook nbr [m_out, 9] with the weight
 // matrix W [cout, 9 * cin] bf16 (the spconv-2 layout [cout, 3, 3, cin] flattened).  cin in {128, 256, 384}, cout % 128 == 0.
 static int igemm_launch(const void* feat, int64_t ldf, int64_t m_in, int cin, const int32_t* nbr, int64_t m_out,
@@ -326,7 +502,20 @@ static int igemm_launch(const void* feat, int64_t ldf, int64_t m_in, int cin, co
                        (const __hip_bfloat16*)feat, ldf, nbr, m_out, (const __hip_bfloat16*)w, cout,                  \
                        (__hip_bfloat16*)out, ldo);                                                                    \
   } while (0)
-    if (bn == 256) {
+    const int64_t fbytes = ((m_in - 1) * ldf + cin) * 2;
+    static const int gen2 = TMAE_AB_INT("TMAE_IGEMM_RING2", 1);
+    if (bn == 256 && gen2 != 0 && fbytes < (int64_t)IR2_OOB && ldf * 2 < (1 << 24) && m_in < (1 << 24)) {
+#define IR2_LAUNCH(C)                                                                                                 \
+  do {                                                                                                                \
+    static TmaeLdsAttr attr;                                                                                          \
+    if (int e_ = tmae_allow_lds(attr, (const void*)spconv_igemm_ring256_kernel<C>, lds)) return e_;                   \
+    hipLaunchKernelGGL((spconv_igemm_ring256_kernel<C>), dim3((unsigned)grid), dim3(512), lds, stream,                \
+                       (const __hip_bfloat16*)feat, ldf, (unsigned)fbytes, nbr, m_out, (const __hip_bfloat16*)w, cout, \
+                       (__hip_bfloat16*)out, ldo);                                                                    \
+  } while (0)
+      if (cin == 128) IR2_LAUNCH(128); else if (cin == 256) IR2_LAUNCH(256); else IR2_LAUNCH(384);
+#undef IR2_LAUNCH
+    } else if (bn == 256) {
       if (cin == 128) IR_LAUNCH(128, 256); else if (cin == 256) IR_LAUNCH(256, 256); else IR_LAUNCH(384, 256);
     } else {
       if (cin == 128) IR_LAUNCH(128, 128); else if (cin == 256) IR_LAUNCH(256, 128); else IR_LAUNCH(384, 128);
