@@ -337,6 +337,11 @@ int tmae_token_gemm_dgelu(const void* x, int64_t ldx, int64_t m, int k, const vo
                           const void* aux, void* y, int64_t ldy, void* stream_) {
   (void)hipGetLastError();
   if (!aux || ((uintptr_t)aux & 15)) return TMAE_EARG;
+  static const int wreg = TMAE_AB_INT("TMAE_TG_WREG_DGELU", 1);
+  if (wreg != 0 && m >= 32768) {                        // heavy shapes: the W-in-registers kernel (h_pre rides in its LDS ring)
+    const int rc = tmae_token_gemm_wreg_dgelu(x, ldx, m, k, w, n, bias, aux, y, ldy, stream_);
+    if (rc != TMAE_EARG) return rc;
+  }
   return token_gemm_launch(x, ldx, m, k, w, n, bias, y, ldy, aux, nullptr, stream_);
 }
 

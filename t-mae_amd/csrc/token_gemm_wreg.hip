@@ -52,6 +52,15 @@ __device__ __forceinline__ unsigned tgw_gelu2(unsigned u) {
   return tgw_pack2(tgw_gelu(__uint_as_float(u << 16)), tgw_gelu(__uint_as_float(u & 0xFFFF0000u)));
 }
 
+// d/dx of the exact GELU, Phi(x) + x phi(x): the same arithmetic as token_gemm.hip's dgelu()
+__device__ __forceinline__ float tgw_dgelu(float x) {
+  const float e = __expf(-0.5f * x * x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * 0.70710678f * fabsf(x));
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;
+  return 0.5f * (1.0f + copysignf(erf_abs, x)) + x * e * 0.39894228040143267794f;
+}
+
 #define TGW_OOB 0x7FFFFFF0u          // voffset past every buffer: loads return zeros, stores are dropped
 #define TGW_NT 2                     // cache policy of the y stores (written once, streamed)
 
@@ -59,7 +68,10 @@ __device__ __forceinline__ unsigned tgw_gelu2(unsigned u) {
 // the bf16-rounded tile it is about to store -- a second trip through the staging patch and a second set of full-line
 // stores.  The separate GELU pass (read [m, dff], write [m, dff]: 84 us per layer at 466 k tokens, as fast as a copy)
 // becomes one extra write here; this kernel's step has ~3x the VALU slack the ~13 instructions per element need.
-template <int K, int NTC, int NWC, bool POS, bool ACC = false, bool GELU2 = false>
+// DG (the FFN's first Linear backwards, d h_pre = (dy W2) * gelu'(h_pre), sst_basic_block.py:81-82): y2 is the READ-ONLY
+// [m, N] tile source h_pre (same pitch as y); its step tile rides in the ring slot like ACC's y tile and the epilogue multiplies
+// by gelu'() of it.  Steps of half the tokens (16 KB of x + 32 KB of h_pre per slot, 3 slots).
+template <int K, int NTC, int NWC, bool POS, bool ACC = false, bool GELU2 = false, bool DG = false>
 __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfloat16* __restrict__ x, int ldx,
                                                                 const __hip_bfloat16* __restrict__ W,
                                                                 const __hip_bfloat16* __restrict__ bias,
@@ -67,8 +79,9 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
                                                                 unsigned xbytes, unsigned ybytes,
                                                                 const uint8_t* __restrict__ cells,
                                                                 __hip_bfloat16* __restrict__ y2) {
+  static_assert(!(DG && (ACC || GELU2 || POS)), "DG is a mode of its own");
   constexpr int TEAMS = 8 / NWC;                  // teams of NWC waves; a team covers all columns of the group
-  constexpr int STEP = 16384 / K;                 // tokens per ring slot (32 KB): 128 / 64 / 32 for K = 128 / 256 / 512
+  constexpr int STEP = (DG ? 8192 : 16384) / K;   // tokens per ring slot (32 KB of x; DG 16 KB): 128 / 64 / 32 for K = 128 / 256 / 512
   constexpr int TGW = (STEP / 16) / TEAMS;        // 16-token groups per wave and step
   constexpr int KX = K / 32, KA = K + (POS ? 32 : 0), KS = KA / 32;
   constexpr int ROWB = K * 2;                     // bytes per x row
@@ -78,11 +91,11 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
   // in the ring slot beside x (a register load of y in the epilogue would have to be waited for IN ORDER, i.e. together
   // with the three steps of x prefetched before it) and the accumulators start from it
   constexpr int YROWB = NWC * NTC * 32;           // bytes per row of the y tile (the group's columns)
-  constexpr int YB = ACC ? STEP * YROWB : 0, PPY = YB / 1024 / 8;
+  constexpr int YB = (ACC || DG) ? STEP * YROWB : 0, PPY = YB / 1024 / 8;
   constexpr int SLOT = STEP * ROWB + CELLB + YB;
-  constexpr int NS = ACC ? 3 : 4;
+  constexpr int NS = (ACC || DG) ? 3 : 4;
   constexpr int ND = PPW + (POS ? STEP / 64 : 0) + PPY; // DMA instructions per wave and step
-  static_assert(!ACC || YB % 8192 == 0, "y tile must divide into 1-KiB pieces per wave");
+  static_assert(!(ACC || DG) || YB % 8192 == 0, "y tile must divide into 1-KiB pieces per wave");
   constexpr int NST = TGW * (NTC / 2) * (GELU2 ? 2 : 1);   // 16-byte store instructions per wave and step
   constexpr int WAITN = (NS - 1) * NST + (NS - 2) * ND;
   static_assert(TGW >= 1 && (NTC == 2 || NTC == 4) && WAITN < 64 && ROWB <= 1024, "shape");
@@ -97,7 +110,7 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)ybytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc((void*)(GELU2 ? y2 : y), 0, (int)ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc((void*)((GELU2 || DG) ? y2 : y), 0, (int)ybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)(POS ? cells : (const uint8_t*)x), 0, POS ? m : 0, 0x00020000);
 
   // ---- what this lane fetches in every step: PPW pieces; piece p = w * PPW + jj covers LDS bytes [1024 p, +1024) of the slot
@@ -120,14 +133,14 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(slot + (w * PPW + jj) * 1024),
                                                16, vo, 0, 0, 0);
     }
-    if constexpr (ACC) {
+    if constexpr (ACC || DG) {
 #pragma unroll
       for (int jj = 0; jj < PPY; ++jj) {
         const int lb = (w * PPY + jj) * 1024 + lane * 16;
         const int R = lb / YROWB, cpos = (lb % YROWB) / 16;
         const unsigned vo = tok0 + R < m ? (unsigned)(tok0 + R) * (unsigned)(ldy * 2) +
                                                (unsigned)(cg * YROWB + ((cpos ^ (R & 15)) << 4)) : TGW_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (__attribute__((address_space(3))) void*)(slot + STEP * ROWB + CELLB +
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(DG ? y2r : yr, (__attribute__((address_space(3))) void*)(slot + STEP * ROWB + CELLB +
                                                                                                 (w * PPY + jj) * 1024),
                                                  16, vo, 0, 0, 0);
       }
@@ -240,13 +253,22 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
   // not bytes, then bounds the kernel (stores alone: 314 us for 477 MB).  So the tile takes a turn through a wave-private
   // LDS patch (2 KB, 16-byte chunks XOR-swizzled by the row: conflict-free both ways) and leaves as FULL 128-byte
   // lines: lane l stores chunk l & 7 of token l >> 3, 8 whole lines per instruction (stores alone: 109 us).
-  auto epi_tg = [&](int tokb) {                      // tokb = first token of the PT groups
+  auto epi_tg = [&](int tokb, const char* slot, int tgi) {   // tokb = first token of the PT groups (tgi: their index in the step)
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
       u32x4 pk[NTC / 2];
 #pragma unroll
       for (int h = 0; h < NTC / 2; ++h) {
-        const f32x4 v0 = acc[2 * h][t], v1 = acc[2 * h + 1][t];
+        f32x4 v0 = acc[2 * h][t], v1 = acc[2 * h + 1][t];
+        if constexpr (DG) {                             // this lane's 8 columns of token i of h_pre (layout: see ACC above)
+          const char* yt = slot + STEP * ROWB + CELLB + ((tgi + t) * 16 + i) * YROWB;
+          const int ch = wc * (NTC / 2) * 4 + (NTC / 2) * g + h;
+          const u32x4 a = *reinterpret_cast<const u32x4*>(yt + ((ch ^ i) << 4));
+          v0[0] *= tgw_dgelu(__uint_as_float(a[0] << 16)); v0[1] *= tgw_dgelu(__uint_as_float(a[0] & 0xFFFF0000u));
+          v0[2] *= tgw_dgelu(__uint_as_float(a[1] << 16)); v0[3] *= tgw_dgelu(__uint_as_float(a[1] & 0xFFFF0000u));
+          v1[0] *= tgw_dgelu(__uint_as_float(a[2] << 16)); v1[1] *= tgw_dgelu(__uint_as_float(a[2] & 0xFFFF0000u));
+          v1[2] *= tgw_dgelu(__uint_as_float(a[3] << 16)); v1[3] *= tgw_dgelu(__uint_as_float(a[3] & 0xFFFF0000u));
+        }
         pk[h] = u32x4{tgw_pack2(v0[0], v0[1]), tgw_pack2(v0[2], v0[3]), tgw_pack2(v1[0], v1[1]), tgw_pack2(v1[2], v1[3])};
         *reinterpret_cast<u32x4*>(stg + i * (NTC * 32) + ((((NTC / 2) * g + h) ^ (i & (CPL - 1))) << 4)) = pk[h];
       }
@@ -284,25 +306,25 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
 #pragma unroll
     for (int k2 = 0; k2 < NPR; ++k2) {
       mfma_tg(slot, team * TGW + k2 * PT);
-      epi_tg(tok0 + k2 * PT * 16);
+      epi_tg(tok0 + k2 * PT * 16, slot, team * TGW + k2 * PT);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot are done before the next barrier
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA may land after the workgroup has released its LDS
 }
 
-template <int K, int NTC, int NWC, bool POS, bool ACC = false, bool GELU2 = false>
+template <int K, int NTC, int NWC, bool POS, bool ACC = false, bool GELU2 = false, bool DG = false>
 static int tgw_launch(const void* x, int64_t ldx, int64_t m, const void* w, int n, const void* bias, void* y, int64_t ldy,
                       const void* cells, hipStream_t stream, void* y2 = nullptr) {
   constexpr int NG = NWC * NTC * 16;
-  constexpr int STEP = 16384 / K;
-  constexpr int lds = (ACC ? 3 : 4) * (STEP * K * 2 + (POS ? STEP * 4 : 0) + (ACC ? STEP * NG * 2 : 0)) + 8 * 16 * NTC * 32;
+  constexpr int STEP = (DG ? 8192 : 16384) / K;
+  constexpr int lds = ((ACC || DG) ? 3 : 4) * (STEP * K * 2 + (POS ? STEP * 4 : 0) + ((ACC || DG) ? STEP * NG * 2 : 0)) + 8 * 16 * NTC * 32;
   const int ncg = n / NG;
   static TmaeLdsAttr attr;
-  if (int e = tmae_allow_lds(attr, (const void*)token_gemm_wreg_kernel<K, NTC, NWC, POS, ACC, GELU2>, lds)) return e;
+  if (int e = tmae_allow_lds(attr, (const void*)token_gemm_wreg_kernel<K, NTC, NWC, POS, ACC, GELU2, DG>, lds)) return e;
   const int64_t xbytes = ((m - 1) * ldx + K) * 2, ybytes = ((m - 1) * ldy + n) * 2;
   const int grid = 8 * ncg * (32 / ncg);
-  hipLaunchKernelGGL((token_gemm_wreg_kernel<K, NTC, NWC, POS, ACC, GELU2>), dim3(grid), dim3(512), lds, stream,
+  hipLaunchKernelGGL((token_gemm_wreg_kernel<K, NTC, NWC, POS, ACC, GELU2, DG>), dim3(grid), dim3(512), lds, stream,
                      (const __hip_bfloat16*)x, (int)ldx, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias,
                      (__hip_bfloat16*)y, (int)ldy, (int)m, ncg, (unsigned)xbytes, (unsigned)ybytes, (const uint8_t*)cells,
                      (__hip_bfloat16*)y2);
@@ -362,5 +384,21 @@ int tmae_token_gemm_wreg_gelu(const void* x, int64_t ldx, int64_t m, int k, cons
   if (((m - 1) * ldx + k) * 2 >= (int64_t)TGW_OOB || ((m - 1) * ldy + n) * 2 >= (int64_t)TGW_OOB) return TMAE_EARG;
   if (k == 256 && n == 512) return tgw_launch<256, 4, 8, false, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream, y_gelu);
   if (k == 128 && n == 256) return tgw_launch<128, 4, 4, false, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream, y_gelu);
+  return TMAE_EARG;
+}
+
+// y = (x W^T + bias) * gelu'(aux) in one pass (tmae_token_gemm_dgelu on the heavy shapes): the input gradient of the FFN's
+// first Linear through its GELU, (k, n) = (256, 512) or (128, 256); aux [m, n] has y's pitch.  TMAE_EARG for anything else.
+int tmae_token_gemm_wreg_dgelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias,
+                               const void* aux, void* y, int64_t ldy, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m <= 0 || !x || !w || !y || !aux || !bias || ldx < k || ldy < n || (ldx % 8) || (ldy % 8)) return TMAE_EARG;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)aux & 15) || ((uintptr_t)bias & 1)) return TMAE_EARG;
+  if (((m - 1) * ldx + k) * 2 >= (int64_t)TGW_OOB || ((m - 1) * ldy + n) * 2 >= (int64_t)TGW_OOB) return TMAE_EARG;
+  if (k == 256 && n == 512)
+    return tgw_launch<256, 4, 8, false, false, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream, const_cast<void*>(aux));
+  if (k == 128 && n == 256)
+    return tgw_launch<128, 4, 4, false, false, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream, const_cast<void*>(aux));
   return TMAE_EARG;
 }

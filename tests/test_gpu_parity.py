@@ -751,10 +751,11 @@ def test_refresh_param_copies_casts_and_transposes_in_one_launch():
 
 def test_gelu_linear_fused_backward_vs_torch():
     """ops.gelu_linear: forward = F.linear(F.gelu(x)); backward with the GELU derivative fused into the dX GEMM
-    (tmae_token_gemm_dgelu) vs torch autograd in bf16, for both FFN shapes (d = 128 / dff = 256, d = 256 / dff = 512)."""
+    (tmae_token_gemm_dgelu) vs torch autograd in bf16, for both FFN shapes (d = 128 / dff = 256, d = 256 / dff = 512);
+    token counts below and above 32768 (above: the W-in-registers kernel with h_pre in its LDS ring; ragged last step)."""
     from tmae_amd import ops
     torch.manual_seed(4)
-    for (m, dff, d) in ((30001, 256, 128), (20000, 512, 256)):
+    for (m, dff, d) in ((30001, 256, 128), (20000, 512, 256), (40003, 256, 128), (33001, 512, 256)):
         hp = (torch.randn(m, dff, device=dev()) * 1.5).bfloat16().requires_grad_(True)
         w = (torch.randn(d, dff, device=dev()) * 0.05).requires_grad_(True)
         b = torch.randn(d, device=dev(), requires_grad=True)
