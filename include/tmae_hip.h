@@ -229,6 +229,14 @@ int tmae_dense_conv3x3(const void* in, int batch, int ny, int nx, int cin, const
  * sst_bev_backbone.py:20-30, t_mae.yaml:107-112): 16 x 16 cell blocks with a (16 + 2d)^2 halo. */
 int tmae_dense_conv3x3_dilated(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout,
                                int dilation, void* out, void* stream);
+/* Weight gradient of that convolution (SiamWCA_MAE.py:100-115, sst_bev_backbone.py:20-30; torch's conv2d weight gradient in
+ * the reference): dw [cout, 9*cin] fp32 (the weight's layout) from dy [batch, ny, nx, cout] and x [batch, ny, nx, cin], bf16,
+ * contiguous.  Halo-tiled like the forward (the nine shifted copies of x are read out of one staged image), fixed-order
+ * slab reduction.  cout = 128, cin % 64 == 0 (<= 512), dilation in {1, 2}; TMAE_EARG otherwise (then: tmae_spconv_wgrad
+ * over a full-grid rulebook).  ws: tmae_dense_conv3x3_wgrad_workspace(cin, cout) bytes. */
+size_t tmae_dense_conv3x3_wgrad_workspace(int cin, int cout);
+int tmae_dense_conv3x3_wgrad(const void* dy, const void* x, int batch, int ny, int nx, int cin, int cout, int dilation,
+                             float* dw, void* ws, size_t ws_bytes, void* stream);
 
 /* gather-GEMM form: cols [m_out, 9*c] = rows of feat selected by nbr (zeros where -1), to be
  * multiplied by the [cout, 9*c] view of the spconv-2 weight [cout,3,3,cin]; and its adjoint

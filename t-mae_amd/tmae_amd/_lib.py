@@ -51,6 +51,8 @@ SIGNATURES = {
     'tmae_spconv_bwd_data': (I, [P, L, L, I, P, L, P, I, P, L, P]),
     'tmae_dense_conv3x3': (I, [P, I, I, I, I, P, I, P, P]),
     'tmae_dense_conv3x3_dilated': (I, [P, I, I, I, I, P, I, I, P, P]),
+    'tmae_dense_conv3x3_wgrad_workspace': (Z, [I, I]),
+    'tmae_dense_conv3x3_wgrad': (I, [P, P, I, I, I, I, I, I, P, P, Z, P]),
     'tmae_spconv_gather': (I, [P, I, L, I, P, L, P, P]),
     'tmae_spconv_gather_t': (I, [P, I, L, I, P, L, P, P]),
     'tmae_sparse_to_dense': (I, [P, I, L, I, P, I, I, I, P, P]),

@@ -1724,6 +1724,7 @@ def _dense_rulebook(batch, ny, nx, device, dil=1):
     return nbr
 
 
+_DENSE_WGRAD = _os.environ.get('TMAE_DENSE_WGRAD', 'halo')   # halo: csrc/dense_wgrad.hip; rulebook: tmae_spconv_wgrad over the full grid
 _DENSE_CONV = _os.environ.get('TMAE_DENSE_CONV', 'halo')     # native: all three passes on our kernels; wgrad: only dW; miopen
 
 
@@ -1783,6 +1784,13 @@ class _DenseConv3x3(torch.autograd.Function):
                     [1, 1], [dil, dil], [dil, dil], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1).to(ctx.meta[0])
         dy2, x2 = dy.view(n, cout), x.view(n, cin)
         dw = torch.empty((cout, 9 * cin), dtype=torch.float32, device=x.device)
+        if ctx.native and _DENSE_WGRAD == 'halo' and x.dtype == torch.bfloat16:
+            wsb = lib.tmae_dense_conv3x3_wgrad_workspace(cin, cout)
+            if wsb:                                    # 0: a shape the halo weight-gradient kernel does not cover
+                ws = _ws(wsb, x.device)
+                check(lib.tmae_dense_conv3x3_wgrad(_p(dy), _p(x), B, Y, X, cin, cout, int(dil), _p(dw), _p(ws), wsb, _s()),
+                      'tmae_dense_conv3x3_wgrad')
+                return dx, dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2).to(ctx.meta[1]), None
         wsb = lib.tmae_linear_wgrad_workspace(n, cout, 9 * cin)
         ws = _ws(wsb, x.device)
         check(lib.tmae_spconv_wgrad(_p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(nbr), n, cout, cin, _p(dw), _p(ws),
