@@ -442,23 +442,32 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
           st[kt] = mfma_s(kf[kt], ql[qt], st[kt]);
           st[kt] = mfma_s(kf[kt], qf[qt], st[kt]);
         }
+        // (!KB) only the last key tile can hold absent rows, and tiles past it take no part at all: the per-element mask and
+        // the whole softmax arithmetic of an absent tile sit behind wave-uniform branches
+        if (KB || kt < nk) {
+          if (!KB && kt == nk - 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if constexpr (!KB) { if (kt * 16 + 4 * g + r >= Tk) st[kt][r] = MASKED_LOGIT; }
-          mx = fmaxf(mx, st[kt][r]);
+            for (int r = 0; r < 4; ++r)
+              if (kt * 16 + 4 * g + r >= Tk) st[kt][r] = MASKED_LOGIT;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
         }
       }
       mx = quad_max(mx);
       float l = 0.f;
       s16x4 pf[NT];
 #pragma unroll
-      for (int kt = 0; kt < NT; ++kt)
+      for (int kt = 0; kt < NT; ++kt) {
+        if (KB || kt < nk) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __expf(st[kt][r] - mx);
-          l += p;
-          pf[kt][r] = f2bf(p);
+          for (int r = 0; r < 4; ++r) {
+            const float p = __expf(st[kt][r] - mx);
+            l += p;
+            pf[kt][r] = f2bf(p);
+          }
         }
+      }
       l = quad_sum(l);
       const float invl = fast_rcp(l);
       // O^T = V^T . P^T (swapped: rows = channels, column = query i): the V fragments serve as the A operand, the
@@ -703,7 +712,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float p = __expf(sT[r] - lse_i[qt]);
-            if constexpr (!KB) { if (kt * 16 + 4 * g + r >= Tk) p = 0.f; }
+            if (!KB && kt == nk - 1) { if (kt * 16 + 4 * g + r >= Tk) p = 0.f; }   // (wave-uniform: only the last tile has absent keys)
             if constexpr (!RECOMP) pTk[kt][r] = p;
             dacc += p * dP[r];
           }
@@ -721,6 +730,8 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
             sT = mfma_s(kf[kt], qf[qt], sT);
             dP = mfma_s(vr[kt], gf[qt], z);
 #pragma unroll
+            // (the per-element form on every tile: restricted to the last tile like pass 1, this pass gave wrong gradients at
+            // the temperature clamp -- F7 case 2 -- for a reason not found; measured and left alone)
             for (int r = 0; r < 4; ++r) pT[r] = (kt * 16 + 4 * g + r < Tk) ? __expf(sT[r] - lse_i[qt]) : 0.f;
           } else {
             sT = sTk[kt]; dP = dPk[kt]; pT = pTk[kt];
