@@ -89,11 +89,17 @@ __global__ __launch_bounds__(512, 1) void dense_wgrad_halo_kernel(const __hip_bf
   }
   // stage u = (tile u >> 1, half u & 1): its cell origin, then one transfer per call (spread over the MFMA groups of the
   // stage before: issued back to back at the stage's top they kept both waves of every SIMD off the matrix core at once)
-  int ob = 0, oy = 0, ox = 0;
-  auto origin = [&](int u) {
-    const int tile = u >> 1, half = u & 1;
-    const int tx = tile % txN, t2 = tile / txN, ty = t2 % tyN;
-    ob = t2 / tyN; oy = ty * 16 + 8 * half; ox = tx * 16;
+  int ob = 0, oy = 0, ox = 0;                                            // origin of the stage the transfers are issued for
+  int ctx = 0, cty = 0;                                                  // its tile coordinates (walked, not divided)
+  auto origin_first = [&](int u) {
+    const int tile = u >> 1, t2 = tile / txN;
+    ctx = tile - t2 * txN; cty = t2 % tyN; ob = t2 / tyN;
+    oy = cty * 16 + 8 * (u & 1); ox = ctx * 16;
+  };
+  auto origin_next = [&](int u) {                                        // stage u, given the values of stage u - 1
+    if (u & 1) { oy += 8; return; }
+    if (++ctx == txN) { ctx = 0; if (++cty == tyN) { cty = 0; ++ob; } }
+    oy = cty * 16; ox = ctx * 16;
   };
   auto issue_piece = [&](int jj, int buf) {
     const int P = w * PPW + jj;
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(512, 1) void dense_wgrad_halo_kernel(const __hip_bf
     if ((GI) < PPW && more) issue_piece(GI, buf ^ 1);                    /* the other buffer: read in the previous stage */ \
   } while (0)
   if (u0 < u1) {
-    origin(u0);
+    origin_first(u0);
 #pragma unroll
     for (int jj = 0; jj < PPW; ++jj) issue_piece(jj, 0);
   }
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(512, 1) void dense_wgrad_halo_kernel(const __hip_bf
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const bool more = u + 1 < u1;
-    if (more) origin(u + 1);
+    if (more) origin_next(u + 1);
     DW_READS(0);
     DW_GROUP(0, 6); DW_GROUP(1, 6); DW_GROUP(2, 14);
     DW_GROUP(3, 6); DW_GROUP(4, 6); DW_GROUP(5, 14);
