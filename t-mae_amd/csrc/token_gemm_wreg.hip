@@ -61,6 +61,10 @@ __device__ __forceinline__ float tgw_dgelu(float x) {
   return 0.5f * (1.0f + copysignf(erf_abs, x)) + x * e * 0.39894228040143267794f;
 }
 
+// tokens per ring slot: 32 KB of x (DG: 16 KB); contraction 384 / 768 (the attention in-projections' input gradients,
+// W = 96 / 192 registers per lane): 24 KB
+__host__ __device__ constexpr int tgw_step(int k, bool dg) { return k == 768 ? 16 : (k == 384 ? 32 : (dg ? 8192 : 16384) / k); }
+
 #define TGW_OOB 0x7FFFFFF0u          // voffset past every buffer: loads return zeros, stores are dropped
 #define TGW_NT 2                     // cache policy of the y stores (written once, streamed)
 
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
                                                                 __hip_bfloat16* __restrict__ y2) {
   static_assert(!(DG && (ACC || GELU2 || POS)), "DG is a mode of its own");
   constexpr int TEAMS = 8 / NWC;                  // teams of NWC waves; a team covers all columns of the group
-  constexpr int STEP = (DG ? 8192 : 16384) / K;   // tokens per ring slot (32 KB of x; DG 16 KB): 128 / 64 / 32 for K = 128 / 256 / 512
+  constexpr int STEP = tgw_step(K, DG);           // tokens per ring slot (32 KB of x; DG 16 KB): 128 / 64 / 32 for K = 128 / 256 / 512
   constexpr int TGW = (STEP / 16) / TEAMS;        // 16-token groups per wave and step
   constexpr int KX = K / 32, KA = K + (POS ? 32 : 0), KS = KA / 32;
   constexpr int ROWB = K * 2;                     // bytes per x row
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
   static_assert(!(ACC || DG) || YB % 8192 == 0, "y tile must divide into 1-KiB pieces per wave");
   constexpr int NST = TGW * (NTC / 2) * (GELU2 ? 2 : 1);   // 16-byte store instructions per wave and step
   constexpr int WAITN = (NS - 1) * NST + (NS - 2) * ND;
-  static_assert(TGW >= 1 && (NTC == 2 || NTC == 4) && WAITN < 64 && ROWB <= 1024, "shape");
+  static_assert(TGW >= 1 && (NTC == 2 || NTC == 4) && WAITN < 64 && ROWB <= 1536 && (STEP * ROWB) % 8192 == 0, "shape");
   extern __shared__ __attribute__((aligned(1024))) char ring[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15;
   const int team = w / NWC, wc = w % NWC;
@@ -317,7 +321,7 @@ template <int K, int NTC, int NWC, bool POS, bool ACC = false, bool GELU2 = fals
 static int tgw_launch(const void* x, int64_t ldx, int64_t m, const void* w, int n, const void* bias, void* y, int64_t ldy,
                       const void* cells, hipStream_t stream, void* y2 = nullptr) {
   constexpr int NG = NWC * NTC * 16;
-  constexpr int STEP = (DG ? 8192 : 16384) / K;
+  constexpr int STEP = tgw_step(K, DG);
   constexpr int lds = ((ACC || DG) ? 3 : 4) * (STEP * K * 2 + (POS ? STEP * 4 : 0) + ((ACC || DG) ? STEP * NG * 2 : 0)) + 8 * 16 * NTC * 32;
   const int ncg = n / NG;
   static TmaeLdsAttr attr;
@@ -344,9 +348,12 @@ int tmae_token_gemm_wreg(const void* x, int64_t ldx, int64_t m, int k, const voi
     if (accumulate) return tgw_launch<512, 2, 8, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
     return tgw_launch<512, 2, 8, false>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
   }
-  if (accumulate) {        // the d = 128 FFN-1 input gradient [m, 128] += [m, 256] W
-    if (k != 256 || n != 128 || cells) return TMAE_EARG;
-    return tgw_launch<256, 4, 2, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
+  if (accumulate) {        // the d = 128 FFN-1 input gradient [m, 128] += [m, 256] W; the in-projections' input gradients
+    if (cells) return TMAE_EARG;                                    // [m, 256] += [m, 768] W and [m, 128] += [m, 384] W
+    if (k == 256 && n == 128) return tgw_launch<256, 4, 2, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
+    if (k == 768 && n == 256) return tgw_launch<768, 2, 8, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
+    if (k == 384 && n == 128) return tgw_launch<384, 2, 4, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
+    return TMAE_EARG;
   }
   if (n % 128 || (k != 128 && k != 256)) return TMAE_EARG;
   // column blocks of 512 (8 waves x 64 columns), then one of 256 (2 teams of 4 waves) or 128 (4 teams of 2 waves);

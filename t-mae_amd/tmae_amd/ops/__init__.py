@@ -112,10 +112,12 @@ def token_gemm_gelu(x, w, bias):
 
 def addmm_inplace(dx, dy, w):
     """dx += dy @ w in place (w [n,k]: dx [m,k], dy [m,n]): the W-in-registers kernel's accumulate form on the shapes it
-    covers (tmae_token_gemm_acc: contraction 512 -> 256 and 256 -> 128, >= 32 k tokens), torch's addmm_ otherwise."""
+    covers (tmae_token_gemm_acc: contraction 512 -> 256, 256 -> 128 and -- the attention in-projections -- 768 -> 256,
+    384 -> 128; >= 32 k tokens), torch's addmm_ otherwise."""
     n, k = w.shape
     m = dx.shape[0]
-    if (m >= (65536 if n == 512 else 32768) and (n, k) in ((512, 256), (256, 128)) and dx.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
+    if (m >= (65536 if n in (512, 768) else 32768) and (n, k) in ((512, 256), (256, 128), (768, 256), (384, 128))
+            and dx.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
             and w.dtype == torch.bfloat16 and dx.is_contiguous() and dy.stride(1) == 1 and dy.stride(0) % 8 == 0
             and dy.data_ptr() % 16 == 0 and dx.data_ptr() % 16 == 0 and m * max(n, k) * 2 < 2 ** 31):
         wt = _transposed(w)
@@ -630,7 +632,7 @@ class _PosProj(torch.autograd.Function):
                 if dx is None:
                     dx = dout @ w
                 elif ctx.inplace_dx:
-                    dx.addmm_(dout, w)                         # see _ProjFork.backward
+                    addmm_inplace(dx, dout, w)                 # see _ProjFork.backward
                 else:
                     dx = torch.addmm(dx, dout, w)
             if ctx.needs_input_grad[1]:
@@ -691,7 +693,7 @@ class _PosProjCross(torch.autograd.Function):
             if dxq is None:
                 dxq = dq @ wq[:, :d]
             elif ctx.inplace_dx:
-                dxq.addmm_(dq, wq[:, :d])                      # see _ProjFork.backward
+                addmm_inplace(dxq, dq, wq[:, :d])              # see _ProjFork.backward
             else:
                 dxq = torch.addmm(dxq, dq, wq[:, :d])
         if ctx.needs_input_grad[1] and dkv is not None:

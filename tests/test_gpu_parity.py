@@ -630,9 +630,12 @@ def test_token_gemm_wreg_kernel_every_instantiation_vs_torch():
     ref = x.float() @ w.float().t()
     assert (out[:, 256:512].float() - ref).abs().max().item() <= 2e-2 * float(ref.abs().max())
     # in-place accumulate (FFN-1 input gradient): dx += dy @ w
-    for (m, n, k) in ((65536 + 33, 512, 256), (120001, 512, 256), (32768 + 5, 256, 128), (470001, 256, 128)):
+    # (contraction 768 / 384: the attention in-projections' input gradients; their weight is a column slice of the
+    # position-augmented weight, pitch k + 32)
+    for (m, n, k) in ((65536 + 33, 512, 256), (120001, 512, 256), (32768 + 5, 256, 128), (470001, 256, 128),
+                      (65536 + 17, 768, 256), (200003, 768, 256), (32768 + 9, 384, 128), (150001, 384, 128)):
         dy = torch.randn(m, n, device=dev()).bfloat16()
-        w = (torch.randn(n, k, device=dev()) * 0.1).bfloat16()
+        w = (torch.randn(n, k + 32, device=dev()) * 0.1).bfloat16()[:, :k] if n in (768, 384) else (torch.randn(n, k, device=dev()) * 0.1).bfloat16()
         dx0 = torch.randn(m, k, device=dev()).bfloat16()
         dx = dx0.clone()
         r = ops.addmm_inplace(dx, dy, w)
