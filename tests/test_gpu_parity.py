@@ -1013,6 +1013,40 @@ def test_dense_conv3x3_own_wgrad_vs_torch(dil, cin, cout):
     assert (w.grad - wr.grad).abs().max().item() < 2e-2 * wr.grad.abs().max().item()
 
 
+@pytest.mark.parametrize('dil,cin,shape', [(1, 64, (1, 7, 5)), (1, 384, (2, 33, 47)), (2, 128, (3, 16, 16)), (2, 256, (1, 40, 21))])
+def test_dense_conv3x3_wgrad_c_abi_vs_torch(dil, cin, shape):
+    """tmae_dense_conv3x3_wgrad (halo-tiled weight gradient, csrc/dense_wgrad.hip) through the C ABI against torch's conv2d
+    weight gradient in fp32 on the same bf16-representable data: grids smaller than a tile, partial tiles, both dilations,
+    channel counts 64 .. 384; deterministic (two calls bit-identical); argument errors."""
+    from tmae_amd._lib import lib, check
+    torch.manual_seed(11)
+    B, Y, X = shape
+    cout = 128
+    x = torch.randn(B, Y, X, cin, device=dev()).bfloat16()
+    dy = torch.randn(B, Y, X, cout, device=dev()).bfloat16()
+    wsb = lib.tmae_dense_conv3x3_wgrad_workspace(cin, cout)
+    assert wsb > 0 and lib.tmae_dense_conv3x3_wgrad_workspace(cin, 256) == 0 and lib.tmae_dense_conv3x3_wgrad_workspace(96, cout) == 0
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for _ in range(2):
+        dw = torch.full((cout, 9 * cin), float('nan'), device=dev())
+        check(lib.tmae_dense_conv3x3_wgrad(dy.data_ptr(), x.data_ptr(), B, Y, X, cin, cout, dil, dw.data_ptr(), ws.data_ptr(), wsb, st),
+              'tmae_dense_conv3x3_wgrad')
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    w = torch.zeros(cout, cin, 3, 3, device=dev(), requires_grad=True)
+    yr = F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=dil, dilation=dil)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    ref = w.grad.permute(0, 2, 3, 1).reshape(cout, 9 * cin)                  # [cout, ky, kx, cin]
+    err = (outs[0] - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, float(ref.abs().max())), (err, float(ref.abs().max()))
+    # refusals: unsupported width / dilation (TMAE_EARG), workspace too small (TMAE_EWS)
+    assert lib.tmae_dense_conv3x3_wgrad(dy.data_ptr(), x.data_ptr(), B, Y, X, cin, 256, dil, outs[0].data_ptr(), ws.data_ptr(), wsb, st) == -1
+    assert lib.tmae_dense_conv3x3_wgrad(dy.data_ptr(), x.data_ptr(), B, Y, X, cin, cout, 3, outs[0].data_ptr(), ws.data_ptr(), wsb, st) == -1
+    assert lib.tmae_dense_conv3x3_wgrad(dy.data_ptr(), x.data_ptr(), B, Y, X, cin, cout, dil, outs[0].data_ptr(), ws.data_ptr(), 1024, st) == -2
+
+
 def test_sparse_conv_golden_and_dense(oracle):
     from tmae_amd.modules.sparse import SparseConvTensor, SubMConv2d, SparseConv2d
     g = golden('F9_sparse_conv')
