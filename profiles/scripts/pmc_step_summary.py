@@ -16,7 +16,7 @@ WARM, STEPS = 2, 3
 
 
 def family(n):
-    if n.startswith('wgrad'): return 'weight gradients (wgrad*)'
+    if n.startswith('wgrad') or n.startswith('dense_wgrad'): return 'weight gradients (wgrad*)'
     if n.startswith('token_gemm'): return 'token GEMMs'
     if n.startswith('win_attn') or n.startswith('dtau') or n.startswith('win_worklist') or n.startswith('win_class'): return 'window attention'
     if 'igemm' in n or n.startswith('dense_conv3x3'): return 'implicit-GEMM convolutions'
