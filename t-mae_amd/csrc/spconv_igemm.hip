@@ -594,7 +594,7 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   const int y0 = ty * 16, x0 = tx * 16, n0 = ct * IG_BN;
   const int r8 = lane >> 3, slot8 = lane & 7;
   // All addresses of the main loop are set up here (the loop itself then spends ~10 VALU instructions per 32 MFMAs; computed
-  // in the loop they were 77 -- 3.6 VALU per MFMA, as much SIMD time as the MFMAs themselves: profiles/round4_pmc_counters).
+  // in the loop they were 77 -- 3.6 VALU per MFMA, as much SIMD time as the MFMAs themselves: profiles/round4_pmc_kernels.md).
   // Halo image: row h = hy * HW + hx of the (16 + 2 DIL)^2 halo, 128 bytes; the 16-byte chunk c of a row sits at chunk
   // position c ^ (hx & 7) -- a swizzle by the COLUMN only, so that a tap shift (ky, kx) of a reader is an immediate offset
   // plus one of three per-lane bases.  Piece p = t * 8 + w (tap step t, wave w) = halo rows 8 p .. 8 p + 7.
