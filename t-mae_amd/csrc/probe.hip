@@ -51,33 +51,34 @@ int tmae_probe_copy(const void* src, void* dst, int64_t bytes, int nontemporal, 
   return tmae_launch_status();
 }
 
+template <int NA, int NB>
 __global__ __launch_bounds__(512, 2) void probe_mfma_kernel(int iters, float* __restrict__ sink) {
   // pseudo-random bf16 operands in [0.5, 2) with random signs (exponent bits fixed: no inf / nan, no denormals)
   unsigned s = (blockIdx.x * 512u + threadIdx.x) * 2654435761u + 12345u;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s; };
-  u32x4 au[4], bu[4];
+  u32x4 au[NA], bu[NB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NA; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      au[i][j] = (rnd() & 0x807F807Fu) | 0x3F803F80u;
-      bu[i][j] = (rnd() & 0x807F807Fu) | 0x3F003F00u;
-    }
-  }
-  f32x4 acc[16];
+    for (int j = 0; j < 4; ++j) au[i][j] = (rnd() & 0x807F807Fu) | 0x3F803F80u;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bu[i][j] = (rnd() & 0x807F807Fu) | 0x3F003F00u;
+  f32x4 acc[NA * NB];
+#pragma unroll
+  for (int i = 0; i < NA * NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, au[i]), __builtin_bit_cast(bf16x8, bu[j]),
-                                                                 acc[i * 4 + j], 0, 0, 0);
+      for (int i = 0; i < NA; ++i)
+        acc[i * NB + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, au[i]), __builtin_bit_cast(bf16x8, bu[j]),
+                                                                  acc[i * NB + j], 0, 0, 0);
   }
   float t = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < NA * NB; ++i) t += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   if (t == 123.456f) sink[0] = t;                 // keeps the loop alive; practically never taken
 }
 
@@ -85,7 +86,17 @@ int tmae_probe_mfma(int iters, float* sink, int64_t* flops, void* stream_) {
   (void)hipGetLastError();
   if (iters <= 0 || !sink) return TMAE_EARG;
   const unsigned grid = 256;                       // one 512-thread workgroup per CU: two waves on every SIMD
-  hipLaunchKernelGGL(probe_mfma_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream_, iters, sink);
-  if (flops) *flops = (int64_t)grid * 8 * (int64_t)iters * 16 * (2LL * 16 * 16 * 32);
+  // (A/B build: TMAE_PROBE_ACC=36 runs 4 x 9 = 36 accumulator tiles per wave -- 144 registers, the dense weight-gradient kernel's count)
+  static const int nacc = TMAE_AB_INT("TMAE_PROBE_ACC", 16);
+  int per_iter = 16;
+#ifdef TMAE_AB
+  if (nacc == 36) {
+    hipLaunchKernelGGL((probe_mfma_kernel<4, 9>), dim3(grid), dim3(512), 0, (hipStream_t)stream_, iters, sink);
+    per_iter = 36;
+  } else
+#endif
+  hipLaunchKernelGGL((probe_mfma_kernel<4, 4>), dim3(grid), dim3(512), 0, (hipStream_t)stream_, iters, sink);
+  (void)nacc;
+  if (flops) *flops = (int64_t)grid * 8 * (int64_t)iters * per_iter * (2LL * 16 * 16 * 32);
   return tmae_launch_status();
 }
