@@ -44,7 +44,7 @@ class SeparateHead(nn.Module):
         for name in self.sep_head_dict:
             y = x
             for layer in getattr(self, name):
-                y = conv_bn_relu_nhwc(layer, y) if isinstance(layer, nn.Sequential) else layer(y)
+                y = conv_bn_relu_nhwc(layer, y) if isinstance(layer, nn.Sequential) else ops.conv3x3_channel_bias(y, layer)
             ret[name] = y
         return ret
 

@@ -1801,6 +1801,59 @@ class _DenseConv3x3(torch.autograd.Function):
         return dx, dw, None
 
 
+def _channel_sums(dy):
+    """sum over (0, 2, 3) of a [B, k, Y, X] tensor in channels-last memory, fp32: the column sums of the contiguous
+    [B*Y*X, k] view.  For small k the view is re-cut into rows of L = lcm(64, k) elements (column c holds channel c % k), which
+    is a shape tmae_column_sums takes; anything else: torch."""
+    import math
+    k = dy.shape[1]
+    rows = dy.permute(0, 2, 3, 1)
+    rows = rows.reshape(-1, k) if rows.is_contiguous() else rows.contiguous().view(-1, k)
+    n = rows.shape[0]
+    L = 64 * k // math.gcd(64, k)
+    if L <= 512 and (n * k) % L == 0 and rows.dtype in (torch.bfloat16, torch.float32):
+        view = rows.view(n * k // L, L)
+        sums = torch.empty((L,), dtype=torch.float32, device=dy.device)
+        wsb = lib.tmae_column_sums_workspace(view.shape[0], L)
+        ws = _ws(wsb, dy.device)
+        check(lib.tmae_column_sums(_p(view), _dt(view), view.shape[0], L, _p(sums), _p(ws), wsb, _s()), 'tmae_column_sums')
+        return sums.view(L // k, k).sum(0)
+    return rows.float().sum(0)
+
+
+class _ConvOwnBiasGrad(torch.autograd.Function):
+    """A biased Conv2d on a channels-last CUDA tensor: the library's forward (bias inside, one rounding), the library's input
+    and weight gradients, but the bias gradient from _channel_sums.  torch's convolution backward sums it over (0, 2, 3) of the
+    NCHW view of the channels-last gradient -- a strided reduction that took 0.7 ms per head on the [8, k <= 5, 468, 468] maps of
+    CenterHead's last convs (center_head.py:11-45); the same sum over the rows of the contiguous view is one short pass."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation):
+        cdt = compute_dtype(x)
+        x_c = x.to(cdt)
+        w_c, b_c = weight.to(cdt), bias.to(cdt)
+        ctx.save_for_backward(x_c, w_c)
+        ctx.conf = (stride, padding, dilation, x.dtype, weight.dtype, bias.dtype)
+        return torch.nn.functional.conv2d(x_c, w_c, b_c, stride, padding, dilation)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_c = ctx.saved_tensors
+        stride, padding, dilation, xdt, wdt, bdt = ctx.conf
+        dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w_c, None, list(stride), list(padding), list(dilation), False,
+                                                        [0, 0], 1, [ctx.needs_input_grad[0], True, False])
+        return (None if dx is None else dx.to(xdt)), dw.to(wdt), _channel_sums(dy).to(bdt), None, None, None
+
+
+def conv3x3_channel_bias(x, conv):
+    """conv(x) for a biased nn.Conv2d on a channels-last CUDA tensor (training): see _ConvOwnBiasGrad."""
+    if (conv.bias is None or not x.is_cuda or not torch.is_grad_enabled() or conv.groups != 1
+            or not x.is_contiguous(memory_format=torch.channels_last)):
+        return conv(x)
+    return _ConvOwnBiasGrad.apply(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation)
+
+
 def dense_conv3x3_halo(x_nhwc, w2d, dil=1):
     """[B, Y, X, cin] bf16 (contiguous) x w2d [cout, 9*cin] bf16 -> [B, Y, X, cout] (csrc/spconv_igemm.hip, halo kernel);
     padding = dilation in {1, 2}."""

@@ -182,6 +182,32 @@ def _rand_boxes(rng, n, spread=20.0):
     return b
 
 
+def test_head_conv_bias_gradient_vs_torch():
+    """ops.conv3x3_channel_bias (CenterHead's last convs, center_head.py:11-45: the library's forward and input / weight
+    gradients, the bias gradient as a column sum over the contiguous [B*Y*X, k] view) against nn.Conv2d itself; k = 1, 2, 3, 5;
+    a map whose size does not fit the periodic view (falls back to torch's sum)."""
+    from tmae_amd import ops
+    torch.manual_seed(5)
+    for k, (B, Y, X) in ((1, (2, 32, 32)), (2, (2, 32, 32)), (3, (2, 64, 32)), (5, (4, 64, 64)), (3, (1, 7, 5))):
+        conv = torch.nn.Conv2d(64, k, 3, padding=1, bias=True).cuda()
+        x = torch.randn(B, 64, Y, X, device='cuda').contiguous(memory_format=torch.channels_last)
+        go = torch.randn(B, k, Y, X, device='cuda').contiguous(memory_format=torch.channels_last)
+        res = []
+        for fn in (lambda t: ops.conv3x3_channel_bias(t, conv), conv):
+            xa = x.clone().requires_grad_(True)
+            conv.zero_grad()
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y = fn(xa)
+            y.backward(go.to(y.dtype))
+            res.append((y.detach().float(), xa.grad.float(), conv.weight.grad.clone(), conv.bias.grad.clone()))
+        (y1, dx1, dw1, db1), (y2, dx2, dw2, db2) = res
+        assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+        assert (dw1 - dw2).abs().max().item() <= 1e-2 * max(1.0, float(dw2.abs().max()))      # a bf16 weight gradient: one ulp
+        # torch sums the bias gradient in bf16 steps; ours in fp32: compare both with the fp32 sum
+        want = go.to(torch.bfloat16).float().sum((0, 2, 3))
+        assert (db1.float() - want).abs().max().item() <= 2e-2 * max(1.0, float(want.abs().max())), (k, db1, want)
+
+
 def test_rotated_iou_and_nms_vs_oracle(ft_oracle):
     """csrc/iou3d_nms.hip vs the float64 convex-clipping restatement: BEV overlap / IoU, 3-D IoU, edge cases
     (identical, disjoint, contained, 45 degrees, touching), and the kept set + order of the rotated NMS."""
