@@ -584,14 +584,19 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   constexpr int BRING = 2 * HC_ABYTES;                 // 2 halo images (channel slices kc, kc+1), then 3 weight slots of 16 KB
   constexpr int SCRATCH = BRING + 3 * (IG_BN * 128);   // 1 KB sink of the dummy transfers
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, i = lane & 15;
+  // ALLCT (cin = 128: the two halo images hold the WHOLE input of the tile): one workgroup walks over all column tiles of its
+  // cell block -- the halo is fetched once instead of once per column tile and the prologue / epilogue of a workgroup is paid per
+  // 54 tap steps instead of 18 (the decoder conv's input gradient, 128 -> 384: 1.50 -> 1.2x ms)
+  constexpr bool ALLCT = KC == 2;
   const int nct = cout / IG_BN;
   const int bx = (X + 15) / 16, by = (Y + 15) / 16;
   int bid = blockIdx.x;
-  const int ct = bid % nct; bid /= nct;
+  int ct = 0;
+  if (!ALLCT) { ct = bid % nct; bid /= nct; }
   const int tx = bid % bx; bid /= bx;
   const int ty = bid % by;
   const int b = bid / by;
-  const int y0 = ty * 16, x0 = tx * 16, n0 = ct * IG_BN;
+  const int y0 = ty * 16, x0 = tx * 16;
   const int r8 = lane >> 3, slot8 = lane & 7;
   // All addresses of the main loop are set up here (the loop itself then spends ~10 VALU instructions per 32 MFMAs; computed
   // in the loop they were 77 -- 3.6 VALU per MFMA, as much SIMD time as the MFMAs themselves: profiles/round4_pmc_kernels.md).
@@ -613,7 +618,7 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   for (int j = 0; j < 2; ++j) {
     const int L = w * 16 + j * 8 + r8, s64 = L & 63;
     const int n = (L & ~63) + 32 * (s64 >> 5) + 8 * ((s64 >> 2) & 3) + 4 * ((s64 >> 4) & 1) + (s64 & 3);
-    wk[j] = (uintptr_t)(W + (int64_t)(n0 + n) * (9 * CIN)) + ((slot8 ^ r8) << 4);
+    wk[j] = (uintptr_t)(W + (int64_t)(ct * IG_BN + n) * (9 * CIN)) + ((slot8 ^ r8) << 4);
   }
   const int wm = w & 3, wn = w >> 2;
   int vB[3][2], vA[2];                                 // LDS byte offsets of this lane's operand reads (image 0, slot 0)
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   const int wdst = (w * 16) * 128;
   auto issue_halo = [&](int t, int img, bool real) {
     const int p = t * 8 + w;
-    ig_glds16(reinterpret_cast<const void*>(real ? hsrc[t] : zlane), lds + (p < NP ? img + p * 1024 : SCRATCH));
+    ig_glds16(reinterpret_cast<const void*>(real ? hsrc[t] : zlane), lds + ((p < NP && real) ? img + p * 1024 : SCRATCH));
   };
   auto issue_w = [&](int j, int t, int extra, bool real) {    // piece j of tap t of the slice `extra` bytes further
     ig_glds16(reinterpret_cast<const void*>(wk[j] + (real ? t * CIN * 2 + extra : 0)),
@@ -648,10 +653,6 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   ig_glds16(reinterpret_cast<const void*>(zlane), lds + SCRATCH);
   issue_w(0, 2, 0, true);
   f32x4 acc[4][4];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   // Operand registers are double-buffered: the reads of a half step (32 channels of a tap) are issued one half step ahead
   // and land under the 16 MFMAs of the current one.  One barrier per tap step, in its MIDDLE: after the first half's MFMAs
   // a wave drains its LDS reads (issued a half step ago: done), issues the step's 3 transfers, waits until everything older
@@ -700,48 +701,61 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   do {                                                                                                                 \
     HC_LOAD_OPS(1, T, 1, img);                                                                                         \
     HC_WAIT_OPS(0, 8);                                                                                                 \
-    HC_MFMAS(0, issue_w(1, ((T) + 2) % 9, (T) < 7 ? 0 : 128, (T) < 7 || more),                                         \
-             (issue_halo(T, img ^ HC_ABYTES, more), hsrc[T] += 128));                                                  \
+    HC_MFMAS(0, issue_w(1, ((T) + 2) % 9, (T) < 7 ? 0 : xnext, (T) < 7 || more_w),                                     \
+             (issue_halo(T, img ^ HC_ABYTES, more_h), hsrc[T] += 128));                                                \
     HC_WAIT_OPS(1, 0);                                                                                                 \
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                                   \
     __builtin_amdgcn_s_barrier();                                                                                      \
     asm volatile("" ::: "memory");                                                                                     \
-    HC_LOAD_OPS(0, ((T) + 1) % 9, 0, (T) < 8 ? img : img ^ HC_ABYTES);                                                 \
-    HC_MFMAS(1, (void)0, issue_w(0, ((T) + 3) % 9, (T) < 6 ? 0 : 128, (T) < 6 || more));                               \
+    HC_LOAD_OPS(0, ((T) + 1) % 9, 0, (T) < 8 ? img : imgn);                                                            \
+    HC_MFMAS(1, (void)0, issue_w(0, ((T) + 3) % 9, (T) < 6 ? 0 : xnext, (T) < 6 || more_w));                           \
   } while (0)
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // the halo of slice 0 and weight slice 0
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  int img = 0;
-  HC_LOAD_OPS(0, 0, 0, img);
-  for (int kc = 0; kc < KC; ++kc) {
-    const bool more = kc + 1 < KC;
-    HC_STEP(0); HC_STEP(1); HC_STEP(2); HC_STEP(3); HC_STEP(4); HC_STEP(5); HC_STEP(6); HC_STEP(7); HC_STEP(8);
-    img ^= HC_ABYTES;
-    wk[0] += 128;
-    wk[1] += 128;
+  HC_LOAD_OPS(0, 0, 0, 0);
+  const int nloop = ALLCT ? nct : 1;
+  for (int cti = 0; cti < nloop; ++cti) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool more_ct = cti + 1 < nloop;
+    for (int kc = 0; kc < KC; ++kc) {
+      const bool more_s = kc + 1 < KC;
+      const bool more_h = more_s && cti == 0;              // the halo is streamed once; later column tiles find it in LDS
+      const bool more_w = more_s || more_ct;               // weights of the taps that wrap into the next slice / column tile
+      const int xnext = more_s ? 128 : IG_BN * 9 * CIN * 2 - (KC - 1) * 128;
+      const int img = (kc & 1) * HC_ABYTES, imgn = (((kc + 1) % KC) & 1) * HC_ABYTES;
+      HC_STEP(0); HC_STEP(1); HC_STEP(2); HC_STEP(3); HC_STEP(4); HC_STEP(5); HC_STEP(6); HC_STEP(7); HC_STEP(8);
+      wk[0] += 128;
+      wk[1] += 128;
+    }
+    wk[0] += IG_BN * 9 * CIN * 2 - KC * 128;               // the next column tile's rows
+    wk[1] += IG_BN * 9 * CIN * 2 - KC * 128;
+    const int n0 = (ALLCT ? cti : ct) * IG_BN;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int y = y0 + 4 * wm + mt, x = x0 + i;
+      if (y < Y && x < X) {
+        __hip_bfloat16* p = out + (((int64_t)b * Y + y) * X + x) * cout + n0 + wn * 64 + 8 * g;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          u32x4 v;
+          v[0] = ig_bf16_bits(acc[2 * h][mt][0]) | (ig_bf16_bits(acc[2 * h][mt][1]) << 16);
+          v[1] = ig_bf16_bits(acc[2 * h][mt][2]) | (ig_bf16_bits(acc[2 * h][mt][3]) << 16);
+          v[2] = ig_bf16_bits(acc[2 * h + 1][mt][0]) | (ig_bf16_bits(acc[2 * h + 1][mt][1]) << 16);
+          v[3] = ig_bf16_bits(acc[2 * h + 1][mt][2]) | (ig_bf16_bits(acc[2 * h + 1][mt][3]) << 16);
+          *reinterpret_cast<u32x4*>(p + 32 * h) = v;
+        }
+      }
+    }
   }
 #undef HC_MFMAS
 #undef HC_STEP
 #undef HC_WAIT_OPS
 #undef HC_LOAD_OPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the dummy transfers of the last steps
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int y = y0 + 4 * wm + mt, x = x0 + i;
-    if (y < Y && x < X) {
-      __hip_bfloat16* p = out + (((int64_t)b * Y + y) * X + x) * cout + n0 + wn * 64 + 8 * g;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        u32x4 v;
-        v[0] = ig_bf16_bits(acc[2 * h][mt][0]) | (ig_bf16_bits(acc[2 * h][mt][1]) << 16);
-        v[1] = ig_bf16_bits(acc[2 * h][mt][2]) | (ig_bf16_bits(acc[2 * h][mt][3]) << 16);
-        v[2] = ig_bf16_bits(acc[2 * h + 1][mt][0]) | (ig_bf16_bits(acc[2 * h + 1][mt][1]) << 16);
-        v[3] = ig_bf16_bits(acc[2 * h + 1][mt][2]) | (ig_bf16_bits(acc[2 * h + 1][mt][3]) << 16);
-        *reinterpret_cast<u32x4*>(p + 32 * h) = v;
-      }
-    }
-  }
 }
 
 // out [B, Y, X, cout] = conv3x3(in [B, Y, X, cin], padding = dilation) with weight [cout, 9 * cin] (taps ky-major, then
@@ -754,7 +768,8 @@ static int dense_conv3x3_launch(const void* in, int batch, int ny, int nx, int c
       (dil != 1 && dil != 2))
     return TMAE_EARG;
   if (!in || !weight || !out || ((uintptr_t)in & 15) || ((uintptr_t)weight & 15) || ((uintptr_t)out & 15)) return TMAE_EARG;
-  const int64_t blocks = (int64_t)batch * ((ny + 15) / 16) * ((nx + 15) / 16) * (cout / IG_BN);
+  // (cin = 128: one workgroup per cell block walks over all column tiles, see ALLCT in the kernel)
+  const int64_t blocks = (int64_t)batch * ((ny + 15) / 16) * ((nx + 15) / 16) * (cin == 128 ? 1 : cout / IG_BN);
   if (blocks >= ((int64_t)1 << 31)) return TMAE_EARG;
 #define HC_LAUNCH(C, D)                                                                                               \
   do {                                                                                                                \
