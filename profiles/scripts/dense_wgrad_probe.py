@@ -20,4 +20,4 @@ for _ in range(10): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
 fl = 2.0 * B * Y * X * 9 * cin * cout
-print(f'TMAE_DW_DBG={os.environ.get("TMAE_DW_DBG", "0")} cin={cin}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s')
+print(f'dense conv weight gradient, cin={cin}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s')
