@@ -575,7 +575,7 @@ template <int DIL> struct HaloGeom {
 template <int CIN, int DIL = 1>
 __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_bfloat16* __restrict__ in, int B, int Y,
                                                                    int X, const __hip_bfloat16* __restrict__ W, int cout,
-                                                                   __hip_bfloat16* __restrict__ out) {
+                                                                   __hip_bfloat16* __restrict__ out, int nunits) {
   constexpr int KC = CIN / 64;
   constexpr int HW = HaloGeom<DIL>::HW, NH = HaloGeom<DIL>::NH, NP = HaloGeom<DIL>::NP, HC_ABYTES = HaloGeom<DIL>::ABYTES;
   static_assert(NP <= 64, "the piece issued in the last tap step of a slice must be a dummy (it may still be in flight)");
@@ -584,42 +584,53 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   constexpr int BRING = 2 * HC_ABYTES;                 // 2 halo images (channel slices kc, kc+1), then 3 weight slots of 16 KB
   constexpr int SCRATCH = BRING + 3 * (IG_BN * 128);   // 1 KB sink of the dummy transfers
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, i = lane & 15;
-  // ALLCT (cin = 128: the two halo images hold the WHOLE input of the tile): one workgroup walks over all column tiles of its
-  // cell block -- the halo is fetched once instead of once per column tile and the prologue / epilogue of a workgroup is paid per
-  // 54 tap steps instead of 18 (the decoder conv's input gradient, 128 -> 384: 1.50 -> 1.2x ms)
+  // ALLCT (cin = 128: the two halo images hold the WHOLE input of the tile): one unit of work = a cell block with ALL its column
+  // tiles -- the halo is fetched once instead of once per column tile (the decoder conv's input gradient, 128 -> 384: 1.50 ->
+  // 1.26 ms); otherwise a unit = (cell block, column tile).
+  // PERSISTENT: a workgroup walks over the units u = blockIdx.x, + gridDim.x, ... (one workgroup per CU); the next unit's first
+  // halo slice and first weight slices are fetched during the last channel slice of the current one, exactly like the next
+  // channel slice inside a unit, so a unit boundary costs its output stores and nothing else (one workgroup per unit paid the
+  // HBM latency of its prologue and the workgroup turnaround once per 18-54 tap steps).
   constexpr bool ALLCT = KC == 2;
   const int nct = cout / IG_BN;
   const int bx = (X + 15) / 16, by = (Y + 15) / 16;
-  int bid = blockIdx.x;
-  int ct = 0;
-  if (!ALLCT) { ct = bid % nct; bid /= nct; }
-  const int tx = bid % bx; bid /= bx;
-  const int ty = bid % by;
-  const int b = bid / by;
-  const int y0 = ty * 16, x0 = tx * 16;
   const int r8 = lane >> 3, slot8 = lane & 7;
-  // All addresses of the main loop are set up here (the loop itself then spends ~10 VALU instructions per 32 MFMAs; computed
+  int ct = 0, b = 0, y0 = 0, x0 = 0;                   // the unit whose transfers are being issued (decode()), then computed
+  auto decode = [&](int u) {
+    if (!ALLCT) { ct = u % nct; u /= nct; }
+    const int tx = u % bx, t2 = u / bx;
+    b = t2 / by; y0 = (t2 - b * by) * 16; x0 = tx * 16;
+  };
+  // All addresses of the main loop are set up per unit (the loop itself then spends ~10 VALU instructions per 32 MFMAs; computed
   // in the loop they were 77 -- 3.6 VALU per MFMA, as much SIMD time as the MFMAs themselves: profiles/round4_pmc_kernels.md).
   // Halo image: row h = hy * HW + hx of the (16 + 2 DIL)^2 halo, 128 bytes; the 16-byte chunk c of a row sits at chunk
   // position c ^ (hx & 7) -- a swizzle by the COLUMN only, so that a tap shift (ky, kx) of a reader is an immediate offset
   // plus one of three per-lane bases.  Piece p = t * 8 + w (tap step t, wave w) = halo rows 8 p .. 8 p + 7.
   const uintptr_t zlane = (uintptr_t)ig_zero_row + slot8 * 16;
   uintptr_t hsrc[9];
+  auto halo_sources = [&]() {                          // of slice 0 of the unit in (b, y0, x0)
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int p = t * 8 + w, h = 8 * p + r8;
-    const int hy = h / HW, hx = h - hy * HW;
-    const int y = y0 - DIL + hy, x = x0 - DIL + hx;
-    const bool ok = p < NP && h < NH && y >= 0 && y < Y && x >= 0 && x < X;
-    hsrc[t] = ok ? (uintptr_t)in + ((uintptr_t)(((int64_t)b * Y + y) * X + x) * CIN) * 2 + ((slot8 ^ (hx & 7)) << 4) : zlane;
-  }
-  uintptr_t wk[2];                                     // weight rows of this lane, tap 0 of the current channel slice
+    for (int t = 0; t < 9; ++t) {
+      const int p = t * 8 + w, h = 8 * p + r8;
+      const int hy = h / HW, hx = h - hy * HW;
+      const int y = y0 - DIL + hy, x = x0 - DIL + hx;
+      const bool ok = p < NP && h < NH && y >= 0 && y < Y && x >= 0 && x < X;
+      hsrc[t] = ok ? (uintptr_t)in + ((uintptr_t)(((int64_t)b * Y + y) * X + x) * CIN) * 2 + ((slot8 ^ (hx & 7)) << 4) : zlane;
+    }
+  };
+  uintptr_t wrow[2], wk[2];                            // this lane's weight rows: column tile 0 / the current channel slice
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int L = w * 16 + j * 8 + r8, s64 = L & 63;
     const int n = (L & ~63) + 32 * (s64 >> 5) + 8 * ((s64 >> 2) & 3) + 4 * ((s64 >> 4) & 1) + (s64 & 3);
-    wk[j] = (uintptr_t)(W + (int64_t)(ct * IG_BN + n) * (9 * CIN)) + ((slot8 ^ r8) << 4);
+    wrow[j] = (uintptr_t)(W + (int64_t)n * (9 * CIN)) + ((slot8 ^ r8) << 4);
   }
+  int unit = blockIdx.x;
+  if (unit >= nunits) return;
+  decode(unit);
+  halo_sources();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) wk[j] = wrow[j] + (uintptr_t)ct * (IG_BN * 9 * CIN * 2);
   const int wm = w & 3, wn = w >> 2;
   int vB[3][2], vA[2];                                 // LDS byte offsets of this lane's operand reads (image 0, slot 0)
 #pragma unroll
@@ -638,20 +649,21 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
     const int p = t * 8 + w;
     ig_glds16(reinterpret_cast<const void*>(real ? hsrc[t] : zlane), lds + ((p < NP && real) ? img + p * 1024 : SCRATCH));
   };
-  auto issue_w = [&](int j, int t, int extra, bool real) {    // piece j of tap t of the slice `extra` bytes further
-    ig_glds16(reinterpret_cast<const void*>(wk[j] + (real ? t * CIN * 2 + extra : 0)),
+  uintptr_t wnx[2] = {0, 0};                           // the slice that follows the current one (next slice / column tile / unit)
+  auto issue_w = [&](int j, int t, bool next, bool real) {    // piece j of tap t of the current or the following slice
+    ig_glds16(reinterpret_cast<const void*>((next ? wnx[j] : wk[j]) + (real ? t * CIN * 2 : 0)),
               lds + (real ? BRING + (t % 3) * (IG_BN * 128) + wdst + 8 * j * 128 : SCRATCH));
   };
 #pragma unroll
   for (int q = 0; q < HaloGeom<DIL>::PQ; ++q) issue_halo(q, 0, true);
 #pragma unroll
   for (int t = 0; t < 9; ++t) hsrc[t] += 128;
-  issue_w(0, 0, 0, true);
-  issue_w(1, 0, 0, true);
-  issue_w(0, 1, 0, true);
-  issue_w(1, 1, 0, true);
+  issue_w(0, 0, false, true);
+  issue_w(1, 0, false, true);
+  issue_w(0, 1, false, true);
+  issue_w(1, 1, false, true);
   ig_glds16(reinterpret_cast<const void*>(zlane), lds + SCRATCH);
-  issue_w(0, 2, 0, true);
+  issue_w(0, 2, false, true);
   f32x4 acc[4][4];
   // Operand registers are double-buffered: the reads of a half step (32 channels of a tap) are issued one half step ahead
   // and land under the 16 MFMAs of the current one.  One barrier per tap step, in its MIDDLE: after the first half's MFMAs
@@ -701,52 +713,63 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   do {                                                                                                                 \
     HC_LOAD_OPS(1, T, 1, img);                                                                                         \
     HC_WAIT_OPS(0, 8);                                                                                                 \
-    HC_MFMAS(0, issue_w(1, ((T) + 2) % 9, (T) < 7 ? 0 : xnext, (T) < 7 || more_w),                                     \
+    HC_MFMAS(0, issue_w(1, ((T) + 2) % 9, (T) >= 7, (T) < 7 || more_w),                                                \
              (issue_halo(T, img ^ HC_ABYTES, more_h), hsrc[T] += 128));                                                \
     HC_WAIT_OPS(1, 0);                                                                                                 \
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                                   \
     __builtin_amdgcn_s_barrier();                                                                                      \
     asm volatile("" ::: "memory");                                                                                     \
     HC_LOAD_OPS(0, ((T) + 1) % 9, 0, (T) < 8 ? img : imgn);                                                            \
-    HC_MFMAS(1, (void)0, issue_w(0, ((T) + 3) % 9, (T) < 6 ? 0 : xnext, (T) < 6 || more_w));                           \
+    HC_MFMAS(1, (void)0, issue_w(0, ((T) + 3) % 9, (T) >= 6, (T) < 6 || more_w));                                      \
   } while (0)
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // the halo of slice 0 and weight slice 0
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   HC_LOAD_OPS(0, 0, 0, 0);
   const int nloop = ALLCT ? nct : 1;
-  for (int cti = 0; cti < nloop; ++cti) {
+  for (; unit < nunits; unit += gridDim.x) {
+    const int ub = b, uy0 = y0, ux0 = x0, uct = ct;        // this unit (decode() moves on to the next one below)
+    const bool more_u = unit + (int)gridDim.x < nunits;
+    for (int cti = 0; cti < nloop; ++cti) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool more_ct = cti + 1 < nloop;
-    for (int kc = 0; kc < KC; ++kc) {
-      const bool more_s = kc + 1 < KC;
-      const bool more_h = more_s && cti == 0;              // the halo is streamed once; later column tiles find it in LDS
-      const bool more_w = more_s || more_ct;               // weights of the taps that wrap into the next slice / column tile
-      const int xnext = more_s ? 128 : IG_BN * 9 * CIN * 2 - (KC - 1) * 128;
-      const int img = (kc & 1) * HC_ABYTES, imgn = (((kc + 1) % KC) & 1) * HC_ABYTES;
-      HC_STEP(0); HC_STEP(1); HC_STEP(2); HC_STEP(3); HC_STEP(4); HC_STEP(5); HC_STEP(6); HC_STEP(7); HC_STEP(8);
-      wk[0] += 128;
-      wk[1] += 128;
-    }
-    wk[0] += IG_BN * 9 * CIN * 2 - KC * 128;               // the next column tile's rows
-    wk[1] += IG_BN * 9 * CIN * 2 - KC * 128;
-    const int n0 = (ALLCT ? cti : ct) * IG_BN;
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool more_ct = cti + 1 < nloop;
+      for (int kc = 0; kc < KC; ++kc) {
+        const bool more_s = kc + 1 < KC;
+        const bool last = !more_s && !more_ct;               // the unit's last slice: the slot of "the next slice" is the next unit's
+        if (last && more_u) {                                // first one (every piece of this unit's halo has been issued by now)
+          decode(unit + (int)gridDim.x);
+          halo_sources();
+        }
+        // the halo is streamed once per unit (ALLCT: later column tiles find it in LDS); weights of the taps that wrap around
+        const bool more_h = (more_s && cti == 0) || (last && more_u);
+        const bool more_w = more_s || more_ct || more_u;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int y = y0 + 4 * wm + mt, x = x0 + i;
-      if (y < Y && x < X) {
-        __hip_bfloat16* p = out + (((int64_t)b * Y + y) * X + x) * cout + n0 + wn * 64 + 8 * g;
+        for (int j = 0; j < 2; ++j)
+          wnx[j] = more_s ? wk[j] + 128 : (more_ct ? wk[j] + (IG_BN * 9 * CIN * 2 - (KC - 1) * 128)
+                                                   : wrow[j] + (uintptr_t)ct * (IG_BN * 9 * CIN * 2));
+        const int img = (kc & 1) * HC_ABYTES, imgn = (((kc + 1) % KC) & 1) * HC_ABYTES;
+        HC_STEP(0); HC_STEP(1); HC_STEP(2); HC_STEP(3); HC_STEP(4); HC_STEP(5); HC_STEP(6); HC_STEP(7); HC_STEP(8);
+        wk[0] = wnx[0];
+        wk[1] = wnx[1];
+      }
+      const int n0 = (ALLCT ? cti : uct) * IG_BN;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          u32x4 v;
-          v[0] = ig_bf16_bits(acc[2 * h][mt][0]) | (ig_bf16_bits(acc[2 * h][mt][1]) << 16);
-          v[1] = ig_bf16_bits(acc[2 * h][mt][2]) | (ig_bf16_bits(acc[2 * h][mt][3]) << 16);
-          v[2] = ig_bf16_bits(acc[2 * h + 1][mt][0]) | (ig_bf16_bits(acc[2 * h + 1][mt][1]) << 16);
-          v[3] = ig_bf16_bits(acc[2 * h + 1][mt][2]) | (ig_bf16_bits(acc[2 * h + 1][mt][3]) << 16);
-          *reinterpret_cast<u32x4*>(p + 32 * h) = v;
+      for (int mt = 0; mt < 4; ++mt) {
+        const int y = uy0 + 4 * wm + mt, x = ux0 + i;
+        if (y < Y && x < X) {
+          __hip_bfloat16* p = out + (((int64_t)ub * Y + y) * X + x) * cout + n0 + wn * 64 + 8 * g;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            u32x4 v;
+            v[0] = ig_bf16_bits(acc[2 * h][mt][0]) | (ig_bf16_bits(acc[2 * h][mt][1]) << 16);
+            v[1] = ig_bf16_bits(acc[2 * h][mt][2]) | (ig_bf16_bits(acc[2 * h][mt][3]) << 16);
+            v[2] = ig_bf16_bits(acc[2 * h + 1][mt][0]) | (ig_bf16_bits(acc[2 * h + 1][mt][1]) << 16);
+            v[3] = ig_bf16_bits(acc[2 * h + 1][mt][2]) | (ig_bf16_bits(acc[2 * h + 1][mt][3]) << 16);
+            *reinterpret_cast<u32x4*>(p + 32 * h) = v;
+          }
         }
       }
     }
@@ -768,9 +791,18 @@ static int dense_conv3x3_launch(const void* in, int batch, int ny, int nx, int c
       (dil != 1 && dil != 2))
     return TMAE_EARG;
   if (!in || !weight || !out || ((uintptr_t)in & 15) || ((uintptr_t)weight & 15) || ((uintptr_t)out & 15)) return TMAE_EARG;
-  // (cin = 128: one workgroup per cell block walks over all column tiles, see ALLCT in the kernel)
-  const int64_t blocks = (int64_t)batch * ((ny + 15) / 16) * ((nx + 15) / 16) * (cin == 128 ? 1 : cout / IG_BN);
-  if (blocks >= ((int64_t)1 << 31)) return TMAE_EARG;
+  // units of work: cell blocks (cin = 128: with all their column tiles, see ALLCT in the kernel) or (cell block, column tile);
+  // one persistent workgroup per CU walks over them
+  const int64_t units = (int64_t)batch * ((ny + 15) / 16) * ((nx + 15) / 16) * (cin == 128 ? 1 : cout / IG_BN);
+  if (units >= ((int64_t)1 << 31)) return TMAE_EARG;
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    ncu = v;
+  }
+  const int64_t blocks = units < ncu ? units : ncu;
 #define HC_LAUNCH(C, D)                                                                                               \
   do {                                                                                                                \
     const int lds = 2 * HaloGeom<D>::ABYTES + 3 * (IG_BN * 128) + 1024;                                               \
@@ -778,7 +810,7 @@ static int dense_conv3x3_launch(const void* in, int batch, int ny, int nx, int c
     if (int e_ = tmae_allow_lds(attr, (const void*)dense_conv3x3_halo_kernel<C, D>, lds)) return e_;                  \
     hipLaunchKernelGGL((dense_conv3x3_halo_kernel<C, D>), dim3((unsigned)blocks), dim3(512), lds, stream,            \
                        (const __hip_bfloat16*)in, batch, ny, nx, (const __hip_bfloat16*)weight, cout,                 \
-                       (__hip_bfloat16*)out);                                                                         \
+                       (__hip_bfloat16*)out, (int)units);                                                             \
   } while (0)
   if (dil == 1) {
     if (cin == 128) HC_LAUNCH(128, 1); else if (cin == 256) HC_LAUNCH(256, 1); else HC_LAUNCH(384, 1);
