@@ -229,6 +229,10 @@ int tmae_dense_conv3x3(const void* in, int batch, int ny, int nx, int cin, const
  * sst_bev_backbone.py:20-30, t_mae.yaml:107-112): 16 x 16 cell blocks with a (16 + 2d)^2 halo. */
 int tmae_dense_conv3x3_dilated(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout,
                                int dilation, void* out, void* stream);
+/* out = conv + post (post: the shape of out, bf16): the input gradient of a residual block's conv plus the gradient that
+ * arrives through its shortcut (autograd's gradient accumulation at `out` in sst_bev_backbone.py:35-41), one rounding. */
+int tmae_dense_conv3x3_add(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, int dilation,
+                           const void* post, void* out, void* stream);
 /* Weight gradient of that convolution (SiamWCA_MAE.py:100-115, sst_bev_backbone.py:20-30; torch's conv2d weight gradient in
  * the reference): dw [cout, 9*cin] fp32 (the weight's layout) from dy [batch, ny, nx, cout] and x [batch, ny, nx, cin], bf16,
  * contiguous.  Halo-tiled like the forward (the nine shifted copies of x are read out of one staged image), fixed-order
@@ -321,6 +325,12 @@ int tmae_layernorm_bwd(const void* dy, const void* x, int dtype, int64_t m, int 
 size_t tmae_bn_workspace(int64_t m, int c);
 int tmae_bn_relu_fwd(const void* x, int dtype, int64_t m, int c, const float* gamma, const float* beta, float eps,
                      int relu, void* y, float* mean, float* var, float* rstd, void* ws, size_t ws_bytes, void* stream);
+/* The same forward with a residual operand: y = relu?(norm(x)) + post ([m,c] in `dtype`) -- `out = conv_bn_relu(out) + out` of
+ * SSTBEVBackbone (sst_bev_backbone.py:35-41): the shortcut is added where the normalised row is in registers.  The backward is
+ * tmae_bn_relu_bwd (the ReLU mask is recomputed from x), the gradient of post is dy itself. */
+int tmae_bn_relu_add_fwd(const void* x, int dtype, int64_t m, int c, const float* gamma, const float* beta, float eps,
+                         int relu, const void* post, void* y, float* mean, float* var, float* rstd, void* ws,
+                         size_t ws_bytes, void* stream);
 int tmae_bn_relu_bwd(const void* dy, const void* x, int dtype, int64_t m, int c, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, int relu, void* dx, float* dgamma, float* dbeta,
                      void* ws, size_t ws_bytes, void* stream);

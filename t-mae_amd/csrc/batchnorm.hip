@@ -117,7 +117,9 @@ template <class T, int VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int64_t m,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      int relu, T* __restrict__ y) {
+                                                      int relu, T* __restrict__ y, const T* __restrict__ post = nullptr) {
+  // post (optional, [m, C]): y = relu?(norm(x)) + post -- the residual shortcut of SSTBEVBackbone (sst_bev_backbone.py:35-41)
+  // added where the normalised row is in registers anyway, one rounding instead of two
   BN_LAYOUT;
   float sc[8], sh[8];
 #pragma unroll
@@ -133,6 +135,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
       const int64_t r = r0 + u * RPW + sub;
       load8<T>(x + (r < m ? r : m - 1) * C + cl * 8, v[u]);      // unconditional (clamped): both rows in flight
     }
+    float pv[2][8];
+    if (post) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t r = r0 + u * RPW + sub;
+        load8<T>(post + (r < m ? r : m - 1) * C + cl * 8, pv[u]);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int64_t r = r0 + u * RPW + sub;
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         for (int i = 0; i < 8; ++i) {
           const float z = v[u][i] * sc[i] + sh[i];
           v[u][i] = relu ? fmaxf(z, 0.f) : z;
+          if (post) v[u][i] += pv[u][i];
         }
         store8<T>(y + r * C + cl * 8, v[u]);
       }
@@ -266,10 +277,9 @@ size_t tmae_bn_workspace(int64_t m, int c) { return ((size_t)bn_grid(m) * 2 * c 
     else hipLaunchKernelGGL((KERNEL<T, 4>), grid, block, 0, stream, __VA_ARGS__);                 \
   } while (0)
 
-int tmae_bn_relu_fwd(const void* x_, int dtype, int64_t m, int c, const float* gamma, const float* beta, float eps,
-                     int relu, void* y_, float* mean, float* var, float* rstd, void* wsp, size_t ws_bytes,
-                     void* stream_) {
-  (void)hipGetLastError();
+static int bn_relu_fwd(const void* x_, int dtype, int64_t m, int c, const float* gamma, const float* beta, float eps,
+                       int relu, const void* post_, void* y_, float* mean, float* var, float* rstd, void* wsp, size_t ws_bytes,
+                       void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (m <= 0 || (c != 64 && c != 128 && c != 256) || !x_ || !gamma || !beta || !y_ || !mean || !var || !rstd)
     return TMAE_EARG;
@@ -284,15 +294,29 @@ int tmae_bn_relu_fwd(const void* x_, int dtype, int64_t m, int c, const float* g
     float* y = (float*)y_;
     BN_DISPATCH(float, bn_stats_kernel, x, m, 1, part);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, (double)m, eps, mean, var, rstd);
-    BN_DISPATCH(float, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y);
+    BN_DISPATCH(float, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y, (const float*)post_);
   } else {
     const __hip_bfloat16* x = (const __hip_bfloat16*)x_;
     __hip_bfloat16* y = (__hip_bfloat16*)y_;
     BN_DISPATCH(__hip_bfloat16, bn_stats_kernel, x, m, 1, part);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, (double)m, eps, mean, var, rstd);
-    BN_DISPATCH(__hip_bfloat16, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y);
+    BN_DISPATCH(__hip_bfloat16, bn_apply_kernel, x, m, mean, rstd, gamma, beta, relu, y, (const __hip_bfloat16*)post_);
   }
   return tmae_launch_status();
+}
+
+int tmae_bn_relu_fwd(const void* x, int dtype, int64_t m, int c, const float* gamma, const float* beta, float eps, int relu,
+                     void* y, float* mean, float* var, float* rstd, void* ws, size_t ws_bytes, void* stream) {
+  (void)hipGetLastError();
+  return bn_relu_fwd(x, dtype, m, c, gamma, beta, eps, relu, nullptr, y, mean, var, rstd, ws, ws_bytes, stream);
+}
+
+int tmae_bn_relu_add_fwd(const void* x, int dtype, int64_t m, int c, const float* gamma, const float* beta, float eps, int relu,
+                         const void* post, void* y, float* mean, float* var, float* rstd, void* ws, size_t ws_bytes,
+                         void* stream) {
+  (void)hipGetLastError();
+  if (!post) return TMAE_EARG;
+  return bn_relu_fwd(x, dtype, m, c, gamma, beta, eps, relu, post, y, mean, var, rstd, ws, ws_bytes, stream);
 }
 
 int tmae_bn_relu_bwd(const void* dy_, const void* x_, int dtype, int64_t m, int c, const float* mean, const float* rstd,

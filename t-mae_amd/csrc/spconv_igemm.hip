@@ -575,7 +575,10 @@ template <int DIL> struct HaloGeom {
 template <int CIN, int DIL = 1>
 __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_bfloat16* __restrict__ in, int B, int Y,
                                                                    int X, const __hip_bfloat16* __restrict__ W, int cout,
-                                                                   __hip_bfloat16* __restrict__ out, int nunits) {
+                                                                   __hip_bfloat16* __restrict__ out, int nunits,
+                                                                   const __hip_bfloat16* __restrict__ post) {
+  // post (optional, the shape of out): out = conv + post -- the gradient that reaches a residual block's input through its
+  // shortcut, added where the input gradient of its conv is in registers (sst_bev_backbone.py:35-41 backwards)
   constexpr int KC = CIN / 64;
   constexpr int HW = HaloGeom<DIL>::HW, NH = HaloGeom<DIL>::NH, NP = HaloGeom<DIL>::NP, HC_ABYTES = HaloGeom<DIL>::ABYTES;
   static_assert(NP <= 64, "the piece issued in the last tap step of a slice must be a dummy (it may still be in flight)");
@@ -760,7 +763,21 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
       for (int mt = 0; mt < 4; ++mt) {
         const int y = uy0 + 4 * wm + mt, x = ux0 + i;
         if (y < Y && x < X) {
-          __hip_bfloat16* p = out + (((int64_t)ub * Y + y) * X + x) * cout + n0 + wn * 64 + 8 * g;
+          const int64_t eo = (((int64_t)ub * Y + y) * X + x) * cout + n0 + wn * 64 + 8 * g;
+          __hip_bfloat16* p = out + eo;
+          if (post) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const u32x4 pv = *reinterpret_cast<const u32x4*>(post + eo + 32 * h);
+#pragma unroll
+              for (int q2 = 0; q2 < 2; ++q2) {
+                acc[2 * h + q2][mt][0] += __uint_as_float(pv[2 * q2] << 16);
+                acc[2 * h + q2][mt][1] += __uint_as_float(pv[2 * q2] & 0xFFFF0000u);
+                acc[2 * h + q2][mt][2] += __uint_as_float(pv[2 * q2 + 1] << 16);
+                acc[2 * h + q2][mt][3] += __uint_as_float(pv[2 * q2 + 1] & 0xFFFF0000u);
+              }
+            }
+          }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             u32x4 v;
@@ -786,7 +803,7 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
 // cout % 128 == 0, dilation in {1, 2}.  The input gradient of such a conv is the same call on dout with
 // weight_t[c, (2-ky)*3 + (2-kx), n] = weight[n, ky, kx, c].
 static int dense_conv3x3_launch(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, int dil,
-                                void* out, hipStream_t stream) {
+                                const void* post, void* out, hipStream_t stream) {
   if (batch <= 0 || ny <= 0 || nx <= 0 || (cin != 128 && cin != 256 && cin != 384) || cout <= 0 || (cout % IG_BN) ||
       (dil != 1 && dil != 2))
     return TMAE_EARG;
@@ -810,7 +827,7 @@ static int dense_conv3x3_launch(const void* in, int batch, int ny, int nx, int c
     if (int e_ = tmae_allow_lds(attr, (const void*)dense_conv3x3_halo_kernel<C, D>, lds)) return e_;                  \
     hipLaunchKernelGGL((dense_conv3x3_halo_kernel<C, D>), dim3((unsigned)blocks), dim3(512), lds, stream,            \
                        (const __hip_bfloat16*)in, batch, ny, nx, (const __hip_bfloat16*)weight, cout,                 \
-                       (__hip_bfloat16*)out, (int)units);                                                             \
+                       (__hip_bfloat16*)out, (int)units, (const __hip_bfloat16*)post);                                \
   } while (0)
   if (dil == 1) {
     if (cin == 128) HC_LAUNCH(128, 1); else if (cin == 256) HC_LAUNCH(256, 1); else HC_LAUNCH(384, 1);
@@ -824,11 +841,18 @@ static int dense_conv3x3_launch(const void* in, int batch, int ny, int nx, int c
 int tmae_dense_conv3x3(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, void* out,
                        void* stream_) {
   (void)hipGetLastError();
-  return dense_conv3x3_launch(in, batch, ny, nx, cin, weight, cout, 1, out, (hipStream_t)stream_);
+  return dense_conv3x3_launch(in, batch, ny, nx, cin, weight, cout, 1, nullptr, out, (hipStream_t)stream_);
 }
 
 int tmae_dense_conv3x3_dilated(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout,
                                int dilation, void* out, void* stream_) {
   (void)hipGetLastError();
-  return dense_conv3x3_launch(in, batch, ny, nx, cin, weight, cout, dilation, out, (hipStream_t)stream_);
+  return dense_conv3x3_launch(in, batch, ny, nx, cin, weight, cout, dilation, nullptr, out, (hipStream_t)stream_);
+}
+
+int tmae_dense_conv3x3_add(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, int dilation,
+                           const void* post, void* out, void* stream_) {
+  (void)hipGetLastError();
+  if (!post || ((uintptr_t)post & 15)) return TMAE_EARG;
+  return dense_conv3x3_launch(in, batch, ny, nx, cin, weight, cout, dilation, post, out, (hipStream_t)stream_);
 }

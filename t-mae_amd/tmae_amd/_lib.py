@@ -51,6 +51,7 @@ SIGNATURES = {
     'tmae_spconv_bwd_data': (I, [P, L, L, I, P, L, P, I, P, L, P]),
     'tmae_dense_conv3x3': (I, [P, I, I, I, I, P, I, P, P]),
     'tmae_dense_conv3x3_dilated': (I, [P, I, I, I, I, P, I, I, P, P]),
+    'tmae_dense_conv3x3_add': (I, [P, I, I, I, I, P, I, I, P, P, P]),
     'tmae_dense_conv3x3_wgrad_workspace': (Z, [I, I]),
     'tmae_dense_conv3x3_wgrad': (I, [P, P, I, I, I, I, I, I, P, P, Z, P]),
     'tmae_spconv_gather': (I, [P, I, L, I, P, L, P, P]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     'tmae_layernorm_bwd': (I, [P, P, I, L, I, P, P, P, P, P, P, P, P, P, P, P, Z, P]),
     'tmae_bn_workspace': (Z, [L, I]),
     'tmae_bn_relu_fwd': (I, [P, I, L, I, P, P, F, I, P, P, P, P, P, Z, P]),
+    'tmae_bn_relu_add_fwd': (I, [P, I, L, I, P, P, F, I, P, P, P, P, P, P, Z, P]),
     'tmae_bn_relu_bwd': (I, [P, P, I, L, I, P, P, P, P, I, P, P, P, P, Z, P]),
     'tmae_bn_stats': (I, [P, I, L, I, D, F, P, P, P, P, Z, P]),
     'tmae_bn_apply': (I, [P, I, L, I, P, P, P, P, I, P, P]),

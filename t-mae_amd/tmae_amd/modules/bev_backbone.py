@@ -12,12 +12,21 @@ import torch.nn as nn
 from .. import ops
 
 
-def conv_bn_relu_nhwc(seq, x):
-    """seq = Sequential(Conv2d, BatchNorm2d, ReLU) on a channels-last tensor; fused norm+ReLU in training."""
+def conv_bn_relu_nhwc(seq, x, shortcut=False):
+    """seq = Sequential(Conv2d, BatchNorm2d, ReLU) on a channels-last tensor; fused norm+ReLU in training.
+    shortcut: returns seq(x) + x (sst_bev_backbone.py:35-41).  On the halo-conv path the shortcut is added inside the norm's apply
+    kernel forward and inside the conv's input-gradient kernel backward (TMAE_BEV_SHORTCUT=add: as separate elementwise passes)."""
     conv, bn = seq[0], seq[1]
     nhwc = x.permute(0, 2, 3, 1)
     if (bn.training and os.environ.get('TMAE_DENSE_CONV', 'halo') != 'miopen' and nhwc.is_contiguous()
             and ops.dense_conv3x3_ok(nhwc, conv) and conv.out_channels % 128 == 0):
+        if (shortcut and conv.out_channels == conv.in_channels and conv.out_channels in (64, 128, 256) and len(seq) == 3
+                and isinstance(seq[2], nn.ReLU) and os.environ.get('TMAE_BEV_SHORTCUT', 'fused') == 'fused'):
+            y, res = ops.dense_conv3x3(nhwc, conv.weight, conv.dilation[0], fork=True)
+            b, ny, nx, c = y.shape
+            rows = ops.batch_norm_relu(y.reshape(b * ny * nx, c), bn, relu=True, pre_bias=conv.bias,
+                                       post=res.reshape(b * ny * nx, c))
+            return rows.view(b, ny, nx, c).permute(0, 3, 1, 2)
         y = ops.dense_conv3x3(nhwc, conv.weight, conv.dilation[0]).permute(0, 3, 1, 2)
         fused = True
     else:
@@ -30,11 +39,13 @@ def conv_bn_relu_nhwc(seq, x):
             and y.shape[1] in (64, 128, 256) and len(seq) == 3 and isinstance(seq[2], nn.ReLU)):
         b, c, ny, nx = y.shape
         rows = ops.batch_norm_relu(y.permute(0, 2, 3, 1).reshape(b * ny * nx, c), bn, relu=True, pre_bias=conv.bias)
-        return rows.view(b, ny, nx, c).permute(0, 3, 1, 2)
+        out = rows.view(b, ny, nx, c).permute(0, 3, 1, 2)
+        return out + x if shortcut else out
     if fused and conv.bias is not None:
         y = y + conv.bias.view(1, -1, 1, 1).to(y.dtype)
     y = bn(y)
-    return seq[2](y) if len(seq) > 2 else y
+    y = seq[2](y) if len(seq) > 2 else y
+    return y + x if shortcut else y
 
 
 class SSTBEVBackbone(nn.Module):
@@ -57,7 +68,7 @@ class SSTBEVBackbone(nn.Module):
     def forward(self, data_dict):
         out = data_dict['spatial_features']
         for i, conv in enumerate(self.conv_layer):
-            t = conv_bn_relu_nhwc(conv, out)
-            out = t + out if (t.shape == out.shape and i in self.conv_shortcut) else t
+            sc = i in self.conv_shortcut and conv[0].out_channels == out.shape[1] and conv[0].stride == (1, 1)
+            out = conv_bn_relu_nhwc(conv, out, shortcut=sc)
         data_dict['spatial_features_2d'] = out
         return data_dict

@@ -898,10 +898,15 @@ class _BatchNormReLU(torch.autograd.Function):
     (torch.nn.SyncBatchNorm semantics: the gradients of gamma / beta stay the rank's own sums, DDP averages them)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, relu, bounds, pg=None):
+    def forward(ctx, x, weight, bias, eps, relu, bounds, pg=None, post=None):
+        """post [m, c] (single row range, no process group): y = relu?(norm(x)) + post; its gradient is dy itself."""
         x = x.contiguous()
         m, c = x.shape
         ng = len(bounds) - 1
+        if post is not None:
+            assert ng == 1 and pg is None and post.shape == x.shape
+            post = post.to(x.dtype).contiguous()
+        ctx.has_post = post is not None
         y = torch.empty_like(x)
         mean = torch.empty((ng, c), dtype=torch.float32, device=x.device)
         var, rstd = torch.empty_like(mean), torch.empty_like(mean)
@@ -912,9 +917,14 @@ class _BatchNormReLU(torch.autograd.Function):
             wsb = lib.tmae_bn_workspace(r1 - r0, c)
             ws = _ws(wsb, x.device)
             if pg is None:
-                check(lib.tmae_bn_relu_fwd(_p(x[r0:r1]), _dt(x), r1 - r0, c, _p(g32), _p(b32), float(eps), 1 if relu else 0,
-                                           _p(y[r0:r1]), _p(mean[g]), _p(var[g]), _p(rstd[g]), _p(ws), wsb, _s()),
-                      'tmae_bn_relu_fwd')
+                if post is not None:
+                    check(lib.tmae_bn_relu_add_fwd(_p(x), _dt(x), m, c, _p(g32), _p(b32), float(eps), 1 if relu else 0, _p(post),
+                                                   _p(y), _p(mean[g]), _p(var[g]), _p(rstd[g]), _p(ws), wsb, _s()),
+                          'tmae_bn_relu_add_fwd')
+                else:
+                    check(lib.tmae_bn_relu_fwd(_p(x[r0:r1]), _dt(x), r1 - r0, c, _p(g32), _p(b32), float(eps), 1 if relu else 0,
+                                               _p(y[r0:r1]), _p(mean[g]), _p(var[g]), _p(rstd[g]), _p(ws), wsb, _s()),
+                          'tmae_bn_relu_fwd')
                 counts.append(float(r1 - r0))
                 continue
             check(lib.tmae_bn_stats(_p(x[r0:r1]), _dt(x), r1 - r0, c, float(r1 - r0), float(eps), _p(mean[g]), _p(var[g]),
@@ -935,7 +945,7 @@ class _BatchNormReLU(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _m, _v):
         if dy is None:
-            return (None,) * 7
+            return (None,) * 8
         x, mean, rstd, g32, b32 = ctx.saved_tensors
         dy = dy.to(x.dtype).contiguous()
         m, c = x.shape
@@ -967,7 +977,7 @@ class _BatchNormReLU(torch.autograd.Function):
             dg, db = dg.sum(0), db.sum(0)
         else:
             dg, db = dg[0], db[0]
-        return dx, dg.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None, None, None
+        return dx, dg.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None, None, None, (dy if ctx.has_post else None)
 
 
 class _DeadBias(torch.autograd.Function):
@@ -985,7 +995,7 @@ class _DeadBias(torch.autograd.Function):
         return dy, torch.zeros(shape, dtype=dtype, device=device)
 
 
-def batch_norm_relu(x, bn, relu=True, groups=None, pre_bias=None):
+def batch_norm_relu(x, bn, relu=True, groups=None, pre_bias=None, post=None):
     """nn.BatchNorm1d `bn` (+ ReLU) over the rows of x [m,c]; fused HIP kernels in training mode for c in
     {64,128,256}; updates bn's running statistics like torch does.  `groups` (row counts summing to m): each row
     range is a separate BatchNorm call (own batch statistics, running statistics updated in order).
@@ -1003,7 +1013,11 @@ def batch_norm_relu(x, bn, relu=True, groups=None, pre_bias=None):
         for g in sizes:
             bounds.append(bounds[-1] + g)
         pg = _sync_group(bn)
-        y, mean, var = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.eps, relu, tuple(bounds), pg)
+        if post is not None and (groups is not None or pg is not None):
+            y, mean, var = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.eps, relu, tuple(bounds), pg)
+            y = y + post
+        else:
+            y, mean, var = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.eps, relu, tuple(bounds), pg, post)
         if pre_bias is not None:
             y = _DeadBias.apply(y, pre_bias)
             mean = mean + pre_bias.detach().float()
@@ -1019,7 +1033,8 @@ def batch_norm_relu(x, bn, relu=True, groups=None, pre_bias=None):
         y = torch.cat(ys, 0)
     else:
         y = bn(x)
-    return torch.relu(y) if relu else y
+    y = torch.relu(y) if relu else y
+    return y if post is None else y + post
 
 
 class _SplitRows(torch.autograd.Function):
@@ -1737,7 +1752,10 @@ class _DenseConv3x3(torch.autograd.Function):
     im2col(X), never materialised).  The library's implicit GEMMs ran at 0.52-0.68 PFLOP/s on this shape."""
 
     @staticmethod
-    def forward(ctx, x_nhwc, weight, dil=1):
+    def forward(ctx, x_nhwc, weight, dil=1, fork=False):
+        """fork: also returns an alias of the input for a residual shortcut (SSTBEVBackbone, sst_bev_backbone.py:35-41); the
+        gradient that arrives for the alias is added to the input gradient INSIDE the conv's input-gradient kernel
+        (tmae_dense_conv3x3_add) instead of by autograd's accumulation pass."""
         cdt = compute_dtype(x_nhwc)
         x = x_nhwc.to(cdt).contiguous()
         w = cast_param(weight, cdt)
@@ -1758,11 +1776,18 @@ class _DenseConv3x3(torch.autograd.Function):
                                            padding=dil, dilation=dil).permute(0, 2, 3, 1)
             ctx.save_for_backward(x, w)
         ctx.meta = (x_nhwc.dtype, weight.dtype)
+        ctx.fork = bool(fork)
+        if fork:
+            ctx.set_materialize_grads(False)
+            return y, x_nhwc.view_as(x_nhwc)
         return y
 
     @staticmethod
-    def backward(ctx, dy_nhwc):
+    def backward(ctx, dy_nhwc, dalias=None):
         x, w = ctx.saved_tensors
+        if dy_nhwc is None:                                  # only the alias was used downstream
+            return (None if dalias is None else dalias.to(ctx.meta[0])), None, None, None
+        skip = None if dalias is None else dalias.to(x.dtype).contiguous()
         B, Y, X, cin = x.shape
         cout = w.shape[0]
         n = B * Y * X
@@ -1774,7 +1799,8 @@ class _DenseConv3x3(torch.autograd.Function):
             if ctx.native and (_DENSE_CONV == 'halo' or dil != 1) and cout in (128, 256, 384) and cin % 128 == 0:
                 # weight_t[c, 2-ky, 2-kx, n] = w[n, ky, kx, c]: the input gradient is a conv of dY with the flipped taps
                 wt = w.view(cout, 3, 3, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * cout).contiguous()
-                dx = dense_conv3x3_halo(dy, wt, dil).to(ctx.meta[0])
+                dx = dense_conv3x3_halo(dy, wt, dil, post=skip).to(ctx.meta[0])
+                skip = None                                  # added inside the kernel
             elif ctx.native:
                 nbr_t = _DENSE_NBR.get(('t', B, Y, X, dil, x.device))
                 if nbr_t is None:                      # transposed rulebook of a stride-1 conv = flipped taps
@@ -1784,6 +1810,8 @@ class _DenseConv3x3(torch.autograd.Function):
                 dx = torch.ops.aten.convolution_backward(
                     dy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w.contiguous(memory_format=torch.channels_last), None,
                     [1, 1], [dil, dil], [dil, dil], False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1).to(ctx.meta[0])
+        if skip is not None:                                 # a path without the fused add
+            dx = skip.to(ctx.meta[0]) if dx is None else dx + skip.to(dx.dtype)
         dy2, x2 = dy.view(n, cout), x.view(n, cin)
         dw = torch.empty((cout, 9 * cin), dtype=torch.float32, device=x.device)
         if ctx.native and _DENSE_WGRAD == 'halo' and x.dtype == torch.bfloat16:
@@ -1792,13 +1820,13 @@ class _DenseConv3x3(torch.autograd.Function):
                 ws = _ws(wsb, x.device)
                 check(lib.tmae_dense_conv3x3_wgrad(_p(dy), _p(x), B, Y, X, cin, cout, int(dil), _p(dw), _p(ws), wsb, _s()),
                       'tmae_dense_conv3x3_wgrad')
-                return dx, dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2).to(ctx.meta[1]), None
+                return dx, dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2).to(ctx.meta[1]), None, None
         wsb = lib.tmae_linear_wgrad_workspace(n, cout, 9 * cin)
         ws = _ws(wsb, x.device)
         check(lib.tmae_spconv_wgrad(_p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(nbr), n, cout, cin, _p(dw), _p(ws),
                                     wsb, _s()), 'tmae_spconv_wgrad')
         dw = dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2).to(ctx.meta[1])
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 def _channel_sums(dy):
@@ -1854,12 +1882,17 @@ def conv3x3_channel_bias(x, conv):
     return _ConvOwnBiasGrad.apply(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation)
 
 
-def dense_conv3x3_halo(x_nhwc, w2d, dil=1):
+def dense_conv3x3_halo(x_nhwc, w2d, dil=1, post=None):
     """[B, Y, X, cin] bf16 (contiguous) x w2d [cout, 9*cin] bf16 -> [B, Y, X, cout] (csrc/spconv_igemm.hip, halo kernel);
-    padding = dilation in {1, 2}."""
+    padding = dilation in {1, 2}; post [B, Y, X, cout] bf16: added to the result inside the kernel."""
     B, Y, X, cin = x_nhwc.shape
     cout = w2d.shape[0]
     y = torch.empty((B, Y, X, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    if post is not None:
+        assert post.shape == y.shape and post.dtype == torch.bfloat16 and post.is_contiguous()
+        check(lib.tmae_dense_conv3x3_add(_p(x_nhwc), B, Y, X, cin, _p(w2d), cout, int(dil), _p(post), _p(y), _s()),
+              'tmae_dense_conv3x3_add')
+        return y
     if dil == 1:
         check(lib.tmae_dense_conv3x3(_p(x_nhwc), B, Y, X, cin, _p(w2d), cout, _p(y), _s()), 'tmae_dense_conv3x3')
     else:
@@ -1875,8 +1908,9 @@ def dense_conv3x3_ok(x_nhwc, conv):
             and conv.out_channels % 8 == 0 and x_nhwc.shape[0] * x_nhwc.shape[1] * x_nhwc.shape[2] >= 4096)
 
 
-def dense_conv3x3(x_nhwc, weight, dilation=1):
-    return _DenseConv3x3.apply(x_nhwc, weight, int(dilation))
+def dense_conv3x3(x_nhwc, weight, dilation=1, fork=False):
+    """fork: returns (y, alias of x_nhwc) -- see _DenseConv3x3.forward."""
+    return _DenseConv3x3.apply(x_nhwc, weight, int(dilation), bool(fork))
 
 
 class _DenseGather(torch.autograd.Function):

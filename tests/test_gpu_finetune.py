@@ -208,6 +208,48 @@ def test_head_conv_bias_gradient_vs_torch():
         assert (db1.float() - want).abs().max().item() <= 2e-2 * max(1.0, float(want.abs().max())), (k, db1, want)
 
 
+@pytest.mark.parametrize('dil', [1, 2])
+def test_bev_block_shortcut_fused_vs_separate_adds(dil, monkeypatch):
+    """`out = conv_bn_relu(out) + out` of SSTBEVBackbone (sst_bev_backbone.py:35-41) with the shortcut added inside the norm's apply
+    kernel (forward) and inside the conv's input-gradient kernel (backward: tmae_bn_relu_add_fwd, tmae_dense_conv3x3_add) against
+    the same block with the two adds as separate elementwise passes, and against torch in fp32."""
+    import torch.nn as nn
+    from tmae_amd.modules.bev_backbone import conv_bn_relu_nhwc
+    torch.manual_seed(9)
+    B, C, Y, X = 2, 128, 70, 52
+    seq = nn.Sequential(nn.Conv2d(C, C, 3, padding=dil, dilation=dil, bias=False), nn.BatchNorm2d(C, eps=1e-3, momentum=0.01),
+                        nn.ReLU(inplace=True)).cuda().train()
+    x0 = torch.randn(B, Y, X, C, device='cuda').bfloat16().permute(0, 3, 1, 2)           # channels-last memory
+    go = torch.randn(B, Y, X, C, device='cuda').bfloat16().permute(0, 3, 1, 2)
+    res = {}
+    for mode in ('fused', 'add'):
+        monkeypatch.setenv('TMAE_BEV_SHORTCUT', mode)
+        seq.zero_grad()
+        seq[1].running_mean.zero_(); seq[1].running_var.fill_(1.0)
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = conv_bn_relu_nhwc(seq, x, shortcut=True)
+        y.backward(go)
+        res[mode] = (y.detach().float(), x.grad.float(), seq[0].weight.grad.clone(), seq[1].weight.grad.clone(),
+                     seq[1].bias.grad.clone(), seq[1].running_mean.clone(), seq[1].running_var.clone())
+    f, a = res['fused'], res['add']
+    assert torch.equal(f[5], a[5]) and torch.equal(f[6], a[6])                              # same statistics
+    # one rounding (fused) against two (separate adds): within one bf16 ulp of the larger operand
+    assert (f[0] - a[0]).abs().max().item() <= 2.0 ** -7 * float(a[0].abs().max())
+    assert (f[1] - a[1]).abs().max().item() <= 2.0 ** -7 * float(a[1].abs().max())
+    for i in (2, 3, 4):
+        assert torch.equal(f[i], a[i])                                                      # the branch's own gradients: same inputs
+    # fp32 torch reference of the block
+    xr = x0.float().clone().requires_grad_(True)
+    ref = nn.Sequential(nn.Conv2d(C, C, 3, padding=dil, dilation=dil, bias=False), nn.BatchNorm2d(C, eps=1e-3, momentum=0.01),
+                        nn.ReLU()).cuda().train()
+    ref[0].weight.data.copy_(seq[0].weight.data.bfloat16().float())
+    yr = ref(xr) + xr
+    yr.backward(go.float())
+    assert ((f[0] - yr.detach()).norm() / yr.detach().norm()).item() < 1e-2
+    assert ((f[1] - xr.grad).norm() / xr.grad.norm()).item() < 2e-2
+
+
 def test_rotated_iou_and_nms_vs_oracle(ft_oracle):
     """csrc/iou3d_nms.hip vs the float64 convex-clipping restatement: BEV overlap / IoU, 3-D IoU, edge cases
     (identical, disjoint, contained, 45 degrees, touching), and the kept set + order of the rotated NMS."""
