@@ -59,42 +59,54 @@ def parse():
     return ap.parse_args()
 
 
-def _pmc_source():
-    for name in ('round4_pmc.json', 'round3_pmc.json', 'round2_pmc.json', 'round1_pmc.json'):
-        if os.path.exists(os.path.join(ROOT, 'profiles', name)):
-            return f'profiles/{name} (FETCH_SIZE x2 + WRITE_SIZE, bytes per op; a committed counter pass of `bench.py --probe-only`, not measured in this run)'
-    return None
+def _pmc_files():
+    """Committed counter passes of `bench.py --probe-only` (profiles/roundN_pmc.json), latest round first."""
+    import glob
+    import re
+    fs = glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc.json'))
+    return sorted(fs, key=lambda f: -int(re.search(r'round(\d+)_pmc', f).group(1)))
 
 
-_PMC_FILES = {'token_gemm': 'token_gemm_wreg.hip', 'wgrad': 'wgrad.hip', 'attention': 'attention_mfma.hip'}
+_PMC_FILES = {'token_gemm': 'token_gemm_wreg.hip', 'token_gemm_gelu': 'token_gemm_wreg.hip', 'wgrad': 'wgrad.hip',
+              'attention': 'attention_mfma.hip'}
+
+
+def _pmc_entry(key):
+    """(file, json, bytes per op) of the latest pass that holds a VALID figure for `key`: a missing, empty or zero entry is
+    'absent' (round 4 committed a 0 for the priced kernel -- a summariser whose name pattern had gone stale -- and `0 is not
+    None` put it into the driver's line)."""
+    for f in _pmc_files():
+        d = json.load(open(f))
+        v = d.get(key, {}).get('traffic_bytes_per_op')
+        if v:
+            return f, d, v
+    return None, None, None
+
+
+def _pmc_source(key):
+    f, _, _ = _pmc_entry(key)
+    if f is None:
+        return None
+    return (f'profiles/{os.path.basename(f)} (FETCH_SIZE x2 + WRITE_SIZE, bytes per op; a committed counter pass of '
+            f'`bench.py --probe-only`, not measured in this run)')
 
 
 def _pmc_current(key):
     """Is the committed counter pass still about THIS kernel source?  (sha256 of the .hip file at measurement time, written by
     profiles/scripts/pmc_summary.py, against the file in this tree; None for passes of earlier rounds that carry no hash.)"""
     import hashlib
-    for name in ('round4_pmc.json', 'round3_pmc.json', 'round2_pmc.json', 'round1_pmc.json'):
-        f = os.path.join(ROOT, 'profiles', name)
-        if os.path.exists(f):
-            d = json.load(open(f))
-            if d.get(key, {}).get('traffic_bytes_per_op') is None:
-                continue
-            want = d.get('source_sha16', {}).get(_PMC_FILES[key])
-            if want is None:
-                return None
-            src = os.path.join(ROOT, 't-mae_amd', 'csrc', _PMC_FILES[key])
-            return hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16] == want
-    return None
+    _, d, _ = _pmc_entry(key)
+    if d is None:
+        return None
+    want = d.get('source_sha16', {}).get(_PMC_FILES[key])
+    if want is None:
+        return None
+    src = os.path.join(ROOT, 't-mae_amd', 'csrc', _PMC_FILES[key])
+    return hashlib.sha256(open(src, 'rb').read()).hexdigest()[:16] == want
 
 
 def _pmc(key):
-    for name in ('round4_pmc.json', 'round3_pmc.json', 'round2_pmc.json', 'round1_pmc.json'):          # rocprofv3 --pmc passes of --probe-only (latest round first)
-        f = os.path.join(ROOT, 'profiles', name)
-        if os.path.exists(f):
-            v = json.load(open(f)).get(key, {}).get('traffic_bytes_per_op')
-            if v is not None:
-                return v
-    return None
+    return _pmc_entry(key)[2]
 
 
 def _counters(*kernels):
@@ -218,13 +230,13 @@ def token_gemm_roofline(model, batch, amp_dtype, iters=20):
                       'stage-2 token list; one launch per op)', 'bound': 'hbm', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
             'traffic': _pmc('token_gemm'), 'traffic_is_of_this_source': _pmc_current('token_gemm'),
-            'traffic_source': _pmc_source(),
+            'traffic_source': _pmc_source('token_gemm'),
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k,
             'utilisation': _counters('token_gemm_wreg_kernel<256, 4, 8, false, false>')}
 
 
 def gelu_gemm_roofline(model, batch, amp_dtype, iters=20):
-    """`roofline_gemm_gelu` (round 4): the FFN's first Linear with its exact GELU as a second store of the epilogue
+    """`roofline` (round 5; `roofline_gemm_gelu` in round 4): the FFN's first Linear with its exact GELU as a second store of the epilogue
     (token_gemm_wreg_kernel<256,4,8,...,GELU2>, csrc/token_gemm_wreg.hip) on the token-GEMM probe's shape: x read once, the
     pre-activation AND the activation written once each -- algorithmic bytes M (K + 2N) 2 + W."""
     from tmae_amd._lib import lib, check
@@ -255,8 +267,9 @@ def gelu_gemm_roofline(model, batch, amp_dtype, iters=20):
     achieved = bytes_alg / (ms * 1e-3) / 1e9
     return {'kernel': 'token_gemm_wreg_kernel<256,4,8,..,GELU2> (Y = X W^T + b and gelu(Y) in one launch, stage-2 token list)',
             'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None, 'ms_per_launch': round(ms, 4),
-            'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k}
+            'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': _pmc('token_gemm_gelu'),
+            'traffic_is_of_this_source': _pmc_current('token_gemm_gelu'), 'traffic_source': _pmc_source('token_gemm_gelu'),
+            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k}
 
 
 def wgrad_roofline(model, batch, amp_dtype, iters=20):
@@ -287,7 +300,7 @@ def wgrad_roofline(model, batch, amp_dtype, iters=20):
                       'op = the kernel + its slab-reduction launch)', 'bound': 'hbm',
             'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': _pmc('wgrad'), 'traffic_is_of_this_source': _pmc_current('wgrad'),
-            'traffic_source': _pmc_source(),
+            'traffic_source': _pmc_source('wgrad'),
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k,
             'utilisation': _counters('wgrad256_kernel<false, 1>', 'wgrad_reduce_kernel')}
 
@@ -350,7 +363,7 @@ def attention_roofline(model, batch, amp_dtype, iters=20):
                       'tile-class launches NT=1,2,4)', 'bound': 'hbm', 'achieved': round(achieved, 2),
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
             'traffic_is_of_this_source': _pmc_current('attention') if code == 1 else None,
-            'traffic_source': _pmc_source(),
+            'traffic_source': _pmc_source('attention'),
             'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': int(m),
             'utilisation': _counters('win_attn_bwd_mfma_kernel<16, 1, false>', 'win_attn_bwd_mfma_kernel<16, 1, true>',
                                      'win_attn_bwd_mfma_kernel<16, 2, false>', 'win_attn_bwd_mfma_kernel<16, 4, false>')}
@@ -689,8 +702,8 @@ def main():
 
     if args.probe_only:
         print(json.dumps({'box_peaks': box_peaks(dev),
-                          'roofline': token_gemm_roofline(model, dict(batches[0]), amp),
-                          'roofline_gemm_gelu': gelu_gemm_roofline(model, dict(batches[0]), amp),
+                          'roofline': gelu_gemm_roofline(model, dict(batches[0]), amp),
+                          'roofline_token_gemm_plain': token_gemm_roofline(model, dict(batches[0]), amp),
                           'roofline_wgrad': wgrad_roofline(model, dict(batches[0]), amp),
                           'roofline_attention': attention_roofline(model, dict(batches[0]), amp),
                           'roofline_igemm': igemm_roofline(args.batch_per_gpu)}), flush=True)
@@ -780,9 +793,15 @@ def main():
                     'hbm_gbs_achieved': round(sb['bytes'] / (elapsed / args.steps) / 1e9, 1),
                     'hbm_floor_ms_at_measured_copy_rate': round(sb['bytes'] / (peaks['hbm_copy_gbs'] * 1e9) * 1e3, 2),
                     'hbm_families_gb': sb['families_gb'], 'hbm_source': sb['source']})
-        line['roofline'] = _with_measured(token_gemm_roofline(model, dict(batches[0]), amp), peaks)
+        # `roofline` = the instance of the token-GEMM family that carries the most step time today: the dual-store FFN-1 kernel
+        # (12 launches x 147 us per step, profiles/round4_z_kernel_stats.md); the plain instance that rounds 3-4 priced runs 5
+        # launches / 0.2 ms per step and stays as a secondary entry
+        plain = _with_measured(token_gemm_roofline(model, dict(batches[0]), amp), peaks)
         if amp is not None:
-            line['roofline_gemm_gelu'] = _with_measured(gelu_gemm_roofline(model, dict(batches[0]), amp), peaks)
+            line['roofline'] = _with_measured(gelu_gemm_roofline(model, dict(batches[0]), amp), peaks)
+            line['roofline_token_gemm_plain'] = plain
+        else:
+            line['roofline'] = plain
         # round-1 history: the two kernels that led the profile before this one, still priced the same way
         line['roofline_wgrad'] = _with_measured(wgrad_roofline(model, dict(batches[0]), amp), peaks)
         line['roofline_attention'] = _with_measured(attention_roofline(model, dict(batches[0]), amp), peaks)

@@ -1,6 +1,8 @@
 """Summarise a rocprofv3 --kernel-trace CSV of `bench.py --steps 3 --warmup 2`: per-step kernel time of the timed steps.
 usage: python profiles/scripts/summarize_trace.py <kernel_trace.csv> [top_n]"""
-import collections, csv, re, sys
+import collections, csv, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _kernels as K
 rows = list(csv.DictReader(open(sys.argv[1])))
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
@@ -31,17 +33,16 @@ def grid_of(r):
     return r.get('Grid_Size_X', r.get('Grid_Size', ''))
 
 
-for title, pats in (('token GEMM op (one launch)', ('token_gemm_wreg_kernel<256, 4, 8, false, false, false>', 'token_gemm_wreg_kernel<256, 4, 8, false, false>', 'token_gemm_res_kernel<256, 4>')),
-                    ('wgrad256 op (kernel + slab reduction)', ('wgrad256_kernel', 'wgrad_reduce_kernel')),
-                    ('stage-1 attention backward op (3 tile classes)', ('win_attn_bwd_mfma_kernel<16',))):
-    probe = [r for r in tail if any(p in r['Kernel_Name'] for p in pats)]
-    if not probe:
-        continue
-    if 'token_gemm' in pats[0]:      # the probe's forward pass launches this kernel too: the probe = its last 23 launches
-        probe = probe[-23:]
+for title, matchers, last in (('token GEMM op, dual-store GELU2 instance = `roofline` (one launch)', (K.is_tgw_gelu,), 23),
+                             ('token GEMM op, plain instance (one launch)', (K.is_tgw_plain,), 23),
+                             ('wgrad256 op (kernel + slab reduction)', (K.prefix('wgrad256_kernel'), K.prefix('wgrad_reduce_kernel')), 0),
+                             ('stage-1 attention backward op (3 tile classes)', (K.prefix('win_attn_bwd_mfma_kernel<16'),), 0)):
+    probe = K.require(title, [r for r in tail if any(m(r['Kernel_Name']) for m in matchers)])
+    if last:      # the probe's forward pass launches this kernel too: the probe = its last 23 launches (3 warm-up + 20 timed)
+        probe = probe[-last:]
     pa = collections.defaultdict(lambda: [0, 0])
     for r in probe:
-        n = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')
+        n = K.clean(r['Kernel_Name'])
         pa[n][0] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
         pa[n][1] += 1
     print(f'\nroofline probe, {title}, per launch:')

@@ -150,7 +150,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert abs(d['value'] - 8 * 3 / (d['ms_per_step'] * 3e-3)) <= 1e-2 * d['value']
     for key in ('roofline', 'roofline_wgrad', 'roofline_attention', 'roofline_step', 'box_peaks'):
         assert key in d, key
-    assert 'roofline_gemm_gelu' in d
+    assert 'GELU2' in d['roofline']['kernel'] and 'roofline_token_gemm_plain' in d     # the priced instance = the dual-store kernel
     assert d['roofline']['peak_measured'] == d['box_peaks']['hbm_copy_gbs'] > 1000
     assert d['roofline_step']['peak_measured'] == d['box_peaks']['mfma_bf16_tflops'] > 100
 
