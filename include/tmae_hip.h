@@ -36,8 +36,13 @@ extern "C" {
 #define TMAE_F32 0
 #define TMAE_BF16 1
 
-/* library identification; returns ABI version (bumped on any signature change). */
+/* Library identification.  TMAE_ABI_VERSION is bumped by hand on every change of the export list, of a signature or of what an
+ * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
+ * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
+ * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
+#define TMAE_ABI_VERSION 7
 int tmae_abi_version(void);
+int tmae_abi_hash(void);
 
 /* ---------------------------------------------------------------------------------------
  * A1  dynamic voxelisation.   Replaces get_in_range_mask (pcdet/utils/common_utils.py:66-76)

@@ -28,21 +28,31 @@ def _newer(src, dst, extra=()):
     return any(os.path.getmtime(s) > t for s in (src,) + tuple(extra))
 
 
+def _abi_hash():
+    """Fingerprint of include/tmae_hip.h's prototypes (tmae_amd/_abi.py, loaded by path: importing the package would load the
+    library this script is about to build)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_tmae_abi', os.path.join(HERE, 'tmae_amd', '_abi.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.header_hash(open(os.path.join(HERE, '..', 'include', 'tmae_hip.h')).read())
+
+
 def build(force=False, verbose=False, ab=False):
     """ab=True: the A/B debug build (-DTMAE_AB: environment switches and the retired kernel variants behind them, see
     csrc/common.h) -> t-mae_amd/build_ab/libtmae_ab.so; load it with TMAE_LIB_PATH (profiles/scripts/ab_env.sh)."""
     global OBJ, LIBDIR, LIB
-    flags = FLAGS
+    flags = FLAGS + [f'-DTMAE_ABI_HASH={_abi_hash()}']
     if ab:
         OBJ = os.path.join(HERE, 'build_ab', 'obj')
         LIBDIR = os.path.join(HERE, 'build_ab')
         LIB = os.path.join(LIBDIR, 'libtmae_ab.so')
-        flags = FLAGS + ['-DTMAE_AB']
+        flags = flags + ['-DTMAE_AB']
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
     hdrs = tuple(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + (
-        os.path.join(HERE, '..', 'include', 'tmae_hip.h'),)
+        os.path.join(HERE, '..', 'include', 'tmae_hip.h'), os.path.join(HERE, 'tmae_amd', '_abi.py'))
     jobs = []
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + '.o')

@@ -730,17 +730,34 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
             sT = mfma_s(kf[kt], qf[qt], sT);
             dP = mfma_s(vr[kt], gf[qt], z);
 #pragma unroll
-            // (the per-element form on every tile: restricted to the last tile like pass 1, this pass gave wrong gradients at
-            // the temperature clamp -- F7 case 2 -- for a reason not found; measured and left alone)
-            for (int r = 0; r < 4; ++r) pT[r] = (kt * 16 + 4 * g + r < Tk) ? __expf(sT[r] - lse_i[qt]) : 0.f;
+            for (int r = 0; r < 4; ++r) pT[r] = __expf(sT[r] - lse_i[qt]);
+            // dP - D is taken HERE, in front of the wave-uniform branch below.  An MFMA result is not interlocked against its
+            // first VALU reader; the compiler pads straight-line code, but with the branch between the dP MFMA and this
+            // subtraction it left the TAKEN path without a single wait state (its hazard search visits each predecessor block
+            // once, and had reached the join through the long fall-through block first): the subtraction then read the exp()
+            // argument that had lived in those registers before -- -inf for an absent query, so ds = 0 * -inf = NaN went into
+            // dK and finite garbage into dQ while dV (P alone) stayed right: round 4's F7 case 2.
+            // tools/check_mfma_hazards.py (tests/test_isa_hazards.py) walks both sides of every branch behind every MFMA.
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              dP[r] -= dacc;
+              asm volatile("" : "+v"(dP[r]));          // pins the subtraction in front of the branch (the compiler sinks it otherwise)
+            }
+            if (kt == nk - 1) {                          // only the last key tile can hold absent keys (wave-uniform)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (kt * 16 + 4 * g + r >= Tk) pT[r] = 0.f;
+            }
           } else {
             sT = sTk[kt]; dP = dPk[kt]; pT = pTk[kt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dP[r] -= dacc;
           }
           s16x4 dsT, pTb;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float p = pT[r];
-            const float ds = p * (dP[r] - dacc);
+            const float ds = p * dP[r];                    // dP holds dP - D here
             dtau_acc += ds * sT[r];                        // p = 0 entries: 0 * finite
             dsT[r] = f2bf(ds);
             pTb[r] = f2bf(p);

@@ -264,5 +264,3 @@ int tmae_chamfer_bwd(const float* pred, const float* gt, const float* weights, c
                        scale, m, np, ng, dpred);
   return tmae_launch_status();
 }
-
-int tmae_abi_version(void) { return 6; }

@@ -28,6 +28,19 @@ static inline int tmae_allow_lds(TmaeLdsAttr& a, const void* func, int bytes) {
   return 0;
 }
 
+// CU count of the CURRENT device, cached per device ordinal (a process-wide value would be the first device's: wrong the day
+// one process drives two device types), relaxed atomics: two threads racing on the first call store the same value
+static inline int tmae_num_cus() {
+  static int cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int v = __atomic_load_n(&cache[dev & 63], __ATOMIC_RELAXED);
+  if (v > 0) return v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  __atomic_store_n(&cache[dev & 63], v, __ATOMIC_RELAXED);
+  return v;
+}
+
 // Carves 256-byte aligned sub-buffers out of the caller's workspace.
 struct WsCarver {
   char* base;

@@ -812,13 +812,7 @@ static int dense_conv3x3_launch(const void* in, int batch, int ny, int nx, int c
   // one persistent workgroup per CU walks over them
   const int64_t units = (int64_t)batch * ((ny + 15) / 16) * ((nx + 15) / 16) * (cin == 128 ? 1 : cout / IG_BN);
   if (units >= ((int64_t)1 << 31)) return TMAE_EARG;
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-      v = 256;
-    ncu = v;
-  }
+  const int ncu = tmae_num_cus();
   const int64_t blocks = units < ncu ? units : ncu;
 #define HC_LAUNCH(C, D)                                                                                               \
   do {                                                                                                                \

@@ -19,6 +19,7 @@ P, I, L, F, D, Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_si
 # name -> (restype, argtypes); mirrors include/tmae_hip.h one to one
 SIGNATURES = {
     'tmae_abi_version': (I, []),
+    'tmae_abi_hash': (I, []),
     'tmae_voxelize_workspace': (Z, [L, I, I, I, I]),
     'tmae_voxelize': (I, [P, I, L, I, F, F, F, F, F, F, I, I, I, P, P, P, P, P, P, Z, P]),
     'tmae_segment_csr_workspace': (Z, [L, L]),
@@ -107,15 +108,39 @@ if not os.path.exists(LIB_PATH):
         f'{LIB_PATH} not found: build the HIP extension first (python t-mae_amd/build.py, or '
         f'__graft_entry__.build()).  tmae_amd has no CPU / eager fallback.')
 
+def _strict(fn, name, nargs):
+    """ctypes checks a cdecl call for TOO FEW arguments only; extra ones are passed on as 32-bit ints (a truncated pointer or
+    stream handle).  Every entry point is therefore called through this arity check."""
+    def call(*args):
+        if len(args) != nargs:
+            raise TypeError(f'{name} takes {nargs} arguments ({len(args)} given)')
+        return fn(*args)
+    call.__name__ = name
+    call.raw = fn
+    return call
+
+
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header and library out of sync
     _fn.restype = _res
     _fn.argtypes = _args
+    setattr(lib, _name, _strict(_fn, _name, len(_args)))
 
-ABI_VERSION = 6
+ABI_VERSION = 7            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
 if lib.tmae_abi_version() != ABI_VERSION:
-    raise ImportError('libtmae_hip.so ABI version mismatch; rebuild with t-mae_amd/build.py')
+    raise ImportError(f'libtmae_hip.so ABI version {lib.tmae_abi_version()} != binding {ABI_VERSION}; rebuild with '
+                      f't-mae_amd/build.py')
+
+# signature fingerprint: the library carries the hash of the header it was compiled against, the table above yields the same
+# canonical text (tmae_amd/_abi.py) -- any disagreement in a function's argument count, order or width ends the import here
+from . import _abi  # noqa: E402
+_CODE = {P: 'P', I: 'I', L: 'L', F: 'F', D: 'D', Z: 'Z'}
+ABI_HASH = _abi.fnv1a31(_abi.canonical({n: (_CODE[r], [_CODE[a] for a in args]) for n, (r, args) in SIGNATURES.items()}))
+if lib.tmae_abi_hash() != ABI_HASH:
+    raise ImportError(f'libtmae_hip.so was built from a header whose prototypes differ from the ctypes table of {__file__} '
+                      f'(fingerprint {lib.tmae_abi_hash()} != {ABI_HASH}): rebuild with t-mae_amd/build.py, and if that does '
+                      f'not help compare SIGNATURES with include/tmae_hip.h (tests/test_abi_and_host.py names the function)')
 
 
 class TmaeHipError(RuntimeError):

@@ -28,6 +28,32 @@ def test_library_exports_every_declared_symbol():
     assert lib.tmae_abi_version() == _lib.ABI_VERSION
 
 
+def test_binding_table_matches_header_prototypes():
+    """Every row of _lib.SIGNATURES against its prototype in include/tmae_hip.h: argument COUNT, ORDER and type class (pointer /
+    int / int64 / size_t / float / double), and the return class.  The same canonical text, hashed, is what the library carries
+    from its build (tmae_abi_hash) and what _lib recomputes from the table at import: a stale .so or a wrong row stops the import.
+    (round 4: a host segfault inside a brand-new entry point, gpurun_out/r5u_tests.log; nothing checked rows then.)"""
+    from tmae_amd import _abi, _lib
+    hdr = _abi.header_signatures(open(os.path.join(ROOT, 'include', 'tmae_hip.h')).read())
+    code = {_lib.P: 'P', _lib.I: 'I', _lib.L: 'L', _lib.F: 'F', _lib.D: 'D', _lib.Z: 'Z'}
+    for name, (res, args) in sorted(_lib.SIGNATURES.items()):
+        assert name in hdr, name
+        assert (code[res], [code[a] for a in args]) == hdr[name], (name, code[res], ''.join(code[a] for a in args), hdr[name])
+    assert _abi.header_hash(open(os.path.join(ROOT, 'include', 'tmae_hip.h')).read()) == _lib.ABI_HASH == _lib.lib.tmae_abi_hash()
+    m = re.search(r'#define\s+TMAE_ABI_VERSION\s+(\d+)', open(os.path.join(ROOT, 'include', 'tmae_hip.h')).read())
+    assert int(m.group(1)) == _lib.ABI_VERSION
+
+
+def test_entry_points_refuse_a_wrong_argument_count():
+    """ctypes lets a cdecl call carry EXTRA arguments (converted to 32-bit ints): the binding's wrappers do not."""
+    from tmae_amd import _lib
+    with pytest.raises(TypeError, match='takes 0 arguments'):
+        _lib.lib.tmae_abi_version(1)
+    with pytest.raises(TypeError, match='takes 5 arguments'):
+        _lib.lib.tmae_voxelize_workspace(1, 2, 3, 4, 5, 6)
+    assert _lib.lib.tmae_voxelize_workspace(1000, 1, 8, 8, 1) > 0
+
+
 def test_ops_refuse_cpu_tensors():
     from tmae_amd import ops
     with pytest.raises(RuntimeError, match='GPU only'):
@@ -43,6 +69,17 @@ def test_product_does_not_import_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(d, f)).read()
                 assert 'tmae_oracle' not in src and 'ref_import' not in src, os.path.join(d, f)
+
+
+def test_shipped_yamls_parse_equal_to_the_reference():
+    """All three config files on the path -- the base dataset YAML included -- against fixture C1 (the reference's files through
+    yaml.safe_load, oracle/gen_golden_configs.py): every key and value equal."""
+    import json
+    import yaml
+    want = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'C1_configs.json')))
+    for rel, ref in want.items():
+        got = yaml.safe_load(open(os.path.join(ROOT, 't-mae_amd', 'tools', 'cfgs', rel)))
+        assert json.loads(json.dumps(got)) == ref, rel
 
 
 def test_config_api():

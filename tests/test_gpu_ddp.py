@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT
+from conftest import ROOT, fl
 
 pytestmark = pytest.mark.gpu
 
@@ -51,7 +51,7 @@ def _worker(rank, world, port, q, shipped=False):
     wl = [torch.zeros_like(wts) for _ in range(world)]
     dist.all_gather(gl, g)
     dist.all_gather(wl, wts)
-    q.put((rank, float(loss), bool(torch.equal(gl[0], gl[1])), bool(torch.equal(wl[0], wl[1])),
+    q.put((rank, fl(loss), bool(torch.equal(gl[0], gl[1])), bool(torch.equal(wl[0], wl[1])),
            bool(torch.isfinite(g).all()), float(g.norm())))
     dist.destroy_process_group()
 
@@ -105,7 +105,7 @@ def _rccl_worker(port, q):
         losses = []
         for it in range(2):
             loss, _, _ = train_one_step(net, opt, sch, dict(batch), it, model_fn_decorator(), amp_dtype=torch.bfloat16)
-            losses.append(float(loss))
+            losses.append(fl(loss))
         wts = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
         out.append((losses, wts))
     t = torch.ones(1024, device=dev)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import build_finetune_model, golden
+from conftest import build_finetune_model, golden, fl
 
 pytestmark = pytest.mark.gpu
 
@@ -65,7 +65,7 @@ def test_focal_loss_golden():
     heat = cu(_dense_heat(g1))
     loss = ops.focal_loss_centernet(logits, heat)
     loss.backward()
-    assert abs(float(loss) - float(g2['focal'])) <= 2e-5 * abs(float(g2['focal']))
+    assert abs(fl(loss) - float(g2['focal'])) <= 2e-5 * abs(float(g2['focal']))
     # d loss / d p = d loss / d logits / (p (1 - p))
     gp = (logits.grad.cpu() / (p * (1 - p))).flatten()[torch.from_numpy(g2['grad_probe_index'])].numpy()
     np.testing.assert_allclose(gp, g2['grad_probe_hm'], rtol=2e-4, atol=2e-8)
@@ -93,7 +93,7 @@ def test_finetune_e2e_golden_and_oracle(oracle, ft_oracle):
     ret, tb, _ = model(bd)
     ret['loss'].backward()
     ref = float(g['loss'])
-    assert abs(float(ret['loss']) - ref) <= 1e-4 * max(1.0, abs(ref)), (float(ret['loss']), ref)
+    assert abs(fl(ret['loss']) - ref) <= 1e-4 * max(1.0, abs(ref)), (fl(ret['loss']), ref)
     assert abs(float(tb['hm_loss_head_0']) - float(g['hm_loss'])) <= 1e-4 * max(1.0, float(g['hm_loss']))
     assert abs(float(tb['loc_loss_head_0']) - float(g['loc_loss'])) <= 1e-4 * max(1.0, float(g['loc_loss']))
     sf = bd['spatial_features_2d'].detach().double()
@@ -131,7 +131,7 @@ def test_finetune_gradients_vs_float64_oracle(ft_oracle):
           'gt_boxes': cu(g['gt_boxes'])}
     ret, _, _ = model(bd)
     ret['loss'].backward()
-    assert abs(float(ret['loss']) - float(d['loss64'])) <= 3 * abs(float(d['loss32']) - float(d['loss64'])) + 1e-4
+    assert abs(fl(ret['loss']) - float(d['loss64'])) <= 3 * abs(float(d['loss32']) - float(d['loss64'])) + 1e-4
     grads = dict(model.named_parameters())
     p64, p32 = d['proj64'], d['proj32']
     scale = float(np.median(p64[:, 0]))
@@ -396,7 +396,7 @@ def test_iou_head_loss_vs_reference():
     ref = dict(zip((str(k) for k in g['tb_names']), g['tb_values']))
     for k, v in ref.items():
         assert abs(float(tb[k]) - v) <= 2e-4 * max(1.0, abs(v)), (k, float(tb[k]), v)
-    assert abs(float(loss) - float(g['loss'])) <= 2e-4 * float(g['loss'])
+    assert abs(fl(loss) - float(g['loss'])) <= 2e-4 * float(g['loss'])
     grads = dict(head.named_parameters())
     for n, gn in zip(g['grad_names'], g['grad_norms']):
         assert abs(float(grads[str(n)].grad.norm()) - gn) <= 2e-2 * max(1.0, gn), (n, float(grads[str(n)].grad.norm()), gn)

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import build_product_model, golden
+from conftest import build_product_model, golden, fl
 
 pytestmark = pytest.mark.gpu
 
@@ -162,7 +162,7 @@ def test_group_points_and_chamfer(oracle):
     po = pred.clone().requires_grad_(True)
     lo = oracle.chamfer_distance(po, gt_ref, w)
     lo.backward()
-    assert abs(float(loss) - float(lo)) < 1e-5                               # north-star: Chamfer within 1e-4
+    assert abs(fl(loss) - fl(lo)) < 1e-5                               # north-star: Chamfer within 1e-4
     np.testing.assert_allclose(pg.grad.cpu().numpy(), po.grad.numpy(), atol=1e-7)
     z, _ = ops.chamfer_distance(pg.detach(), gt, weights=torch.zeros(m, device=dev()))
     assert float(z) == 0.0
@@ -1213,7 +1213,7 @@ def test_e2e_golden_and_oracle(oracle, name, nst):
     model, _, _ = build_product_model(nst, params=P, device=dev())
     model.train()
     loss, bd = _run_product(model, g['points'], g['points_prev'], g['noise'], bs)
-    assert abs(float(loss) - float(g['loss'])) < 1e-4, (float(loss), float(g['loss']))   # north-star bar
+    assert abs(fl(loss) - float(g['loss'])) < 1e-4, (fl(loss), float(g['loss']))   # north-star bar
     assert np.array_equal(bd['voxel_mae_mask'].cpu().numpy(), g['mask'])
     assert np.array_equal(bd['voxel_coords'].cpu().numpy(), g['voxel_coords'])
     pred = model.backbone_3d.forward_ret_dict['pred_points']
@@ -1235,7 +1235,7 @@ def test_e2e_golden_and_oracle(oracle, name, nst):
     Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     lo = oracle.forward_loss(Pg, g['points'], g['points_prev'], g['noise'], bs, cfg)
     lo.backward()
-    assert abs(float(lo) - float(loss)) < 1e-4
+    assert abs(fl(lo) - fl(loss)) < 1e-4
     for n in names:
         a, b = grads[n].grad.cpu(), Pg[n].grad
         assert (a - b).abs().max().item() <= 5e-3 * max(1.0, b.abs().max().item()), n
@@ -1254,7 +1254,7 @@ def test_pair_encode_equals_two_encoder_calls(oracle):
         model.train()
         model.backbone_3d.pair_encode = pair
         loss, bd = _run_product(model, g['points'], g['points_prev'], g['noise'], bs)
-        res.append((float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None},
+        res.append((fl(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None},
                     {n: b.clone() for n, b in model.named_buffers() if 'running' in n or 'num_batches' in n}))
     assert abs(res[0][0] - res[1][0]) < 2e-6
     assert res[0][1].keys() == res[1][1].keys()
@@ -1289,7 +1289,7 @@ def test_e2e_waymo_shape_config(oracle):
     cap = {}
     lo = oracle.forward_loss(Pg, pts, prv, noise, 2, cfg, cap)
     lo.backward()
-    assert abs(float(lo) - float(loss)) < 1e-4, (float(lo), float(loss))
+    assert abs(fl(lo) - fl(loss)) < 1e-4, (fl(lo), fl(loss))
     assert np.array_equal(bd['voxel_mae_mask'].cpu().numpy(), cap['mask'])
     assert np.array_equal(bd['voxel_coords'].cpu().numpy(), cap['vfe_cur']['voxel_coords'])
     grads = dict(model.named_parameters())
@@ -1313,10 +1313,10 @@ def test_e2e_bf16_autocast_close_to_fp32(oracle):
         l32, _ = _run_product(model, g['points'], g['points_prev'], g['noise'], int(g['batch_size']))
         assert torch.isfinite(loss)
         if bar is not None:
-            assert abs(float(loss) - float(l32)) < bar, (float(loss), float(l32))
-            assert abs(float(loss) - float(g['loss'])) < bar, (float(loss), float(g['loss']))
+            assert abs(fl(loss) - fl(l32)) < bar, (fl(loss), fl(l32))
+            assert abs(fl(loss) - float(g['loss'])) < bar, (fl(loss), float(g['loss']))
         else:
-            assert abs(float(loss) - float(l32)) < 0.01 * max(1.0, abs(float(l32))), (float(loss), float(l32))
+            assert abs(fl(loss) - fl(l32)) < 0.01 * max(1.0, abs(fl(l32))), (fl(loss), fl(l32))
         assert all(torch.isfinite(v).all() for v in g16.values())
         # gradient direction of the big tensors survives bf16 (cosine against the fp32 gradient)
         for n, p in model.named_parameters():
@@ -1411,7 +1411,7 @@ def test_e2e_full_size_120k_vs_oracle(oracle):
     cap = {}
     lo = oracle.forward_loss(Pg, pts, prv, noise, 1, cfg, cap)
     lo.backward()
-    assert abs(float(lo) - float(loss)) < 1e-4, (float(lo), float(loss))
+    assert abs(fl(lo) - fl(loss)) < 1e-4, (fl(lo), fl(loss))
     assert np.array_equal(bd['voxel_mae_mask'].cpu().numpy(), cap['mask'])
     assert np.array_equal(bd['voxel_coords'].cpu().numpy(), cap['vfe_cur']['voxel_coords'])
     feats = bd['multi_scale_3d_features']
@@ -1426,7 +1426,7 @@ def test_e2e_full_size_120k_vs_oracle(oracle):
         assert (a - b).abs().max().item() <= 5e-3 * max(1.0, b.abs().max().item()), n
     # --- bf16 autocast on the same pair (the benched dtype)
     l16, _ = _run_product(model, pts, prv, noise, 1, amp=True)
-    assert abs(float(l16) - float(lo)) < 3e-3, (float(l16), float(lo))
+    assert abs(float(l16) - fl(lo)) < 3e-3, (float(l16), fl(lo))
     # ... and its gradients (the position-folded in-projections run here: > 8192 tokens per stage): in-projection weights
     # incl. their position part, an FFN weight, a sparse conv and the decoder conv against the oracle's fp32 gradients.
     # The bar is what bf16 activations allow on ONE frame pair -- these gradients are sums of ~1e5 cancelling rows:
@@ -1458,8 +1458,8 @@ def test_e2e_full_size_120k_vs_oracle(oracle):
             torch.set_num_threads(nthr)
     spread = abs(l_one - l_all)
     bar = max(3 * spread, 1e-4)
-    assert min(abs(float(ret['loss']) - l_all), abs(float(ret['loss']) - l_one)) <= bar, \
-        (float(ret['loss']), l_all, l_one, spread)
+    assert min(abs(fl(ret['loss']) - l_all), abs(fl(ret['loss']) - l_one)) <= bar, \
+        (fl(ret['loss']), l_all, l_one, spread)
 
 
 def test_full_size_properties(oracle):
@@ -1601,7 +1601,7 @@ def test_e2e_token_dropping_vs_reference(oracle):
     model = model.to(dev()).train()
     assert all(b.can_drop for b in model.backbone_3d.sst_blocks) and all(b.can_drop for b in model.backbone_3d.wca_blocks)
     loss, bd = _run_product(model, g['points'], g['points_prev'], g['noise'], bs)
-    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-4, (float(loss.detach()), float(g['loss']))
+    assert abs(fl(loss) - float(g['loss'])) < 1e-4, (fl(loss), float(g['loss']))
     assert np.array_equal(bd['voxel_mae_mask'].cpu().numpy(), g['mask'])
     pred = model.backbone_3d.forward_ret_dict['pred_points']
     np.testing.assert_allclose(pred.detach().cpu().numpy(), g['pred_points'], atol=2e-3)

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from conftest import build_finetune_model, build_product_model, golden, load_cfg
+from conftest import build_finetune_model, build_product_model, golden, load_cfg, fl
 
 
 # the fixture's tiny model (oracle/gen_golden_optim.py), restated
@@ -343,7 +343,7 @@ def test_reference_checkpoint_forward_on_gpu(tmp_path, spconv1):
     bd = {'points': torch.from_numpy(g['points']).to(dev), 'points_prev': torch.from_numpy(g['points_prev']).to(dev),
           'batch_size': 2, 'mae_noise': torch.from_numpy(g['noise']).to(dev)}
     ret, _, _ = model(bd)
-    assert abs(float(ret['loss']) - float(g['loss'])) < 1e-4, (float(ret['loss']), float(g['loss']))
+    assert abs(fl(ret['loss']) - float(g['loss'])) < 1e-4, (fl(ret['loss']), float(g['loss']))
 
 
 @pytest.mark.gpu
@@ -369,7 +369,7 @@ def test_two_training_steps_follow_the_reference_loop():
               'points_prev': torch.from_numpy(g[f'b{it}_points_prev']).to(dev),
               'mae_noise': torch.from_numpy(g[f'b{it}_noise']).to(dev)}
         loss, _, _ = train_one_step(model, opt, sched, bd, it, model_fn_decorator(), amp_dtype=None)
-        assert abs(float(loss) - float(g['step_losses'][it])) < 1e-4, (it, float(loss), float(g['step_losses'][it]))
+        assert abs(fl(loss) - float(g['step_losses'][it])) < 1e-4, (it, fl(loss), float(g['step_losses'][it]))
     sd = model.state_dict()
     init = {str(n): torch.from_numpy(np.array(g[f'init_{i}'])) for i, n in enumerate(g['state_names'])}
     cosines, moved = {}, set(str(n) for n in g['group0']) | set(str(n) for n in g['group1'])

@@ -4,7 +4,7 @@ oracle/gen_golden_finetune.py)."""
 import numpy as np
 import torch
 
-from conftest import golden
+from conftest import golden, fl
 
 
 def _dense_heat(g):
@@ -53,9 +53,9 @@ def test_g3_finetune_e2e(ft_oracle):
     cap = {}
     loss = ft_oracle.finetune_loss(P, g['points'], g['points_prev'], g['gt_boxes'], int(g['batch_size']), cfg, cap)
     loss.backward()
-    assert abs(float(loss) - float(g['loss'])) <= 2e-5 * max(1.0, abs(float(g['loss'])))
-    assert abs(float(cap['parts']['hm_loss_head_0']) - float(g['hm_loss'])) <= 2e-5 * max(1.0, float(g['hm_loss']))
-    assert abs(float(cap['parts']['loc_loss_head_0']) - float(g['loc_loss'])) <= 2e-5 * max(1.0, float(g['loc_loss']))
+    assert abs(fl(loss) - float(g['loss'])) <= 2e-5 * max(1.0, abs(float(g['loss'])))
+    assert abs(fl(cap['parts']['hm_loss_head_0']) - float(g['hm_loss'])) <= 2e-5 * max(1.0, float(g['hm_loss']))
+    assert abs(fl(cap['parts']['loc_loss_head_0']) - float(g['loc_loss'])) <= 2e-5 * max(1.0, float(g['loc_loss']))
     for n, gn in zip(g['grad_names'], g['grad_norms']):
         assert abs(float(P[str(n)].grad.norm()) - gn) <= 3e-3 * max(1.0, gn), n
 
