@@ -406,6 +406,7 @@ def test_attention_mfma_bf16_fwd_bwd_vs_fp32_kernel(seed):
         return cu(c, torch.int32)
 
     def rel(a, b):
+        a, b = a.detach(), b.detach()
         return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
 
     for d, H, tauv, cross in ((128, 8, 0.3, False), (256, 8, 1.0, False), (256, 8, 0.05, True), (128, 8, 0.005, True)):
