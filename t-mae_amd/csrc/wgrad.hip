@@ -33,6 +33,28 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds_ptr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)lds_ptr);
 }
 
+// Row loads of the token-list (non-gathered) operands: BUFFER loads with a workgroup-uniform descriptor over the workgroup's own
+// rows, a per-lane byte offset that never changes (row-in-slice x pitch + column) and the slice's offset as the SCALAR operand.
+// Rounds 1-4 used flat loads from clamped 64-bit addresses computed per slice; the register allocator put those address
+// temporaries into the destination registers of the loads still in flight for the OTHER parity, and the write-after-write
+// hazard became `s_waitcnt vmcnt(1)`, `vmcnt(0)` at the top of every second step: "two slices in flight" was one (this is the
+// 4.1 TB/s of the 256-tile kernel).  Here a step's loads need no VALU work at all, rows past the workgroup's range and columns
+// past N / K return zeros from the descriptor's range check (no clamps, no selects when the registers are staged into LDS).
+#define WG_OOB 0x7FFFFFF0u          // per-lane offset past every buffer (pitch x rows < 2^31, checked by the launcher)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// the cell bytes of a lane's 8 tokens: same addressing (fixed per-lane offset 8 g, the slice's offset as the scalar operand)
+__device__ __forceinline__ uint2 wg_load_cells(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0));
+  return make_uint2(v[0], v[1]);
+}
+template <bool NT>
+__device__ __forceinline__ u32x4 wg_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, NT ? 2 : 0));
+}
+
 // fragment (8 consecutive tokens 8g..8g+7 for column cb*16 + (lane&15)) of a [32][128] image
 __device__ __forceinline__ bf16x8 load_frag(const char* img, int cb, int lane) {
   const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
@@ -56,6 +78,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
                                                    const int32_t* __restrict__ nbr, int cin,
                                                    const uint8_t* __restrict__ cells, int pos_n) {
   __shared__ __attribute__((aligned(16))) char lds[2][2][WG_MS * 256];
+  __shared__ uint2 ldsC[2][4];         // CL: the slice's 32 cell bytes, staged with the rows (8 bytes per lane group g)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w >> 1, wk = w & 1;
   // XCD-aware 1-D grid: block ids are dealt round-robin over the 8 XCDs (speed only, never correctness), so all
   // (n, k) output blocks of one token chunk s get ids of the same residue: they stream the same dY / X rows at the
@@ -69,9 +92,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
   const int64_t m_begin = (int64_t)s * rows_per_split;
   const int64_t m_end = min(M, m_begin + (int64_t)rows_per_split);
   const int steps = m_end > m_begin ? (int)((m_end - m_begin + WG_MS - 1) / WG_MS) : 0;
-  const bool want_bias = has_bias && kblk == 0 && wk == 0;     // wave-uniform
-  const bool cell_wave = CL && kblk == 0 && wk == 0;           // writes the cell block of its rows (zeros if n0 >= pos_n)
+  // bias and per-cell sums: the four row tiles of a wave row (wn) are shared out over its two waves -- wave wk takes the tiles
+  // {2 wk, 2 wk + 1} -- and are computed UNCONDITIONALLY (a branch inside the step makes the compiler drain vmcnt at its join):
+  // wave wk walks the row tiles in the order a ^ 2 wk, so its two tiles are a = 0, 1 (literal register indices).  Results
+  // nobody wants (no bias, k-blocks > 0, rows past pos_n) are simply not stored / multiplied by an all-zero one-hot operand.
+  const bool want_bias = !G && has_bias && kblk == 0;          // workgroup-uniform
+  const bool cell_wave = CL && kblk == 0;                      // writes the cell block of its rows (zeros if n0 >= pos_n)
   const bool want_cells = cell_wave && n0 < pos_n;
+  const int rot = G ? 0 : 2 * wk;                              // row tile of accumulator a: a ^ rot
   // gathered X (sparse conv): column block k0 lies inside tap k0 / cin; row m reads feature row nbr[m, tap]
   const int tap = G ? k0 / cin : 0, c0 = G ? k0 % cin : k0;
   float* __restrict__ slab_w = slab + (int64_t)s * count;
@@ -90,8 +118,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
   int xi[2][2] = {{0, 0}, {0, 0}};     // gathered mode: feature-row ids, fetched one slice before their row loads so
                                        // the row loads never wait on an index load (no dependent round trip)
   uint2 c8[2] = {{0u, 0u}, {0u, 0u}};  // CL: cell bytes of the lane's 8 tokens (8g .. 8g+7 of the slice)
-  const uint8_t* __restrict__ baseC = CL ? cells + m_begin + 8 * (lane >> 4) : nullptr;
-  const int rows_here = (int)(m_end - m_begin);
+  // (the cells buffer is padded to round_up(M, 32) + 64 bytes: slices up to one past the end are staged)
+  const __amdgpu_buffer_rsrc_t rsC = wg_rsrc(CL ? cells + m_begin : nullptr, 0x7FFFFFFFu);
+  const unsigned voc = 8u * (unsigned)(lane >> 4);
+  const int rows_here = max((int)(m_end - m_begin), 0);
   const char* __restrict__ baseY = reinterpret_cast<const char*>(dY + m_begin * ldy);
   const char* __restrict__ baseX = reinterpret_cast<const char*>(G ? X : X + m_begin * ldx);
   const int32_t* __restrict__ baseI = G ? nbr + m_begin * 9 + tap : nullptr;
@@ -105,44 +135,67 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
       }
     }
   };
-  auto gload = [&](int step, int P) {
-    if constexpr (CL) {                 // (slices up to one past the end are staged: the cells buffer is padded for that)
-      if (want_cells) c8[P] = *reinterpret_cast<const uint2*>(baseC + (unsigned)step * WG_MS);
-    }
+  // non-gathered operands: buffer loads (see wg_load): per-lane offsets of the thread's two chunks, fixed for the whole kernel
+  const __amdgpu_buffer_rsrc_t rsY = wg_rsrc(baseY, (unsigned)rows_here * pitchY);
+  const __amdgpu_buffer_rsrc_t rsX = wg_rsrc(baseX, G ? 0u : (unsigned)rows_here * pitchX);
+  unsigned voy[2], vox[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
-      const int r = step * WG_MS + row, rc = min(r, rows_here - 1);
-      const int cy = n0 + ch * 8, cx = k0 + ch * 8;
-      oky[P][i] = r < rows_here && cy < N;
-      ry[P][i] = *reinterpret_cast<const u32x4*>(baseY + ((unsigned)rc * pitchY + (unsigned)(cy < N ? cy : 0) * 2u));
-      const unsigned xc = (unsigned)(cx < K ? c0 + ch * 8 : 0) * 2u;
-      if constexpr (G) {
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+    const int cy = n0 + ch * 8, cx = k0 + ch * 8;
+    voy[i] = cy < N ? (unsigned)row * pitchY + (unsigned)cy * 2u : WG_OOB;
+    vox[i] = cx < K ? (unsigned)row * pitchX + (unsigned)(c0 + ch * 8) * 2u : WG_OOB;
+  }
+  auto gload = [&](int step, int P) {
+    // (slices up to one past the end are staged: the cells buffer is padded for that)
+    if constexpr (CL) c8[P] = wg_load_cells(rsC, voc, (unsigned)step * WG_MS);
+    if constexpr (!G) {
+      const unsigned soy = (unsigned)step * (WG_MS * pitchY), sox = (unsigned)step * (WG_MS * pitchX);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ry[P][i] = wg_load<false>(rsY, voy[i], soy);
+        rx[P][i] = wg_load<false>(rsX, vox[i], sox);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+        const int r = step * WG_MS + row, rc = min(r, rows_here - 1);
+        const int cy = n0 + ch * 8, cx = k0 + ch * 8;
+        oky[P][i] = r < rows_here && cy < N;
+        ry[P][i] = *reinterpret_cast<const u32x4*>(baseY + ((unsigned)rc * pitchY + (unsigned)(cy < N ? cy : 0) * 2u));
+        const unsigned xc = (unsigned)(cx < K ? c0 + ch * 8 : 0) * 2u;
         const int xr = xi[P][i];
         okx[P][i] = r < rows_here && cx < K && xr >= 0;
         rx[P][i] = *reinterpret_cast<const u32x4*>(baseX + ((int64_t)max(xr, 0) * pitchX + xc));
-      } else {
-        okx[P][i] = r < rows_here && cx < K;
-        rx[P][i] = *reinterpret_cast<const u32x4*>(baseX + ((unsigned)rc * pitchX + xc));
       }
     }
   };
   auto lwrite = [&](int buf, int P) {
     const u32x4 z = {0u, 0u, 0u, 0u};
+    // the cell bytes travel like the rows: registers two slices ahead, LDS one slice ahead, read at use.  (Read from the
+    // registers at the top of the step, the compiler waited there for loads of the PREVIOUS step: its count at the loop header)
+    if constexpr (CL) { if (w == 0 && (lane & 15) == 0) ldsC[buf][lane >> 4] = c8[P]; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
-      *reinterpret_cast<u32x4*>(&lds[buf][0][tile_off(row, ch)]) = oky[P][i] ? ry[P][i] : z;
-      *reinterpret_cast<u32x4*>(&lds[buf][1][tile_off(row, ch)]) = okx[P][i] ? rx[P][i] : z;
+      if constexpr (!G) {
+        *reinterpret_cast<u32x4*>(&lds[buf][0][tile_off(row, ch)]) = ry[P][i];
+        *reinterpret_cast<u32x4*>(&lds[buf][1][tile_off(row, ch)]) = rx[P][i];
+      } else {
+        *reinterpret_cast<u32x4*>(&lds[buf][0][tile_off(row, ch)]) = oky[P][i] ? ry[P][i] : z;
+        *reinterpret_cast<u32x4*>(&lds[buf][1][tile_off(row, ch)]) = okx[P][i] ? rx[P][i] : z;
+      }
     }
   };
 
-  f32x4 acc[4][4], accb[4], accs[CL ? 4 : 1];
+  f32x4 acc[4][4], accb[2], accs[CL ? 2 : 1];
 #pragma unroll
-  for (int a = 0; a < (CL ? 4 : 1); ++a) accs[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < (CL ? 2 : 1); ++a) accs[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 2; ++a) accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -161,43 +214,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
   auto step = [&](int st, int P) {      // P == st & 1, a literal at both call sites
     // no branches around the loads / LDS writes (slices past the end read clamped rows and stage zeros): the
     // compiler's wait-count bookkeeping turns conservative (vmcnt(0)) at every control-flow join
-    const uint2 ccur = c8[P]; // CL: this slice's cell bytes, before the register set is refilled
     iload(st + 3, P ^ 1);     // index loads first: vmcnt retires in order, and the next step's row
     gload(st + 2, P);         // loads must be able to wait for the ids without draining these
     __builtin_amdgcn_sched_barrier(0);   // keep the loads up here and their consumers below the MFMAs: left alone, the
                                          // scheduler sinks the loads and hoists the waits to shorten live ranges
+    uint2 ccur = {0u, 0u};
+    if constexpr (CL) ccur = ldsC[P][lane >> 4];
     bf16x8 fa[4], fb[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      fa[t] = load_frag(lds[P][0], wn * 4 + t, lane);
+      fa[t] = load_frag(lds[P][0], wn * 4 + (t ^ rot), lane);
       fb[t] = load_frag(lds[P][1], wk * 4 + t, lane);
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
-    if (want_bias) {
+    if constexpr (!G) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
+      for (int a = 0; a < 2; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], ones, accb[a], 0, 0, 0);
     }
     if constexpr (CL) {
-      if (want_cells) {
-        // one-hot B fragment of THIS slice (its cell bytes were loaded two steps ago with the rows): column lane & 15
-        // = cell slot (0..7 xc, 8..15 yc), the lane's 8 tokens 8g .. 8g+7
-        const int ci_ = lane & 15;
-        const unsigned want_ = (unsigned)(ci_ & 7), sh_ = ci_ < 8 ? 0u : 3u;
-        unsigned wds[4];
+      // one-hot B fragment of THIS slice (its cell bytes were loaded two steps ago with the rows): column lane & 15
+      // = cell slot (0..7 xc, 8..15 yc), the lane's 8 tokens 8g .. 8g+7; a workgroup past the position columns matches nothing
+      const int ci_ = lane & 15;
+      const unsigned want_ = want_cells ? (unsigned)(ci_ & 7) : 8u, sh_ = ci_ < 8 ? 0u : 3u;
+      unsigned wds[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const unsigned src = j < 2 ? ccur.x : ccur.y;
-          const unsigned ca = (src >> (16 * (j & 1))) & 0xFFu, cb = (src >> (16 * (j & 1) + 8)) & 0xFFu;
-          wds[j] = ((((ca >> sh_) & 7u) == want_) ? 0x00003F80u : 0u) | ((((cb >> sh_) & 7u) == want_) ? 0x3F800000u : 0u);
-        }
-        const u32x4 ohu = {wds[0], wds[1], wds[2], wds[3]};
-        const bf16x8 oh = __builtin_bit_cast(bf16x8, ohu);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) accs[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], oh, accs[a], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        const unsigned src = j < 2 ? ccur.x : ccur.y;
+        const unsigned ca = (src >> (16 * (j & 1))) & 0xFFu, cb = (src >> (16 * (j & 1) + 8)) & 0xFFu;
+        wds[j] = ((((ca >> sh_) & 7u) == want_) ? 0x00003F80u : 0u) | ((((cb >> sh_) & 7u) == want_) ? 0x3F800000u : 0u);
       }
+      const u32x4 ohu = {wds[0], wds[1], wds[2], wds[3]};
+      const bf16x8 oh = __builtin_bit_cast(bf16x8, ohu);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) accs[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], oh, accs[a], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     lwrite(P ^ 1, P ^ 1);
@@ -213,15 +265,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
   for (int a = 0; a < 4; ++a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = n0 + (wn * 4 + a) * 16 + 4 * g + r;
+      const int n = n0 + (wn * 4 + (a ^ rot)) * 16 + 4 * g + r;
       if (n >= N) continue;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int k = k0 + (wk * 4 + b) * 16 + ci;
         if (k < K) slab_w[(int64_t)n * K + k] = acc[a][b][r];
       }
-      if (want_bias && ci == 0) slab_b[n] = accb[a][r];
-      if constexpr (CL) { if (cell_wave) slab_c[(int64_t)ci * N + n] = accs[a][r]; }
+      if (a < 2) {
+        if (want_bias && ci == 0) slab_b[n] = accb[a][r];
+        if constexpr (CL) { if (cell_wave) slab_c[(int64_t)ci * N + n] = accs[a][r]; }
+      }
     }
   }
 }
@@ -235,19 +289,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __r
 // staged dY chunks (a thread always stages the same 8 columns), not with an extra MFMA: no accumulator registers.
 // ------------------------------------------------------------------------------------------------
 #define WG2_B 256
-// (No per-cell sums here: the kernel has no registers left for a one-hot MFMA, and LDS float atomics from the staged
-// dY chunks -- tried -- made it 12x slower.  The launcher takes them from a second, narrow pass of the 128-tile kernel.)
+// CL (round 5): the per-cell column sums of dY (see wgrad_kernel) inside this kernel too.  Rounds 2-4 took them from a second, narrow
+// pass of the 128-tile kernel over dY ("no registers left for a one-hot MFMA": true for a ninth accumulator column PER WAVE TILE ROW,
+// i.e. 32 registers) -- 24 launches and 1.75 ms per step that only re-read dY.  Here the 8 row tiles of a wave row (wn) are shared out
+// over its four waves: wave wk adds the one-hot product for the tiles {2 wk, 2 wk + 1} only -- 2 MFMAs on top of 32 per step and 8
+// accumulator registers.  To keep every register index a literal without a branch per tile, wave wk walks the row tiles in the
+// order a ^ 2 wk (a bijection on 0..7 that puts ITS two tiles at a = 0, 1); in the swizzled image that rotation is one XOR of the
+// fragment's byte offset with 64 wk.
 // VAR (A/B, csrc/common.h TMAE_AB): 1 = waves 4-7 -- the SIMD partners of waves 0-3 -- stage the next slice into LDS BEFORE their
 // MFMA block instead of after it, so that on every SIMD one wave's LDS stores run beside the other's matrix work
 // (MI355X_MICROARCH.md, "Two waves per SIMD", item 9: partners running the same program in lockstep); 2 = 1 + raised priority
 // around the MFMA block.
-template <bool G, int NTL = 0, int VAR = 0>      // NTL: bit 0 / 1 = dY / X rows are loaded with the non-temporal policy (read by one workgroup only)
+template <bool G, int NTL = 0, int VAR = 0, bool CL = false>      // NTL: bit 0 / 1 = dY / X rows are loaded with the non-temporal policy (read by one workgroup only)
 __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
                                                          const __hip_bfloat16* __restrict__ X, int64_t ldx, int64_t M,
                                                          int N, int K, int rows_per_split, float* __restrict__ slab,
                                                          int64_t count, bool has_bias, int NB, int KB, int S,
-                                                         const int32_t* __restrict__ nbr, int cin) {
+                                                         const int32_t* __restrict__ nbr, int cin,
+                                                         const uint8_t* __restrict__ cells, int pos_n) {
+  static_assert(!(G && CL), "per-cell sums belong to the Linear in-projections, not to the gathered sparse-conv gradient");
   __shared__ __attribute__((aligned(16))) char lds[2][2][2][WG_MS * 256];     // [buffer][operand][column half]
+  __shared__ uint2 ldsC[2][4];         // CL: the slice's 32 cell bytes, staged with the rows (8 bytes per lane group g)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w >> 2, wk = w & 3;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int per_s = NB * KB;
@@ -259,8 +321,12 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
   const int64_t m_end = min(M, m_begin + (int64_t)rows_per_split);
   const int steps = m_end > m_begin ? (int)((m_end - m_begin + WG_MS - 1) / WG_MS) : 0;
   const bool want_bias = has_bias && kblk == 0;                 // workgroup-uniform
+  const bool cell_wg = CL && kblk == 0;                         // writes the cell block of its rows (zeros if n0 >= pos_n)
+  const bool want_cells = cell_wg && n0 < pos_n;
   float* __restrict__ slab_w = slab + (int64_t)s * count;
   float* __restrict__ slab_b = slab_w + (int64_t)N * K;
+  float* __restrict__ slab_c = slab_b + N;                      // [16][N] per-cell sums (CL)
+  const int rot = CL ? 2 * wk : 0;                              // row tile of accumulator a: a ^ rot
   // staging: thread owns 16-byte chunk ch (0..31) of rows r0 and r0 + 16 of both operands
   const int r0 = tid >> 5, ch = tid & 31;
   const int cy = n0 + ch * 8, cx = k0 + ch * 8;
@@ -270,7 +336,11 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
   bool oky[2][2], okx[2][2];
   int xi[2][2] = {{0, 0}, {0, 0}};
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int rows_here = (int)(m_end - m_begin);
+  uint2 c8[2] = {{0u, 0u}, {0u, 0u}};  // CL: cell bytes of the lane's 8 tokens (8g .. 8g+7 of the slice)
+  // (the cells buffer is padded to round_up(M, 32) + 64 bytes: slices up to one past the end are staged)
+  const __amdgpu_buffer_rsrc_t rsC = wg_rsrc(CL ? cells + m_begin : nullptr, 0x7FFFFFFFu);
+  const unsigned voc = 8u * (unsigned)(lane >> 4);
+  const int rows_here = max((int)(m_end - m_begin), 0);
   const unsigned pitchY = (unsigned)ldy * 2u, pitchX = (unsigned)ldx * 2u;
   const char* __restrict__ baseY = reinterpret_cast<const char*>(dY + m_begin * ldy) + (cy < N ? cy : 0) * 2;
   const char* __restrict__ baseX = reinterpret_cast<const char*>(G ? X : X + m_begin * ldx) + (cx < K ? xcol : 0) * 2;
@@ -282,32 +352,49 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
       for (int i = 0; i < 2; ++i) xi[P][i] = baseI[(unsigned)min(step * WG_MS + r0 + 16 * i, rows_here - 1) * 9u];
     }
   };
-  auto gload = [&](int step, int P) {
+  // non-gathered operands: buffer loads (see wg_load): per-lane offsets of the thread's rows r0 and r0 + 16, fixed for the kernel
+  const __amdgpu_buffer_rsrc_t rsY = wg_rsrc(reinterpret_cast<const char*>(dY + m_begin * ldy), (unsigned)rows_here * pitchY);
+  const __amdgpu_buffer_rsrc_t rsX = wg_rsrc(reinterpret_cast<const char*>(X + (G ? 0 : m_begin * ldx)), G ? 0u : (unsigned)rows_here * pitchX);
+  unsigned voy[2], vox[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = step * WG_MS + r0 + 16 * i, rc = min(r, rows_here - 1);
-      oky[P][i] = r < rows_here && coly;
-      if constexpr (NTL & 1) ry[P][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(baseY + (unsigned)rc * pitchY));
-      else ry[P][i] = *reinterpret_cast<const u32x4*>(baseY + (unsigned)rc * pitchY);
-      if constexpr (G) {
+  for (int i = 0; i < 2; ++i) {
+    voy[i] = coly ? (unsigned)(r0 + 16 * i) * pitchY + (unsigned)cy * 2u : WG_OOB;
+    vox[i] = colx ? (unsigned)(r0 + 16 * i) * pitchX + (unsigned)xcol * 2u : WG_OOB;
+  }
+  auto gload = [&](int step, int P) {
+    // (slices up to one past the end are staged: the cells buffer is padded for that.  Unconditional, like every load of this
+    // loop: a branch inside the step makes the compiler drain vmcnt at its join, i.e. wait for the slices meant to stay in flight)
+    if constexpr (CL) c8[P] = wg_load_cells(rsC, voc, (unsigned)step * WG_MS);
+    if constexpr (!G) {
+      const unsigned soy = (unsigned)step * (WG_MS * pitchY), sox = (unsigned)step * (WG_MS * pitchX);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ry[P][i] = wg_load<(NTL & 1) != 0>(rsY, voy[i], soy);
+        rx[P][i] = wg_load<(NTL & 2) != 0>(rsX, vox[i], sox);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = step * WG_MS + r0 + 16 * i, rc = min(r, rows_here - 1);
+        oky[P][i] = r < rows_here && coly;
+        ry[P][i] = *reinterpret_cast<const u32x4*>(baseY + (unsigned)rc * pitchY);
         const int xr = xi[P][i];
         okx[P][i] = r < rows_here && colx && xr >= 0;
         rx[P][i] = *reinterpret_cast<const u32x4*>(baseX + (int64_t)max(xr, 0) * pitchX);
-      } else {
-        okx[P][i] = r < rows_here && colx;
-        if constexpr (NTL & 2) rx[P][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(baseX + (unsigned)rc * pitchX));
-        else rx[P][i] = *reinterpret_cast<const u32x4*>(baseX + (unsigned)rc * pitchX);
       }
     }
   };
   auto lwrite = [&](int buf, int P) {
     const u32x4 z = {0u, 0u, 0u, 0u};
+    // the cell bytes travel like the rows: registers two slices ahead, LDS one slice ahead, read at use.  (Read from the
+    // registers at the top of the step, the compiler waited there for loads of the PREVIOUS step: its count at the loop header)
+    if constexpr (CL) { if (w == 0 && (lane & 15) == 0) ldsC[buf][lane >> 4] = c8[P]; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int off = tile_off(r0 + 16 * i, ch & 15);
-      const u32x4 vy = oky[P][i] ? ry[P][i] : z;
+      const u32x4 vy = G ? (oky[P][i] ? ry[P][i] : z) : ry[P][i];
       *reinterpret_cast<u32x4*>(&lds[buf][0][ch >> 4][off]) = vy;
-      *reinterpret_cast<u32x4*>(&lds[buf][1][ch >> 4][off]) = okx[P][i] ? rx[P][i] : z;
+      *reinterpret_cast<u32x4*>(&lds[buf][1][ch >> 4][off]) = G ? (okx[P][i] ? rx[P][i] : z) : rx[P][i];
       if (want_bias) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -318,7 +405,9 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
     }
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[8][4], accs[CL ? 2 : 1];
+#pragma unroll
+  for (int a = 0; a < (CL ? 2 : 1); ++a) accs[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < 8; ++a)
 #pragma unroll
@@ -345,15 +434,36 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
       lwrite(P ^ 1, P ^ 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    uint2 ccur = {0u, 0u};
+    if constexpr (CL) ccur = ldsC[P][lane >> 4];
     bf16x8 fb[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) fb[t] = load_frag(lds[P][1][wk >> 1], (wk & 1) * 4 + t, lane);
+    bf16x8 oh;
+    if constexpr (CL) {
+      // one-hot B fragment of THIS slice (wgrad_kernel): column lane & 15 = cell slot (0..7 xc, 8..15 yc), the lane's 8 tokens
+      const int ci_ = lane & 15;
+      // a workgroup past the position columns (n0 >= pos_n) matches nothing: its products are zeros, no branch in the loop
+      const unsigned want_ = want_cells ? (unsigned)(ci_ & 7) : 8u, sh_ = ci_ < 8 ? 0u : 3u;
+      unsigned wds[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned src = j < 2 ? ccur.x : ccur.y;
+        const unsigned ca = (src >> (16 * (j & 1))) & 0xFFu, cb = (src >> (16 * (j & 1) + 8)) & 0xFFu;
+        wds[j] = ((((ca >> sh_) & 7u) == want_) ? 0x00003F80u : 0u) | ((((cb >> sh_) & 7u) == want_) ? 0x3F800000u : 0u);
+      }
+      const u32x4 ohu = {wds[0], wds[1], wds[2], wds[3]};
+      oh = __builtin_bit_cast(bf16x8, ohu);
+    }
     if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-      const bf16x8 fa = load_frag(lds[P][0][wn], a, lane);
+      const bf16x8 fa = load_frag(lds[P][0][wn], a ^ rot, lane);
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[b], acc[a][b], 0, 0, 0);
+      if constexpr (CL) {
+        if (a < 2) accs[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, oh, accs[a], 0, 0, 0);
+      }
     }
     if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -369,12 +479,15 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
   for (int a = 0; a < 8; ++a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * 128 + a * 16 + 4 * g + r;
+      const int n = n0 + wn * 128 + (a ^ rot) * 16 + 4 * g + r;
       if (n >= N) continue;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int k = k0 + wk * 64 + b * 16 + ci;
         if (k < K) slab_w[(int64_t)n * K + k] = acc[a][b][r];
+      }
+      if constexpr (CL) {
+        if (a < 2) { if (cell_wg) slab_c[(int64_t)ci * N + n] = accs[a][r]; }
       }
     }
   }
@@ -481,18 +594,6 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
   if (cells && (nbr || !dc || pos_n < 0 || pos_n > n || ldc < n || (((uintptr_t)cells) & 7))) return TMAE_EARG;
   if (m > 0 && (!dy || !x)) return TMAE_EARG;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return TMAE_EARG;
-  if (cells && wgrad_big_tile(n, k)) {
-    // the 256-tile kernel for dW / db, then the per-cell sums from a narrow pass of the 128-tile kernel over the
-    // position columns of dY and the first 8 columns of x (its [pos_n, 8] "weight gradient" goes to scratch)
-    int r = wgrad_launch(dy, ldy, x, ldx, m, n, k, dw, db, nullptr, 0, nullptr, 0, nullptr, 0, wsp, ws_bytes, stream);
-    if (r || pos_n == 0) return r;
-    const int pn = (pos_n + 7) / 8 * 8;
-    const size_t tail = tmae_align((size_t)n * 8 * 4);
-    if (ws_bytes < tail) return TMAE_EWS;
-    float* scratch = reinterpret_cast<float*>(static_cast<char*>(wsp) + (ws_bytes - tail) / 256 * 256);
-    return wgrad_launch(dy, ldy, x, ldx, m, pn, 8, scratch, nullptr, nullptr, 0, cells, pos_n, dc, ldc, wsp,
-                        (ws_bytes - tail) / 256 * 256, stream);
-  }
   int splits, rows;
   wgrad_plan(m, n, k, splits, rows);
   const bool cl = cells != nullptr;
@@ -508,8 +609,11 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
   if (wgrad_big_tile(n, k)) {
     const int NB = (n + WG2_B - 1) / WG2_B, KB = (k + WG2_B - 1) / WG2_B;
     const unsigned nblocks = 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
-    if (nbr) hipLaunchKernelGGL((wgrad256_kernel<true>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
-    else {
+    if (nbr) hipLaunchKernelGGL((wgrad256_kernel<true>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS, cells, pos_n);
+    else if (cl) {                 // per-cell sums inside the 256-tile kernel (dY non-temporal when nobody re-reads it)
+      if (KB == 1) hipLaunchKernelGGL((wgrad256_kernel<false, 1, 0, true>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS, cells, pos_n);
+      else hipLaunchKernelGGL((wgrad256_kernel<false, 0, 0, true>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS, cells, pos_n);
+    } else {
       // dY columns belong to one n-block each: with a single k-block nobody re-reads them; likewise X with one n-block
       // (measured on the priced shape: -3 %; TMAE_WGRAD_NT=0 in a -DTMAE_AB build turns it off)
       static const int ntl_env = TMAE_AB_INT("TMAE_WGRAD_NT", 3);
@@ -517,16 +621,16 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
 #ifdef TMAE_AB
       static const int var = TMAE_AB_INT("TMAE_WGRAD_VAR", 0);
       if (var == 1 || var == 2) {
-#define WG_V(NT_, V_) hipLaunchKernelGGL((wgrad256_kernel<false, NT_, V_>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS)
+#define WG_V(NT_, V_) hipLaunchKernelGGL((wgrad256_kernel<false, NT_, V_>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS, cells, pos_n)
         if (var == 1) { if (ntl == 1) WG_V(1, 1); else if (ntl == 2) WG_V(2, 1); else if (ntl == 3) WG_V(3, 1); else WG_V(0, 1); }
         else { if (ntl == 1) WG_V(1, 2); else if (ntl == 2) WG_V(2, 2); else if (ntl == 3) WG_V(3, 2); else WG_V(0, 2); }
 #undef WG_V
       } else
 #endif
-      if (ntl == 1) hipLaunchKernelGGL((wgrad256_kernel<false, 1>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
-      else if (ntl == 2) hipLaunchKernelGGL((wgrad256_kernel<false, 2>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
-      else if (ntl == 3) hipLaunchKernelGGL((wgrad256_kernel<false, 3>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
-      else hipLaunchKernelGGL((wgrad256_kernel<false, 0>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS);
+      if (ntl == 1) hipLaunchKernelGGL((wgrad256_kernel<false, 1>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS, cells, pos_n);
+      else if (ntl == 2) hipLaunchKernelGGL((wgrad256_kernel<false, 2>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS, cells, pos_n);
+      else if (ntl == 3) hipLaunchKernelGGL((wgrad256_kernel<false, 3>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS, cells, pos_n);
+      else hipLaunchKernelGGL((wgrad256_kernel<false, 0>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS, cells, pos_n);
     }
   } else {
     const int NB = (n + WG_BN - 1) / WG_BN, KB = (k + WG_BK - 1) / WG_BK;

@@ -541,6 +541,32 @@ def test_linear_wgrad_kernel_vs_torch():
     assert (g1[2] - b.grad).abs().max().item() <= 1e-2 * float(b.grad.abs().max())
 
 
+def test_linear_wgrad_cell_sums_both_tile_sizes():
+    """tmae_linear_wgrad_cells: dW, db and the per-cell column sums dcell[c, n] = sum of dy[m, n] over the tokens of cell slot c
+    (0..7 x cell, 8..15 y cell) for n < pos_n, zeros past pos_n -- in ONE pass for the 128-tile kernel and (round 5) for the
+    256-tile kernel, whose four waves of a row share out the one-hot products; ragged token counts, 1-3 row blocks, pos_n below n."""
+    from tmae_amd import ops
+    torch.manual_seed(5)
+    for (m, n, k, pos_n) in ((40001, 512, 256, 512), (131072, 512, 256, 256), (9000, 768, 256, 512), (333, 512, 512, 512),
+                             (50000, 256, 128, 256), (20011, 256, 256, 256), (65, 768, 256, 256)):
+        ind = torch.stack([torch.zeros(m, dtype=torch.int64), torch.randint(0, 468, (m,)), torch.randint(0, 468, (m,))], 1).int().to(dev())
+        cells, onehot = ops.window_cells(ind, [8, 8, 1], True, want_onehot=True)
+        dy = (torch.randn(m, n, device=dev()) * 0.5).bfloat16()
+        x = torch.randn(m, k, device=dev()).bfloat16()
+        dw, db, dcell = ops.linear_wgrad(dy, x, True, cells=cells, pos_n=pos_n)
+        ref_w = dy.float().t() @ x.float()
+        ref_b = dy.float().sum(0)
+        ref_c = onehot.float().t() @ dy.float()
+        ref_c[:, pos_n:] = 0
+        assert (dw - ref_w).abs().max().item() <= 2e-3 * max(1.0, float(ref_w.abs().max())), (m, n, k)
+        assert (db - ref_b).abs().max().item() <= 2e-3 * float(ref_b.abs().max()) + 1e-3, (m, n, k)
+        assert dcell.shape == (16, n)
+        assert (dcell - ref_c).abs().max().item() <= 2e-3 * max(1.0, float(ref_c.abs().max())), (m, n, k, pos_n)
+        assert float(dcell[:, pos_n:].abs().max()) == 0.0 if pos_n < n else True
+        # the x-cell sums and the y-cell sums both add up to the bias gradient
+        assert (dcell[:8, :pos_n].sum(0) - ref_b[:pos_n]).abs().max().item() <= 4e-3 * float(ref_b.abs().max()) + 1e-3
+
+
 def test_token_gemm_kernel_vs_torch():
     """x-stationary token GEMM (csrc/token_gemm.hip) vs fp32 matmul on the same bf16 inputs: forward with bias,
     strided input (column slice of a packed buffer), ragged token counts, and the dX use on W^T."""
