@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 7
+#define TMAE_ABI_VERSION 9
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -135,7 +135,10 @@ int tmae_index_grid(const int32_t* indices, int64_t m, int batch, int ny, int nx
  * levels: n_levels rows {max_tokens, lower, upper}.  Per-voxel outputs [m]:
  *   batch_win_inds_i64, coors_in_win_i64 [m,3] (z,y,x), inner_i32 (stable rank in window),
  *   level_i32, keep_u8, flat2win_i64 (= rank_of_window_in_level*max_tokens + inner; -1 if dropped).
- *   win_per_level [n_levels] device int32 = number of kept windows per level. */
+ *   win_per_level [n_levels] device int32 = number of kept windows per level.
+ * batch_win_inds / coors_in_win / level / keep / flat2win may each be NULL (not wanted).  flat2win and win_per_level both NULL:
+ * the per-level window ranks (one device scan per level) are not computed at all -- the cross-attention blocks, which need
+ * keep_u8 alone (wca_block.py:93-96), run three launches instead of 3 + n_levels. */
 size_t tmae_window_bucket_workspace(int batch, int ny, int nx, int wy, int wx, int n_levels);
 int tmae_window_bucket(const int32_t* indices, int64_t m, const int32_t* grid, const int32_t* grid_other,
                        int batch, int ny, int nx, int wy, int wx, int do_shift,
@@ -287,12 +290,14 @@ int tmae_linear_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, i
  * (tmae_token_gemm_pos): besides dw / db it returns dcell [16, n] f32, the per-cell column sums of dy --
  * dcell[c, j] = sum of dy[i, j] over the tokens i with xc == c (c < 8) / yc == c - 8 (c >= 8), for the output columns
  * j < pos_n (the others are not defined) -- so that dW[:pos_n] += dcell[:, :pos_n]^T . E (E [16,k]: the separable embedding)
- * completes the gradient of (x + pos) W^T (one pass over dy with the 128-tile kernel; for n, k >= 256 the 256-tile
- * kernel plus a narrow second pass over dy[:, :pos_n]).  cells: u8 xc | yc << 3 per token, 8-byte
- * aligned, readable up to round_up(m, 32) + 64 bytes (tmae_window_cells callers pad the buffer).  Same workspace. */
+ * completes the gradient of (x + pos) W^T (ONE pass over dy for both tile sizes: the one-hot products ride on the
+ * weight-gradient kernel's own dy fragments).  pos_e (may be NULL): E [16,k] f32, 16-byte aligned -- the slab reduction then
+ * adds dcell^T . E to dw itself (needs k in {64, 128, 256, 512, ...}: 256 % k == 0 or k % 256 == 0, and n k % 256 == 0;
+ * TMAE_EARG otherwise) and dcell may be NULL.  cells: u8 xc | yc << 3 per token, 8-byte aligned, readable up to
+ * round_up(m, 32) + 64 bytes (tmae_window_cells callers pad the buffer).  Same workspace. */
 int tmae_linear_wgrad_cells(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k,
-                            const uint8_t* cells, int pos_n, float* dw, float* db, float* dcell, void* ws,
-                            size_t ws_bytes, void* stream);
+                            const uint8_t* cells, int pos_n, const float* pos_e, float* dw, float* db, float* dcell,
+                            void* ws, size_t ws_bytes, void* stream);
 
 /* Weight gradient of the 3x3 sparse conv without materialising the gathered [m_out, 9*cin] matrix: the token-split
  * kernel reads row nbr[o,t] of feat [m_in, cin] (bf16) for the column block of tap t.  dw [cout, 9*cin] f32 = the

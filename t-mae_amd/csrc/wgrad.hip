@@ -512,36 +512,70 @@ __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* 
 // db.  (Two launches with the partials in global memory cost a second ~5 us dispatch per weight gradient, 112 per
 // step; a last-arriving-block finish across workgroups needs a device-scope fence per block and measured 2-4x slower.)
 #define WG_RG 16
+// posE (round 5, the in-projections with the position embedding folded into the GEMM): E [16, k] fp32, the separable embedding.
+// The weight gradient of (x + pos) W^T is dY^T x + dcell^T E; rounds 2-4 added the second term with a [n,16] x [16,k] library GEMM
+// per in-projection (24 launches of 6-17 us per step).  Here the workgroup that finishes the weight elements of output row j
+// also sums the 16 per-cell partials of row j over the slabs (one extra 64-byte load per wave and slab) and adds
+// sum_c dcell[c, j] E[c, :] to the row before it is written.  Needs 256 % k == 0 or k % 256 == 0 and n k % 256 == 0 (checked by
+// the launcher): a workgroup's 256 elements then cover whole rows or a piece of one.
 __global__ __launch_bounds__(64 * WG_RG) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits,
                                                                  int64_t count, int n, int k, float* __restrict__ dw,
                                                                  float* __restrict__ db, float* __restrict__ dc,
-                                                                 int ldc) {
+                                                                 int ldc, const float* __restrict__ posE) {
   __shared__ float4 red[WG_RG][64];
+  __shared__ float redc[WG_RG][64], cs[64];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t e = ((int64_t)blockIdx.x * 64 + lane) * 4;
+  const int64_t e0 = (int64_t)blockIdx.x * 256, e = e0 + lane * 4;
+  const int64_t nk = (int64_t)n * k;
+  // the per-cell partials this workgroup needs: lane rr * 16 + c <-> cell slot c of its rr-th row (rows e0 / k ...)
+  const bool pe = posE != nullptr && e0 < nk;                               // workgroup-uniform
+  const int nrows = k >= 256 ? 1 : 256 / k, row0 = (int)(e0 / k);
+  const bool cl_lane = pe && lane < 16 * nrows && row0 + (lane >> 4) < n;
+  const int64_t ce = nk + n + (int64_t)(lane & 15) * n + row0 + (lane >> 4);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float cacc = 0.f;
   if (e < count) {
     for (int s = w; s < splits; s += WG_RG) {
       const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)s * count + e);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
   }
+  if (cl_lane)
+    for (int s = w; s < splits; s += WG_RG) cacc += slab[(int64_t)s * count + ce];
   red[w][lane] = acc;
+  redc[w][lane] = cacc;
   __syncthreads();
-  if (w == 0 && e < count) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (w == 0) {
+    if (pe) {
+      float c = 0.f;
 #pragma unroll
-    for (int y = 0; y < WG_RG; ++y) { const float4 v = red[y][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-    const float tv[4] = {t.x, t.y, t.z, t.w};
-    const int64_t nk = (int64_t)n * k;
+      for (int y = 0; y < WG_RG; ++y) c += redc[y][lane];
+      cs[lane] = c;                                      // same wave reads it below: LDS operations of a wave run in order
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (e < count) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t idx = e + j;
-      if (idx < nk) dw[idx] = tv[j];
-      else if (idx < nk + n) { if (db) db[idx - nk] = tv[j]; }
-      else if (dc && idx < nk + 17 * (int64_t)n) {                             // [16][n] per-cell sums -> pitch ldc
-        const int64_t e2 = idx - nk - n;
-        dc[(e2 / n) * ldc + e2 % n] = tv[j];
+      for (int y = 0; y < WG_RG; ++y) { const float4 v = red[y][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+      if (pe) {
+        const int lr = (lane * 4) / k, kc = (int)((e - (int64_t)(row0 + lr) * k));      // local row, column of the lane's 4 elements
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const float dcv = cs[lr * 16 + c];
+          const float4 ev = *reinterpret_cast<const float4*>(posE + (int64_t)c * k + kc);
+          t.x += dcv * ev.x; t.y += dcv * ev.y; t.z += dcv * ev.z; t.w += dcv * ev.w;
+        }
+      }
+      const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t idx = e + j;
+        if (idx < nk) dw[idx] = tv[j];
+        else if (idx < nk + n) { if (db) db[idx - nk] = tv[j]; }
+        else if (dc && idx < nk + 17 * (int64_t)n) {                             // [16][n] per-cell sums -> pitch ldc
+          const int64_t e2 = idx - nk - n;
+          dc[(e2 / n) * ldc + e2 % n] = tv[j];
+        }
       }
     }
   }
@@ -588,10 +622,12 @@ size_t tmae_linear_wgrad_workspace(int64_t m, int n, int k) {
 
 static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k, float* dw,
                         float* db, const int32_t* nbr, int cin, const uint8_t* cells, int pos_n, float* dc, int ldc,
-                        void* wsp, size_t ws_bytes, hipStream_t stream) {
+                        void* wsp, size_t ws_bytes, hipStream_t stream, const float* posE = nullptr) {
   if (m < 0 || n <= 0 || k <= 0 || !dw || (n % 8) || (k % 8) || (ldy % 8) || (ldx % 8)) return TMAE_EARG;
   if (nbr && (cin <= 0 || cin % WG_BK || k != 9 * cin || (((uintptr_t)nbr) & 3))) return TMAE_EARG;
-  if (cells && (nbr || !dc || pos_n < 0 || pos_n > n || ldc < n || (((uintptr_t)cells) & 7))) return TMAE_EARG;
+  if (cells && (nbr || (!dc && !posE) || pos_n < 0 || pos_n > n || (dc && ldc < n) || (((uintptr_t)cells) & 7))) return TMAE_EARG;
+  if (posE && (!cells || (((uintptr_t)posE) & 15) || !((256 % k) == 0 || (k % 256) == 0) || k < 64 || (((int64_t)n * k) % 256)))
+    return TMAE_EARG;
   if (m > 0 && (!dy || !x)) return TMAE_EARG;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return TMAE_EARG;
   int splits, rows;
@@ -641,7 +677,7 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
   }
 #undef WG_ARGS
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(tmae_cdiv(count / 4, 64)), dim3(64 * WG_RG), 0, stream, slab, splits,
-                     count, n, k, dw, db, dc, ldc);
+                     count, n, k, dw, db, dc, ldc, posE);
   return tmae_launch_status();
 }
 
@@ -653,12 +689,12 @@ int tmae_linear_wgrad(const void* dy, int64_t ldy, const void* x, int64_t ldx, i
 }
 
 int tmae_linear_wgrad_cells(const void* dy, int64_t ldy, const void* x, int64_t ldx, int64_t m, int n, int k,
-                            const uint8_t* cells, int pos_n, float* dw, float* db, float* dcell, void* wsp,
-                            size_t ws_bytes, void* stream_) {
+                            const uint8_t* cells, int pos_n, const float* pos_e, float* dw, float* db, float* dcell,
+                            void* wsp, size_t ws_bytes, void* stream_) {
   (void)hipGetLastError();
-  if (!cells || !dcell) return TMAE_EARG;
+  if (!cells || (!dcell && !pos_e)) return TMAE_EARG;
   return wgrad_launch(dy, ldy, x, ldx, m, n, k, dw, db, nullptr, 0, cells, pos_n, dcell, n, wsp, ws_bytes,
-                      (hipStream_t)stream_);
+                      (hipStream_t)stream_, pos_e);
 }
 
 int tmae_spconv_wgrad(const void* dy, int64_t ldy, const void* feat, int64_t ldf, const int32_t* nbr, int64_t m_out,

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void win_level_kernel(const int32_t* __restric
   const int lvl = level_of(eff, lt);
   const bool kept = (c > 0) && !dropped && lvl >= 0;
   wlevel[dw] = dropped ? (-2 - max(lvl, 0)) : lvl;   // <= -2 encodes "window dropped", level = -2 - value
-  for (int l = 0; l < lt.n; ++l) flags[(int64_t)l * nwin + dw] = (kept && lvl == l) ? 1 : 0;
+  if (flags)
+    for (int l = 0; l < lt.n; ++l) flags[(int64_t)l * nwin + dw] = (kept && lvl == l) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void win_emit_kernel(const int32_t* __restrict__ ind, int64_t m, int wy, int wx,
@@ -136,8 +137,12 @@ int tmae_window_bucket(const int32_t* indices, int64_t m, const int32_t* grid, c
   (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   if (m < 0 || batch <= 0 || ny <= 0 || nx <= 0 || wy <= 0 || wx <= 0 || wy * wx > 64 || !grid || !levels_host ||
-      n_levels <= 0 || n_levels > MAX_LEVELS || !inner || !win_per_level || (m > 0 && !indices))
+      n_levels <= 0 || n_levels > MAX_LEVELS || !inner || (m > 0 && !indices))
     return TMAE_EARG;
+  // the per-level window ranks (one scan per level) only serve flat2win and the per-level window counts: a caller that wants
+  // neither -- the cross-attention blocks need `keep` alone -- passes both as NULL and gets three launches instead of 3 + n_levels
+  const bool need_ranks = f2w != nullptr || win_per_level != nullptr;
+  if (need_ranks && !win_per_level) return TMAE_EARG;
   LevelTable lt;
   lt.n = n_levels;
   for (int l = 0; l < n_levels; ++l) {
@@ -161,8 +166,8 @@ int tmae_window_bucket(const int32_t* indices, int64_t m, const int32_t* grid, c
   hipLaunchKernelGGL(win_count_kernel, dim3(tmae_cdiv(nwin, 4)), dim3(256), 0, stream, grid, grid_other, batch, ny,
                      nx, wy, wx, Wy, Wx, sy, sx, wcount, wcount_o, inner);
   hipLaunchKernelGGL(win_level_kernel, dim3(tmae_cdiv(nwin, 256)), dim3(256), 0, stream, wcount,
-                     grid_other ? wcount_o : (const int32_t*)nullptr, nwin, lt, wlevel, flags);
-  for (int l = 0; l < n_levels; ++l) {
+                     grid_other ? wcount_o : (const int32_t*)nullptr, nwin, lt, wlevel, need_ranks ? flags : (int32_t*)nullptr);
+  for (int l = 0; need_ranks && l < n_levels; ++l) {
     int r = tmae_scan_i32(flags + (int64_t)l * nwin, ranks + (int64_t)l * nwin, nwin, win_per_level + l,
                           scanws + sb * l, sb, stream);
     if (r) return r;

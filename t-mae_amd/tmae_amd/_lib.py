@@ -97,7 +97,7 @@ SIGNATURES = {
     'tmae_window_cells': (I, [P, L, L, I, I, I, P, P, P]),
     'tmae_linear_wgrad_workspace': (Z, [L, I, I]),
     'tmae_linear_wgrad': (I, [P, L, P, L, L, I, I, P, P, P, Z, P]),
-    'tmae_linear_wgrad_cells': (I, [P, L, P, L, L, I, I, P, I, P, P, P, P, Z, P]),
+    'tmae_linear_wgrad_cells': (I, [P, L, P, L, L, I, I, P, I, P, P, P, P, P, Z, P]),
     'tmae_spconv_wgrad': (I, [P, L, P, L, P, L, I, I, P, P, Z, P]),
     'tmae_probe_copy': (I, [P, P, L, I, P]),
     'tmae_probe_mfma': (I, [I, P, P, P]),
@@ -127,7 +127,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     setattr(lib, _name, _strict(_fn, _name, len(_args)))
 
-ABI_VERSION = 7            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
+ABI_VERSION = 9            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError(f'libtmae_hip.so ABI version {lib.tmae_abi_version()} != binding {ABI_VERSION}; rebuild with '
                       f't-mae_amd/build.py')

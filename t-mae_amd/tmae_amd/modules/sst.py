@@ -349,11 +349,12 @@ class SSTBlockV1(nn.Module):
         under shift 1 and dropped by the same rule.  None when everybody stays.  Two host syncs (the survivor counts):
         only configurations that can drop at all come here."""
         ny, nx = sp.spatial_shape
-        wb0 = ops.window_bucket(sp.indices, sp.grid, None, sp.batch_size, ny, nx, self.window_shape, False, self.drop_info)
+        wb0 = ops.window_bucket(sp.indices, sp.grid, None, sp.batch_size, ny, nx, self.window_shape, False, self.drop_info,
+                                keep_only=True)
         idx0 = wb0['keep'].bool().nonzero().squeeze(1)
         ind1 = sp.indices[idx0].contiguous()
         grid1 = ops.index_grid(ind1, sp.batch_size, ny, nx)
-        wb1 = ops.window_bucket(ind1, grid1, None, sp.batch_size, ny, nx, self.window_shape, True, self.drop_info)
+        wb1 = ops.window_bucket(ind1, grid1, None, sp.batch_size, ny, nx, self.window_shape, True, self.drop_info, keep_only=True)
         kept = idx0[wb1['keep'].bool().nonzero().squeeze(1)]
         return None if kept.shape[0] == sp.indices.shape[0] else kept
 
@@ -430,14 +431,14 @@ class WCABlock(nn.Module):
         kept = []
         for shift in (False, True):
             wb = ops.window_bucket(plan.indices, plan.grid, plan_prv.grid, plan.batch, plan.ny, plan.nx,
-                                   self.window_shape, shift, self.drop_info)
+                                   self.window_shape, shift, self.drop_info, keep_only=True)
             kept.append(wb['keep'].view(-1, 1).to(x.dtype))
             if self.can_drop:
                 # per-shift keep sets of BOTH frames (drop_single_shift_ref_to_prv, SiamWCA.py:65-140): dropped queries
                 # get no update (bmask above), dropped previous-frame tokens are no keys -- both vanish from the grids
                 # this shift's attention reads
                 wbp = ops.window_bucket(plan_prv.indices, plan_prv.grid, plan.grid, plan.batch, plan.ny, plan.nx,
-                                        self.window_shape, shift, self.drop_info)
+                                        self.window_shape, shift, self.drop_info, keep_only=True)
                 plan.set_shift_grids(shift, _mask_grid(plan, wb['keep']), _mask_grid(plan_prv, wbp['keep']))
         return self.encoder_blocks[0](x, plan, sp_prev.features, plan_prv, self.pos_table, self.window_shape, kept,
                                       residual=residual)

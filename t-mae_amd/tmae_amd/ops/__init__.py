@@ -355,12 +355,13 @@ def _multi_cast_transpose(mats):
 
 # ----------------------------------------------------------------------------- token-list Linear
 
-def linear_wgrad(dy, x, want_bias=True, out_w=None, out_b=None, cells=None, pos_n=0):
+def linear_wgrad(dy, x, want_bias=True, out_w=None, out_b=None, cells=None, pos_n=0, pos_e=None):
     """dW [n,k] f32 = dy^T @ x, db [n] f32 = column sums of dy; dy [m,n], x [m,k] bf16 (row-major, last dim
     contiguous).  One streaming pass, token axis split over the chip (csrc/wgrad.hip).  out_w / out_b: contiguous f32
     destinations (e.g. a row slice of a packed gradient) written in place of fresh tensors.
     cells (ops.window_cells): also returns dcell [16, n] f32, the per-cell column sums of dy[:, :pos_n]
-    (tmae_linear_wgrad_cells) -- the return value is then (dw, db, dcell)."""
+    (tmae_linear_wgrad_cells) -- the return value is then (dw, db, dcell).  pos_e (E [16, k] f32, ops.pos_axes): the position
+    part dcell^T E of the in-projection's weight gradient is added to dw inside the slab reduction; dcell is then None."""
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(1) == 1 and x.stride(1) == 1
     m, n = dy.shape
     k = x.shape[1]
@@ -377,9 +378,15 @@ def linear_wgrad(dy, x, want_bias=True, out_w=None, out_b=None, cells=None, pos_
     wsb = lib.tmae_linear_wgrad_workspace(m, n, k)
     ws = _ws(wsb, dy.device)
     if cells is not None:
-        dcell = torch.empty((16, n), dtype=torch.float32, device=dy.device)
-        check(lib.tmae_linear_wgrad_cells(_p(dy), dy.stride(0), _p(x), x.stride(0), m, n, k, _p(cells), int(pos_n), _p(dw),
-                                          _p(db), _p(dcell), _p(ws), wsb, _s()), 'tmae_linear_wgrad_cells')
+        fold = (pos_e is not None and pos_e.dtype == torch.float32 and pos_e.is_contiguous() and pos_e.shape == (16, k)
+                and k >= 64 and (256 % k == 0 or k % 256 == 0) and (n * k) % 256 == 0)
+        dcell = None if fold else torch.empty((16, n), dtype=torch.float32, device=dy.device)
+        check(lib.tmae_linear_wgrad_cells(_p(dy), dy.stride(0), _p(x), x.stride(0), m, n, k, _p(cells), int(pos_n),
+                                          _p(pos_e) if fold else None, _p(dw), _p(db), _p(dcell), _p(ws), wsb, _s()),
+              'tmae_linear_wgrad_cells')
+        if pos_e is not None and not fold and pos_n > 0:
+            dw[:pos_n].addmm_(dcell[:, :pos_n].t(), pos_e)
+            dcell = None
         return dw, db, dcell
     check(lib.tmae_linear_wgrad(_p(dy), dy.stride(0), _p(x), x.stride(0), m, n, k, _p(dw), _p(db), _p(ws), wsb, _s()),
           'tmae_linear_wgrad')
@@ -641,10 +648,9 @@ class _PosProj(torch.autograd.Function):
                 dW = mk((rows, d), dtype=torch.float32, device=x_c.device)
                 want_b = ctx.has_bias and ctx.needs_input_grad[2]
                 dB = mk((rows,), dtype=torch.float32, device=x_c.device) if want_b else None
-                _, _, dcell = linear_wgrad(dout, x_c, want_b, out_w=dW[lo:hi], out_b=None if dB is None else dB[lo:hi],
-                                           cells=cells, pos_n=p1 - p0)
-                if p1 > p0:
-                    dW[p0:p1].addmm_(dcell[:, :p1 - p0].t(), E)
+                # (p0 == lo: the position rows lead the slice; dcell^T E is added inside the slab reduction)
+                linear_wgrad(dout, x_c, want_b, out_w=dW[lo:hi], out_b=None if dB is None else dB[lo:hi], cells=cells,
+                             pos_n=p1 - p0, pos_e=E)
         return (None if dx is None else dx.to(xdt), None if dW is None else dW.to(wdt),
                 None if dB is None else dB.to(bdt), None, None, None, None, None, None, None, None)
 
@@ -705,13 +711,9 @@ class _PosProjCross(torch.autograd.Function):
             want_b = ctx.has_bias and ctx.needs_input_grad[3]
             dB = mk((3 * d,), dtype=torch.float32, device=xq.device) if want_b else None
             if dq is not None:
-                _, _, dc = linear_wgrad(dq, xq, want_b, out_w=dW[:d], out_b=None if dB is None else dB[:d], cells=cells_q,
-                                        pos_n=d)
-                dW[:d].addmm_(dc.t(), E)
+                linear_wgrad(dq, xq, want_b, out_w=dW[:d], out_b=None if dB is None else dB[:d], cells=cells_q, pos_n=d, pos_e=E)
             if dkv is not None:
-                _, _, dc = linear_wgrad(dkv, xk, want_b, out_w=dW[d:], out_b=None if dB is None else dB[d:], cells=cells_k,
-                                        pos_n=d)
-                dW[d:2 * d].addmm_(dc[:, :d].t(), E)
+                linear_wgrad(dkv, xk, want_b, out_w=dW[d:], out_b=None if dB is None else dB[d:], cells=cells_k, pos_n=d, pos_e=E)
         return (None if dxq is None else dxq.to(qdt), None if dxk is None else dxk.to(kdt),
                 None if dW is None else dW.to(wdt), None if dB is None else dB.to(bdt), None, None, None, None)
 
@@ -1250,9 +1252,11 @@ def index_grid(indices, batch_size, ny, nx):
     return grid
 
 
-def window_bucket(indices, grid, grid_other, batch_size, ny, nx, window_shape, do_shift, drop_info):
+def window_bucket(indices, grid, grid_other, batch_size, ny, nx, window_shape, do_shift, drop_info, keep_only=False):
     """Window partition + region batching of one shift (spt_backbone.py:47-71,137-184; sst_utils.py:6-107;
-    joint two-frame form SiamWCA.py:65-140 when grid_other is given)."""
+    joint two-frame form SiamWCA.py:65-140 when grid_other is given).
+    keep_only: only `keep` (and `inner`) -- what the cross-attention blocks and the token-dropping paths read; flat2win and the
+    per-level window counts (one device scan per drop level) are then not computed."""
     import ctypes as C
     m = indices.shape[0]
     dev = indices.device
@@ -1261,21 +1265,21 @@ def window_bucket(indices, grid, grid_other, batch_size, ny, nx, window_shape, d
     arr = (C.c_int32 * (3 * len(lv)))()
     for i, (_, info) in enumerate(lv):
         arr[3 * i], arr[3 * i + 1], arr[3 * i + 2] = info['max_tokens'], info['drop_range'][0], info['drop_range'][1]
-    out = dict(
-        batch_win_inds=torch.empty((m,), dtype=torch.int64, device=dev),
-        coors_in_win=torch.empty((m, 3), dtype=torch.int64, device=dev),
-        inner=torch.empty((m,), dtype=torch.int32, device=dev),
-        level=torch.empty((m,), dtype=torch.int32, device=dev),
-        keep=torch.empty((m,), dtype=torch.uint8, device=dev),
-        flat2win=torch.empty((m,), dtype=torch.int64, device=dev),
-        win_per_level=torch.zeros((len(lv),), dtype=torch.int32, device=dev),
-    )
+    out = dict(inner=torch.empty((m,), dtype=torch.int32, device=dev), keep=torch.empty((m,), dtype=torch.uint8, device=dev))
+    if not keep_only:
+        out.update(
+            batch_win_inds=torch.empty((m,), dtype=torch.int64, device=dev),
+            coors_in_win=torch.empty((m, 3), dtype=torch.int64, device=dev),
+            level=torch.empty((m,), dtype=torch.int32, device=dev),
+            flat2win=torch.empty((m,), dtype=torch.int64, device=dev),
+            win_per_level=torch.zeros((len(lv),), dtype=torch.int32, device=dev),
+        )
     wsb = lib.tmae_window_bucket_workspace(batch_size, ny, nx, wy, wx, len(lv))
     ws = _ws(wsb, dev)
     check(lib.tmae_window_bucket(_p(indices), m, _p(grid), _p(grid_other), batch_size, ny, nx, wy, wx,
                                  1 if do_shift else 0, C.cast(arr, C.c_void_p), len(lv),
-                                 _p(out['batch_win_inds']), _p(out['coors_in_win']), _p(out['inner']),
-                                 _p(out['level']), _p(out['keep']), _p(out['flat2win']), _p(out['win_per_level']),
+                                 _p(out.get('batch_win_inds')), _p(out.get('coors_in_win')), _p(out['inner']),
+                                 _p(out.get('level')), _p(out['keep']), _p(out.get('flat2win')), _p(out.get('win_per_level')),
                                  _p(ws), wsb, _s()), 'tmae_window_bucket')
     return out
 

@@ -199,7 +199,11 @@ def _bucket(coords4, grid_n, other4=None, shift=False, batch=3):
     gother = None
     if other4 is not None:
         gother = ops.index_grid(cu(other4[:, [0, 2, 3]], torch.int32).contiguous(), batch, grid_n, grid_n)
-    return ops.window_bucket(ind, grid, gother, batch, grid_n, grid_n, [8, 8, 1], shift, DROP)
+    wb = ops.window_bucket(ind, grid, gother, batch, grid_n, grid_n, [8, 8, 1], shift, DROP)
+    # the keep-only form (no flat2win, no per-level counts: the rank scans are skipped) returns the same keep mask and ranks
+    ko = ops.window_bucket(ind, grid, gother, batch, grid_n, grid_n, [8, 8, 1], shift, DROP, keep_only=True)
+    assert set(ko) == {'keep', 'inner'} and torch.equal(ko['keep'], wb['keep']) and torch.equal(ko['inner'], wb['inner'])
+    return wb
 
 
 def test_window_partition_golden():
@@ -565,6 +569,12 @@ def test_linear_wgrad_cell_sums_both_tile_sizes():
         assert float(dcell[:, pos_n:].abs().max()) == 0.0 if pos_n < n else True
         # the x-cell sums and the y-cell sums both add up to the bias gradient
         assert (dcell[:8, :pos_n].sum(0) - ref_b[:pos_n]).abs().max().item() <= 4e-3 * float(ref_b.abs().max()) + 1e-3
+        # pos_e: the position part dcell^T E of the weight gradient added inside the slab reduction (no dcell tensor, no GEMM)
+        E = torch.randn(16, k, device=dev())
+        dw2, db2, none = ops.linear_wgrad(dy, x, True, cells=cells, pos_n=pos_n, pos_e=E)
+        ref_w2 = ref_w + ref_c.t() @ E
+        assert none is None and torch.equal(db2, db)
+        assert (dw2 - ref_w2).abs().max().item() <= 2e-3 * max(1.0, float(ref_w2.abs().max())), (m, n, k, pos_n)
 
 
 def test_token_gemm_kernel_vs_torch():
