@@ -333,8 +333,12 @@ struct AttnBufs {          // byte sizes of the tensors for the buffer descripto
   unsigned q, k, v, o, g, lse, dq, dk, dv;
 };
 
+// __launch_bounds__(256, 2): at least two waves per SIMD, i.e. at most 256 registers per lane.  Not for occupancy (the kernels use
+// 28-107) but for the MFMA FORM: with a budget above 256 the compiler assumes it may need the AGPR half of the register file and
+// selects the AGPR-destination MFMAs -- every logit then travels to the VALU through a v_accvgpr_read (508 moves in the dh-32
+// 64-token forward, 16 % of its instructions).  Below 257 it selects the VGPR form and the moves are gone.
 template <int DH, int NT, bool PAIR>
-__global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
+__global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
     const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
     const __hip_bfloat16* __restrict__ v, int64_t ldv, int nhead, const int32_t* __restrict__ grid_q,
     const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx, int sy, int sx,
@@ -428,7 +432,15 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) kbias[kt][r] = key_bias<PAIR>(kt * 16 + 4 * g + r, i, wi);
+  } else {
+    // (!KB, the 64-token class: no registers for a bias per tile) only the LAST key tile can hold absent rows: ONE bias vector,
+    // selected as the C operand of that tile's first MFMA by a wave-uniform condition.  No branch between a logit MFMA and its
+    // first VALU reader anywhere in these kernels: the compiler leaves the taken side of such a branch without the wait states
+    // an MFMA result needs (tools/check_mfma_hazards.py).
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kbias[0][r] = ((nk - 1) * 16 + 4 * g + r >= Tk) ? MASKED_LOGIT : 0.f;
   }
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int qt = 0; qt < NT; ++qt) {
     if (qt < nq) {
@@ -436,22 +448,17 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(
       float mx = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
-        if constexpr (KB) st[kt] = kbias[kt]; else st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (kt < nk) {
-          st[kt] = mfma_s(kl[kt], qf[qt], st[kt]);                   // S^T tile: rows = keys 4g+r, col = query i
+          f32x4 c0;
+          if constexpr (KB) c0 = kbias[kt]; else c0 = (kt == nk - 1) ? kbias[0] : zero4;
+          st[kt] = mfma_s(kl[kt], qf[qt], c0);                       // S^T tile: rows = keys 4g+r, col = query i
           st[kt] = mfma_s(kf[kt], ql[qt], st[kt]);
           st[kt] = mfma_s(kf[kt], qf[qt], st[kt]);
-        }
-        // (!KB) only the last key tile can hold absent rows, and tiles past it take no part at all: the per-element mask and
-        // the whole softmax arithmetic of an absent tile sit behind wave-uniform branches
-        if (KB || kt < nk) {
-          if (!KB && kt == nk - 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (kt * 16 + 4 * g + r >= Tk) st[kt][r] = MASKED_LOGIT;
-          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
+          asm volatile("" : "+v"(mx));                               // the first reader stays in the MFMAs' block
+        } else if constexpr (KB) {
+          st[kt] = kbias[kt];                                        // all rows absent: p = 0 below
         }
       }
       mx = quad_max(mx);
@@ -561,7 +568,7 @@ int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
 // NT = 4 is compiled for two waves per SIMD (the LDS images allow no more): 233 registers, no scratch.
 // ------------------------------------------------------------------------------------------------
 template <int DH, int NT, bool PAIR>
-__global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel(
+__global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
     const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
     const __hip_bfloat16* __restrict__ v, int64_t ldv, const __hip_bfloat16* __restrict__ outp, int64_t ldo,
     const __hip_bfloat16* __restrict__ dout, int64_t lddo, const float* __restrict__ lse, int nhead,
@@ -674,7 +681,11 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) kbias[kt][r] = key_bias<PAIR>(kt * 16 + 4 * g + r, i, wi);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kbias[0][r] = ((nk - 1) * 16 + 4 * g + r >= Tk) ? MASKED_LOGIT : 0.f;   // the last key tile's bias
   }
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int qt = 0; qt < NT; ++qt) {
@@ -702,20 +713,22 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         if (kt < nk) {
-          const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-          // swapped: rows = keys 4g+r of this tile, column = query i; masked keys / absent queries give p = 0
-          f32x4 sT = mfma_s(kl[kt], qf[qt], KB ? kbias[KB ? kt : 0] : z);
+          // swapped: rows = keys 4g+r of this tile, column = query i; masked keys (MASKED_LOGIT through the C operand) and
+          // absent queries (lse = +inf) give p = 0
+          f32x4 c0;
+          if constexpr (KB) c0 = kbias[kt]; else c0 = (kt == nk - 1) ? kbias[0] : zero4;
+          f32x4 sT = mfma_s(kl[kt], qf[qt], c0);
           sT = mfma_s(kf[kt], ql[qt], sT);
           sT = mfma_s(kf[kt], qf[qt], sT);
-          const f32x4 dP = mfma_s(vr[kt], gf[qt], z);
+          const f32x4 dP = mfma_s(vr[kt], gf[qt], zero4);
           if constexpr (!RECOMP) { sTk[kt] = sT; dPk[kt] = dP; }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float p = __expf(sT[r] - lse_i[qt]);
-            if (!KB && kt == nk - 1) { if (kt * 16 + 4 * g + r >= Tk) p = 0.f; }   // (wave-uniform: only the last tile has absent keys)
+            const float p = __expf(sT[r] - lse_i[qt]);
             if constexpr (!RECOMP) pTk[kt][r] = p;
             dacc += p * dP[r];
           }
+          asm volatile("" : "+v"(dacc));                             // the MFMAs' first readers stay in their block
         }
       }
       dacc = quad_sum(dacc);
@@ -724,29 +737,21 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 1) void win_attn_bwd_mfma_kernel
         if (kt < nk) {
           f32x4 sT, dP, pT;
           if constexpr (RECOMP) {
-            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-            sT = mfma_s(kl[kt], qf[qt], z);
+            const f32x4 c0 = (kt == nk - 1) ? kbias[0] : zero4;          // (RECOMP implies !KB)
+            sT = mfma_s(kl[kt], qf[qt], c0);
             sT = mfma_s(kf[kt], ql[qt], sT);
             sT = mfma_s(kf[kt], qf[qt], sT);
-            dP = mfma_s(vr[kt], gf[qt], z);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pT[r] = __expf(sT[r] - lse_i[qt]);
-            // dP - D is taken HERE, in front of the wave-uniform branch below.  An MFMA result is not interlocked against its
-            // first VALU reader; the compiler pads straight-line code, but with the branch between the dP MFMA and this
-            // subtraction it left the TAKEN path without a single wait state (its hazard search visits each predecessor block
-            // once, and had reached the join through the long fall-through block first): the subtraction then read the exp()
-            // argument that had lived in those registers before -- -inf for an absent query, so ds = 0 * -inf = NaN went into
-            // dK and finite garbage into dQ while dV (P alone) stayed right: round 4's F7 case 2.
-            // tools/check_mfma_hazards.py (tests/test_isa_hazards.py) walks both sides of every branch behind every MFMA.
+            dP = mfma_s(vr[kt], gf[qt], zero4);
+            // Round 4 masked the absent keys per element here and found that restricting the mask to the last tile (a wave-uniform
+            // branch between the dP MFMA and `dP - D`) gave NaN in dK and garbage in dQ at the temperature clamp: not arithmetic --
+            // the compiler had left the TAKEN side of that branch without the wait states an MFMA result needs before its first
+            // VALU reader, so `dP - D` read the registers' previous content (-inf for an absent query).  DESIGN.md section 6h;
+            // tools/check_mfma_hazards.py walks both sides of every branch behind every MFMA.  Now the mask rides on the C
+            // operand and no branch is left between these MFMAs and their readers.
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+              pT[r] = __expf(sT[r] - lse_i[qt]);
               dP[r] -= dacc;
-              asm volatile("" : "+v"(dP[r]));          // pins the subtraction in front of the branch (the compiler sinks it otherwise)
-            }
-            if (kt == nk - 1) {                          // only the last key tile can hold absent keys (wave-uniform)
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                if (kt * 16 + 4 * g + r >= Tk) pT[r] = 0.f;
             }
           } else {
             sT = sTk[kt]; dP = dPk[kt]; pT = pTk[kt];
