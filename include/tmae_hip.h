@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 9
+#define TMAE_ABI_VERSION 10
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -378,6 +378,13 @@ int tmae_deblock_gather(const void* dcat, int dtype, int ldc, int coff, const in
 size_t tmae_column_sums_workspace(int64_t rows, int c);
 int tmae_column_sums(const void* x, int dtype, int64_t rows, int c, float* out, void* ws, size_t ws_bytes,
                      void* stream);
+/* Backward of that norm, the inactive output cells' share (they all hold z0 = beta - mean rstd gamma, xhat0 = -mean rstd):
+ *   rest = (s_all - s_act) [z0 > 0],  dbeta = sum_dz + rest,  dgamma = sum_dzx + rest xhat0     (all [c] f32)
+ * s_all / s_act: column sums of dy over all cells / over the active cells (tmae_column_sums), sum_dz / sum_dzx: the active
+ * cells' sums from tmae_bn_bwd_sums.  torch autograd of BatchNorm2d + ReLU on the dense map in the reference. */
+int tmae_deblock_bn_tail(const float* mean, const float* rstd, const float* gamma, const float* beta, const float* s_all,
+                         const float* s_act, const float* sum_dz, const float* sum_dzx, int c, float* dbeta, float* dgamma,
+                         void* stream);
 
 /* bf16 copies of fp32 parameter matrices after the optimizer step (what autocast reads: torch casts a weight on every
  * use; the dX GEMMs of the token-list Linears additionally want W^T): ONE launch for a list of matrices.

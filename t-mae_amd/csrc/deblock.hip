@@ -190,3 +190,32 @@ int tmae_column_sums(const void* x, int dtype, int64_t rows, int c, float* out, 
   hipLaunchKernelGGL(colsum_finish_kernel, dim3(tmae_cdiv(c, 16)), dim3(256), 0, stream, part, nb, c, out);
   return tmae_launch_status();
 }
+
+// The inactive cells' share of a deblock norm's parameter gradients.  Every output cell that no active input cell feeds holds
+// the same value per channel, z0 = beta - mean rstd gamma with xhat0 = -mean rstd, so its part of the sums over ALL cells is
+// (sum of dy over the inactive cells) x [z0 > 0]: dbeta = sum_dz + rest, dgamma = sum_dzx + rest xhat0 with
+// rest = (s_all - s_act) [z0 > 0].  One launch instead of eleven [c]-sized elementwise launches per deblock.
+__global__ __launch_bounds__(256) void deblock_bn_tail_kernel(const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ s_all, const float* __restrict__ s_act,
+                                                             const float* __restrict__ sum_dz,
+                                                             const float* __restrict__ sum_dzx, int c,
+                                                             float* __restrict__ dbeta, float* __restrict__ dgamma) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= c) return;
+  const float xhat0 = -mean[j] * rstd[j];
+  const float live = (beta[j] + xhat0 * gamma[j]) > 0.f ? 1.f : 0.f;
+  const float rest = (s_all[j] - s_act[j]) * live;
+  dbeta[j] = sum_dz[j] + rest;
+  dgamma[j] = sum_dzx[j] + rest * xhat0;
+}
+
+int tmae_deblock_bn_tail(const float* mean, const float* rstd, const float* gamma, const float* beta, const float* s_all,
+                         const float* s_act, const float* sum_dz, const float* sum_dzx, int c, float* dbeta, float* dgamma,
+                         void* stream_) {
+  (void)hipGetLastError();
+  if (c <= 0 || !mean || !rstd || !gamma || !beta || !s_all || !s_act || !sum_dz || !sum_dzx || !dbeta || !dgamma) return TMAE_EARG;
+  hipLaunchKernelGGL(deblock_bn_tail_kernel, dim3(tmae_cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream_, mean, rstd, gamma,
+                     beta, s_all, s_act, sum_dz, sum_dzx, c, dbeta, dgamma);
+  return tmae_launch_status();
+}

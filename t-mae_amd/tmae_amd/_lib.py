@@ -76,6 +76,7 @@ SIGNATURES = {
     'tmae_deblock_gather': (I, [P, I, I, I, P, L, I, I, I, I, P, P]),
     'tmae_column_sums_workspace': (Z, [L, I]),
     'tmae_column_sums': (I, [P, I, L, I, P, P, Z, P]),
+    'tmae_deblock_bn_tail': (I, [P, P, P, P, P, P, P, P, I, P, P, P]),
     'tmae_centerhead_targets': (I, [P, I, I, I, P, I, I, I, I, F, F, F, F, F, I, D, I, P, P, P, P, P]),
     'tmae_focal_loss_workspace': (Z, [L]),
     'tmae_focal_loss_fwd': (I, [P, I, P, L, P, P, Z, P]),
@@ -127,7 +128,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     setattr(lib, _name, _strict(_fn, _name, len(_args)))
 
-ABI_VERSION = 9            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
+ABI_VERSION = 10            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError(f'libtmae_hip.so ABI version {lib.tmae_abi_version()} != binding {ABI_VERSION}; rebuild with '
                       f't-mae_amd/build.py')

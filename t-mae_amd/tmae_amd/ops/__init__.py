@@ -110,17 +110,18 @@ def token_gemm_gelu(x, w, bias):
     return y, torch.nn.functional.gelu(y)
 
 
-def addmm_inplace(dx, dy, w):
+def addmm_inplace(dx, dy, w, wt=None):
     """dx += dy @ w in place (w [n,k]: dx [m,k], dy [m,n]): the W-in-registers kernel's accumulate form on the shapes it
     covers (tmae_token_gemm_acc: contraction 512 -> 256, 256 -> 128 and -- the attention in-projections -- 768 -> 256,
-    384 -> 128; >= 32 k tokens), torch's addmm_ otherwise."""
+    384 -> 128; >= 32 k tokens), torch's addmm_ otherwise.  wt: w^T contiguous if the caller keeps one (else made here)."""
     n, k = w.shape
     m = dx.shape[0]
     if (m >= (65536 if n in (512, 768) else 32768) and (n, k) in ((512, 256), (256, 128), (768, 256), (384, 128))
             and dx.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
             and w.dtype == torch.bfloat16 and dx.is_contiguous() and dy.stride(1) == 1 and dy.stride(0) % 8 == 0
             and dy.data_ptr() % 16 == 0 and dx.data_ptr() % 16 == 0 and m * max(n, k) * 2 < 2 ** 31):
-        wt = _transposed(w)
+        if wt is None:
+            wt = _transposed(w)
         check(lib.tmae_token_gemm_acc(_p(dy), dy.stride(0), m, n, _p(wt), k, _p(_zero_bias(k, dx.device)), _p(dx), k, _s()),
               'tmae_token_gemm_acc')
         return dx
@@ -616,6 +617,10 @@ class _PosProj(torch.autograd.Function):
                                       hi - lo, _s()), 'tmae_token_gemm_pos')
         ctx.save_for_backward(x_c, w_aug, cells, E)
         ctx.rng = (lo, hi, p0, p1, weight.shape[0])
+        # W[lo:hi]^T for the in-place input gradient, cached with the folded weight (it was transposed again in every backward:
+        # one launch per attention layer and step)
+        ctx.wt = (_derived(weight, ('plainT', lo, hi), lambda w: w[lo:hi].to(torch.bfloat16).t().contiguous())
+                  if (inplace_dx and fork) else None)
         ctx.fork, ctx.has_bias = fork, bias is not None
         ctx.inplace_dx = bool(inplace_dx and fork)
         ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
@@ -639,7 +644,7 @@ class _PosProj(torch.autograd.Function):
                 if dx is None:
                     dx = dout @ w
                 elif ctx.inplace_dx:
-                    addmm_inplace(dx, dout, w)                 # see _ProjFork.backward
+                    addmm_inplace(dx, dout, w, ctx.wt)         # see _ProjFork.backward
                 else:
                     dx = torch.addmm(dx, dout, w)
             if ctx.needs_input_grad[1]:
@@ -1647,12 +1652,10 @@ class _DeblocksToDense(torch.autograd.Function):
             ws = _ws(wsb, dev)
             check(lib.tmae_bn_bwd_sums(_p(g), _p(v), _dt(v), rows, cout, _p(mean), _p(rstd), _p(g32), _p(b32), 1,
                                        _p(sum_dz), _p(sum_dzx), _p(ws), wsb, _s()), 'tmae_bn_bwd_sums')
-            # inactive cells: z = beta - mean*rstd*gamma (constant per channel), xhat = -mean*rstd
-            xhat0 = -mean * rstd
-            live0 = ((b32 + xhat0 * g32) > 0).float()
-            rest = (s_all[coff:coff + cout] - s_act) * live0
-            dbeta = (sum_dz + rest).contiguous()
-            dgamma = (sum_dzx + rest * xhat0).contiguous()
+            # inactive cells: z = beta - mean*rstd*gamma (constant per channel), xhat = -mean*rstd: their share of the sums
+            dbeta, dgamma = torch.empty_like(sum_dz), torch.empty_like(sum_dz)
+            check(lib.tmae_deblock_bn_tail(_p(mean), _p(rstd), _p(g32), _p(b32), s_all.data_ptr() + 4 * coff, _p(s_act),
+                                           _p(sum_dz), _p(sum_dzx), cout, _p(dbeta), _p(dgamma), _s()), 'tmae_deblock_bn_tail')
             tb, tg, tcount = dbeta, dgamma, count
             if ctx.pg is not None:                # the sums of every rank enter dx; dgamma / dbeta stay this rank's
                 import torch.distributed as dist
