@@ -369,6 +369,15 @@ def attention_roofline(model, batch, amp_dtype, iters=20):
                                      'win_attn_bwd_mfma_kernel<16, 2, false>', 'win_attn_bwd_mfma_kernel<16, 4, false>')}
 
 
+def _cpu_now():
+    """The CPU this thread runs on (diagnostic: is the launching thread being moved between cores / NUMA nodes?)."""
+    try:
+        import ctypes
+        return int(ctypes.CDLL(None).sched_getcpu())
+    except Exception:
+        return -1
+
+
 def _host_cores():
     try:
         cores = len(os.sched_getaffinity(0))
@@ -723,11 +732,19 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
+    host_s, cpus = 0.0, set()
     for i in range(args.steps):
+        th = time.perf_counter()
         loss = step(args.warmup + i)
+        host_s += time.perf_counter() - th            # time inside step(): enqueue + the step's own host syncs (not the final wait)
+        cpus.add(_cpu_now())
     torch.cuda.synchronize()
     t_own = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats(dev)
+    alloc_delta = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries', 'num_sync_all_streams')}
+    alloc_delta['reserved_gb'] = round(ms1.get('reserved_bytes.all.current', 0) / 2 ** 30, 2)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -754,6 +771,12 @@ def main():
             'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            # host side of the timed region: wall time spent inside the step calls (launch enqueue + the step's host syncs) and the
+            # CPUs the launching thread ran on; ms_per_step close to host_ms_per_step = the host, not the GPU, set the pace
+            'host_ms_per_step': round(1e3 * host_s / args.steps, 3), 'host_cpus_seen': sorted(cpus),
+            'host_affinity': len(os.sched_getaffinity(0)),
+            # the caching allocator inside the timed region: a device malloc / free there is a host stall with the queue draining
+            'allocator_in_timed_region': alloc_delta,
             'config': {'workload': (f'configs[{1 if args.shape == "once" else 3}]: {"ONCE" if args.shape == "once" else "Waymo"}-shape synthetic {args.points}-pt frame-pairs, full 3-stage SST '
                                     f'encoder + temporal cross-attn + decoder + Chamfer, fwd+bwd+Adam one-cycle') if args.task == 'pretrain' else
                                    (f'configs[4]: ONCE-shape synthetic {args.points}-pt frame-pairs with 40 boxes, SiamWCA encoder (both frames '

@@ -25,6 +25,25 @@ print('| ms/step | % | launches/step | avg us | kernel |\n|---:|---:|---:|---:|-
 for n, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
     print(f'| {d / 3e6:.2f} | {100 * d / busy:.1f} | {c / 3:.1f} | {d / c / 1e3:.1f} | `{n}` |')
 
+# idle intervals of the timed steps: where the GPU waited for the host (a host sync drains the queue; the launches behind it arrive one
+# by one).  Gaps above 20 us, summed per (kernel before -> kernel after), per step.
+ivs = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')[:50]) for r in seg)
+gaps = collections.defaultdict(lambda: [0, 0])
+end, last, idle_all, idle_big = ivs[0][1], ivs[0][2], 0, 0
+for st, en, nm in ivs[1:]:
+    if st > end:
+        g = st - end
+        idle_all += g
+        if g > 20000:
+            idle_big += g
+            gaps[(last, nm)][0] += g
+            gaps[(last, nm)][1] += 1
+    if en > end:
+        end, last = en, nm
+print(f'\nidle: {idle_all / 3e6:.2f} ms/step in all gaps, {idle_big / 3e6:.2f} ms/step in gaps > 20 us:')
+for (a, b), (g, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:12]:
+    print(f'- {g / 3e6:.3f} ms/step, {c / 3:.1f} x: `{a}` -> `{b}`')
+
 # the roofline probes of bench.py (token_gemm_roofline, wgrad_roofline, attention_roofline): the launches after the last voxelisation of
 # the training steps (+1: the probe's own forward pass voxelises both frames once more); an op = one launch of each
 # kernel of its group, its duration = the sum of the per-kernel averages

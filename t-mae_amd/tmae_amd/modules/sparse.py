@@ -100,7 +100,7 @@ def _down_rulebooks(x, depth):
                 counts.append((out_grid[:cells] >= 0).sum().view(1))
         levels.append((grid, ny, nx, out_grid, out_ind, oy, ox))
         grid, ny, nx = out_grid, oy, ox
-    host = torch.cat(counts).cpu().tolist()                       # the one sync
+    host = ops.to_host(torch.cat(counts)).tolist()                # the one sync
     per = len(host) // depth
     rbs, in_ind = [], x.indices
     for d, (grid, ny, nx, out_grid, out_ind, oy, ox) in enumerate(levels):

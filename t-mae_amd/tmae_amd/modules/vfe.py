@@ -89,7 +89,7 @@ class TemporalDynVFE(VFETemplate):
         bs = int(batch_dict['batch_size'])
         launched = [ops.voxelize_launch(batch_dict[k], bs, self.point_cloud_range, self.voxel_size, self.grid_size)
                     for k in ('points', 'points_prev')]
-        counts = torch.stack([o['counts'] for o in launched]).cpu()     # the one host sync of the VFE
+        counts = ops.to_host(torch.stack([o['counts'] for o in launched]))     # the one host sync of the VFE
         for suffix, out, cnt in (('', launched[0], counts[0]), ('_prev', launched[1], counts[1])):
             vox = ops.voxelize_finish(out, cnt)
             x = self._features(vox)

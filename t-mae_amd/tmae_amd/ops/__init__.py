@@ -620,7 +620,7 @@ class _PosProj(torch.autograd.Function):
         # W[lo:hi]^T for the in-place input gradient, cached with the folded weight (it was transposed again in every backward:
         # one launch per attention layer and step)
         ctx.wt = (_derived(weight, ('plainT', lo, hi), lambda w: w[lo:hi].to(torch.bfloat16).t().contiguous())
-                  if (inplace_dx and fork) else None)
+                  if (inplace_dx and fork and not _os.environ.get('TMAE_NO_WT')) else None)
         ctx.fork, ctx.has_bias = fork, bias is not None
         ctx.inplace_dx = bool(inplace_dx and fork)
         ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
@@ -1086,6 +1086,26 @@ def voxelize_launch(points, batch_size, pc_range, voxel_size, grid_size):
     return out
 
 
+_HOST_BUFS = {}
+
+
+def to_host(t):
+    """A small device tensor on the host: asynchronous copy into a pinned buffer, then a wait on an event recorded right behind
+    it -- not Tensor.cpu(), whose pageable destination makes the runtime stage the copy and block the calling thread in a
+    stream-wide wait.  The step's two data-dependent sizes (voxel counts, strided-conv output counts) come through here."""
+    t = t.detach()
+    n = t.numel()
+    key = (t.device, t.dtype)
+    ent = _HOST_BUFS.get(key)
+    if ent is None or ent[0].numel() < n:
+        ent = _HOST_BUFS[key] = (torch.empty((max(n, 256),), dtype=t.dtype).pin_memory(), torch.cuda.Event())
+    buf = ent[0][:n].view(t.shape)
+    buf.copy_(t, non_blocking=True)
+    ent[1].record(torch.cuda.current_stream(t.device))
+    ent[1].synchronize()
+    return buf.clone()
+
+
 def voxelize_finish(out, counts_host):
     n_kept, m = int(counts_host[0]), int(counts_host[1])
     return dict(points=out['points'][:n_kept], point_coords=out['point_coords'][:n_kept],
@@ -1095,7 +1115,7 @@ def voxelize_finish(out, counts_host):
 
 def voxelize(points, batch_size, pc_range, voxel_size, grid_size):
     out = voxelize_launch(points, batch_size, pc_range, voxel_size, grid_size)
-    return voxelize_finish(out, out['counts'].cpu())
+    return voxelize_finish(out, to_host(out['counts']))
 
 
 def segment_csr(inverse, m):
@@ -1654,7 +1674,14 @@ class _DeblocksToDense(torch.autograd.Function):
                                        _p(sum_dz), _p(sum_dzx), _p(ws), wsb, _s()), 'tmae_bn_bwd_sums')
             # inactive cells: z = beta - mean*rstd*gamma (constant per channel), xhat = -mean*rstd: their share of the sums
             dbeta, dgamma = torch.empty_like(sum_dz), torch.empty_like(sum_dz)
-            check(lib.tmae_deblock_bn_tail(_p(mean), _p(rstd), _p(g32), _p(b32), s_all.data_ptr() + 4 * coff, _p(s_act),
+            if _os.environ.get('TMAE_NO_TAIL'):
+                xhat0 = -mean * rstd
+                live0 = ((b32 + xhat0 * g32) > 0).float()
+                rest = (s_all[coff:coff + cout] - s_act) * live0
+                dbeta = (sum_dz + rest).contiguous()
+                dgamma = (sum_dzx + rest * xhat0).contiguous()
+            else:
+              check(lib.tmae_deblock_bn_tail(_p(mean), _p(rstd), _p(g32), _p(b32), s_all.data_ptr() + 4 * coff, _p(s_act),
                                            _p(sum_dz), _p(sum_dzx), cout, _p(dbeta), _p(dgamma), _s()), 'tmae_deblock_bn_tail')
             tb, tg, tcount = dbeta, dgamma, count
             if ctx.pg is not None:                # the sums of every rank enter dx; dgamma / dbeta stay this rank's

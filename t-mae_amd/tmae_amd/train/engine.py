@@ -25,6 +25,26 @@ def wrap_ddp(model, local_rank):
     return torch.nn.parallel.DistributedDataParallel(model)
 
 
+_GC_SETTLED = False
+
+
+def settle_gc():
+    """Once, after the first training step: collect what set-up and the first step left behind and FREEZE the survivors (the
+    interpreter's ~275 k long-lived objects: torch itself, the module tree, the optimizer state, cached index tables) out of the
+    cyclic collector's sight.  Python's full collection is triggered by allocation COUNTS, walks every tracked object and, with
+    that heap, takes 80 - 190 ms in the launching thread: in round 5 it fell on the 10th step of every run started as
+    `python bench.py --warmup 5 --steps 20` -- one stalled step, +3.5 ms on the 20-step mean, queue drained, GPU idle -- and moved
+    with every unrelated edit that changed the number of objects created at import (profiles/round5_gc_stall.txt).  After the
+    freeze a full collection only looks at objects made since (about a thousand), i.e. it stays automatic and costs microseconds."""
+    global _GC_SETTLED
+    if _GC_SETTLED:
+        return
+    import gc
+    gc.collect()
+    gc.freeze()
+    _GC_SETTLED = True
+
+
 def train_one_step(model, optimizer, scheduler, batch_dict, it, model_func, amp_dtype=torch.bfloat16,
                    grad_norm_clip=None):
     """lr_scheduler.step -> zero_grad -> autocast forward -> backward (DDP all-reduce overlaps) ->
@@ -45,4 +65,5 @@ def train_one_step(model, optimizer, scheduler, batch_dict, it, model_func, amp_
     if use_amp:
         from .. import ops
         ops.refresh_param_copies(optimizer.params if hasattr(optimizer, 'params') else model.parameters(), amp_dtype)
+    settle_gc()                                     # first call only
     return loss, tb_dict, disp_dict
