@@ -620,7 +620,7 @@ class _PosProj(torch.autograd.Function):
         # W[lo:hi]^T for the in-place input gradient, cached with the folded weight (it was transposed again in every backward:
         # one launch per attention layer and step)
         ctx.wt = (_derived(weight, ('plainT', lo, hi), lambda w: w[lo:hi].to(torch.bfloat16).t().contiguous())
-                  if (inplace_dx and fork and not _os.environ.get('TMAE_NO_WT')) else None)
+                  if (inplace_dx and fork) else None)
         ctx.fork, ctx.has_bias = fork, bias is not None
         ctx.inplace_dx = bool(inplace_dx and fork)
         ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
@@ -1674,14 +1674,7 @@ class _DeblocksToDense(torch.autograd.Function):
                                        _p(sum_dz), _p(sum_dzx), _p(ws), wsb, _s()), 'tmae_bn_bwd_sums')
             # inactive cells: z = beta - mean*rstd*gamma (constant per channel), xhat = -mean*rstd: their share of the sums
             dbeta, dgamma = torch.empty_like(sum_dz), torch.empty_like(sum_dz)
-            if _os.environ.get('TMAE_NO_TAIL'):
-                xhat0 = -mean * rstd
-                live0 = ((b32 + xhat0 * g32) > 0).float()
-                rest = (s_all[coff:coff + cout] - s_act) * live0
-                dbeta = (sum_dz + rest).contiguous()
-                dgamma = (sum_dzx + rest * xhat0).contiguous()
-            else:
-              check(lib.tmae_deblock_bn_tail(_p(mean), _p(rstd), _p(g32), _p(b32), s_all.data_ptr() + 4 * coff, _p(s_act),
+            check(lib.tmae_deblock_bn_tail(_p(mean), _p(rstd), _p(g32), _p(b32), s_all.data_ptr() + 4 * coff, _p(s_act),
                                            _p(sum_dz), _p(sum_dzx), cout, _p(dbeta), _p(dgamma), _s()), 'tmae_deblock_bn_tail')
             tb, tg, tcount = dbeta, dgamma, count
             if ctx.pg is not None:                # the sums of every rank enter dx; dgamma / dbeta stay this rank's
