@@ -27,8 +27,12 @@ __device__ __forceinline__ short f2bf(float v) {
   __hip_bfloat16 b = __float2bfloat16(v);
   return *reinterpret_cast<short*>(&b);
 }
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// two floats -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32 (the scalar conversions compiled to a
+// convert per element plus shifts and ors to pack them)
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-  return (unsigned)(unsigned short)f2bf(a) | ((unsigned)(unsigned short)f2bf(b) << 16);
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 __device__ __forceinline__ float bf2f(short s) { return __uint_as_float(((unsigned)(unsigned short)s) << 16); }
 // 1/x in one instruction (1 ulp); an IEEE division costs ~10 VALU instructions and these kernels are VALU-bound
@@ -113,24 +117,35 @@ template <int DH> struct Frag;
 template <> struct Frag<32> { typedef s16x8 T; };
 template <> struct Frag<16> { typedef s16x4 T; };
 
+// a raw row fragment IS the MFMA fragment of its bf16 values (same element order): V and dO go straight from the load to the
+// matrix core -- rounds 1-4 unpacked them to fp32 and packed them again (exact, and 20 VALU instructions per fragment)
+template <int FR>
+__device__ __forceinline__ typename Frag<FR * 4>::T raw_as_frag(const typename RawFrag<FR>::T& u) {
+  return __builtin_bit_cast(typename Frag<FR * 4>::T, u);
+}
+
+
 template <int FR>
 __device__ __forceinline__ typename Frag<FR * 4>::T pack_frag(const float* f) {
-  typename Frag<FR * 4>::T r;
+  typename RawFrag<FR>::T u;
 #pragma unroll
-  for (int j = 0; j < FR; ++j) r[j] = f2bf(f[j]);
-  return r;
+  for (int j = 0; j < FR / 2; ++j) u[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]);
+  return __builtin_bit_cast(typename Frag<FR * 4>::T, u);
 }
 
 // hi/lo split of an fp32 fragment into two bf16 fragments (f ~= hi + lo): three MFMAs (hi.hi + hi.lo + lo.hi) give
 // the cosine logits to ~2^-16 relative instead of bf16's 2^-8 -- they are divided by tau >= 0.01 before the exp.
 template <int FR>
 __device__ __forceinline__ void split_frag(const float* f, typename Frag<FR * 4>::T& hi, typename Frag<FR * 4>::T& lo) {
+  typename RawFrag<FR>::T uh, ul;
 #pragma unroll
-  for (int j = 0; j < FR; ++j) {
-    const short h = f2bf(f[j]);
-    hi[j] = h;
-    lo[j] = f2bf(f[j] - bf2f(h));
+  for (int j = 0; j < FR / 2; ++j) {
+    const unsigned h = pack_bf16x2(f[2 * j], f[2 * j + 1]);
+    uh[j] = h;
+    ul[j] = pack_bf16x2(f[2 * j] - __uint_as_float(h << 16), f[2 * j + 1] - __uint_as_float(h & 0xFFFF0000u));
   }
+  hi = __builtin_bit_cast(typename Frag<FR * 4>::T, uh);
+  lo = __builtin_bit_cast(typename Frag<FR * 4>::T, ul);
 }
 
 
@@ -397,8 +412,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
       unpack_row<FR>(rk[t], f);
       normalize_frag<FR>(f, 1.0f);
       split_frag<FR>(f, kf[t], kl[t]);
-      unpack_row<FR>(rv[t], f);
-      store_img_frag<DH>(&vimg[w][slot * RB], g, pack_frag<FR>(f));
+      store_img_frag<DH>(&vimg[w][slot * RB], g, raw_as_frag<FR>(rv[t]));
     } else {
 #pragma unroll
       for (int j = 0; j < FR; ++j) { kf[t][j] = 0; kl[t][j] = 0; }
@@ -467,12 +481,14 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         if (KB || kt < nk) {
+          float pe[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = __expf(st[kt][r] - mx);
-            l += p;
-            pf[kt][r] = f2bf(p);
+            pe[r] = __expf(st[kt][r] - mx);
+            l += pe[r];
           }
+          const u32x2 pu = {pack_bf16x2(pe[0], pe[1]), pack_bf16x2(pe[2], pe[3])};
+          pf[kt] = __builtin_bit_cast(s16x4, pu);
         }
       }
       l = quad_sum(l);
@@ -647,8 +663,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
       const float nrm = normalize_frag<FR>(f, 1.0f);
       split_frag<FR>(f, kf[t], kl[t]);
       if (g == 0) knorm[w][slot] = nrm;
-      unpack_row<FR>(rv[t], f);
-      vr[t] = pack_frag<FR>(f);
+      vr[t] = raw_as_frag<FR>(rv[t]);
     } else {
 #pragma unroll
       for (int j = 0; j < FR; ++j) { kf[t][j] = 0; kl[t][j] = 0; vr[t][j] = 0; }
@@ -661,9 +676,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
       split_frag<FR>(f, qf[t], ql[t]);
       store_img_frag<DH>(&qimg[w][slot * RB], g, qf[t]);
       if (g == 0) qnorm[w][slot] = nrm;
-      float gfl[FR];
-      unpack_row<FR>(rg[t], gfl);
-      gf[t] = pack_frag<FR>(gfl);                                        // exact: bf16 -> f32 -> bf16
+      gf[t] = raw_as_frag<FR>(rg[t]);
       store_img_frag<DH>(&gimg[w][slot * RB], g, gf[t]);
     }
   }
@@ -758,15 +771,15 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) dP[r] -= dacc;
           }
-          s16x4 dsT, pTb;
+          float dsv[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = pT[r];
-            const float ds = p * dP[r];                    // dP holds dP - D here
-            dtau_acc += ds * sT[r];                        // p = 0 entries: 0 * finite
-            dsT[r] = f2bf(ds);
-            pTb[r] = f2bf(p);
+            dsv[r] = pT[r] * dP[r];                        // dP holds dP - D here
+            dtau_acc += dsv[r] * sT[r];                    // p = 0 entries: 0 * finite
           }
+          const u32x2 dsu = {pack_bf16x2(dsv[0], dsv[1]), pack_bf16x2(dsv[2], dsv[3])};
+          const u32x2 ptu = {pack_bf16x2(pT[0], pT[1]), pack_bf16x2(pT[2], pT[3])};
+          const s16x4 dsT = __builtin_bit_cast(s16x4, dsu), pTb = __builtin_bit_cast(s16x4, ptu);
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
             const s16x4 trK = tr_read4(&kimg[w][(kt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3)]);
