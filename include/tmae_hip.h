@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 10
+#define TMAE_ABI_VERSION 11
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -86,16 +86,20 @@ int tmae_vfe_point_features(const float* points, int row, const int64_t* point_c
 
 /* The same point features for the bf16 (autocast) path, which must not round absolute coordinates (up to 75 m) to
  * 8 mantissa bits before the first Linear (temporal_dyn_vfe.py:110-112 under AMP keeps 11): feats_hl [n,32] bf16 =
- * [hi(16) | lo(16)] with hi + lo = the fp32 feature to ~2^-17 relative, columns >= F+6 of each half zero. */
+ * [hi(16) | lo(16)] with hi + lo = the fp32 feature to ~2^-17 relative, columns >= F+6 of each half zero.
+ * inverse_csr (may be NULL) [n] i64: when given, the rows of feats_hl come out in CSR order -- row j = point perm[j], i.e.
+ * sorted by voxel -- and inverse_csr[j] = the voxel of that row: the point MLP is row-wise, and the segment max behind it
+ * (tmae_segment_max_fwd with perm = NULL, _bwd with inverse_csr) then walks consecutive rows. */
 int tmae_vfe_point_features_bf16x2(const float* points, int row, const int64_t* point_coords_i64,
                                    const int64_t* inverse_i64, const int32_t* perm, const int32_t* offsets,
                                    int64_t n, int64_t m,
                                    float rmin_x, float rmin_y, float rmin_z, float vs_x, float vs_y, float vs_z,
-                                   float* voxel_mean, void* feats_hl, void* stream);
+                                   float* voxel_mean, void* feats_hl, int64_t* inverse_csr, void* stream);
 
 /* torch_scatter.scatter_max (temporal_dyn_vfe.py:113): out[v,c] = max over the voxel's points,
  * argmax[v,c] = first point (ascending id) attaining it.  x [n,c]; backward routes the
- * gradient to the argmax rows (dx fully written, no pre-zeroing needed). */
+ * gradient to the argmax rows (dx fully written, no pre-zeroing needed).  perm may be NULL: the rows of x are in CSR
+ * order already (row j belongs to the voxel v with offsets[v] <= j < offsets[v+1]); argmax then holds CSR row ids. */
 int tmae_segment_max_fwd(const void* x, int dtype, int64_t n, int64_t m, int c,
                          const int32_t* perm, const int32_t* offsets,
                          void* out, int32_t* argmax, void* stream);

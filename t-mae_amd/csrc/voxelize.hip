@@ -280,9 +280,15 @@ __global__ __launch_bounds__(256) void point_feat_split_kernel(const float* __re
                                                               const int64_t* __restrict__ inv,
                                                               const float* __restrict__ mean, int64_t n, float rx,
                                                               float ry, float rz, float vx, float vy, float vz,
-                                                              __hip_bfloat16* __restrict__ out) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+                                                              __hip_bfloat16* __restrict__ out,
+                                                              const int32_t* __restrict__ perm,
+                                                              int64_t* __restrict__ inv_csr) {
+  // perm / inv_csr (both or neither): row j of `out` is point perm[j] -- the rows come out SORTED BY VOXEL, inv_csr[j] = that
+  // point's voxel -- so that everything downstream that walks a voxel's points (the segment max and its backward) reads
+  // consecutive rows instead of gathering 256-byte rows all over the point list
+  const int64_t j_ = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j_ >= n) return;
+  const int64_t i = perm ? (int64_t)perm[j_] : j_;
   const int F = row - 1;
   const float* p = pts + i * row;
   const int64_t* c = pc + i * 4;
@@ -310,7 +316,8 @@ __global__ __launch_bounds__(256) void point_feat_split_kernel(const float* __re
     hi[k] = __float2bfloat16(f[k]);
     lo[k] = __float2bfloat16(f[k] - __bfloat162float(hi[k]));
   }
-  uint4* o = reinterpret_cast<uint4*>(out + i * 32);
+  if (inv_csr) inv_csr[j_] = inv[i];
+  uint4* o = reinterpret_cast<uint4*>(out + j_ * 32);
   o[0] = reinterpret_cast<const uint4*>(hi)[0];
   o[1] = reinterpret_cast<const uint4*>(hi)[1];
   o[2] = reinterpret_cast<const uint4*>(lo)[0];
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(256) void point_feat_split_kernel(const float* __re
 int tmae_vfe_point_features_bf16x2(const float* points, int row, const int64_t* pc, const int64_t* inverse,
                                    const int32_t* perm, const int32_t* offsets, int64_t n, int64_t m, float rx,
                                    float ry, float rz, float vx, float vy, float vz, float* voxel_mean, void* feats_hl,
-                                   void* stream_) {
+                                   int64_t* inverse_csr, void* stream_) {
   (void)hipGetLastError();
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || m < 0 || row < 4 || row - 1 > VFE_MAXF) return TMAE_EARG;
@@ -329,7 +336,8 @@ int tmae_vfe_point_features_bf16x2(const float* points, int row, const int64_t* 
   hipLaunchKernelGGL(voxel_mean_kernel, dim3(tmae_cdiv(m, 256)), dim3(256), 0, stream, points, row, perm, offsets, m,
                      voxel_mean);
   hipLaunchKernelGGL(point_feat_split_kernel, dim3(tmae_cdiv(n, 256)), dim3(256), 0, stream, points, row, pc, inverse,
-                     voxel_mean, n, rx, ry, rz, vx, vy, vz, (__hip_bfloat16*)feats_hl);
+                     voxel_mean, n, rx, ry, rz, vx, vy, vz, (__hip_bfloat16*)feats_hl,
+                     inverse_csr ? perm : (const int32_t*)nullptr, inverse_csr);
   return tmae_launch_status();
 }
 
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(256) void segmax_fwd_kernel(const T* __restrict__ x
     float best = -INFINITY;
     int arg = -1;
     for (int j = lo; j < hi; ++j) {
-      const int row = perm[j];
+      const int row = perm ? perm[j] : j;
       const float val = ld_f<T>(x + (int64_t)row * c + ch);
       if (val > best || arg < 0) { best = val; arg = row; }
     }
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(256) void segmax_fwd8_kernel(const T* __restrict__ 
 #pragma unroll
   for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; arg[i] = -1; }
   for (int j = lo; j < hi; ++j) {
-    const int row = perm[j];
+    const int row = perm ? perm[j] : j;             // perm == NULL: the rows of x are already sorted by voxel
     float val[8];
     load8<T>(x + (int64_t)row * C + cl * 8, val);
 #pragma unroll
@@ -463,7 +471,7 @@ int tmae_segment_max_fwd(const void* x, int dtype, int64_t n, int64_t m, int c, 
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || m < 0 || c <= 0) return TMAE_EARG;
   if (m == 0) return TMAE_OK;
-  if (!x || !perm || !offsets || !out || !argmax) return TMAE_EARG;
+  if (!x || !offsets || !out || !argmax) return TMAE_EARG;       // perm may be NULL: rows already in CSR order
   if (segmax_vec_ok(c, x, out) && !((uintptr_t)argmax & 15) && (dtype == TMAE_F32 || dtype == TMAE_BF16)) {
     const dim3 g8(tmae_cdiv(m, 4 * (512 / c)));
     if (dtype == TMAE_F32)

@@ -27,7 +27,7 @@ SIGNATURES = {
     'tmae_ingroup_rank_workspace': (Z, [L, L]),
     'tmae_ingroup_rank': (I, [P, L, L, P, P, Z, P]),
     'tmae_vfe_point_features': (I, [P, I, P, P, P, P, L, L, F, F, F, F, F, F, P, P, P]),
-    'tmae_vfe_point_features_bf16x2': (I, [P, I, P, P, P, P, L, L, F, F, F, F, F, F, P, P, P]),
+    'tmae_vfe_point_features_bf16x2': (I, [P, I, P, P, P, P, L, L, F, F, F, F, F, F, P, P, P, P]),
     'tmae_segment_max_fwd': (I, [P, I, L, L, I, P, P, P, P, P]),
     'tmae_segment_max_bwd': (I, [P, I, L, L, I, P, P, P, P]),
     'tmae_group_points': (I, [P, I, P, P, P, L, I, F, F, F, F, F, F, P, P, P]),
@@ -128,7 +128,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     setattr(lib, _name, _strict(_fn, _name, len(_args)))
 
-ABI_VERSION = 10            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
+ABI_VERSION = 11            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError(f'libtmae_hip.so ABI version {lib.tmae_abi_version()} != binding {ABI_VERSION}; rebuild with '
                       f't-mae_amd/build.py')

@@ -61,12 +61,16 @@ class TemporalDynVFE(VFETemplate):
         vox['perm'], vox['offsets'] = perm, offsets
         layers = list(self.dvfe_mlps[0])
         first = layers[0]
+        inv_rows, perm_rows = vox['inverse'], perm
         if ops.compute_dtype(vox['points']) == torch.bfloat16 and first.in_features <= 16:
             # bf16 autocast: the first Linear sees ABSOLUTE coordinates (up to 75 m), which bf16 would round to
             # 0.25-0.5 m steps -- coarser than the pillar.  The features arrive as hi + lo bf16 pairs instead
             # (~16 mantissa bits; the reference's fp16 AMP keeps 11) and the Linear contracts over both halves.
-            _, x2 = ops.vfe_point_features_bf16x2(vox['points'], vox['point_coords'], vox['inverse'], perm, offsets, m,
-                                                  self.point_cloud_range, self.voxel_size)
+            # rows sorted by voxel from here on (the MLP and the norms are row-wise / order-free): the voxel max below and its
+            # backward walk consecutive rows instead of gathering 256-byte rows all over the point list
+            _, x2, inv_rows = ops.vfe_point_features_bf16x2(vox['points'], vox['point_coords'], vox['inverse'], perm, offsets,
+                                                            m, self.point_cloud_range, self.voxel_size, csr_order=True)
+            perm_rows = None
             x = ops.linear_split_input(x2, first.weight)
             layers = layers[1:]
         else:
@@ -82,7 +86,7 @@ class TemporalDynVFE(VFETemplate):
                 x = ops.linear(x, w, None)
             elif isinstance(layer, (nn.BatchNorm1d, nn.SyncBatchNorm)):
                 x = ops.batch_norm_relu(x, layer, relu=True)         # the ReLU that follows is fused
-        x_max, _ = ops.scatter_max(x, vox['inverse'], perm, offsets, m)
+        x_max, _ = ops.scatter_max(x, inv_rows, perm_rows, offsets, m)
         return x_max
 
     def forward(self, batch_dict, **kwargs):

@@ -1157,16 +1157,19 @@ def vfe_point_features(points, point_coords, inverse, perm, offsets, m, pc_range
     return mean, feats
 
 
-def vfe_point_features_bf16x2(points, point_coords, inverse, perm, offsets, m, pc_range, voxel_size):
-    """The point features as [n,32] bf16 = [hi(16) | lo(16)], hi + lo = the fp32 feature (see the header)."""
+def vfe_point_features_bf16x2(points, point_coords, inverse, perm, offsets, m, pc_range, voxel_size, csr_order=False):
+    """The point features as [n,32] bf16 = [hi(16) | lo(16)], hi + lo = the fp32 feature (see the header).
+    csr_order: the rows come out sorted by voxel (row j = point perm[j]) and the third result is inverse_csr [n] (the voxel
+    of every row): the segment max behind the row-wise point MLP then streams (scatter_max(x, inverse_csr, None, ...))."""
     n, row = points.shape
     mean = torch.empty((m, row - 1), dtype=torch.float32, device=points.device)
     feats = torch.empty((n, 32), dtype=torch.bfloat16, device=points.device)
+    inv_csr = torch.empty((n,), dtype=torch.int64, device=points.device) if csr_order else None
     r, vs = [float(v) for v in pc_range[:3]], [float(v) for v in voxel_size]
     check(lib.tmae_vfe_point_features_bf16x2(_p(points), row, _p(point_coords), _p(inverse), _p(perm), _p(offsets), n, m,
-                                             r[0], r[1], r[2], vs[0], vs[1], vs[2], _p(mean), _p(feats), _s()),
+                                             r[0], r[1], r[2], vs[0], vs[1], vs[2], _p(mean), _p(feats), _p(inv_csr), _s()),
           'tmae_vfe_point_features_bf16x2')
-    return mean, feats
+    return (mean, feats, inv_csr) if csr_order else (mean, feats)
 
 
 class _LinearSplitInput(torch.autograd.Function):

@@ -1406,6 +1406,21 @@ def test_vfe_bf16_keeps_far_range_coordinates(oracle):
     rec = hl[:, :16].float() + hl[:, 16:].float()
     assert (rec[:, :10] - f32).abs().max().item() <= 2.0 ** -16 * 75.0
     assert (rec[:, 10:] == 0).all()
+    # CSR order (what the model uses): the same rows, sorted by voxel; inverse_csr names the voxel of every row; the segment max
+    # over them with perm = None equals the one over the unsorted rows with the permutation, values AND gradient
+    _, hl_csr, inv_csr = ops.vfe_point_features_bf16x2(*args, csr_order=True)
+    assert torch.equal(hl_csr, hl[perm.long()]) and torch.equal(inv_csr, v['inverse'][perm.long()])
+    assert bool((inv_csr[1:] >= inv_csr[:-1]).all())
+    mvox = v['voxel_coords'].shape[0]
+    xa = torch.randn(hl.shape[0], 128, device=dev()).bfloat16()
+    xb = xa[perm.long()].contiguous()
+    xa.requires_grad_(True), xb.requires_grad_(True)
+    ya, _ = ops.scatter_max(xa, v['inverse'], perm, offs, mvox)
+    yb, _ = ops.scatter_max(xb, inv_csr, None, offs, mvox)
+    assert torch.equal(ya, yb)
+    go = torch.randn_like(ya)
+    ya.backward(go), yb.backward(go)
+    assert torch.equal(xb.grad, xa.grad[perm.long()])
 
 
 def test_proj_fork_out_of_place_is_hook_safe():
