@@ -412,13 +412,26 @@ __global__ __launch_bounds__(256) void segmax_fwd8_kernel(const T* __restrict__ 
   int arg[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; arg[i] = -1; }
-  for (int j = lo; j < hi; ++j) {
-    const int row = perm ? perm[j] : j;             // perm == NULL: the rows of x are already sorted by voxel
-    float val[8];
-    load8<T>(x + (int64_t)row * C + cl * 8, val);
+  // four rows per round, all four loads in flight before the first comparison (a voxel holds 2-3 points: one dependent load
+  // per point left this kernel waiting for memory latency, not bandwidth); rows past the segment re-read its last row
+  for (int j0 = lo; j0 < hi; j0 += 4) {
+    int rows[4];
+    float val[4][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (val[i] > best[i] || arg[i] < 0) { best[i] = val[i]; arg[i] = row; }
+    for (int u = 0; u < 4; ++u) {
+      const int j = min(j0 + u, hi - 1);
+      rows[u] = perm ? perm[j] : j;                 // perm == NULL: the rows of x are already sorted by voxel
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load8<T>(x + (int64_t)rows[u] * C + cl * 8, val[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (j0 + u < hi) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (val[u][i] > best[i] || arg[i] < 0) { best[i] = val[u][i]; arg[i] = rows[u]; }
+      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
