@@ -1180,12 +1180,24 @@ class _LinearSplitInput(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, weight):
         k = weight.shape[1]
-        w = torch.zeros((weight.shape[0], 32), dtype=torch.bfloat16, device=x2.device)
-        wb = weight.detach().to(torch.bfloat16)
-        w[:, :k] = wb
-        w[:, 16:16 + k] = wb
+
+        def dup(wt):                                    # [W | 0 | W | 0]: the same weight against the hi and the lo half
+            w = torch.zeros((wt.shape[0], 32), dtype=torch.bfloat16, device=wt.device)
+            wb = wt.detach().to(torch.bfloat16)
+            w[:, :k] = wb
+            w[:, 16:16 + k] = wb
+            return w
+        w = _derived(weight, ('hilo', k), dup)           # once per weight version (both frames of a step share it)
         ctx.save_for_backward(x2)
         ctx.k, ctx.wdtype = k, weight.dtype
+        n = w.shape[0]
+        if (x2.is_cuda and x2.dtype == torch.bfloat16 and x2.is_contiguous() and n % 64 == 0 and x2.shape[0] >= _TOKEN_GEMM_MIN_ROWS
+                and x2.shape[0] * n * 2 < 2 ** 31):
+            # contraction 32 on the token GEMM (csrc/token_gemm.hip): the library ran this 174 MB pass at 1.4 TB/s
+            y = torch.empty((x2.shape[0], n), dtype=torch.bfloat16, device=x2.device)
+            check(lib.tmae_token_gemm(_p(x2), 32, x2.shape[0], 32, _p(w), n, _p(_zero_bias(n, x2.device)), _p(y), n, _s()),
+                  'tmae_token_gemm')
+            return y
         return torch.nn.functional.linear(x2, w)
 
     @staticmethod

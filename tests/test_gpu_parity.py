@@ -597,6 +597,16 @@ def test_token_gemm_kernel_vs_torch():
         assert (y0.float() - x.float() @ w.float().t()).abs().max().item() <= 2e-2 * max(1.0, float(ref.abs().max()))
         lib_y = F.linear(x, w, b)
         assert (y.float() - lib_y.float()).abs().max().item() <= 4e-2 * max(1.0, float(ref.abs().max()))
+    # contraction 32 (the VFE's first Linear on the hi | lo split point features): one k-step, 64 output columns
+    for m in (8192, 905005, 33):
+        x = torch.randn(m, 32, device=dev()).bfloat16()
+        w = (torch.randn(64, 32, device=dev()) * 0.3).bfloat16()
+        y = torch.empty((m, 64), dtype=torch.bfloat16, device=dev())
+        from tmae_amd._lib import lib, check
+        check(lib.tmae_token_gemm(x.data_ptr(), 32, m, 32, w.data_ptr(), 64, torch.zeros(64, device=dev()).bfloat16().data_ptr(),
+                                  y.data_ptr(), 64, torch.cuda.current_stream().cuda_stream), 'tmae_token_gemm')
+        ref = x.float() @ w.float().t()
+        assert (y.float() - ref).abs().max().item() <= 2e-2 * max(1.0, float(ref.abs().max())), m
     big = torch.randn(30000, 384, device=dev()).bfloat16()
     xs = big[:, 128:384]                                   # pitch 384, 256 columns
     w = (torch.randn(128, 256, device=dev()) * 0.1).bfloat16()
