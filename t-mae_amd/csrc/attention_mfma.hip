@@ -600,8 +600,12 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
   typedef typename Frag<DH>::T frag_t;
   __shared__ int toks[2][64];
   __shared__ __attribute__((aligned(16))) char kimg[4][ROWS * RB];   // K-hat
-  __shared__ __attribute__((aligned(16))) char qimg[4][ROWS * RB];   // Q-hat / tau_c
-  __shared__ __attribute__((aligned(16))) char gimg[4][ROWS * RB];   // dO
+  // Q-hat / tau_c and dO: ONE 16-row tile each, rewritten by its wave at the top of every query tile (round 5).  Holding all NT
+  // tiles cost 41 KB of the 69 KB a dh-32 64-token workgroup used: two workgroups per CU, two waves per SIMD, in a kernel that
+  // waits on latency (its first 2 us are global loads, every logit tile is an MFMA -> VALU -> exp -> MFMA chain).  With 28 KB and
+  // the 168-register build the launch bounds ask for, three workgroups fit.
+  __shared__ __attribute__((aligned(16))) char qimg[4][16 * RB];     // Q-hat / tau_c of the current query tile
+  __shared__ __attribute__((aligned(16))) char gimg[4][16 * RB];     // dO of the current query tile
   __shared__ float qnorm[4][ROWS], knorm[4][ROWS];
   constexpr int TP = 40;                                              // pitch (bytes) of the 16x16 bf16 transpose tiles
   __shared__ __attribute__((aligned(16))) char ptile[4][2][16 * TP];
@@ -674,10 +678,8 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
       unpack_row<FR>(rq[t], f);
       const float nrm = normalize_frag<FR>(f, inv_tau);
       split_frag<FR>(f, qf[t], ql[t]);
-      store_img_frag<DH>(&qimg[w][slot * RB], g, qf[t]);
       if (g == 0) qnorm[w][slot] = nrm;
       gf[t] = raw_as_frag<FR>(rg[t]);
-      store_img_frag<DH>(&gimg[w][slot * RB], g, gf[t]);
     }
   }
   __syncthreads();
@@ -704,14 +706,19 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
   for (int qt = 0; qt < NT; ++qt) {
     if (qt < nq) {
       const int qslot = qt * 16 + i;
-      // transposed right-hand fragments of this query tile
+      // transposed right-hand fragments of this query tile: its rows go into the wave's one-tile images first (LDS operations
+      // of a wave execute in order: the stores land behind the previous tile's transposed reads and in front of these)
+      store_img_frag<DH>(&qimg[w][i * RB], g, qf[qt]);
+      store_img_frag<DH>(&gimg[w][i * RB], g, gf[qt]);
+      __builtin_amdgcn_wave_barrier();
       s16x4 trQ[CT], trG[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const int off = (qt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3);
+        const int off = (4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3);
         trQ[ct] = tr_read4(&qimg[w][off]);
         trG[ct] = tr_read4(&gimg[w][off]);
       }
+      __builtin_amdgcn_wave_barrier();
       f32x4 dQa[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) dQa[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
