@@ -38,6 +38,15 @@ def _abi_hash():
     return mod.header_hash(open(os.path.join(HERE, '..', 'include', 'tmae_hip.h')).read())
 
 
+# Per-file flags.  -fno-slp-vectorize: the SLP vectoriser turns adjacent scalar f32 adds / multiplies into v_pk_*_f32, which beside
+# MFMAs cost several times the two scalar instructions they replace (MI355X_MICROARCH.md, per-instruction constants); the files
+# below were A/B-measured with and without it (profiles/round5_ab_no_slp.txt).  tools/check_mfma_hazards.py compiles with the same.
+PER_FILE_FLAGS = {
+    'attention_mfma.hip': ['-fno-slp-vectorize'],          # attention family -0.27 ms per step
+    # measured and NOT set: token_gemm_wreg.hip (its GELU epilogues run 2-6 % SLOWER unpacked), wgrad.hip, spconv_igemm.hip (neutral)
+}
+
+
 def build(force=False, verbose=False, ab=False):
     """ab=True: the A/B debug build (-DTMAE_AB: environment switches and the retired kernel variants behind them, see
     csrc/common.h) -> t-mae_amd/build_ab/libtmae_ab.so; load it with TMAE_LIB_PATH (profiles/scripts/ab_env.sh)."""
@@ -52,7 +61,7 @@ def build(force=False, verbose=False, ab=False):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
     hdrs = tuple(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + (
-        os.path.join(HERE, '..', 'include', 'tmae_hip.h'), os.path.join(HERE, 'tmae_amd', '_abi.py'))
+        os.path.join(HERE, '..', 'include', 'tmae_hip.h'), os.path.join(HERE, 'tmae_amd', '_abi.py'), os.path.abspath(__file__))
     jobs = []
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + '.o')
@@ -61,7 +70,7 @@ def build(force=False, verbose=False, ab=False):
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + flags + ['-c', src, '-o', obj]
+        cmd = [HIPCC] + flags + PER_FILE_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         if verbose:
             cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
         r = subprocess.run(cmd, capture_output=True, text=True)

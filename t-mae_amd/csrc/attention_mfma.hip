@@ -35,6 +35,15 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 __device__ __forceinline__ float bf2f(short s) { return __uint_as_float(((unsigned)(unsigned short)s) << 16); }
+// exp(s - m) with m given as m * log2(e): one fused multiply-add and the bare v_exp_f32 -- __expf(s - m) compiles to subtract,
+// multiply, v_exp_f32.  m = +inf (no query) gives exp2(-inf) = 0, MASKED_LOGIT underflows to exactly 0 as before.
+// Scalar on purpose, and this file is compiled with -fno-slp-vectorize (build.py): v_pk_*_f32 beside MFMAs costs several times
+// the two scalar instructions it replaces (MI355X_MICROARCH.md, per-instruction constants; same-box A/B of the packed form of
+// the loops below: +0.2 ms per step).
+#define LOG2E_F 1.4426950408889634f
+__device__ __forceinline__ float exp_minus(const float s, const float m_log2e) {
+  return __builtin_amdgcn_exp2f(__builtin_fmaf(s, LOG2E_F, -m_log2e));
+}
 // 1/x in one instruction (1 ulp); an IEEE division costs ~10 VALU instructions and these kernels are VALU-bound
 #define MASKED_LOGIT (-30000.0f)   // finite: 0 * MASKED_LOGIT stays 0 in the tau gradient
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -476,6 +485,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
         }
       }
       mx = quad_max(mx);
+      const float mxl = mx * LOG2E_F;
       float l = 0.f;
       s16x4 pf[NT];
 #pragma unroll
@@ -484,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
           float pe[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            pe[r] = __expf(st[kt][r] - mx);
+            pe[r] = exp_minus(st[kt][r], mxl);
             l += pe[r];
           }
           const u32x2 pu = {pack_bf16x2(pe[0], pe[1]), pack_bf16x2(pe[2], pe[3])};
@@ -730,6 +740,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
       constexpr bool RECOMP = NT >= 4;
       f32x4 sTk[RECOMP ? 1 : NT], pTk[RECOMP ? 1 : NT], dPk[RECOMP ? 1 : NT];
       float dacc = 0.f;
+      const float lse_l = lse_i[qt] * LOG2E_F;
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         if (kt < nk) {
@@ -744,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
           if constexpr (!RECOMP) { sTk[kt] = sT; dPk[kt] = dP; }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = __expf(sT[r] - lse_i[qt]);
+            const float p = exp_minus(sT[r], lse_l);
             if constexpr (!RECOMP) pTk[kt][r] = p;
             dacc += p * dP[r];
           }
@@ -769,19 +780,14 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
             // tools/check_mfma_hazards.py walks both sides of every branch behind every MFMA.  Now the mask rides on the C
             // operand and no branch is left between these MFMAs and their readers.
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              pT[r] = __expf(sT[r] - lse_i[qt]);
-              dP[r] -= dacc;
-            }
+            for (int r = 0; r < 4; ++r) pT[r] = exp_minus(sT[r], lse_l);
           } else {
             sT = sTk[kt]; dP = dPk[kt]; pT = pTk[kt];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dP[r] -= dacc;
           }
           float dsv[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            dsv[r] = pT[r] * dP[r];                        // dP holds dP - D here
+            dsv[r] = pT[r] * (dP[r] - dacc);               // dS = P (dP - D)
             dtau_acc += dsv[r] * sT[r];                    // p = 0 entries: 0 * finite
           }
           const u32x2 dsu = {pack_bf16x2(dsv[0], dsv[1]), pack_bf16x2(dsv[2], dsv[3])};

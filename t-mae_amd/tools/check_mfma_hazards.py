@@ -133,9 +133,18 @@ def check_asm(asm_text):
     return out
 
 
+def _per_file_flags(hip_file):
+    """the flags build.py compiles this file with beyond the common ones (the ISA that is checked must be the ISA that ships)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_tmae_build', os.path.join(PKG, 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return list(mod.PER_FILE_FLAGS.get(os.path.basename(hip_file), []))
+
+
 def compile_to_asm(hip_file, out_file):
     cmd = [HIPCC, '-O3', '--offload-arch=gfx950', '-std=c++17', '-DTMAE_ABI_HASH=0', '-I', os.path.join(PKG, '..', 'include'),
-           '-S', '--cuda-device-only', hip_file, '-o', out_file]
+           '-S', '--cuda-device-only'] + _per_file_flags(hip_file) + [hip_file, '-o', out_file]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr[-2000:])
