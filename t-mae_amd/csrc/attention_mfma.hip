@@ -115,7 +115,7 @@ __device__ __forceinline__ float normalize_frag(float* f, float scale) {
 #pragma unroll
   for (int j = 0; j < FR; ++j) ss += f[j] * f[j];
   ss = quad_sum(ss);
-  const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+  const float nrm = fmaxf(__builtin_amdgcn_sqrtf(ss), 1e-12f);   // v_sqrt_f32 (1 ulp); sqrtf() expands to ~17 instructions
   const float inv = scale * fast_rcp(nrm);
 #pragma unroll
   for (int j = 0; j < FR; ++j) f[j] *= inv;
@@ -449,19 +449,23 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
   // operand (exp underflows to exactly 0): no per-element masking in the loops, and tiles kt >= nk need no special
   // case (only where the 4*NT registers are free: the 64-token class would lose a resident wave and masks per element)
   constexpr bool KB = NT <= 2;
-  f32x4 kbias[KB ? NT : 1];
+  f32x4 kbias[NT];
   if constexpr (KB) {
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) kbias[kt][r] = key_bias<PAIR>(kt * 16 + 4 * g + r, i, wi);
   } else {
-    // (!KB, the 64-token class: no registers for a bias per tile) only the LAST key tile can hold absent rows: ONE bias vector,
-    // selected as the C operand of that tile's first MFMA by a wave-uniform condition.  No branch between a logit MFMA and its
-    // first VALU reader anywhere in these kernels: the compiler leaves the taken side of such a branch without the wait states
-    // an MFMA result needs (tools/check_mfma_hazards.py).
+    // (!KB, the 64-token class) one bias vector per key tile as well, made once per window: all zeros except in the tile that
+    // holds the first absent row.  (Until round 5 a single vector was selected into the C operand by `kt == nk - 1`: a
+    // wave-uniform condition, but the select compiled to four v_cndmask per tile and pass: 100 of the backward's 2 100 VALU
+    // instructions.)  No branch between a logit MFMA and its first VALU reader anywhere in these kernels: the compiler leaves
+    // the taken side of such a branch without the wait states an MFMA result needs (tools/check_mfma_hazards.py).
+    const int first_absent = Tk - 4 * g;       // row kt * 16 + 4 g + r is absent when kt * 16 + r >= Tk - 4 g
 #pragma unroll
-    for (int r = 0; r < 4; ++r) kbias[0][r] = ((nk - 1) * 16 + 4 * g + r >= Tk) ? MASKED_LOGIT : 0.f;
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kbias[kt][r] = (kt * 16 + r >= first_absent) ? MASKED_LOGIT : 0.f;
   }
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -472,13 +476,13 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         if (kt < nk) {
-          f32x4 c0;
-          if constexpr (KB) c0 = kbias[kt]; else c0 = (kt == nk - 1) ? kbias[0] : zero4;
-          st[kt] = mfma_s(kl[kt], qf[qt], c0);                       // S^T tile: rows = keys 4g+r, col = query i
+          st[kt] = mfma_s(kl[kt], qf[qt], kbias[kt]);                      // S^T tile: rows = keys 4g+r, col = query i
           st[kt] = mfma_s(kf[kt], ql[qt], st[kt]);
           st[kt] = mfma_s(kf[kt], qf[qt], st[kt]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
+          // (two v_max3_f32 in inline asm would save the canonicalising v_max_f32 the compiler puts in front of fmaxf() on an MFMA
+          //  result -- but the compiler does not pad the MFMA -> VALU hazard in front of inline asm: check_mfma_hazards.py flags it)
           asm volatile("" : "+v"(mx));                               // the first reader stays in the MFMAs' block
         } else if constexpr (KB) {
           st[kt] = kbias[kt];                                        // all rows absent: p = 0 below
@@ -508,10 +512,9 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
       f32x4 o[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-          if (kt < nk) o[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[kt][ct], pf[kt], o[ct], 0, 0, 0);
+        for (int kt = 0; kt < NT; ++kt)              // key tile 0 is always present: it starts from the inline constant 0
+          if (kt < nk) o[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[kt][ct], pf[kt], kt == 0 ? zero4 : o[ct], 0, 0, 0);
       }
       // lane (g, i): query i, channels (DH/4) g + 4 ct + r -- DH/4 consecutive channels: one wide store (dropped by the
       // descriptor's range check when the slot holds no query)
@@ -693,22 +696,21 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
     }
   }
   __syncthreads();
-  f32x4 dKa[NT][CT], dVa[NT][CT];
-#pragma unroll
-  for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) { dKa[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; dVa[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  f32x4 dKa[NT][CT], dVa[NT][CT];            // first written by query tile 0 (always present; tiles kt >= nk are never read)
   float dtau_acc = 0.f;
   constexpr bool KB = NT <= 2;             // MASKED_LOGIT on absent / foreign key rows through the C operand (see the forward)
-  f32x4 kbias[KB ? NT : 1];
+  f32x4 kbias[NT];
   if constexpr (KB) {
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) kbias[kt][r] = key_bias<PAIR>(kt * 16 + 4 * g + r, i, wi);
   } else {
+    const int first_absent = Tk - 4 * g;       // row kt * 16 + 4 g + r is absent when kt * 16 + r >= Tk - 4 g
 #pragma unroll
-    for (int r = 0; r < 4; ++r) kbias[0][r] = ((nk - 1) * 16 + 4 * g + r >= Tk) ? MASKED_LOGIT : 0.f;   // the last key tile's bias
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) kbias[kt][r] = (kt * 16 + r >= first_absent) ? MASKED_LOGIT : 0.f;
   }
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -729,9 +731,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
         trG[ct] = tr_read4(&gimg[w][off]);
       }
       __builtin_amdgcn_wave_barrier();
-      f32x4 dQa[CT];
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) dQa[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 dQa[CT];                                  // first written by key tile 0 (always present)
       // pass 1 over the key tiles: logits, probabilities and dP; D_i = sum_j P_ij dP_ij is taken from THESE values
       // (not from dO . O with the bf16-rounded saved output), so that sum_j dS_ij = 0 holds to fp32 rounding --
       // the tau gradient sum_ij dS_ij s_ij is a difference of large terms and is biased otherwise
@@ -746,9 +746,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
         if (kt < nk) {
           // swapped: rows = keys 4g+r of this tile, column = query i; masked keys (MASKED_LOGIT through the C operand) and
           // absent queries (lse = +inf) give p = 0
-          f32x4 c0;
-          if constexpr (KB) c0 = kbias[kt]; else c0 = (kt == nk - 1) ? kbias[0] : zero4;
-          f32x4 sT = mfma_s(kl[kt], qf[qt], c0);
+          f32x4 sT = mfma_s(kl[kt], qf[qt], kbias[kt]);
           sT = mfma_s(kf[kt], ql[qt], sT);
           sT = mfma_s(kf[kt], qf[qt], sT);
           const f32x4 dP = mfma_s(vr[kt], gf[qt], zero4);
@@ -768,11 +766,10 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
         if (kt < nk) {
           f32x4 sT, dP, pT;
           if constexpr (RECOMP) {
-            const f32x4 c0 = (kt == nk - 1) ? kbias[0] : zero4;          // (RECOMP implies !KB)
-            sT = mfma_s(kl[kt], qf[qt], c0);
+            sT = mfma_s(kl[kt], qf[qt], kbias[kt]);
             sT = mfma_s(kf[kt], ql[qt], sT);
             sT = mfma_s(kf[kt], qf[qt], sT);
-            dP = mfma_s(vr[kt], gf[qt], zero4);
+            dP = mfma_s(vr[kt], gf[qt], f32x4{-dacc, -dacc, -dacc, -dacc});   // dP - D: D enters through the C operand
             // Round 4 masked the absent keys per element here and found that restricting the mask to the last tile (a wave-uniform
             // branch between the dP MFMA and `dP - D`) gave NaN in dK and garbage in dQ at the temperature clamp: not arithmetic --
             // the compiler had left the TAKEN side of that branch without the wait states an MFMA result needs before its first
@@ -787,7 +784,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
           float dsv[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            dsv[r] = pT[r] * (dP[r] - dacc);               // dS = P (dP - D)
+            dsv[r] = pT[r] * (RECOMP ? dP[r] : dP[r] - dacc);  // dS = P (dP - D)
             dtau_acc += dsv[r] * sT[r];                    // p = 0 entries: 0 * finite
           }
           const u32x2 dsu = {pack_bf16x2(dsv[0], dsv[1]), pack_bf16x2(dsv[2], dsv[3])};
@@ -796,7 +793,8 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
             const s16x4 trK = tr_read4(&kimg[w][(kt * 16 + 4 * g + (i >> 2)) * RB + ct * 32 + 8 * (i & 3)]);
-            dQa[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(trK, dsT, dQa[ct], 0, 0, 0);   // dQ-hat^T
+            // (first tile: C = the inline constant 0 instead of a zeroed accumulator -- kt is a compile-time index here)
+            dQa[ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(trK, dsT, kt == 0 ? zero4 : dQa[ct], 0, 0, 0);   // dQ-hat^T
           }
           // the key-on-lane factors for dV / dK-hat: P and dS of this tile transposed through a 16x16 LDS tile
           // (one 8-byte store + one hardware-transposing read each) instead of recomputing exp() per element
@@ -809,8 +807,8 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
-            dVa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(trG[ct], pU, dVa[kt][ct], 0, 0, 0);    // dV^T
-            dKa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(trQ[ct], dsU, dKa[kt][ct], 0, 0, 0);   // dK-hat^T
+            dVa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(trG[ct], pU, qt == 0 ? zero4 : dVa[kt][ct], 0, 0, 0);    // dV^T
+            dKa[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(trQ[ct], dsU, qt == 0 ? zero4 : dKa[kt][ct], 0, 0, 0);   // dK-hat^T
           }
         }
       }
@@ -818,22 +816,26 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
       // permuted images, so lane (g, i) holds channels FR g + 4 ct + r of query qt*16+i: the SAME channels as its own
       // row fragment qf[qt] -- q-hat comes from registers, the dot product is a quad reduction, one wide store per lane
       {
-        float dqh[FR], qh[FR], dot = 0.f;
+        // with qf = q-hat / tau (bf16 hi part) and dQa = tau * dq-hat: q-hat . dq-hat = qf . dQa, and
+        // dq = dQa (1 / (tau |q|)) - qf (tau (q-hat . dq-hat) / |q|): the scale factors are applied once per row, not per channel
+        float qb[FR], dot = 0.f;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            qh[4 * ct + r] = bf2f(qf[qt][4 * ct + r]) * tau_c;
-            dqh[4 * ct + r] = dQa[ct][r] * inv_tau;
-            dot += qh[4 * ct + r] * dqh[4 * ct + r];
+            qb[4 * ct + r] = bf2f(qf[qt][4 * ct + r]);
+            dot += qb[4 * ct + r] * dQa[ct][r];
           }
         dot = quad_sum(dot);
         const float nrm = qnorm[w][qslot];               // slots without a query: stale, the store below is dropped
         if (nrm <= 1e-12f) dot = 0.f;
         const float inv = fast_rcp(nrm);
+        const float ca = inv_tau * inv, cb = -(tau_c * dot) * inv;
         float o[FR];
 #pragma unroll
-        for (int j = 0; j < FR; ++j) o[j] = (dqh[j] - qh[j] * dot) * inv;
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[4 * ct + r] = __builtin_fmaf(dQa[ct][r], ca, qb[4 * ct + r] * cb);
         store_row_frag<FR>(rsdq, row_off(tokq_[qt], (unsigned)lddq * 2u, colb), o);
       }
     }
@@ -859,9 +861,10 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
       const float nrm = knorm[w][ks];
       if (nrm <= 1e-12f) dot = 0.f;
       const float inv = fast_rcp(nrm);
+      const float cb = -dot * inv;
       float o[FR];
 #pragma unroll
-      for (int j = 0; j < FR; ++j) o[j] = (dkh[j] - kh[j] * dot) * inv;
+      for (int j = 0; j < FR; ++j) o[j] = __builtin_fmaf(dkh[j], inv, kh[j] * cb);
       store_row_frag<FR>(rsdk, row_off(tokk_[kt], (unsigned)lddk * 2u, colb), o);
       store_row_frag<FR>(rsdv, row_off(tokk_[kt], (unsigned)lddv * 2u, colb), dvv);
     }
