@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 11
+#define TMAE_ABI_VERSION 12
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -253,6 +253,21 @@ int tmae_dense_conv3x3_add(const void* in, int batch, int ny, int nx, int cin, c
 size_t tmae_dense_conv3x3_wgrad_workspace(int cin, int cout);
 int tmae_dense_conv3x3_wgrad(const void* dy, const void* x, int batch, int ny, int nx, int cin, int cout, int dilation,
                              float* dw, void* ws, size_t ws_bytes, void* stream);
+
+/* 3x3 convolutions (padding 1) between a 64-channel channels-last map and a narrow one (1 <= k <= 8 channels): the last convs of
+ * CenterHead's branches (pcdet/models/dense_heads/center_head.py:11-45; torch.nn.Conv2d(64, k, 3, padding=1, bias=True) forward,
+ * its input gradient and its weight gradient in the reference).  in / din [batch, ny, nx, 64] bf16 with `ld` elements per cell
+ * (ld >= 64, ld % 8 == 0: a 64-channel slice of a wider map may be passed), out / dout [batch, ny, nx, k] bf16 contiguous,
+ * weight [k, 9, 64] bf16 (the [k, 3, 3, 64] layout flattened), bias [k] fp32 (added before the one rounding to bf16),
+ * dw [k, 9, 64] fp32.  Every tensor < 2 GB.  ws: the matching *_workspace() bytes, 16-byte aligned. */
+int tmae_conv3x3_c64_narrow_fwd(const void* in, int64_t ldi, int batch, int ny, int nx, const void* weight, const float* bias,
+                                int k, void* out, void* stream);
+size_t tmae_conv3x3_c64_narrow_bwd_data_workspace(void);
+int tmae_conv3x3_c64_narrow_bwd_data(const void* dout, int batch, int ny, int nx, int k, const void* weight, void* din,
+                                     int64_t ldo, void* ws, size_t ws_bytes, void* stream);
+size_t tmae_conv3x3_c64_narrow_wgrad_workspace(int k);
+int tmae_conv3x3_c64_narrow_wgrad(const void* dout, const void* in, int64_t ldi, int batch, int ny, int nx, int k, float* dw,
+                                  void* ws, size_t ws_bytes, void* stream);
 
 /* gather-GEMM form: cols [m_out, 9*c] = rows of feat selected by nbr (zeros where -1), to be
  * multiplied by the [cout, 9*c] view of the spconv-2 weight [cout,3,3,cin]; and its adjoint

@@ -208,6 +208,82 @@ def test_head_conv_bias_gradient_vs_torch():
         assert (db1.float() - want).abs().max().item() <= 2e-2 * max(1.0, float(want.abs().max())), (k, db1, want)
 
 
+def test_narrow_head_conv_kernels_vs_torch():
+    """csrc/headconv.hip -- Conv2d(64, k <= 8, 3, padding=1, bias=True) forward, input gradient and weight gradient on a
+    channels-last bf16 map (CenterHead's last convs, center_head.py:11-45) -- against torch's fp32 convolution of the same
+    bf16-representable values: maps that are not multiples of the 16 x 16 block, one smaller than a block, k = 1 .. 8, a map
+    large enough for several blocks per persistent workgroup; a 64-channel slice of a wider map through the C ABI; refusals."""
+    from tmae_amd import ops
+    from tmae_amd._lib import lib
+    torch.manual_seed(6)
+    for k, (B, Y, X) in ((1, (2, 32, 32)), (2, (1, 16, 16)), (3, (2, 40, 23)), (5, (3, 50, 70)), (8, (1, 7, 5)), (4, (1, 3, 90)),
+                         (3, (4, 468, 468))):
+        conv = torch.nn.Conv2d(64, k, 3, padding=1, bias=True).cuda()
+        with torch.no_grad():
+            conv.weight.copy_(conv.weight.bfloat16().float())
+            conv.bias.copy_(torch.randn(k, device='cuda'))
+        x = torch.randn(B, Y, X, 64, device='cuda').bfloat16().permute(0, 3, 1, 2)          # channels-last memory
+        go = torch.randn(B, Y, X, k, device='cuda').bfloat16().permute(0, 3, 1, 2)
+        assert ops.narrow_conv3x3_ok(x, conv)
+        xa = x.clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = ops.conv3x3_channel_bias(xa, conv)
+        assert y.dtype == torch.bfloat16 and y.shape == (B, k, Y, X) and y.permute(0, 2, 3, 1).is_contiguous()
+        y.backward(go)
+        got = (y.detach().float(), xa.grad.float(), conv.weight.grad.clone(), conv.bias.grad.clone())
+        conv.zero_grad()
+        xf = x.float().requires_grad_(True)
+        yr = conv(xf)
+        yr.backward(go.float())
+        want = (yr.detach(), xf.grad, conv.weight.grad.clone(), conv.bias.grad.clone())
+        conv.zero_grad()
+        # outputs rounded once to bf16: half an ulp of the value (+ fp32 summation order)
+        for a, b, what in ((got[0], want[0], 'y'), (got[1], want[1], 'dx')):
+            err = (a - b).abs()
+            assert bool((err <= 2.0 ** -8 * b.abs() + 1e-5 * float(b.abs().max())).all()), (k, B, Y, X, what, float(err.max()))
+        scale = float(want[2].abs().max())
+        assert float((got[2] - want[2]).abs().max()) <= 2e-4 * max(1.0, scale), (k, B, Y, X, 'dw', scale)      # fp32 both sides
+        assert float((got[3] - want[3]).abs().max()) <= 2e-3 * max(1.0, float(want[3].abs().max())), (k, 'db')
+
+    # a 64-channel slice (channels 64 .. 127) of a 128-channel map: channel pitch 128
+    k, B, Y, X = 3, 2, 33, 20
+    wide = torch.randn(B, Y, X, 128, device='cuda').bfloat16()
+    w = (torch.randn(k, 9 * 64, device='cuda') * 0.1).bfloat16()
+    bias = torch.randn(k, device='cuda')
+    out = torch.empty(B, Y, X, k, device='cuda', dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    sl = wide[..., 64:]
+    assert lib.tmae_conv3x3_c64_narrow_fwd(sl.data_ptr(), 128, B, Y, X, w.data_ptr(), bias.data_ptr(), k, out.data_ptr(), st) == 0
+    ref = torch.nn.functional.conv2d(sl.float().permute(0, 3, 1, 2), w.float().view(k, 3, 3, 64).permute(0, 3, 1, 2), bias, padding=1)
+    assert float((out.float().permute(0, 3, 1, 2) - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-5
+    dyr = torch.randn(B, Y, X, k, device='cuda').bfloat16()
+    dwide = torch.full((B, Y, X, 128), 7.0, device='cuda', dtype=torch.bfloat16)
+    wsb = lib.tmae_conv3x3_c64_narrow_bwd_data_workspace()
+    ws = torch.empty(wsb, dtype=torch.uint8, device='cuda')
+    assert lib.tmae_conv3x3_c64_narrow_bwd_data(dyr.data_ptr(), B, Y, X, k, w.data_ptr(), dwide[..., 64:].data_ptr(), 128,
+                                                ws.data_ptr(), wsb, st) == 0
+    xs = sl.float().permute(0, 3, 1, 2).requires_grad_(True)
+    torch.nn.functional.conv2d(xs, w.float().view(k, 3, 3, 64).permute(0, 3, 1, 2), None, padding=1).backward(
+        dyr.float().permute(0, 3, 1, 2))
+    assert float((dwide[..., 64:].float().permute(0, 3, 1, 2) - xs.grad).abs().max()) <= 2.0 ** -8 * float(xs.grad.abs().max()) + 1e-5
+    assert bool((dwide[..., :64] == 7.0).all())                                  # the other half of the wide map is untouched
+    wsb = lib.tmae_conv3x3_c64_narrow_wgrad_workspace(k)
+    ws = torch.empty(wsb, dtype=torch.uint8, device='cuda')
+    dw = torch.empty(k, 9 * 64, device='cuda')
+    assert lib.tmae_conv3x3_c64_narrow_wgrad(dyr.data_ptr(), sl.data_ptr(), 128, B, Y, X, k, dw.data_ptr(), ws.data_ptr(), wsb, st) == 0
+    wp = w.float().view(k, 3, 3, 64).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wref = torch.autograd.grad(torch.nn.functional.conv2d(sl.float().permute(0, 3, 1, 2), wp, None, padding=1), wp,
+                               dyr.float().permute(0, 3, 1, 2))[0]
+    assert float((dw.view(k, 3, 3, 64).permute(0, 3, 1, 2) - wref).abs().max()) <= 2e-4 * max(1.0, float(wref.abs().max()))
+    # refusals: k out of range, a pitch below 64 / not a multiple of 8, a missing pointer, a short workspace
+    assert lib.tmae_conv3x3_c64_narrow_fwd(sl.data_ptr(), 128, B, Y, X, w.data_ptr(), bias.data_ptr(), 9, out.data_ptr(), st) < 0
+    assert lib.tmae_conv3x3_c64_narrow_fwd(sl.data_ptr(), 60, B, Y, X, w.data_ptr(), bias.data_ptr(), k, out.data_ptr(), st) < 0
+    assert lib.tmae_conv3x3_c64_narrow_fwd(sl.data_ptr(), 128, B, Y, X, w.data_ptr(), None, k, out.data_ptr(), st) < 0
+    assert lib.tmae_conv3x3_c64_narrow_wgrad(dyr.data_ptr(), sl.data_ptr(), 128, B, Y, X, k, dw.data_ptr(), ws.data_ptr(), 64, st) < 0
+    assert lib.tmae_conv3x3_c64_narrow_wgrad_workspace(0) == 0 and lib.tmae_conv3x3_c64_narrow_wgrad_workspace(9) == 0
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize('dil', [1, 2])
 def test_bev_block_shortcut_fused_vs_separate_adds(dil, monkeypatch):
     """`out = conv_bn_relu(out) + out` of SSTBEVBackbone (sst_bev_backbone.py:35-41) with the shortcut added inside the norm's apply
