@@ -39,3 +39,22 @@ for k in (1, 2, 3, 5):
         tb = timeit(lambda: torch.autograd.grad(y, (xa, conv.weight, conv.bias), go, retain_graph=True))
         row.append(f'{mode}: fwd {tf:7.1f} us ({mb / tf * 1e3:6.0f} GB/s)  bwd (dx + dw + db) {tb:7.1f} us')
     print('   '.join(row))
+
+# the 64 -> 64 stems (conv + training-mode BatchNorm + ReLU through the module path; the conv alone through the op)
+import torch.nn as nn
+conv = nn.Conv2d(64, 64, 3, padding=1, bias=False).to(dev)
+xn = x.permute(0, 2, 3, 1)
+go = torch.randn(B, Y, X, 64, device=dev).bfloat16()
+row = ['64->64']
+for mode in ('native', 'library'):
+    xa = xn.clone().requires_grad_(True)
+    if mode == 'native':
+        f = lambda: ops.conv3x3_c64(xa, conv.weight)
+    else:
+        f = lambda: torch.nn.functional.conv2d(xa.permute(0, 3, 1, 2), conv.weight.bfloat16().contiguous(memory_format=torch.channels_last),
+                                               padding=1).permute(0, 2, 3, 1)
+    tf = timeit(f)
+    y = f()
+    tb = timeit(lambda: torch.autograd.grad(y, (xa, conv.weight), go, retain_graph=True))
+    row.append(f'{mode}: fwd {tf:7.1f} us  bwd (dx + dw) {tb:7.1f} us')
+print('   '.join(row))

@@ -25,7 +25,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define HN_HW 18                     // halo edge
 #define HN_NH (HN_HW * HN_HW)        // 324 halo rows
 #define HN_CHUNKS (HN_NH * 8)        // 16-byte chunks of a 64-channel halo image
-#define HN_ITERS ((HN_CHUNKS + 255) / 256)
+#define HN_ITERS_OF(NTH) ((HN_CHUNKS + (NTH) - 1) / (NTH))
 #define HN_IMG (HN_NH * 128)         // bytes of a 64-channel halo image
 #define HN_OOB 0xFFFFFFFFu
 
@@ -56,12 +56,14 @@ __device__ __forceinline__ HnBlock hn_block(int u, int bx, int by) {
 // row h = hy * 18 + hx (cell (y0 - 1 + hy, x0 - 1 + hx)), 128 bytes; the 16-byte chunk c of a row sits at position c ^ (hx & 7):
 // a swizzle by the COLUMN only, so that readers of neighbouring cells (consecutive hx, the lanes of an MFMA operand read) hit
 // different banks and a tap shift changes hx by a constant.  Chunks outside the map read as zeros (buffer range check).
-struct HnHalo { u32x4 v[HN_ITERS]; };
-__device__ __forceinline__ void hn_halo_load(HnHalo& r, __amdgpu_buffer_rsrc_t rs, int64_t ld, const HnBlock& blk, int Y, int X,
+template <int NTH = 256> struct HnHaloT { u32x4 v[HN_ITERS_OF(NTH)]; };
+typedef HnHaloT<256> HnHalo;
+template <int NTH>
+__device__ __forceinline__ void hn_halo_load(HnHaloT<NTH>& r, __amdgpu_buffer_rsrc_t rs, int64_t ld, const HnBlock& blk, int Y, int X,
                                              int tid) {
 #pragma unroll
-  for (int it = 0; it < HN_ITERS; ++it) {
-    const int idx = it * 256 + tid, h = idx >> 3, c = idx & 7;
+  for (int it = 0; it < HN_ITERS_OF(NTH); ++it) {
+    const int idx = it * NTH + tid, h = idx >> 3, c = idx & 7;
     const int hy = (h * 3641) >> 16, hx = h - hy * HN_HW;            // h / 18 for h < 2 ^ 11
     const int y = blk.y0 - 1 + hy, x = blk.x0 - 1 + hx;
     const bool ok = idx < HN_CHUNKS && y >= 0 && y < Y && x >= 0 && x < X;
@@ -69,10 +71,11 @@ __device__ __forceinline__ void hn_halo_load(HnHalo& r, __amdgpu_buffer_rsrc_t r
     r.v[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
   }
 }
-__device__ __forceinline__ void hn_halo_store(const HnHalo& r, char* img, int tid) {
+template <int NTH>
+__device__ __forceinline__ void hn_halo_store(const HnHaloT<NTH>& r, char* img, int tid) {
 #pragma unroll
-  for (int it = 0; it < HN_ITERS; ++it) {
-    const int idx = it * 256 + tid, h = idx >> 3, c = idx & 7;
+  for (int it = 0; it < HN_ITERS_OF(NTH); ++it) {
+    const int idx = it * NTH + tid, h = idx >> 3, c = idx & 7;
     const int hy = (h * 3641) >> 16, hx = h - hy * HN_HW;
     if (idx < HN_CHUNKS) *reinterpret_cast<u32x4*>(img + h * 128 + ((c ^ (hx & 7)) << 4)) = r.v[it];
   }
@@ -333,6 +336,166 @@ __global__ __launch_bounds__(256) void headconv_wgrad_reduce_kernel(const float*
   if (w == 0 && e < count) dw[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+// ================================================================================================
+// 64 -> 64 channels: the stem convs of CenterHead's branches (center_head.py:28-31: Conv2d(64, 64, 3, padding=1) in front of
+// BatchNorm + ReLU), their input gradient (the same kernel on dout with flipped, transposed weights) and their weight gradient.
+// The library's implicit GEMMs take 360 / 300 / 500 us per branch; the bytes (41 KB of halo in, 32 KB out per 256 cells) need 90.
+// ================================================================================================
+// A-fragment image of the weights, [t][hf][ct][lane] x 16 bytes = 73 728 bytes (made once per call by the pack kernel, copied
+// into LDS once per persistent workgroup): lane (g, i) of fragment (t, hf, ct) = output channel 16 (i >> 2) + 4 ct + (i & 3)
+// (the row permutation that leaves a lane with consecutive channels), input channels hf * 32 + 8 g .. + 7 of tap t.
+// mode 0: weight [64 out][9][64 in] as it is; mode 1 (input gradient): out' = in, in' = out, tap 8 - t.
+#define HN_WIMG (9 * 2 * 4 * 64 * 16)
+__global__ __launch_bounds__(256) void headconv64_pack_kernel(const __hip_bfloat16* __restrict__ W, int mode,
+                                                              __hip_bfloat16* __restrict__ wimg) {
+  const int e = blockIdx.x * 256 + threadIdx.x;        // ((((t * 2 + hf) * 4 + ct) * 64 + lane) * 8 + j
+  if (e >= HN_WIMG / 2) return;
+  const int j = e & 7, lane = (e >> 3) & 63, ct = (e >> 9) & 3, hf = (e >> 11) & 1, t = e >> 12;
+  const int g = lane >> 4, i = lane & 15;
+  const int co = 16 * (i >> 2) + 4 * ct + (i & 3), ci = hf * 32 + 8 * g + j;
+  wimg[e] = mode == 0 ? W[((int64_t)co * 9 + t) * 64 + ci] : W[((int64_t)ci * 9 + (8 - t)) * 64 + co];
+}
+
+// 512 threads: wave (rg = w & 3, h = w >> 2) owns the cell rows 4 rg .. 4 rg + 3 of a block and the column tiles 2 h, 2 h + 1: per
+// (tap, channel half) 2 weight fragments + 4 row fragments from LDS feed 8 MFMAs; lane (g, i) ends with the 8 consecutive
+// output channels 16 g + 8 h .. of cell i of each row (one 16-byte store).  post (optional, the shape of out): added to the result.
+__global__ __launch_bounds__(512) void headconv64_kernel(const __hip_bfloat16* __restrict__ in, int64_t ldi, unsigned in_bytes, int B,
+                                                         int Y, int X, const __hip_bfloat16* __restrict__ wimg_g,
+                                                         __hip_bfloat16* __restrict__ out, int64_t ldo, int nblocks) {
+  extern __shared__ __attribute__((aligned(16))) char lds64[];
+  char* img = lds64;
+  char* wimg = lds64 + HN_IMG;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15, rg = w & 3, h = w >> 2;
+  const int bx = (X + HN_T - 1) / HN_T, by = (Y + HN_T - 1) / HN_T;
+  const __amdgpu_buffer_rsrc_t rs = hn_rsrc(in, in_bytes);
+  int u = blockIdx.x;
+  if (u >= nblocks) return;
+  HnBlock blk = hn_block(u, bx, by);
+  HnHaloT<512> hal;
+  hn_halo_load(hal, rs, ldi, blk, Y, X, tid);
+#pragma unroll
+  for (int it = 0; it < HN_WIMG / 16 / 512; ++it)
+    reinterpret_cast<u32x4*>(wimg)[it * 512 + tid] = reinterpret_cast<const u32x4*>(wimg_g)[it * 512 + tid];
+  for (;;) {
+    hn_halo_store(hal, img, tid);
+    __syncthreads();
+    const HnBlock cur = blk;
+    const int un = u + gridDim.x;
+    if (un < nblocks) { blk = hn_block(un, bx, by); hn_halo_load(hal, rs, ldi, blk, Y, X, tid); }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) { acc[rr][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[rr][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(wimg + ((((t * 2 + hf) * 4 + 2 * h) * 64 + lane) << 4));
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(wimg + ((((t * 2 + hf) * 4 + 2 * h + 1) * 64 + lane) << 4));
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const u32x4 b = *reinterpret_cast<const u32x4*>(img + hn_row(4 * rg + rr, i, t / 3, t % 3, hf * 4 + g));
+          acc[rr][0] = hn_mfma(a0, b, acc[rr][0]);
+          acc[rr][1] = hn_mfma(a1, b, acc[rr][1]);
+        }
+      }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int gy = cur.y0 + 4 * rg + rr, gx = cur.x0 + i;
+      if (gy < Y && gx < X) {
+        const u32x4 o = {hn_pack(acc[rr][0][0], acc[rr][0][1]), hn_pack(acc[rr][0][2], acc[rr][0][3]),
+                         hn_pack(acc[rr][1][0], acc[rr][1][1]), hn_pack(acc[rr][1][2], acc[rr][1][3])};
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out + (((int64_t)cur.b * Y + gy) * X + gx) * ldo) + 32 * g + 16 * h) = o;
+      }
+    }
+    u = un;
+    if (u >= nblocks) break;
+    __syncthreads();
+  }
+}
+
+// weight gradient dw[n, t, c] = sum over cells of dout[cell, n] * in[cell + tap t, c], n, c < 64: the transposing-read scheme of
+// headconv_wgrad_kernel with a full 64-channel dout image (rows of 128 bytes, chunks swizzled by the cell's column).  512 threads: wave
+// (nt = w & 3, ch = w >> 2) owns the rows n = 16 nt .. and the channels 32 ch .. 32 ch + 31 of all nine taps (18 accumulator tiles).
+__global__ __launch_bounds__(512) void headconv64_wgrad_kernel(const __hip_bfloat16* __restrict__ dout, int64_t lddo, unsigned dout_bytes,
+                                                               const __hip_bfloat16* __restrict__ in, int64_t ldi, unsigned in_bytes,
+                                                               int B, int Y, int X, float* __restrict__ slab, int nblocks) {
+  extern __shared__ __attribute__((aligned(16))) char lds64[];
+  char* img = lds64;
+  char* dimg = lds64 + HN_IMG;                            // [256 cells][128 bytes]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int nt = w & 3, ch = w >> 2;
+  const int bx = (X + HN_T - 1) / HN_T, by = (Y + HN_T - 1) / HN_T;
+  const __amdgpu_buffer_rsrc_t rsi = hn_rsrc(in, in_bytes), rsd = hn_rsrc(dout, dout_bytes);
+  f32x4 acc[2][9];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[cc][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int u = blockIdx.x;
+  if (u < nblocks) {
+    HnBlock blk = hn_block(u, bx, by);
+    HnHaloT<512> hal;
+    u32x4 dv[4];
+    auto dload = [&]() {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = it * 512 + tid, cell = idx >> 3, c = idx & 7;
+        const int y = blk.y0 + (cell >> 4), x = blk.x0 + (cell & 15);
+        const unsigned off = (y < Y && x < X) ? (unsigned)((((int64_t)blk.b * Y + y) * X + x) * lddo * 2 + c * 16) : HN_OOB;
+        dv[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, (int)off, 0, 0));
+      }
+    };
+    hn_halo_load(hal, rsi, ldi, blk, Y, X, tid);
+    dload();
+    const int xq = 8 * (g & 1) + q, yq = g >> 1;
+    for (;;) {
+      hn_halo_store(hal, img, tid);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = it * 512 + tid, cell = idx >> 3, c = idx & 7;
+        *reinterpret_cast<u32x4*>(dimg + cell * 128 + ((c ^ (cell & 7)) << 4)) = dv[it];
+      }
+      __syncthreads();
+      const int un = u + gridDim.x;
+      if (un < nblocks) {
+        blk = hn_block(un, bx, by);
+        hn_halo_load(hal, rsi, ldi, blk, Y, X, tid);
+        dload();
+      }
+#pragma unroll 1
+      for (int s = 0; s < 8; ++s) {
+        const int y = 2 * s + yq;
+        const int c0 = y * HN_T + xq, c1 = c0 + 4;
+        const s16x4 alo = hn_tr_read(dimg + c0 * 128 + (((2 * nt + (p >> 1)) ^ (c0 & 7)) << 4) + 8 * (p & 1));
+        const s16x4 ahi = hn_tr_read(dimg + c1 * 128 + (((2 * nt + (p >> 1)) ^ (c1 & 7)) << 4) + 8 * (p & 1));
+        const s16x8 a8 = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc) {
+            const int chunk = 2 * (2 * ch + cc) + (p >> 1);
+            const s16x4 blo = hn_tr_read(img + hn_row(y, xq, t / 3, t % 3, chunk) + 8 * (p & 1));
+            const s16x4 bhi = hn_tr_read(img + hn_row(y, xq + 4, t / 3, t % 3, chunk) + 8 * (p & 1));
+            const s16x8 b8 = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+            acc[cc][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, b8),
+                                                                 acc[cc][t], 0, 0, 0);
+          }
+      }
+      u = un;
+      if (u >= nblocks) break;
+      __syncthreads();
+    }
+  }
+  // slab [64 n][9][64 c]: lane (g, i) holds dw[16 nt + 4 g + r][t][32 ch + 16 cc + i]
+  float* sl = slab + (int64_t)blockIdx.x * (64 * 576);
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sl[((16 * nt + 4 * g + r) * 9 + t) * 64 + 32 * ch + 16 * cc + i] = acc[cc][t][r];
+}
+
 // ---- C ABI ---------------------------------------------------------------------------------------
 static bool hn_args_ok(int batch, int ny, int nx, int k, int64_t ld, int64_t* cells) {
   if (batch <= 0 || ny <= 0 || nx <= 0 || k < 1 || k > 8 || ld < 64 || (ld % 8)) return false;
@@ -394,6 +557,55 @@ int tmae_conv3x3_c64_narrow_wgrad(const void* dout, const void* in, int64_t ldi,
   hipLaunchKernelGGL(headconv_wgrad_kernel, dim3((unsigned)grid), dim3(256), 0, stream, (const __hip_bfloat16*)dout,
                      (unsigned)(cells * k * 2), (const __hip_bfloat16*)in, ldi, (unsigned)((cells - 1) * ldi * 2 + 128), batch, ny, nx,
                      k, (float*)ws, (int)nb);
+  hipLaunchKernelGGL(headconv_wgrad_reduce_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, stream, (const float*)ws, grid,
+                     count, dw);
+  return tmae_launch_status();
+}
+
+// ---- 64 -> 64 -------------------------------------------------------------------------------------
+size_t tmae_conv3x3_c64_workspace(void) { return tmae_align(HN_WIMG); }
+
+int tmae_conv3x3_c64(const void* in, int64_t ldi, int batch, int ny, int nx, const void* weight, int input_gradient, void* out,
+                     int64_t ldo, void* ws, size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();
+  int64_t cells, cells2;
+  if (!hn_args_ok(batch, ny, nx, 1, ldi, &cells) || !hn_args_ok(batch, ny, nx, 1, ldo, &cells2) || !in || !weight || !out || !ws ||
+      ((uintptr_t)in & 15) || ((uintptr_t)out & 15) || ((uintptr_t)ws & 15) || ((uintptr_t)weight & 1) ||
+      ws_bytes < tmae_conv3x3_c64_workspace() || (input_gradient != 0 && input_gradient != 1))
+    return TMAE_EARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(headconv64_pack_kernel, dim3(HN_WIMG / 2 / 256), dim3(256), 0, stream, (const __hip_bfloat16*)weight,
+                     input_gradient, (__hip_bfloat16*)ws);
+  const int lds = HN_IMG + HN_WIMG;
+  static TmaeLdsAttr attr;
+  if (int e = tmae_allow_lds(attr, (const void*)headconv64_kernel, lds)) return e;
+  const int64_t nb = hn_nblocks(batch, ny, nx);
+  const int64_t cap = tmae_num_cus();                  // one workgroup per CU (115 KB of LDS)
+  hipLaunchKernelGGL(headconv64_kernel, dim3((unsigned)(nb < cap ? nb : cap)), dim3(512), lds, stream, (const __hip_bfloat16*)in, ldi,
+                     (unsigned)((cells - 1) * ldi * 2 + 128), batch, ny, nx, (const __hip_bfloat16*)ws, (__hip_bfloat16*)out, ldo,
+                     (int)nb);
+  return tmae_launch_status();
+}
+
+size_t tmae_conv3x3_c64_wgrad_workspace(void) { return tmae_align((size_t)tmae_num_cus() * 64 * 576 * sizeof(float)); }
+
+int tmae_conv3x3_c64_wgrad(const void* dout, int64_t lddo, const void* in, int64_t ldi, int batch, int ny, int nx, float* dw, void* ws,
+                           size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();
+  int64_t cells, cells2;
+  if (!hn_args_ok(batch, ny, nx, 1, ldi, &cells) || !hn_args_ok(batch, ny, nx, 1, lddo, &cells2) || !dout || !in || !dw || !ws ||
+      ((uintptr_t)in & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)ws & 15) || ws_bytes < tmae_conv3x3_c64_wgrad_workspace())
+    return TMAE_EARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int lds = HN_IMG + HN_T * HN_T * 128;
+  static TmaeLdsAttr attr;
+  if (int e = tmae_allow_lds(attr, (const void*)headconv64_wgrad_kernel, lds)) return e;
+  const int64_t nb = hn_nblocks(batch, ny, nx);
+  const int64_t cap = tmae_num_cus();                  // one workgroup per CU (234 registers x 512 threads)
+  const int grid = (int)(nb < cap ? nb : cap), count = 64 * 576;
+  hipLaunchKernelGGL(headconv64_wgrad_kernel, dim3((unsigned)grid), dim3(512), lds, stream, (const __hip_bfloat16*)dout, lddo,
+                     (unsigned)((cells - 1) * lddo * 2 + 128), (const __hip_bfloat16*)in, ldi, (unsigned)((cells - 1) * ldi * 2 + 128),
+                     batch, ny, nx, (float*)ws, (int)nb);
   hipLaunchKernelGGL(headconv_wgrad_reduce_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, stream, (const float*)ws, grid,
                      count, dw);
   return tmae_launch_status();

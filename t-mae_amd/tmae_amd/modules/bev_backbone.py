@@ -29,6 +29,11 @@ def conv_bn_relu_nhwc(seq, x, shortcut=False):
             return rows.view(b, ny, nx, c).permute(0, 3, 1, 2)
         y = ops.dense_conv3x3(nhwc, conv.weight, conv.dilation[0]).permute(0, 3, 1, 2)
         fused = True
+    elif bn.training and not shortcut and ops.conv3x3_c64_ok(nhwc, conv):
+        # CenterHead's 64 -> 64 stems (center_head.py:28-31): csrc/headconv.hip (a bias is folded into the norm below, as in the
+        # library branch)
+        y = ops.conv3x3_c64(nhwc, conv.weight).permute(0, 3, 1, 2)
+        fused = True
     else:
         fused = (bn.training and x.is_cuda and conv.out_channels in (64, 128, 256) and len(seq) == 3
                  and isinstance(seq[2], nn.ReLU))

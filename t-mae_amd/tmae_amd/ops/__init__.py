@@ -1961,6 +1961,56 @@ class _NarrowConv3x3(torch.autograd.Function):
         return dx, dw, _channel_sums(dyr.permute(0, 3, 1, 2)).to(bdt)
 
 
+class _Conv3x3C64(torch.autograd.Function):
+    """Conv2d(64, 64, 3, padding=1, bias=False) on a channels-last bf16 activation [B, Y, X, 64] -- the stem convs of CenterHead's
+    branches (center_head.py:28-31) -- forward, input gradient (the same kernel on dY with flipped, transposed weights) and
+    weight gradient on csrc/headconv.hip (tmae_conv3x3_c64, tmae_conv3x3_c64_wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, weight):
+        x = x_nhwc.to(torch.bfloat16).contiguous()
+        B, Y, X, cin = x.shape
+        w2 = _derived(weight, ('c64_3x3',), lambda t: t.detach().permute(0, 2, 3, 1).reshape(64, 9 * 64).to(torch.bfloat16).contiguous())
+        y = torch.empty((B, Y, X, 64), dtype=torch.bfloat16, device=x.device)
+        wsb = lib.tmae_conv3x3_c64_workspace()
+        ws = _ws(wsb, x.device)
+        check(lib.tmae_conv3x3_c64(_p(x), 64, B, Y, X, _p(w2), 0, _p(y), 64, _p(ws), wsb, _s()), 'tmae_conv3x3_c64')
+        ctx.save_for_backward(x, w2)
+        ctx.meta = (x_nhwc.dtype, weight.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy_nhwc):
+        x, w2 = ctx.saved_tensors
+        B, Y, X, _ = x.shape
+        dy = dy_nhwc.to(torch.bfloat16).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            wsb = lib.tmae_conv3x3_c64_workspace()
+            ws = _ws(wsb, x.device)
+            check(lib.tmae_conv3x3_c64(_p(dy), 64, B, Y, X, _p(w2), 1, _p(dx), 64, _p(ws), wsb, _s()), 'tmae_conv3x3_c64')
+            dx = dx.to(ctx.meta[0])
+        dw = torch.empty((64, 9 * 64), dtype=torch.float32, device=x.device)
+        wsb = lib.tmae_conv3x3_c64_wgrad_workspace()
+        ws = _ws(wsb, x.device)
+        check(lib.tmae_conv3x3_c64_wgrad(_p(dy), 64, _p(x), 64, B, Y, X, _p(dw), _p(ws), wsb, _s()), 'tmae_conv3x3_c64_wgrad')
+        return dx, dw.view(64, 3, 3, 64).permute(0, 3, 1, 2).to(ctx.meta[1])
+
+
+def conv3x3_c64_ok(x_nhwc, conv):
+    """a Conv2d(64, 64, 3, padding=1) on a contiguous channels-last bf16 map that csrc/headconv.hip takes (a bias in front of a
+    training-mode norm is folded away by the caller)"""
+    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels == 64 and conv.out_channels == 64
+            and x_nhwc.is_cuda and x_nhwc.dim() == 4 and compute_dtype(x_nhwc) == torch.bfloat16 and x_nhwc.is_contiguous()
+            and x_nhwc.numel() * 2 < (1 << 31) and _os.environ.get('TMAE_HEAD_CONV', 'native') == 'native')
+
+
+def conv3x3_c64(x_nhwc, weight):
+    return _Conv3x3C64.apply(x_nhwc, weight)
+
+
 def narrow_conv3x3_ok(x, conv):
     return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None and conv.in_channels == 64

@@ -284,6 +284,94 @@ def test_narrow_head_conv_kernels_vs_torch():
     torch.cuda.synchronize()
 
 
+def test_c64_stem_conv_kernels_vs_torch():
+    """csrc/headconv.hip, 64 -> 64: Conv2d(64, 64, 3, padding=1, bias=False) forward, input gradient (the same kernel with flipped,
+    transposed weights) and weight gradient on channels-last bf16 maps (CenterHead's stem convs, center_head.py:28-31) against
+    torch's fp32 convolution of the same values; ragged maps, a map with several blocks per persistent workgroup; through
+    conv_bn_relu_nhwc (the module path) against the library path; channel pitches above 64 through the C ABI; refusals."""
+    import torch.nn as nn
+    from tmae_amd import ops
+    from tmae_amd._lib import lib
+    from tmae_amd.modules.bev_backbone import conv_bn_relu_nhwc
+    torch.manual_seed(8)
+    for (B, Y, X) in ((1, 16, 16), (2, 40, 23), (1, 7, 5), (3, 50, 70), (2, 468, 468)):
+        conv = nn.Conv2d(64, 64, 3, padding=1, bias=False).cuda()
+        with torch.no_grad():
+            conv.weight.copy_(conv.weight.bfloat16().float())
+        x = torch.randn(B, Y, X, 64, device='cuda').bfloat16()
+        go = torch.randn(B, Y, X, 64, device='cuda').bfloat16()
+        assert ops.conv3x3_c64_ok(x, conv)
+        xa = x.clone().requires_grad_(True)
+        y = ops.conv3x3_c64(xa, conv.weight)
+        y.backward(go)
+        got = (y.detach().float(), xa.grad.float(), conv.weight.grad.clone())
+        conv.zero_grad()
+        xf = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+        yr = conv(xf)
+        yr.backward(go.float().permute(0, 3, 1, 2))
+        want = (yr.detach().permute(0, 2, 3, 1), xf.grad.permute(0, 2, 3, 1), conv.weight.grad.clone())
+        conv.zero_grad()
+        for a, b, what in ((got[0], want[0], 'y'), (got[1], want[1], 'dx')):
+            err = (a - b).abs()
+            assert bool((err <= 2.0 ** -8 * b.abs() + 1e-5 * float(b.abs().max())).all()), (B, Y, X, what, float(err.max()))
+        assert float((got[2] - want[2]).abs().max()) <= 2e-4 * max(1.0, float(want[2].abs().max())), (B, Y, X, 'dw')
+
+    # the module path (conv + training-mode BatchNorm + ReLU) against the library conv in front of the same fused norm
+    seq = nn.Sequential(nn.Conv2d(64, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64, eps=1e-3, momentum=0.01), nn.ReLU(inplace=True)
+                        ).cuda().train()
+    x0 = torch.randn(2, 60, 44, 64, device='cuda').bfloat16().permute(0, 3, 1, 2)
+    go = torch.randn(2, 60, 44, 64, device='cuda').bfloat16().permute(0, 3, 1, 2)
+    res = {}
+    import os
+    for mode in ('native', 'library'):
+        os.environ['TMAE_HEAD_CONV'] = mode
+        try:
+            seq.zero_grad()
+            seq[1].running_mean.zero_(); seq[1].running_var.fill_(1.0)
+            xa = x0.clone().requires_grad_(True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y = conv_bn_relu_nhwc(seq, xa)
+            y.backward(go)
+            res[mode] = (y.detach().float(), xa.grad.float(), seq[0].weight.grad.clone(), seq[1].weight.grad.clone())
+        finally:
+            os.environ.pop('TMAE_HEAD_CONV', None)
+    for a, b, tol in zip(res['native'], res['library'], (2e-2, 3e-2, 3e-2, 3e-2)):
+        assert float((a - b).norm() / (b.norm() + 1e-12)) < tol
+
+    # channel pitches: input = channels 64 .. 127 of a 128-wide map, output into channels 0 .. 63 of a 192-wide one
+    B, Y, X = 2, 33, 20
+    wide = torch.randn(B, Y, X, 128, device='cuda').bfloat16()
+    w = (torch.randn(64, 9 * 64, device='cuda') * 0.05).bfloat16()
+    owide = torch.full((B, Y, X, 192), 3.0, device='cuda', dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    wsb = lib.tmae_conv3x3_c64_workspace()
+    ws = torch.empty(wsb, dtype=torch.uint8, device='cuda')
+    sl = wide[..., 64:]
+    w4 = w.float().view(64, 3, 3, 64).permute(0, 3, 1, 2)
+    for inp_grad in (0, 1):
+        assert lib.tmae_conv3x3_c64(sl.data_ptr(), 128, B, Y, X, w.data_ptr(), inp_grad, owide.data_ptr(), 192, ws.data_ptr(), wsb, st) == 0
+        if inp_grad == 0:
+            ref = torch.nn.functional.conv2d(sl.float().permute(0, 3, 1, 2), w4, padding=1)
+        else:
+            ref = torch.nn.functional.conv_transpose2d(sl.float().permute(0, 3, 1, 2), w4, padding=1)
+        assert float((owide[..., :64].float().permute(0, 3, 1, 2) - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-5
+        assert bool((owide[..., 64:] == 3.0).all())
+    dy = torch.randn(B, Y, X, 192, device='cuda').bfloat16()
+    wsb2 = lib.tmae_conv3x3_c64_wgrad_workspace()
+    ws2 = torch.empty(wsb2, dtype=torch.uint8, device='cuda')
+    dw = torch.empty(64, 9 * 64, device='cuda')
+    assert lib.tmae_conv3x3_c64_wgrad(dy[..., 128:].data_ptr(), 192, sl.data_ptr(), 128, B, Y, X, dw.data_ptr(), ws2.data_ptr(), wsb2, st) == 0
+    wp = w4.clone().requires_grad_(True)
+    wref = torch.autograd.grad(torch.nn.functional.conv2d(sl.float().permute(0, 3, 1, 2), wp, padding=1), wp,
+                               dy[..., 128:].float().permute(0, 3, 1, 2))[0]
+    assert float((dw.view(64, 3, 3, 64).permute(0, 3, 1, 2) - wref).abs().max()) <= 2e-4 * max(1.0, float(wref.abs().max()))
+    assert lib.tmae_conv3x3_c64(sl.data_ptr(), 60, B, Y, X, w.data_ptr(), 0, owide.data_ptr(), 192, ws.data_ptr(), wsb, st) < 0
+    assert lib.tmae_conv3x3_c64(sl.data_ptr(), 128, B, Y, X, w.data_ptr(), 2, owide.data_ptr(), 192, ws.data_ptr(), wsb, st) < 0
+    assert lib.tmae_conv3x3_c64(sl.data_ptr(), 128, B, Y, X, w.data_ptr(), 0, owide.data_ptr(), 192, ws.data_ptr(), 64, st) < 0
+    assert lib.tmae_conv3x3_c64_wgrad(dy.data_ptr(), 192, sl.data_ptr(), 128, B, Y, X, dw.data_ptr(), None, wsb2, st) < 0
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize('dil', [1, 2])
 def test_bev_block_shortcut_fused_vs_separate_adds(dil, monkeypatch):
     """`out = conv_bn_relu(out) + out` of SSTBEVBackbone (sst_bev_backbone.py:35-41) with the shortcut added inside the norm's apply
