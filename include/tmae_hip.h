@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 13
+#define TMAE_ABI_VERSION 14
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -273,10 +273,11 @@ int tmae_conv3x3_c64_narrow_wgrad(const void* dout, const void* in, int64_t ldi,
  * (center_head.py:28-31: torch.nn.Conv2d(64, 64, 3, padding=1, bias=False) in front of BatchNorm + ReLU) -- with weight
  * [64, 9, 64] bf16 (the [64, 3, 3, 64] layout flattened).  input_gradient = 0: out[.., n] = sum in[.. + tap, c] weight[n, tap, c];
  * input_gradient = 1: `in` is the output gradient, `out` the input gradient (taps flipped, weight transposed inside).  ldi / ldo /
- * lddo: elements per cell (>= 64, % 8 == 0).  dw [64, 9, 64] fp32.  ws: the matching *_workspace() bytes, 16-byte aligned. */
+ * lddo: elements per cell (>= 64, % 8 == 0).  accumulate = 1: out += (the second 64-channel half of a wider contraction: the shared
+ * conv 128 -> 64 of CenterHead, center_head.py:85-89, is two calls on the halves of its input).  dw [64, 9, 64] fp32.  ws: the matching *_workspace() bytes, 16-byte aligned. */
 size_t tmae_conv3x3_c64_workspace(void);
-int tmae_conv3x3_c64(const void* in, int64_t ldi, int batch, int ny, int nx, const void* weight, int input_gradient, void* out,
-                     int64_t ldo, void* ws, size_t ws_bytes, void* stream);
+int tmae_conv3x3_c64(const void* in, int64_t ldi, int batch, int ny, int nx, const void* weight, int input_gradient, int accumulate,
+                     void* out, int64_t ldo, void* ws, size_t ws_bytes, void* stream);
 size_t tmae_conv3x3_c64_wgrad_workspace(void);
 int tmae_conv3x3_c64_wgrad(const void* dout, int64_t lddo, const void* in, int64_t ldi, int batch, int ny, int nx, float* dw,
                            void* ws, size_t ws_bytes, void* stream);

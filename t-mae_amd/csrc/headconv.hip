@@ -329,8 +329,16 @@ __global__ __launch_bounds__(256) void headconv_wgrad_reduce_kernel(const float*
   __shared__ float part[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, e = blockIdx.x * 64 + lane;
   float s = 0.f;
-  if (e < count)
-    for (int j = w; j < nslab; j += 4) s += slab[(int64_t)j * count + e];
+  if (e < count) {
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};                  // four loads in flight per lane (fixed order: deterministic)
+    int j = w;
+    for (; j + 12 < nslab; j += 16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s4[q] += slab[(int64_t)(j + 4 * q) * count + e];
+    }
+    for (; j < nslab; j += 4) s4[0] += slab[(int64_t)j * count + e];
+    s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  }
   part[w][lane] = s;
   __syncthreads();
   if (w == 0 && e < count) dw[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(256) void headconv64_pack_kernel(const __hip_bfloat
 // output channels 16 g + 8 h .. of cell i of each row (one 16-byte store).  post (optional, the shape of out): added to the result.
 __global__ __launch_bounds__(512) void headconv64_kernel(const __hip_bfloat16* __restrict__ in, int64_t ldi, unsigned in_bytes, int B,
                                                          int Y, int X, const __hip_bfloat16* __restrict__ wimg_g,
-                                                         __hip_bfloat16* __restrict__ out, int64_t ldo, int nblocks) {
+                                                         __hip_bfloat16* __restrict__ out, int64_t ldo, int nblocks, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) char lds64[];
   char* img = lds64;
   char* wimg = lds64 + HN_IMG;
@@ -384,7 +392,19 @@ __global__ __launch_bounds__(512) void headconv64_kernel(const __hip_bfloat16* _
     if (un < nblocks) { blk = hn_block(un, bx, by); hn_halo_load(hal, rs, ldi, blk, Y, X, tid); }
     f32x4 acc[4][2];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) { acc[rr][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[rr][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int rr = 0; rr < 4; ++rr) {
+      acc[rr][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[rr][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int gy = cur.y0 + 4 * rg + rr, gx = cur.x0 + i;
+      if (accumulate && gy < Y && gx < X) {              // out += : the second half of a 128-channel contraction (one extra rounding)
+        const u32x4 o = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(out + (((int64_t)cur.b * Y + gy) * X + gx) * ldo) +
+                                                        32 * g + 16 * h);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[rr][0][2 * j] = __uint_as_float(o[j] << 16);      acc[rr][0][2 * j + 1] = __uint_as_float(o[j] & 0xFFFF0000u);
+          acc[rr][1][2 * j] = __uint_as_float(o[2 + j] << 16);  acc[rr][1][2 * j + 1] = __uint_as_float(o[2 + j] & 0xFFFF0000u);
+        }
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -565,13 +585,13 @@ int tmae_conv3x3_c64_narrow_wgrad(const void* dout, const void* in, int64_t ldi,
 // ---- 64 -> 64 -------------------------------------------------------------------------------------
 size_t tmae_conv3x3_c64_workspace(void) { return tmae_align(HN_WIMG); }
 
-int tmae_conv3x3_c64(const void* in, int64_t ldi, int batch, int ny, int nx, const void* weight, int input_gradient, void* out,
-                     int64_t ldo, void* ws, size_t ws_bytes, void* stream_) {
+int tmae_conv3x3_c64(const void* in, int64_t ldi, int batch, int ny, int nx, const void* weight, int input_gradient, int accumulate,
+                     void* out, int64_t ldo, void* ws, size_t ws_bytes, void* stream_) {
   (void)hipGetLastError();
   int64_t cells, cells2;
   if (!hn_args_ok(batch, ny, nx, 1, ldi, &cells) || !hn_args_ok(batch, ny, nx, 1, ldo, &cells2) || !in || !weight || !out || !ws ||
       ((uintptr_t)in & 15) || ((uintptr_t)out & 15) || ((uintptr_t)ws & 15) || ((uintptr_t)weight & 1) ||
-      ws_bytes < tmae_conv3x3_c64_workspace() || (input_gradient != 0 && input_gradient != 1))
+      ws_bytes < tmae_conv3x3_c64_workspace() || (input_gradient != 0 && input_gradient != 1) || (accumulate != 0 && accumulate != 1))
     return TMAE_EARG;
   hipStream_t stream = (hipStream_t)stream_;
   hipLaunchKernelGGL(headconv64_pack_kernel, dim3(HN_WIMG / 2 / 256), dim3(256), 0, stream, (const __hip_bfloat16*)weight,
@@ -583,7 +603,7 @@ int tmae_conv3x3_c64(const void* in, int64_t ldi, int batch, int ny, int nx, con
   const int64_t cap = tmae_num_cus();                  // one workgroup per CU (115 KB of LDS)
   hipLaunchKernelGGL(headconv64_kernel, dim3((unsigned)(nb < cap ? nb : cap)), dim3(512), lds, stream, (const __hip_bfloat16*)in, ldi,
                      (unsigned)((cells - 1) * ldi * 2 + 128), batch, ny, nx, (const __hip_bfloat16*)ws, (__hip_bfloat16*)out, ldo,
-                     (int)nb);
+                     (int)nb, accumulate);
   return tmae_launch_status();
 }
 

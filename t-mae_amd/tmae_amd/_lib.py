@@ -56,7 +56,7 @@ SIGNATURES = {
     'tmae_dense_conv3x3_wgrad_workspace': (Z, [I, I]),
     'tmae_dense_conv3x3_wgrad': (I, [P, P, I, I, I, I, I, I, P, P, Z, P]),
     'tmae_conv3x3_c64_workspace': (Z, []),
-    'tmae_conv3x3_c64': (I, [P, L, I, I, I, P, I, P, L, P, Z, P]),
+    'tmae_conv3x3_c64': (I, [P, L, I, I, I, P, I, I, P, L, P, Z, P]),
     'tmae_conv3x3_c64_wgrad_workspace': (Z, []),
     'tmae_conv3x3_c64_wgrad': (I, [P, L, P, L, I, I, I, P, P, Z, P]),
     'tmae_conv3x3_c64_narrow_fwd': (I, [P, L, I, I, I, P, P, I, P, P]),
@@ -137,7 +137,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     setattr(lib, _name, _strict(_fn, _name, len(_args)))
 
-ABI_VERSION = 13            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
+ABI_VERSION = 14            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError(f'libtmae_hip.so ABI version {lib.tmae_abi_version()} != binding {ABI_VERSION}; rebuild with '
                       f't-mae_amd/build.py')

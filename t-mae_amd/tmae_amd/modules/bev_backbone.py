@@ -34,6 +34,9 @@ def conv_bn_relu_nhwc(seq, x, shortcut=False):
         # library branch)
         y = ops.conv3x3_c64(nhwc, conv.weight).permute(0, 3, 1, 2)
         fused = True
+    elif bn.training and not shortcut and ops.conv3x3_c128to64_ok(nhwc, conv):
+        y = ops.conv3x3_c128to64(nhwc, conv.weight).permute(0, 3, 1, 2)         # CenterHead's shared conv (center_head.py:85-89)
+        fused = True
     else:
         fused = (bn.training and x.is_cuda and conv.out_channels in (64, 128, 256) and len(seq) == 3
                  and isinstance(seq[2], nn.ReLU))

@@ -1974,7 +1974,7 @@ class _Conv3x3C64(torch.autograd.Function):
         y = torch.empty((B, Y, X, 64), dtype=torch.bfloat16, device=x.device)
         wsb = lib.tmae_conv3x3_c64_workspace()
         ws = _ws(wsb, x.device)
-        check(lib.tmae_conv3x3_c64(_p(x), 64, B, Y, X, _p(w2), 0, _p(y), 64, _p(ws), wsb, _s()), 'tmae_conv3x3_c64')
+        check(lib.tmae_conv3x3_c64(_p(x), 64, B, Y, X, _p(w2), 0, 0, _p(y), 64, _p(ws), wsb, _s()), 'tmae_conv3x3_c64')
         ctx.save_for_backward(x, w2)
         ctx.meta = (x_nhwc.dtype, weight.dtype)
         return y
@@ -1989,13 +1989,73 @@ class _Conv3x3C64(torch.autograd.Function):
             dx = torch.empty_like(x)
             wsb = lib.tmae_conv3x3_c64_workspace()
             ws = _ws(wsb, x.device)
-            check(lib.tmae_conv3x3_c64(_p(dy), 64, B, Y, X, _p(w2), 1, _p(dx), 64, _p(ws), wsb, _s()), 'tmae_conv3x3_c64')
+            check(lib.tmae_conv3x3_c64(_p(dy), 64, B, Y, X, _p(w2), 1, 0, _p(dx), 64, _p(ws), wsb, _s()), 'tmae_conv3x3_c64')
             dx = dx.to(ctx.meta[0])
         dw = torch.empty((64, 9 * 64), dtype=torch.float32, device=x.device)
         wsb = lib.tmae_conv3x3_c64_wgrad_workspace()
         ws = _ws(wsb, x.device)
         check(lib.tmae_conv3x3_c64_wgrad(_p(dy), 64, _p(x), 64, B, Y, X, _p(dw), _p(ws), wsb, _s()), 'tmae_conv3x3_c64_wgrad')
         return dx, dw.view(64, 3, 3, 64).permute(0, 3, 1, 2).to(ctx.meta[1])
+
+
+class _Conv3x3C128to64(torch.autograd.Function):
+    """Conv2d(128, 64, 3, padding=1, bias=False) on a channels-last bf16 activation -- CenterHead's shared conv
+    (center_head.py:85-89) -- as two 64-channel halves of the contraction on the 64 -> 64 kernels of csrc/headconv.hip: forward =
+    two calls on the halves of the input (the second accumulates), input gradient = one call per half of dx (channel pitch 128),
+    weight gradient = one call per half of the weight's input channels."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, weight):
+        x = x_nhwc.to(torch.bfloat16).contiguous()
+        B, Y, X, _ = x.shape
+
+        def halves(t):
+            w = t.detach().permute(0, 2, 3, 1).to(torch.bfloat16)                  # [64, 3, 3, 128]
+            return tuple(w[..., 64 * h:64 * h + 64].reshape(64, 9 * 64).contiguous() for h in range(2))
+        wa, wb = _derived(weight, ('c128to64_3x3',), halves)
+        y = torch.empty((B, Y, X, 64), dtype=torch.bfloat16, device=x.device)
+        wsb = lib.tmae_conv3x3_c64_workspace()
+        for h, wh in enumerate((wa, wb)):
+            ws = _ws(wsb, x.device)
+            check(lib.tmae_conv3x3_c64(x[..., 64 * h:].data_ptr(), 128, B, Y, X, _p(wh), 0, h, _p(y), 64, _p(ws), wsb, _s()),
+                  'tmae_conv3x3_c64')
+        ctx.save_for_backward(x, wa, wb)
+        ctx.meta = (x_nhwc.dtype, weight.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy_nhwc):
+        x, wa, wb = ctx.saved_tensors
+        B, Y, X, _ = x.shape
+        dy = dy_nhwc.to(torch.bfloat16).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            wsb = lib.tmae_conv3x3_c64_workspace()
+            for h, wh in enumerate((wa, wb)):
+                ws = _ws(wsb, x.device)
+                check(lib.tmae_conv3x3_c64(_p(dy), 64, B, Y, X, _p(wh), 1, 0, dx[..., 64 * h:].data_ptr(), 128, _p(ws), wsb, _s()),
+                      'tmae_conv3x3_c64')
+            dx = dx.to(ctx.meta[0])
+        dw = torch.empty((2, 64, 9 * 64), dtype=torch.float32, device=x.device)
+        wsb = lib.tmae_conv3x3_c64_wgrad_workspace()
+        for h in range(2):
+            ws = _ws(wsb, x.device)
+            check(lib.tmae_conv3x3_c64_wgrad(_p(dy), 64, x[..., 64 * h:].data_ptr(), 128, B, Y, X, _p(dw[h]), _p(ws), wsb, _s()),
+                  'tmae_conv3x3_c64_wgrad')
+        dw = torch.cat((dw[0].view(64, 3, 3, 64), dw[1].view(64, 3, 3, 64)), dim=3).permute(0, 3, 1, 2).to(ctx.meta[1])
+        return dx, dw
+
+
+def conv3x3_c128to64_ok(x_nhwc, conv):
+    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels == 128 and conv.out_channels == 64
+            and x_nhwc.is_cuda and x_nhwc.dim() == 4 and compute_dtype(x_nhwc) == torch.bfloat16 and x_nhwc.is_contiguous()
+            and x_nhwc.numel() * 2 < (1 << 31) and _os.environ.get('TMAE_HEAD_CONV', 'native') == 'native')
+
+
+def conv3x3_c128to64(x_nhwc, weight):
+    return _Conv3x3C128to64.apply(x_nhwc, weight)
 
 
 def conv3x3_c64_ok(x_nhwc, conv):

@@ -316,27 +316,50 @@ def test_c64_stem_conv_kernels_vs_torch():
             assert bool((err <= 2.0 ** -8 * b.abs() + 1e-5 * float(b.abs().max())).all()), (B, Y, X, what, float(err.max()))
         assert float((got[2] - want[2]).abs().max()) <= 2e-4 * max(1.0, float(want[2].abs().max())), (B, Y, X, 'dw')
 
-    # the module path (conv + training-mode BatchNorm + ReLU) against the library conv in front of the same fused norm
-    seq = nn.Sequential(nn.Conv2d(64, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64, eps=1e-3, momentum=0.01), nn.ReLU(inplace=True)
-                        ).cuda().train()
-    x0 = torch.randn(2, 60, 44, 64, device='cuda').bfloat16().permute(0, 3, 1, 2)
-    go = torch.randn(2, 60, 44, 64, device='cuda').bfloat16().permute(0, 3, 1, 2)
-    res = {}
+    # the module path (conv + training-mode BatchNorm + ReLU) against the library conv in front of the same fused norm: the 64 -> 64
+    # stems and the 128 -> 64 shared conv (center_head.py:85-89: two 64-channel halves, the second call accumulates)
     import os
-    for mode in ('native', 'library'):
-        os.environ['TMAE_HEAD_CONV'] = mode
-        try:
-            seq.zero_grad()
-            seq[1].running_mean.zero_(); seq[1].running_var.fill_(1.0)
-            xa = x0.clone().requires_grad_(True)
-            with torch.autocast('cuda', dtype=torch.bfloat16):
-                y = conv_bn_relu_nhwc(seq, xa)
-            y.backward(go)
-            res[mode] = (y.detach().float(), xa.grad.float(), seq[0].weight.grad.clone(), seq[1].weight.grad.clone())
-        finally:
-            os.environ.pop('TMAE_HEAD_CONV', None)
-    for a, b, tol in zip(res['native'], res['library'], (2e-2, 3e-2, 3e-2, 3e-2)):
-        assert float((a - b).norm() / (b.norm() + 1e-12)) < tol
+    for cin in (64, 128):
+        seq = nn.Sequential(nn.Conv2d(cin, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64, eps=1e-3, momentum=0.01),
+                            nn.ReLU(inplace=True)).cuda().train()
+        x0 = torch.randn(2, 60, 44, cin, device='cuda').bfloat16().permute(0, 3, 1, 2)
+        go = torch.randn(2, 60, 44, 64, device='cuda').bfloat16().permute(0, 3, 1, 2)
+        assert (ops.conv3x3_c64_ok if cin == 64 else ops.conv3x3_c128to64_ok)(x0.permute(0, 2, 3, 1), seq[0])
+        res = {}
+        for mode in ('native', 'library'):
+            os.environ['TMAE_HEAD_CONV'] = mode
+            try:
+                seq.zero_grad()
+                seq[1].running_mean.zero_(); seq[1].running_var.fill_(1.0)
+                xa = x0.clone().requires_grad_(True)
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    y = conv_bn_relu_nhwc(seq, xa)
+                y.backward(go)
+                res[mode] = (y.detach().float(), xa.grad.float(), seq[0].weight.grad.clone(), seq[1].weight.grad.clone())
+            finally:
+                os.environ.pop('TMAE_HEAD_CONV', None)
+        for a, b, tol in zip(res['native'], res['library'], (2e-2, 3e-2, 3e-2, 3e-2)):
+            assert float((a - b).norm() / (b.norm() + 1e-12)) < tol, cin
+    # 128 -> 64 against torch's fp32 convolution of the same values (forward: one extra bf16 rounding of the first half's partial sum)
+    conv = nn.Conv2d(128, 64, 3, padding=1, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(conv.weight.bfloat16().float())
+    x = torch.randn(2, 37, 50, 128, device='cuda').bfloat16()
+    go = torch.randn(2, 37, 50, 64, device='cuda').bfloat16()
+    xa = x.clone().requires_grad_(True)
+    y = ops.conv3x3_c128to64(xa, conv.weight)
+    y.backward(go)
+    got = (y.detach().float(), xa.grad.float(), conv.weight.grad.clone())
+    conv.zero_grad()
+    xf = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = conv(xf)
+    yr.backward(go.float().permute(0, 3, 1, 2))
+    want = (yr.detach().permute(0, 2, 3, 1), xf.grad.permute(0, 2, 3, 1), conv.weight.grad.clone())
+    conv.zero_grad()
+    assert float((got[0] - want[0]).abs().max()) <= 2.0 ** -7 * float(want[0].abs().max())
+    err = (got[1] - want[1]).abs()
+    assert bool((err <= 2.0 ** -8 * want[1].abs() + 1e-5 * float(want[1].abs().max())).all())
+    assert float((got[2] - want[2]).abs().max()) <= 2e-4 * max(1.0, float(want[2].abs().max()))
 
     # channel pitches: input = channels 64 .. 127 of a 128-wide map, output into channels 0 .. 63 of a 192-wide one
     B, Y, X = 2, 33, 20
@@ -349,7 +372,7 @@ def test_c64_stem_conv_kernels_vs_torch():
     sl = wide[..., 64:]
     w4 = w.float().view(64, 3, 3, 64).permute(0, 3, 1, 2)
     for inp_grad in (0, 1):
-        assert lib.tmae_conv3x3_c64(sl.data_ptr(), 128, B, Y, X, w.data_ptr(), inp_grad, owide.data_ptr(), 192, ws.data_ptr(), wsb, st) == 0
+        assert lib.tmae_conv3x3_c64(sl.data_ptr(), 128, B, Y, X, w.data_ptr(), inp_grad, 0, owide.data_ptr(), 192, ws.data_ptr(), wsb, st) == 0
         if inp_grad == 0:
             ref = torch.nn.functional.conv2d(sl.float().permute(0, 3, 1, 2), w4, padding=1)
         else:
@@ -365,9 +388,10 @@ def test_c64_stem_conv_kernels_vs_torch():
     wref = torch.autograd.grad(torch.nn.functional.conv2d(sl.float().permute(0, 3, 1, 2), wp, padding=1), wp,
                                dy[..., 128:].float().permute(0, 3, 1, 2))[0]
     assert float((dw.view(64, 3, 3, 64).permute(0, 3, 1, 2) - wref).abs().max()) <= 2e-4 * max(1.0, float(wref.abs().max()))
-    assert lib.tmae_conv3x3_c64(sl.data_ptr(), 60, B, Y, X, w.data_ptr(), 0, owide.data_ptr(), 192, ws.data_ptr(), wsb, st) < 0
-    assert lib.tmae_conv3x3_c64(sl.data_ptr(), 128, B, Y, X, w.data_ptr(), 2, owide.data_ptr(), 192, ws.data_ptr(), wsb, st) < 0
-    assert lib.tmae_conv3x3_c64(sl.data_ptr(), 128, B, Y, X, w.data_ptr(), 0, owide.data_ptr(), 192, ws.data_ptr(), 64, st) < 0
+    assert lib.tmae_conv3x3_c64(sl.data_ptr(), 60, B, Y, X, w.data_ptr(), 0, 0, owide.data_ptr(), 192, ws.data_ptr(), wsb, st) < 0
+    assert lib.tmae_conv3x3_c64(sl.data_ptr(), 128, B, Y, X, w.data_ptr(), 2, 0, owide.data_ptr(), 192, ws.data_ptr(), wsb, st) < 0
+    assert lib.tmae_conv3x3_c64(sl.data_ptr(), 128, B, Y, X, w.data_ptr(), 0, 3, owide.data_ptr(), 192, ws.data_ptr(), wsb, st) < 0
+    assert lib.tmae_conv3x3_c64(sl.data_ptr(), 128, B, Y, X, w.data_ptr(), 0, 0, owide.data_ptr(), 192, ws.data_ptr(), 64, st) < 0
     assert lib.tmae_conv3x3_c64_wgrad(dy.data_ptr(), 192, sl.data_ptr(), 128, B, Y, X, dw.data_ptr(), None, wsb2, st) < 0
     torch.cuda.synchronize()
 
