@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
       // NT == 4: the tiles are recomputed in pass 2 (4 MFMAs + 4 exps per tile pair, far below the budget of this
       // latency-bound kernel) instead of being held in 48 registers, which keeps two waves per SIMD resident.
       constexpr bool RECOMP = NT >= 4;
-      f32x4 sTk[RECOMP ? 1 : NT], pTk[RECOMP ? 1 : NT], dPk[RECOMP ? 1 : NT];
+      f32x4 sTk[RECOMP ? 1 : NT], pTk[NT], dPk[RECOMP ? 1 : NT];   // P is kept in every class (16 registers at NT = 4)
       float dacc = 0.f;
       const float lse_l = lse_i[qt] * LOG2E_F;
 #pragma unroll
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float p = exp_minus(sT[r], lse_l);
-            if constexpr (!RECOMP) pTk[kt][r] = p;
+            pTk[kt][r] = p;
             dacc += p * dP[r];
           }
           asm volatile("" : "+v"(dacc));                             // the MFMAs' first readers stay in their block
@@ -776,8 +776,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
             // VALU reader, so `dP - D` read the registers' previous content (-inf for an absent query).  DESIGN.md section 6h;
             // tools/check_mfma_hazards.py walks both sides of every branch behind every MFMA.  Now the mask rides on the C
             // operand and no branch is left between these MFMAs and their readers.
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pT[r] = exp_minus(sT[r], lse_l);
+            pT = pTk[kt];                                  // (the exponentials are not recomputed: 64 v_exp_f32 + 64 FMAs per item)
           } else {
             sT = sTk[kt]; dP = dPk[kt]; pT = pTk[kt];
           }
