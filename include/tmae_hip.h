@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 14
+#define TMAE_ABI_VERSION 15
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -460,6 +460,12 @@ int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w,
  * addmm_.  Same pointer rules as tmae_token_gemm; y is read and written once. */
 int tmae_token_gemm_acc(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
                         int64_t ldy, void* stream);
+/* Residual form  y[m,n] = res[m,n] + x[m,k] . w[n,k]^T + bias[n]  (res: the pitch of y, 16-byte aligned; res != y) -- `src +
+ * linear2(act)` of EncoderLayer.forward (sst_basic_block.py:81-83): the residual add in front of norm2 rides on the second Linear
+ * of the FFN (one rounding of the sum instead of two, and the norm reads one tensor instead of two).  (k, n) = (512, 256) or
+ * (256, 128), m >= 32768; TMAE_EARG otherwise. */
+int tmae_token_gemm_res(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, const void* res,
+                        void* y, int64_t ldy, void* stream);
 
 /* The FFN's first Linear with its activation (sst_basic_block.py:81: activation(linear1(src)), exact erf GELU):
  * y = x . w^T + bias (the pre-activation, which the backward needs) AND y_gelu = gelu(y), same shape and pitch, written

@@ -158,6 +158,8 @@ int tmae_token_gemm_wreg(const void* x, int64_t ldx, int64_t m, int k, const voi
                          const uint8_t* cells, void* y, int64_t ldy, int accumulate, void* stream);
 int tmae_token_gemm_wreg_gelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
                               void* y_gelu, int64_t ldy, void* stream);
+int tmae_token_gemm_wreg_res(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, const void* res,
+                             void* y, int64_t ldy, void* stream);
 int tmae_token_gemm_wreg_dgelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias,
                                const void* aux, void* y, int64_t ldy, void* stream);
 

@@ -329,6 +329,17 @@ int tmae_token_gemm_acc(const void* x, int64_t ldx, int64_t m, int k, const void
   return tmae_token_gemm_wreg(x, ldx, m, k, w, n, bias, nullptr, y, ldy, 1, stream_);
 }
 
+int tmae_token_gemm_res(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, const void* res,
+                        void* y, int64_t ldy, void* stream_) {
+  (void)hipGetLastError();
+  if (m < 0) return TMAE_EARG;
+  if (m == 0) return TMAE_OK;
+  // the residual tile travels through the W-in-registers kernel's LDS ring (the accumulate form, out of place): the two shapes of
+  // the encoder FFN's second Linear
+  if (m < 32768 || !((k == 512 && n == 256) || (k == 256 && n == 128))) return TMAE_EARG;
+  return tmae_token_gemm_wreg_res(x, ldx, m, k, w, n, bias, res, y, ldy, stream_);
+}
+
 int tmae_token_gemm_gelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
                          void* y_gelu, int64_t ldy, void* stream_) {
   (void)hipGetLastError();

@@ -114,7 +114,10 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)ybytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc((void*)((GELU2 || DG) ? y2 : y), 0, (int)ybytes, 0x00020000);
+  // ACC with y2 != NULL: the accumulators start from y2 (same pitch as y) instead of y itself -- y = y2 + x W^T + b, the residual add
+  // of the encoder FFN riding on its second Linear (sst_basic_block.py:81-83) out of place
+  const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc((void*)((GELU2 || DG || (ACC && y2 != nullptr)) ? y2 : y), 0,
+                                                                       (int)ybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc((void*)(POS ? cells : (const uint8_t*)x), 0, POS ? m : 0, 0x00020000);
 
   // ---- what this lane fetches in every step: PPW pieces; piece p = w * PPW + jj covers LDS bytes [1024 p, +1024) of the slot
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
         const int R = lb / YROWB, cpos = (lb % YROWB) / 16;
         const unsigned vo = tok0 + R < m ? (unsigned)(tok0 + R) * (unsigned)(ldy * 2) +
                                                (unsigned)(cg * YROWB + ((cpos ^ (R & 15)) << 4)) : TGW_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(DG ? y2r : yr, (__attribute__((address_space(3))) void*)(slot + STEP * ROWB + CELLB +
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(y2r, (__attribute__((address_space(3))) void*)(slot + STEP * ROWB + CELLB +
                                                                                                 (w * PPY + jj) * 1024),
                                                  16, vo, 0, 0, 0);
       }
@@ -396,6 +399,20 @@ int tmae_token_gemm_wreg_gelu(const void* x, int64_t ldx, int64_t m, int k, cons
 
 // y = (x W^T + bias) * gelu'(aux) in one pass (tmae_token_gemm_dgelu on the heavy shapes): the input gradient of the FFN's
 // first Linear through its GELU, (k, n) = (256, 512) or (128, 256); aux [m, n] has y's pitch.  TMAE_EARG for anything else.
+int tmae_token_gemm_wreg_res(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, const void* res,
+                             void* y, int64_t ldy, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m <= 0 || !x || !w || !y || !res || !bias || ldx < k || ldy < n || (ldx % 8) || (ldy % 8)) return TMAE_EARG;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15) || ((uintptr_t)res & 15) || ((uintptr_t)bias & 1)) return TMAE_EARG;
+  if (((m - 1) * ldx + k) * 2 >= (int64_t)TGW_OOB || ((m - 1) * ldy + n) * 2 >= (int64_t)TGW_OOB) return TMAE_EARG;
+  if (k == 512 && n == 256)
+    return tgw_launch<512, 2, 8, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream, const_cast<void*>(res));
+  if (k == 256 && n == 128)
+    return tgw_launch<256, 4, 2, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream, const_cast<void*>(res));
+  return TMAE_EARG;
+}
+
 int tmae_token_gemm_wreg_dgelu(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias,
                                const void* aux, void* y, int64_t ldy, void* stream_) {
   (void)hipGetLastError();

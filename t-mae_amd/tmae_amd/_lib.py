@@ -101,6 +101,7 @@ SIGNATURES = {
     'tmae_adam_step': (I, [P, P, L, F, F, F, F, F, P]),
     'tmae_bn_running_update': (I, [P, I, P, P, I, P]),
     'tmae_token_gemm_acc': (I, [P, L, L, I, P, I, P, P, L, P]),
+    'tmae_token_gemm_res': (I, [P, L, L, I, P, I, P, P, P, L, P]),
     'tmae_token_gemm_dgelu': (I, [P, L, L, I, P, I, P, P, P, L, P]),
     'tmae_token_gemm_gelu': (I, [P, L, L, I, P, I, P, P, P, L, P]),
     'tmae_token_gemm_pos': (I, [P, L, L, I, P, I, P, P, P, L, P]),
@@ -137,7 +138,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     setattr(lib, _name, _strict(_fn, _name, len(_args)))
 
-ABI_VERSION = 14            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
+ABI_VERSION = 15            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError(f'libtmae_hip.so ABI version {lib.tmae_abi_version()} != binding {ABI_VERSION}; rebuild with '
                       f't-mae_amd/build.py')

@@ -100,6 +100,9 @@ class WindowPlan:
 _POS_FOLD = os.environ.get('TMAE_POS_FOLD', '1') != '0'
 # TMAE_FFN_GELU=pass: linear1 and the GELU as two launches (A/B of the dual-store epilogue, profiles/scripts/ab_gelu.sh)
 _FFN_GELU_FUSED = os.environ.get('TMAE_FFN_GELU', 'fused') != 'pass'
+# TMAE_FFN_RESIDUAL=add: `src + linear2(act)` as the first summand pair of norm2 (two tensors read, the sum written by the norm)
+# instead of out of linear2's GEMM (ops.gelu_linear(residual=...), tmae_token_gemm_res)
+_FFN_RESIDUAL_FUSED = os.environ.get('TMAE_FFN_RESIDUAL', 'fused') != 'add'
 
 
 class WindowAttention(nn.Module):
@@ -202,6 +205,11 @@ class _EncoderTail(nn.Module):
             # backward fused into the dX GEMM of linear2
             h_pre, h_act, src_res = ops.proj_fork(src, self.linear1.weight, self.linear1.bias,
                                                   ((0, self.linear1.out_features, False),), fork=True, inplace_dx=True, gelu=True)
+            if _FFN_RESIDUAL_FUSED:
+                # ... and `src + linear2(act)` out of linear2's GEMM (the residual tile rides in its LDS ring): norm2 reads one tensor
+                xs = ops.gelu_linear(h_pre, self.linear2.weight, self.linear2.bias, h=h_act, residual=src_res)
+                out = ops.add_layer_norm(xs, None, self.norm2.weight, self.norm2.bias, self.norm2.eps, post=post)
+                return (out, alias) if passthrough else out
             src2 = ops.gelu_linear(h_pre, self.linear2.weight, self.linear2.bias, h=h_act)
         else:
             h_pre, src_res = ops.proj_fork(src, self.linear1.weight, self.linear1.bias,

@@ -739,22 +739,41 @@ class _GeluLinear(torch.autograd.Function):
     (tmae_token_gemm_dgelu: the GEMM's epilogue reads h_pre) instead of a GEMM plus an elementwise GeluBackward."""
 
     @staticmethod
-    def forward(ctx, h_pre, weight, bias, h=None):
+    def forward(ctx, h_pre, weight, bias, h=None, residual=None):
+        """residual [m, d] (optional): y = residual + gelu(h_pre) W^T + b -- `src + linear2(act)` of the encoder layer
+        (sst_basic_block.py:81-83): the add in front of norm2 rides on this GEMM (tmae_token_gemm_res: the residual tile travels
+        through the kernel's LDS ring), so the norm reads ONE tensor and does not write the sum again."""
         cdt = compute_dtype(h_pre)
         hp = h_pre.to(cdt).contiguous()
         if h is None or h.dtype != cdt or h.shape != hp.shape:        # h = gelu(h_pre) already made by the producing GEMM
             h = torch.nn.functional.gelu(hp)
         w_c = cast_param(weight, cdt)
-        y = token_gemm(h, w_c, None if bias is None else cast_param(bias, cdt))
+        b_c = None if bias is None else cast_param(bias, cdt)
+        n, k = w_c.shape                                              # [d, dff]
+        m = h.shape[0]
+        y = None
+        if residual is not None:
+            r = residual.to(cdt)
+            if (cdt == torch.bfloat16 and (k, n) in ((512, 256), (256, 128)) and m >= (65536 if k == 512 else 32768)
+                    and r.is_contiguous() and r.shape == (m, n) and h.is_contiguous() and w_c.is_contiguous()
+                    and m * k * 2 < 2 ** 31 and r.data_ptr() % 16 == 0 and h.data_ptr() % 16 == 0):
+                y = torch.empty((m, n), dtype=cdt, device=h.device)
+                bb = b_c.contiguous() if b_c is not None else _zero_bias(n, h.device)
+                check(lib.tmae_token_gemm_res(_p(h), k, m, k, _p(w_c), n, _p(bb), _p(r), _p(y), n, _s()), 'tmae_token_gemm_res')
+            else:
+                y = token_gemm(h, w_c, b_c) + r
+        if y is None:
+            y = token_gemm(h, w_c, b_c)
         ctx.save_for_backward(hp, h, w_c)
         ctx.has_bias = bias is not None
-        ctx.dtypes = (h_pre.dtype, weight.dtype, None if bias is None else bias.dtype)
+        ctx.has_res = residual is not None
+        ctx.dtypes = (h_pre.dtype, weight.dtype, None if bias is None else bias.dtype, None if residual is None else residual.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         hp, h, w_c = ctx.saved_tensors
-        xdt, wdt, bdt = ctx.dtypes
+        xdt, wdt, bdt, rdt = ctx.dtypes
         dy = dy.to(hp.dtype)
         if dy.stride(-1) != 1:
             dy = dy.contiguous()
@@ -776,15 +795,18 @@ class _GeluLinear(torch.autograd.Function):
         else:
             dw = dy.float().t() @ h.float()
             db = dy.float().sum(0) if ctx.has_bias else None
-        return dhp, dw.to(wdt), (db.to(bdt) if ctx.has_bias else None), None
+        # the residual's gradient IS dy (no copy: a later in-place accumulation into it, ops.proj_fork(inplace_dx=True), runs
+        # after this node has read it -- one stream)
+        return dhp, dw.to(wdt), (db.to(bdt) if ctx.has_bias else None), None, (dy.to(rdt) if ctx.has_res else None)
 
 
-def gelu_linear(h_pre, weight, bias=None, h=None):
+def gelu_linear(h_pre, weight, bias=None, h=None, residual=None):
     """linear(gelu(h_pre), weight, bias) with the GELU backward fused into the input-gradient GEMM (GPU, 2-D).
     h: gelu(h_pre) if the caller already has it (ops.proj_fork(..., gelu=True)); never differentiated through."""
     if h_pre.is_cuda and h_pre.dim() == 2:
-        return _GeluLinear.apply(h_pre, weight, bias, h)
-    return torch.nn.functional.linear(torch.nn.functional.gelu(h_pre), weight, bias)
+        return _GeluLinear.apply(h_pre, weight, bias, h, residual)
+    y = torch.nn.functional.linear(torch.nn.functional.gelu(h_pre), weight, bias)
+    return y if residual is None else y + residual
 
 
 def linear(x, weight, bias=None):

@@ -826,6 +826,52 @@ def test_gelu_linear_fused_backward_vs_torch():
         assert (g1[2] - b.grad).abs().max().item() <= 1e-2 * float(b.grad.abs().max())
 
 
+def test_gelu_linear_with_residual_vs_torch():
+    """ops.gelu_linear(..., residual=r) = r + F.linear(F.gelu(x)) -- `src + linear2(act)` of the encoder layer
+    (sst_basic_block.py:81-83) out of linear2's GEMM (tmae_token_gemm_res: the residual tile rides in the kernel's LDS ring) --
+    against fp32 torch on the same bf16 values: both FFN shapes above the kernel's size limit (ragged last step), one below it
+    (the fallback: GEMM + add); the residual's gradient is the output gradient itself; refusals of the C entry point."""
+    from tmae_amd import ops
+    from tmae_amd._lib import lib
+    torch.manual_seed(14)
+    for (m, dff, d) in ((40003, 256, 128), (70001, 512, 256), (20000, 512, 256)):
+        hp = (torch.randn(m, dff, device=dev()) * 1.5).bfloat16().requires_grad_(True)
+        r = torch.randn(m, d, device=dev()).bfloat16().requires_grad_(True)
+        w = (torch.randn(d, dff, device=dev()) * 0.05).bfloat16().float().requires_grad_(True)
+        b = torch.randn(d, device=dev()).bfloat16().float().requires_grad_(True)
+        go = torch.randn(m, d, device=dev()).bfloat16()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = ops.gelu_linear(hp, w, b, residual=r)
+        y.backward(go)
+        assert torch.equal(r.grad, go)
+        g1 = (hp.grad.float().clone(), w.grad.clone(), b.grad.clone())
+        hp.grad = w.grad = b.grad = r.grad = None
+        h = F.gelu(hp.detach()).float()                               # the kernel's left operand: gelu in bf16, as the producer stores it
+        want = r.detach().float() + h @ w.detach().t() + b.detach()
+        err = (y.float() - want).abs()
+        fused = m >= (65536 if dff == 512 else 32768)                  # ONE rounding of the sum; the fallback (GEMM, then add) has two
+        assert bool((err <= 2.0 ** (-8 if fused else -7) * want.abs() + (2e-3 if fused else 2e-2)).all()), (m, dff, d, float(err.max()))
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y2 = F.linear(F.gelu(hp), w, b) + r
+        y2.backward(go)
+        ref = hp.grad.float()
+        assert ((g1[0] - ref).norm() / ref.norm()).item() < 6e-3
+        assert (g1[1] - w.grad).abs().max().item() <= 1e-2 * float(w.grad.abs().max())
+        assert (g1[2] - b.grad).abs().max().item() <= 1e-2 * float(b.grad.abs().max())
+    x = torch.randn(40000, 512, device=dev()).bfloat16()
+    w = torch.randn(256, 512, device=dev()).bfloat16()
+    bz = torch.zeros(256, device=dev()).bfloat16()
+    r = torch.randn(40000, 256, device=dev()).bfloat16()
+    y = torch.empty_like(r)
+    st = torch.cuda.current_stream().cuda_stream
+    args = lambda **kw: [kw.get('x', x).data_ptr(), 512, kw.get('m', 40000), kw.get('k', 512), w.data_ptr(), kw.get('n', 256), bz.data_ptr(),
+                         kw.get('r', r.data_ptr()), y.data_ptr(), 256, st]
+    assert lib.tmae_token_gemm_res(*args()) == 0
+    assert lib.tmae_token_gemm_res(*args(m=1000)) < 0 and lib.tmae_token_gemm_res(*args(k=256)) < 0
+    assert lib.tmae_token_gemm_res(*args(r=None)) < 0 and lib.tmae_token_gemm_res(*args(r=r.data_ptr() + 2)) < 0
+    torch.cuda.synchronize()
+
+
 def test_add_layernorm_kernel_vs_torch():
     from tmae_amd import ops
     torch.manual_seed(1)
