@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .sparse import SparseConvTensor
+from .sparse import SparseConvTensor, prefetch_down
 from .sst import SSTBlockV1, WCABlock
 
 
@@ -129,6 +129,7 @@ class SiamWCA_MAE(nn.Module):
                              self.sparse_shape, 2 * B, groups=((ind_p.shape[0], B), (ind_c.shape[0], B)))
         out_p, out_c, strides = {}, {}, {}
         self.last_pair_tokens, self.last_stage_indices = [], []
+        prefetch_down(self.sst_blocks, x)
         for i, blk in enumerate(self.sst_blocks):
             x = blk(x)
             key = f'x_conv{i + 1}'

@@ -84,10 +84,9 @@ class SparseConvolution(SparseModule):
                                 cache=None if nxt is None else {'down': nxt})
 
 
-def _down_rulebooks(x, depth):
-    """Rulebooks of `depth` chained SparseConv2d(k3, s2, p1) levels starting at x's sites.  The output sites of a level
-    depend on the previous level's sites only (never on features), so all levels are enqueued first and their counts
-    -- output rows, and the rows of every sample group but the last -- come back in ONE host sync."""
+def _down_levels(x, depth):
+    """enqueue the output-site kernels of `depth` chained SparseConv2d(k3, s2, p1) levels starting at x's sites; returns
+    (levels, counts): what _down_rulebooks needs next and the device tensors whose values it has to read"""
     levels, counts = [], []
     grid, (ny, nx) = x.grid, x.spatial_shape
     for _ in range(depth):
@@ -100,7 +99,29 @@ def _down_rulebooks(x, depth):
                 counts.append((out_grid[:cells] >= 0).sum().view(1))
         levels.append((grid, ny, nx, out_grid, out_ind, oy, ox))
         grid, ny, nx = out_grid, oy, ox
-    host = ops.to_host(torch.cat(counts)).tolist()                # the one sync
+    return levels, counts
+
+
+def prefetch_down_rulebooks(x, depth):
+    """Enqueue the output-site kernels and the copy of their counts NOW (the sites depend on x's sites only) and park the handle in
+    x's rulebook cache: the strided conv that needs the rulebooks one SST block later then finds the counts on the host without
+    stalling -- read at the point of use, the host waited ~10 ms for the GPU to reach kernels enqueued behind a whole stage, the GPU
+    then idled until the host had woken up, and the host's lead over the GPU was gone for the rest of the forward pass."""
+    levels, counts = _down_levels(x, depth)
+    x._cache['down_prefetch'] = (depth, levels, ops.HostCopy(torch.cat(counts), 'down_counts'), x.grid)
+
+
+def _down_rulebooks(x, depth):
+    """Rulebooks of `depth` chained SparseConv2d(k3, s2, p1) levels starting at x's sites.  The output sites of a level
+    depend on the previous level's sites only (never on features), so all levels are enqueued first and their counts
+    -- output rows, and the rows of every sample group but the last -- come back in ONE host sync (or were prefetched:
+    prefetch_down_rulebooks)."""
+    pre = x._cache.pop('down_prefetch', None)
+    if pre is not None and pre[0] == depth and pre[3] is x.grid:      # same levels, same sites (the grid object travels with them)
+        levels, host = pre[1], pre[2].get().tolist()
+    else:
+        levels, counts = _down_levels(x, depth)
+        host = ops.to_host(torch.cat(counts)).tolist()            # the one sync
     per = len(host) // depth
     rbs, in_ind = [], x.indices
     for d, (grid, ny, nx, out_grid, out_ind, oy, ox) in enumerate(levels):
@@ -172,3 +193,20 @@ def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stri
 
 def replace_feature(out, new_features):
     return out.replace_feature(new_features)
+
+
+def prefetch_down(blocks, x):
+    """Before the first encoder block runs: if the first block keeps x's sites (no conv in front of its encoder, or a submanifold
+    one) and the second one starts with the strided conv, enqueue that conv's (and, with `lookahead`, the next level's) output-site
+    kernels and the copy of their counts now -- see prefetch_down_rulebooks.  Anything else: nothing (and _down_rulebooks checks
+    that the sites it is asked about are the prefetched ones)."""
+    if len(blocks) < 2 or not x.features.is_cuda:
+        return
+    first = getattr(blocks[0], 'conv_down', None)
+    c0 = None if first is None else getattr(first, '0', None)
+    if c0 is not None and not getattr(c0, 'subm', False):
+        return
+    nxt = getattr(blocks[1], 'conv_down', None)
+    c1 = None if nxt is None else getattr(nxt, '0', None)
+    if isinstance(c1, SparseConvolution) and not c1.subm:
+        prefetch_down_rulebooks(x, 2 if c1.lookahead else 1)

@@ -1128,6 +1128,29 @@ def to_host(t):
     return buf.clone()
 
 
+class HostCopy:
+    """to_host() in two halves: `HostCopy(t)` enqueues the asynchronous copy of a small device tensor into a pinned buffer of its own
+    and records an event behind it; `.get()` waits for that event and returns the values.  Between the two the caller enqueues
+    work that does not need the values: by the time they are read the copy has long happened, the host does not stall and keeps
+    its lead over the GPU (the strided convs' output counts are enqueued before the first stage and read after it)."""
+    _pool = {}
+
+    def __init__(self, t, tag):
+        t = t.detach()
+        key = (tag, t.device, t.dtype)
+        ent = HostCopy._pool.get(key)
+        if ent is None or ent[0].numel() < t.numel():
+            ent = HostCopy._pool[key] = (torch.empty((max(t.numel(), 64),), dtype=t.dtype).pin_memory(), torch.cuda.Event())
+        self.buf = ent[0][:t.numel()].view(t.shape)
+        self.event = ent[1]
+        self.buf.copy_(t, non_blocking=True)
+        self.event.record(torch.cuda.current_stream(t.device))
+
+    def get(self):
+        self.event.synchronize()
+        return self.buf.clone()
+
+
 def voxelize_finish(out, counts_host):
     n_kept, m = int(counts_host[0]), int(counts_host[1])
     return dict(points=out['points'][:n_kept], point_coords=out['point_coords'][:n_kept],
