@@ -277,6 +277,7 @@ struct WinInfo {
   int Tq, Tk;            // tokens of the window (PAIR: of window A)
   int TqB, TkB;          // PAIR: of window B
   int dwin;              // flat id of window (A): the slot of its tau-gradient partial
+  int dwinB;             // PAIR: flat id of window B, -1 if the unit holds one window
 };
 
 template <bool PAIR>
@@ -304,6 +305,7 @@ __device__ __forceinline__ bool find_tokens(const int32_t* __restrict__ wl, int 
     b[0] = (int)(u / (unsigned)(Wy * Wx));
   }
   wi.dwin = (b[0] * Wx + wcx[0]) * Wy + wcy[0];
+  wi.dwinB = (PAIR && nw == 2) ? (b[1] * Wx + wcx[1]) * Wy + wcy[1] : -1;
   wi.TqB = wi.TkB = 0;
   int tq[2] = {-1, -1}, tk[2] = {-1, -1};
 #pragma unroll
@@ -840,8 +842,19 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
       }
     }
   }
-  dtau_acc = wave_sum(dtau_acc);
-  if (lane == 0) *dtp = dtau_acc;
+  if constexpr (PAIR) {
+    // one partial per WINDOW, not per pair: which two windows share a unit depends on the order of the work list (built with an
+    // atomic counter), and a pair's sum would make the tau gradient differ in its last bits from run to run.  Query column i < 8
+    // belongs to window A, i >= 8 to window B; both sums run over the same lanes in the same order whoever the partner is.
+    const float sa = wave_sum(i < 8 ? dtau_acc : 0.f), sb = wave_sum(i < 8 ? 0.f : dtau_acc);
+    if (lane == 0) {
+      *dtp = sa;
+      if (wi.dwinB >= 0) dtau_partial[(int64_t)wi.dwinB * nhead + head] = sb;
+    }
+  } else {
+    dtau_acc = wave_sum(dtau_acc);
+    if (lane == 0) *dtp = dtau_acc;
+  }
   // ---- dk, dv (transposed accumulators): lane (g, i) holds channels FR g + 4 ct + r of key kt*16+i
 #pragma unroll
   for (int kt = 0; kt < NT; ++kt) {

@@ -3,6 +3,8 @@
  (2) the CPU oracle on seeded inputs,
  (3) size-independent properties at BASELINE configuration sizes.
 Bars: bit-exact for every integer / index / mask output; stated fp tolerances otherwise."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1617,7 +1619,12 @@ def test_bf16_trains_like_fp32():
     within 8 %, the means over the last ten steps within 3 %.  What was measured: the bf16 curve repeats bit for bit from
     run to run; the fp32 curve does not (library reductions on the fp32 path), and from step ~20 on its own runs differ by
     up to 6 % at single steps (0.888 / 0.939 at step 27 in two runs) -- the two dtypes were within 0.5 % of each other in
-    one run and 5.7 % in another, i.e. inside fp32's own run-to-run spread."""
+    one run and 5.7 % in another, i.e. inside fp32's own run-to-run spread.
+    WHICH library call (round 5, test_step_gradients_are_bit_reproducible / profiles/round5_reproducibility.txt): of the 278
+    gradients of one fp32 step exactly one differs between runs from identical state -- `decoder_conv_out.0.weight`, the weight
+    gradient of the decoder's 3x3 conv, which in fp32 is the library's (MIOpen) kernel (1e-7 relative per step; Adam's
+    normalisation amplifies it over 20+ steps).  The library GEMMs, reductions and every kernel of this repository repeat bit
+    for bit."""
     import bench
     c = bench.training_curves(dev())
     a, b = np.array(c['fp32']), np.array(c['bf16'])
@@ -1628,6 +1635,43 @@ def test_bf16_trains_like_fp32():
     assert abs(a[0] - b[0]) <= 2e-3 * abs(a[0])                          # the first step: same weights, bf16 forward error only
     assert c['max_rel_gap'] <= 0.08, c['max_rel_gap']
     assert abs(a[-10:].mean() - b[-10:].mean()) <= 0.03 * a[-10:].mean()
+
+
+def test_step_gradients_are_bit_reproducible():
+    """One forward + backward of the full model (B = 2 x 20 k-point pairs) three times from identical state and masking noise:
+    under bf16 autocast (the benched path) EVERY gradient repeats bit for bit -- all reductions of this repository run in a fixed
+    order, including the tau gradient's per-window partials (until round 5 the paired <= 8-token attention class wrote one
+    partial per PAIR of windows, and which windows share a unit depends on the order of the atomically built work list: the 16
+    tau gradients differed in their last bits) -- and in fp32 everything but the decoder conv's weight gradient, which is the
+    library's (MIOpen) fp32 kernel."""
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    from pcdet.models import model_fn_decorator
+    from tmae_amd.train import SyntheticTemporalDataset, build_model_from_cfg
+    import bench
+    cfg = cfg_from_yaml_file(os.path.join(bench.ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae_ssl.yaml'), EasyDict())
+    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=20000, batch_size=2)
+    b = ds.batch(0)
+    batch = {'points': torch.from_numpy(b['points']).to(dev()), 'points_prev': torch.from_numpy(b['points_prev']).to(dev()),
+             'batch_size': b['batch_size']}
+    torch.manual_seed(1234)
+    model = build_model_from_cfg(cfg, ds).to(dev()).train()
+    mf = model_fn_decorator()
+    for amp in (torch.bfloat16, None):
+        runs = []
+        for _ in range(3):
+            model.zero_grad(set_to_none=True)
+            torch.manual_seed(99)
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp is not None):
+                ret = mf(model, dict(batch))[0]
+            loss = (ret.loss if hasattr(ret, 'loss') else ret).mean()
+            loss.backward()
+            runs.append((loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][0], runs[2][0])
+        differ = sorted({n for n in runs[0][1] for k in (1, 2) if not torch.equal(runs[0][1][n], runs[k][1][n])})
+        if amp is not None:
+            assert differ == [], differ
+        else:
+            assert set(differ) <= {'backbone_3d.decoder_conv_out.0.weight'}, differ
 
 
 def test_token_gemm_gelu_dual_store_vs_torch():
