@@ -682,6 +682,8 @@ class _PosProjCross(torch.autograd.Function):
         check(lib.tmae_token_gemm_pos(_p(xk), xk.stride(0), xk.shape[0], d, _p(wkv), 2 * d, _p(b_c[d:]), _p(cells_k), _p(kv),
                                       2 * d, _s()), 'tmae_token_gemm_pos')
         ctx.save_for_backward(xq, xk, wq, wkv, cells_q, cells_k, E)
+        # (W[d:3d])^T for the k | v input gradient on the token GEMM (contraction 2d -> d), cached with the weight
+        ctx.wkvT = _derived(weight, ('kvT', d), lambda w: w[d:3 * d].to(torch.bfloat16).t().contiguous())
         ctx.has_bias, ctx.inplace_dx = bias is not None, bool(inplace_dx)
         ctx.dtypes = (x_q.dtype, x_kv.dtype, weight.dtype, None if bias is None else bias.dtype)
         ctx.set_materialize_grads(False)
@@ -708,7 +710,7 @@ class _PosProjCross(torch.autograd.Function):
             else:
                 dxq = torch.addmm(dxq, dq, wq[:, :d])
         if ctx.needs_input_grad[1] and dkv is not None:
-            dxk = dkv @ wkv[:, :d]
+            dxk = token_gemm(dkv, ctx.wkvT) if _tg_ok(dkv, 2 * d, d) else dkv @ wkv[:, :d]
         dW = dB = None
         if ctx.needs_input_grad[2]:
             mk = torch.empty if (dq is not None and dkv is not None) else torch.zeros
