@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 15
+#define TMAE_ABI_VERSION 16
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -189,6 +189,13 @@ int tmae_win_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
  * selects kernel instantiations sized for the class; tokens of windows that are in no list (no key / no query in the
  * other frame) are then NOT written: the caller pre-zeroes out / dq / dk / dv and dtau_partial.  NULL = one
  * worst-case kernel over all dense windows. */
+/* The complement of the work lists for cross attention: zeroes the rows that no list-driven launch writes -- rows of q0 [., wq0]
+ * (bf16, pitch ldq0) and qf [., nqf] (f32) of the query tokens whose window holds no key, rows of k0 / k1 [., wk] of the key tokens
+ * whose window holds no query (any pointer may be NULL) -- instead of pre-zeroing whole tensors.  Valid when every token of the two
+ * grids' token lists lies in a window (no token dropping).  Widths and pitches multiples of 8 elements, 16-byte aligned bases. */
+int tmae_win_attn_zero_orphans(const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx, int do_shift, void* q0,
+                               int64_t ldq0, int wq0, float* qf, int nqf, void* k0, int64_t ldk0, void* k1, int64_t ldk1, int wk,
+                               void* stream);
 size_t tmae_window_worklist_size(int batch, int ny, int nx);
 int tmae_window_worklist(const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx, int do_shift,
                          int32_t* worklist, void* stream);

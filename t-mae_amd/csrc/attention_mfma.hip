@@ -226,6 +226,64 @@ __global__ __launch_bounds__(256) void win_class_kernel(const int32_t* __restric
   }
 }
 
+// The complement of the work lists: the rows nobody writes.  A window with queries but no keys (cross attention: the other frame
+// is empty there) is in no list, and its query rows of out / dq must read as zeros; likewise the key rows of dk / dv of a
+// window with keys but no queries.  Callers used to pre-zero those WHOLE tensors (20 fills of 60-240 MB per step); this launch
+// (one wave per window, the two grids read once) zeroes only the orphan rows.  Valid when every token lies in a window of the
+// two grids (no token dropping: a dropped token is in no window and nobody would zero it).
+// q-side rows (Tk == 0): q0 [., wq0 elements] with pitch ldq0, qf [., nq_f] floats (lse);  k-side rows (Tq == 0): k0, k1.
+__global__ __launch_bounds__(256) void win_orphan_zero_kernel(const int32_t* __restrict__ grid_q, const int32_t* __restrict__ grid_k,
+                                                             int batch, int ny, int nx, int Wy, int Wx, int sy, int sx,
+                                                             __hip_bfloat16* __restrict__ q0, int64_t ldq0, int wq0,
+                                                             float* __restrict__ qf, int nqf, __hip_bfloat16* __restrict__ k0,
+                                                             int64_t ldk0, __hip_bfloat16* __restrict__ k1, int64_t ldk1, int wk) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwin = (int64_t)batch * Wy * Wx;
+  const int64_t dw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (dw >= nwin) return;
+  const int wcy = (int)(dw % Wy), wcx = (int)((dw / Wy) % Wx), b = (int)(dw / ((int64_t)Wy * Wx));
+  const int y = wcy * WIN - sy + (lane >> 3), x = wcx * WIN - sx + (lane & 7);
+  const bool in = y >= 0 && y < ny && x >= 0 && x < nx;
+  const int64_t cell = ((int64_t)b * ny + y) * nx + x;
+  const int tq = in ? grid_q[cell] : -1, tk = in ? grid_k[cell] : -1;
+  const int Tq = __popcll(__ballot(tq >= 0)), Tk = __popcll(__ballot(tk >= 0));
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  if (Tq > 0 && Tk == 0 && tq >= 0) {
+    if (q0) {
+      uint4* r = reinterpret_cast<uint4*>(q0 + (int64_t)tq * ldq0);
+      for (int c = 0; c < wq0 / 8; ++c) r[c] = z;
+    }
+    if (qf)
+      for (int c = 0; c < nqf; ++c) qf[(int64_t)tq * nqf + c] = 0.f;
+  }
+  if (Tk > 0 && Tq == 0 && tk >= 0) {
+    if (k0) {
+      uint4* r = reinterpret_cast<uint4*>(k0 + (int64_t)tk * ldk0);
+      for (int c = 0; c < wk / 8; ++c) r[c] = z;
+    }
+    if (k1) {
+      uint4* r = reinterpret_cast<uint4*>(k1 + (int64_t)tk * ldk1);
+      for (int c = 0; c < wk / 8; ++c) r[c] = z;
+    }
+  }
+}
+
+int tmae_win_attn_zero_orphans(const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx, int do_shift, void* q0,
+                               int64_t ldq0, int wq0, float* qf, int nqf, void* k0, int64_t ldk0, void* k1, int64_t ldk1, int wk,
+                               void* stream_) {
+  (void)hipGetLastError();
+  if (!grid_q || !grid_k || batch <= 0 || ny <= 0 || nx <= 0 || (int64_t)batch * ny * nx >= ((int64_t)1 << 31)) return TMAE_EARG;
+  if ((q0 && ((wq0 % 8) || (ldq0 % 8) || ldq0 < wq0 || ((uintptr_t)q0 & 15))) || (qf && nqf <= 0)) return TMAE_EARG;
+  if ((k0 && ((wk % 8) || (ldk0 % 8) || ldk0 < wk || ((uintptr_t)k0 & 15))) || (k1 && ((wk % 8) || (ldk1 % 8) || ldk1 < wk || ((uintptr_t)k1 & 15))))
+    return TMAE_EARG;
+  const int Wy = (ny + WIN - 1) / WIN + 1, Wx = (nx + WIN - 1) / WIN + 1;
+  const int s = do_shift ? WIN / 2 : WIN;
+  const int64_t nwin = (int64_t)batch * Wy * Wx;
+  hipLaunchKernelGGL(win_orphan_zero_kernel, dim3(tmae_cdiv(nwin, 4)), dim3(256), 0, (hipStream_t)stream_, grid_q, grid_k, batch, ny,
+                     nx, Wy, Wx, s, s, (__hip_bfloat16*)q0, ldq0, wq0, qf, nqf, (__hip_bfloat16*)k0, ldk0, (__hip_bfloat16*)k1, ldk1, wk);
+  return tmae_launch_status();
+}
+
 // compaction: one thread per window; a wave reserves its range with ONE atomic per class (list order only affects
 // scheduling, never results)
 __global__ __launch_bounds__(256) void win_worklist_kernel(const int8_t* __restrict__ cls, int64_t nwin, int Wy, int Wx,

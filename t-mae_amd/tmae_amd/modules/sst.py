@@ -82,6 +82,11 @@ class WindowPlan:
     def grid_k(self, shift):
         return self._shift_grids.get(bool(shift), (self.grid, self.key_grid))[1]
 
+    def covered(self, shift):
+        """every token of the stage (and of the key frame) lies in a window of this shift's grids: true unless token dropping
+        masked some out (set_shift_grids) -- ops.win_attn may then zero only the orphan rows instead of whole outputs"""
+        return bool(shift) not in self._shift_grids
+
     def worklist(self, shift):
         shift = bool(shift)
         if shift not in self._wl:
@@ -156,14 +161,14 @@ class WindowCrossAttention(nn.Module):
             q, kv, x_res = ops.pos_proj_cross(x, x_prv, w, b, plan.cells(shift, window_shape),
                                               plan_prv.cells(shift, window_shape), E, inplace_dx=True)
             o = ops.win_attn(q, kv, 'kv', a.tau, plan.grid_q(shift), plan.grid_k(shift), self.nhead, plan.batch, plan.ny,
-                             plan.nx, shift, a.tau_min, worklist=plan.worklist(shift))
+                             plan.nx, shift, a.tau_min, worklist=plan.worklist(shift), covered=plan.covered(shift))
             return o, x_res
         q, x_res = ops.proj_fork(x, w, b, ((0, d, True),), pos=(plan.indices, pos_table, window_shape, shift), fork=True,
                                  inplace_dx=True)
         k, v = ops.proj_fork(x_prv, w, b, ((d, 2 * d, True), (2 * d, 3 * d, False)),
                              pos=(plan_prv.indices, pos_table, window_shape, shift))
         o = ops.win_attn(q, k, v, a.tau, plan.grid_q(shift), plan.grid_k(shift), self.nhead, plan.batch, plan.ny, plan.nx,
-                         shift, a.tau_min, worklist=plan.worklist(shift))
+                         shift, a.tau_min, worklist=plan.worklist(shift), covered=plan.covered(shift))
         return o, x_res
 
 

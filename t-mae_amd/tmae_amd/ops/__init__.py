@@ -1419,7 +1419,7 @@ class _WinAttn(torch.autograd.Function):
         return (a.data_ptr(), d, b.data_ptr(), d, c.data_ptr(), d)
 
     @staticmethod
-    def forward(ctx, a, b, c, tau, grid_q, grid_k, worklist, nhead, batch, ny, nx, do_shift, tau_min):
+    def forward(ctx, a, b, c, tau, grid_q, grid_k, worklist, nhead, batch, ny, nx, do_shift, tau_min, covered=False):
         a = a.contiguous()
         ctx.layout = 'qkv' if b is None else 'qk_v' if c is None else 'q_kv' if isinstance(c, str) else 'q_k_v'
         if b is None:
@@ -1445,13 +1445,20 @@ class _WinAttn(torch.autograd.Function):
             worklist = None                                  # the fp32 kernels walk the dense windows
         # cross mode starts from zeros: with a work list, tokens of windows in no list are not written; and under token
         # dropping (modules/sst.py: per-shift grids with the dropped tokens masked out) a token may be in no window at all
-        alloc = torch.zeros if cross else torch.empty
+        # covered (the caller's promise: no token dropping, every token lies in a window of the two grids) + a work list: only
+        # the rows of the windows that are in no list are zeroed (tmae_win_attn_zero_orphans), not the whole tensors
+        orphans = cross and bool(covered) and worklist is not None and d % 8 == 0
+        alloc = torch.zeros if (cross and not orphans) else torch.empty
         out = alloc((mq, d), dtype=a.dtype, device=a.device)
         lse = alloc((mq, nhead), dtype=torch.float32, device=a.device)
+        if orphans:
+            check(lib.tmae_win_attn_zero_orphans(_p(grid_q), _p(grid_k), batch, ny, nx, 1 if do_shift else 0, _p(out), d, d, _p(lse),
+                                                 nhead, None, 0, None, 0, 0, _s()), 'tmae_win_attn_zero_orphans')
         check(lib.tmae_win_attn_fwd(q, ldq, k, ldk, v, ldv, _dt(a), mq, mk, nhead, dh, _p(grid_q), _p(grid_k),
                                     batch, ny, nx, 1 if do_shift else 0, _p(tau32), float(tau_min), _p(out), d,
                                     _p(lse), _p(worklist), _s()), 'tmae_win_attn_fwd')
         ctx.cross = cross
+        ctx.orphans = orphans
         ctx.has_wl = worklist is not None
         ctx.save_for_backward(a, b if b is not None else a, c if torch.is_tensor(c) else a, tau32, grid_q, grid_k, out,
                               lse, worklist if worklist is not None else grid_q)
@@ -1472,12 +1479,15 @@ class _WinAttn(torch.autograd.Function):
         if not ctx.has_wl:
             worklist = None
         dout = dout.contiguous()
-        alloc = torch.zeros_like if ctx.cross else torch.empty_like
+        alloc = torch.zeros_like if (ctx.cross and not ctx.orphans) else torch.empty_like
         da = alloc(a)
         db = alloc(b) if b is not None else None
         dc = alloc(c) if torch.is_tensor(c) else c
         q, ldq, k, ldk, v, ldv = _WinAttn._ptrs(a, b, c, d)
         dq, lddq, dk, lddk, dv, lddv = _WinAttn._ptrs(da, db, dc, d)
+        if ctx.orphans:
+            check(lib.tmae_win_attn_zero_orphans(_p(grid_q), _p(grid_k), batch, ny, nx, 1 if do_shift else 0, dq, lddq, d, None, 0,
+                                                 dk, lddk, dv, lddv, d, _s()), 'tmae_win_attn_zero_orphans')
         nblk = lib.tmae_win_attn_num_blocks(batch, ny, nx, nhead, dh)
         part = (torch.zeros if worklist is not None else torch.empty)((nblk,), dtype=torch.float32, device=a.device)
         check(lib.tmae_win_attn_bwd(q, ldq, k, ldk, v, ldv, _p(out), d, _p(dout), d, _p(lse), _dt(a), mq, mk,
@@ -1489,11 +1499,12 @@ class _WinAttn(torch.autograd.Function):
         # fixed-order multi-block sum of the partials + the clamp rule, one launch
         check(lib.tmae_win_attn_dtau(_p(part), nblk, _p(tau32), float(tau_min), _p(dtau), _s()), 'tmae_win_attn_dtau')
         dtau = dtau.reshape(tshape).to(tdtype)
-        return da, db, (dc if torch.is_tensor(dc) else None), dtau, None, None, None, None, None, None, None, None, None
+        return da, db, (dc if torch.is_tensor(dc) else None), dtau, None, None, None, None, None, None, None, None, None, None
 
 
-def win_attn(a, b, c, tau, grid_q, grid_k, nhead, batch, ny, nx, do_shift, tau_min, worklist=None):
-    return _WinAttn.apply(a, b, c, tau, grid_q, grid_k, worklist, nhead, batch, ny, nx, do_shift, tau_min)
+def win_attn(a, b, c, tau, grid_q, grid_k, nhead, batch, ny, nx, do_shift, tau_min, worklist=None, covered=False):
+    """covered: see _WinAttn.forward (cross attention with a work list: zero only the orphan rows)."""
+    return _WinAttn.apply(a, b, c, tau, grid_q, grid_k, worklist, nhead, batch, ny, nx, do_shift, tau_min, bool(covered))
 
 
 # ----------------------------------------------------------------------------- sparse conv (A9)

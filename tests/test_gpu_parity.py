@@ -453,6 +453,20 @@ def test_attention_mfma_bf16_fwd_bwd_vs_fp32_kernel(seed):
                     # the tau gradient sums dS*S over every window: instantiations that mask differently (C-operand
                     # bias for <= 32-token windows, per-element select for 64) differ in rounding, not in meaning
                     assert abs(float(tau2.grad) - float(tau.grad)) <= 5e-3 * max(1.0, abs(float(tau.grad)))
+                    if cross:
+                        # covered=True: only the rows of the orphan windows are zeroed (tmae_win_attn_zero_orphans) instead of the
+                        # whole outputs -- the two clouds differ, so windows with queries and no keys (and the reverse) exist; the
+                        # result must be the pre-zeroed one bit for bit, and the buffers are poisoned first to prove it
+                        assert int((ops.index_grid(indq, 2, 234, 234) >= 0).sum()) == mq
+                        junk = [torch.full((mk, d), float('nan'), device=dev(), dtype=torch.bfloat16) for _ in range(4)]
+                        del junk                                                    # NaN-filled blocks for the allocator to hand back
+                        a3, b3, c3 = [None if t is None else t.detach().clone().requires_grad_(True) for t in (a, b_, c_)]
+                        tau3 = torch.full((1, 1, 1), tauv, device=dev(), requires_grad=True)
+                        o3 = ops.win_attn(a3, b3, c3, tau3, gq, gk, H, 2, 234, 234, shift, 0.01, worklist=wl, covered=True)
+                        o3.backward(go.bfloat16().to(dt))
+                        assert torch.equal(o3, o2) and torch.equal(a3.grad, a2.grad) and torch.equal(b3.grad, b2.grad)
+                        assert c3 is None or torch.equal(c3.grad, c2.grad)
+                        assert torch.equal(tau3.grad, tau2.grad)
             f, h = res[torch.float32], res[torch.bfloat16]
             assert all(torch.isfinite(t.float()).all() for t in h if t is not None)
             lim = 0.03 if tauv >= 0.05 else 0.12          # logits reach +-100 at the clamp: bf16 logit error ~0.4
