@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 16
+#define TMAE_ABI_VERSION 17
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -171,9 +171,11 @@ int tmae_win_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
 int64_t tmae_win_attn_num_blocks(int batch, int ny, int nx, int nhead, int dh);
 /* dtau[0] = tau >= tau_min ? -(sum of the n partials) / tau : 0  -- the chain rule through
  * clamp(tau, min=tau_min) of cosine_msa.py:150-152; fixed-order sum over up to 64 strips, one launch.  Calls must be
- * ordered on one stream (a module-scope ticket counter picks the block that finishes). */
+ * ordered on one stream (a module-scope ticket counter picks the block that finishes).  worklist (may be NULL): the work list the
+ * backward ran with -- windows that are in none of its lists wrote no partial and count as zero (no pre-zeroing of dtau_partial);
+ * NULL: every entry is read. */
 int tmae_win_attn_dtau(const float* dtau_partial, int64_t n, const float* tau, float tau_min, float* dtau,
-                       void* stream);
+                       const int32_t* worklist, int nhead, void* stream);
 int tmae_win_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                       const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
                       int dtype, int64_t mq, int64_t mk, int nhead, int dh,

@@ -316,9 +316,15 @@ static inline void attn_dims(int ny, int nx, int& Wy, int& Wx) {
 __device__ unsigned dtau_ticket = 0;
 __device__ float dtau_strip_sum[DTAU_MAX_BLOCKS];
 
-__global__ __launch_bounds__(1024) void dtau_finish_kernel(const float* __restrict__ part, int64_t n,
+// listed (may be NULL) / per: the class byte of window e / per from the work list (attention_mfma.hip: win_class_kernel) -- a
+// window that is in no list wrote no partial and counts as zero, so the caller need not pre-zero the partials.
+__global__ __launch_bounds__(1024) void dtau_finish_kernel(const float* __restrict__ part_raw, int64_t n,
                                                           const float* __restrict__ tau, float tau_min,
-                                                          float* __restrict__ dtau) {
+                                                          float* __restrict__ dtau, const int8_t* __restrict__ listed, int heads) {
+  struct Part {
+    const float* p; const int8_t* l; int per;
+    __device__ __forceinline__ float operator[](int64_t e) const { return (l == nullptr || l[e / per] >= 0) ? p[e] : 0.f; }
+  } part{part_raw, listed, heads};
   __shared__ float red[1024];
   __shared__ bool last;
   const int nb = gridDim.x;
@@ -351,14 +357,16 @@ __global__ __launch_bounds__(1024) void dtau_finish_kernel(const float* __restri
 }
 
 int tmae_win_attn_dtau(const float* dtau_partial, int64_t n, const float* tau, float tau_min, float* dtau,
-                       void* stream_) {
+                       const int32_t* worklist, int nhead, void* stream_) {
   (void)hipGetLastError();
-  if (n < 0 || !tau || !dtau || (n > 0 && !dtau_partial)) return TMAE_EARG;
+  if (n < 0 || !tau || !dtau || (n > 0 && !dtau_partial) || (worklist && (nhead <= 0 || n % nhead))) return TMAE_EARG;
+  // the class bytes behind the four lists (tmae_window_worklist_size: counts | lists | class bytes); n = windows x heads
+  const int8_t* listed = worklist ? reinterpret_cast<const int8_t*>(worklist + 8 + 4 * (n / nhead)) : nullptr;
   int64_t nb = (n + 8191) / 8192;                              // >= 8 elements per thread and block
   if (nb < 1) nb = 1;
   if (nb > DTAU_MAX_BLOCKS) nb = DTAU_MAX_BLOCKS;
   hipLaunchKernelGGL(dtau_finish_kernel, dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream_, dtau_partial, n, tau,
-                     tau_min, dtau);
+                     tau_min, dtau, listed, nhead > 0 ? nhead : 1);
   return tmae_launch_status();
 }
 

@@ -40,7 +40,7 @@ SIGNATURES = {
     'tmae_win_attn_zero_orphans': (I, [P, P, I, I, I, I, P, L, I, P, I, P, L, P, L, I, P]),
     'tmae_window_worklist_size': (Z, [I, I, I]),
     'tmae_window_worklist': (I, [P, P, I, I, I, I, P, P]),
-    'tmae_win_attn_dtau': (I, [P, L, P, F, P, P]),
+    'tmae_win_attn_dtau': (I, [P, L, P, F, P, P, I, P]),
     'tmae_win_attn_num_blocks': (L, [I, I, I, I, I]),
     'tmae_win_attn_bwd': (I, [P, L, P, L, P, L, P, L, P, L, P, I, L, L, I, I, P, P, I, I, I, I, P, F,
                               P, L, P, L, P, L, P, P, P]),
@@ -139,7 +139,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     setattr(lib, _name, _strict(_fn, _name, len(_args)))
 
-ABI_VERSION = 16            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
+ABI_VERSION = 17            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError(f'libtmae_hip.so ABI version {lib.tmae_abi_version()} != binding {ABI_VERSION}; rebuild with '
                       f't-mae_amd/build.py')

@@ -1489,7 +1489,7 @@ class _WinAttn(torch.autograd.Function):
             check(lib.tmae_win_attn_zero_orphans(_p(grid_q), _p(grid_k), batch, ny, nx, 1 if do_shift else 0, dq, lddq, d, None, 0,
                                                  dk, lddk, dv, lddv, d, _s()), 'tmae_win_attn_zero_orphans')
         nblk = lib.tmae_win_attn_num_blocks(batch, ny, nx, nhead, dh)
-        part = (torch.zeros if worklist is not None else torch.empty)((nblk,), dtype=torch.float32, device=a.device)
+        part = torch.empty((nblk,), dtype=torch.float32, device=a.device)       # unlisted windows: skipped by tmae_win_attn_dtau
         check(lib.tmae_win_attn_bwd(q, ldq, k, ldk, v, ldv, _p(out), d, _p(dout), d, _p(lse), _dt(a), mq, mk,
                                     nhead, dh, _p(grid_q), _p(grid_k), batch, ny, nx, 1 if do_shift else 0,
                                     _p(tau32), float(tau_min), dq, lddq, dk, lddk, dv, lddv, _p(part), _p(worklist),
@@ -1497,7 +1497,7 @@ class _WinAttn(torch.autograd.Function):
         # d/d tau of logits = cos / max(tau, tau_min): -(1/tau_c) * sum dS*s, zero in the clamped branch
         dtau = torch.empty((1,), dtype=torch.float32, device=a.device)
         # fixed-order multi-block sum of the partials + the clamp rule, one launch
-        check(lib.tmae_win_attn_dtau(_p(part), nblk, _p(tau32), float(tau_min), _p(dtau), _s()), 'tmae_win_attn_dtau')
+        check(lib.tmae_win_attn_dtau(_p(part), nblk, _p(tau32), float(tau_min), _p(dtau), _p(worklist), nhead, _s()), 'tmae_win_attn_dtau')
         dtau = dtau.reshape(tshape).to(tdtype)
         return da, db, (dc if torch.is_tensor(dc) else None), dtau, None, None, None, None, None, None, None, None, None, None
 
