@@ -650,6 +650,14 @@ def _self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def _affinity_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_tmae_affinity', os.path.join(ROOT, 't-mae_amd', 'tmae_amd', 'train', 'affinity.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -657,11 +665,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert torch.cuda.is_available(), 'bench.py needs a GPU'
     # TEST-ONLY (tests/test_gpu_ddp.py): TMAE_BENCH_SHARED_GPU=1 puts every rank on GPU 0 and swaps RCCL for gloo (two
     # ranks cannot share one GPU under RCCL), so that the launcher, the rank bookkeeping and the JSON relay of an N > 1
     # run can be rehearsed on a one-GPU box.  Such a line says so in `collective_backend` and is not a measurement.
     shared_gpu = world > 1 and os.environ.get('TMAE_BENCH_SHARED_GPU') == '1'
+    # Host cores of this rank: a disjoint slice of the node's allowed cores, next to the rank's GPU where sysfs shows that, set
+    # BEFORE the first GPU call so that the HIP runtime's threads inherit it (tmae_amd/train/affinity.py, loaded by path: importing
+    # the package loads the HIP library).  One rank on the node: nothing is pinned.
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+    pin = _affinity_module().pin_rank(local_rank, local_world, device_indices=[0] * local_world if shared_gpu else None)
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
     dev_index = 0 if shared_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
@@ -758,6 +771,10 @@ def main():
         dist.all_gather(per_rank, own)
         ranks_seen = dist.get_world_size()
     per_rank = [float(v.item()) for v in per_rank]
+    rank_cores = [pin['cores']]
+    if world > 1:
+        rank_cores = [None] * world
+        dist.all_gather_object(rank_cores, pin['cores'])
     elapsed = float(t.item())
     loss_val = float(loss.detach())
     assert np.isfinite(loss_val), 'non-finite loss in the timed region'
@@ -775,6 +792,10 @@ def main():
             # CPUs the launching thread ran on; ms_per_step close to host_ms_per_step = the host, not the GPU, set the pace
             'host_ms_per_step': round(1e3 * host_s / args.steps, 3), 'host_cpus_seen': sorted(cpus),
             'host_affinity': len(os.sched_getaffinity(0)),
+            # cores each rank's process (launcher + the threads it starts) is pinned to; disjoint across the ranks of a node
+            'rank_cores': {'source': pin['source'], 'allowed': pin['allowed'],
+                           'per_rank': [_affinity_module().format_cpulist(c) for c in rank_cores],
+                           'disjoint': all(not (set(a) & set(b)) for i_, a in enumerate(rank_cores) for b in rank_cores[i_ + 1:])},
             # the caching allocator inside the timed region: a device malloc / free there is a host stall with the queue draining
             'allocator_in_timed_region': alloc_delta,
             'config': {'workload': (f'configs[{1 if args.shape == "once" else 3}]: {"ONCE" if args.shape == "once" else "Waymo"}-shape synthetic {args.points}-pt frame-pairs, full 3-stage SST '

@@ -105,7 +105,12 @@ def prune_checkpoints(ckpt_dir, max_ckpt_save_num):
 
 def main():
     args, cfg = parse_config()
+    pin = None
     if args.launcher == 'pytorch':
+        # this rank's host cores (a disjoint slice per rank of the node, next to its GPU where sysfs shows that): set before the
+        # first GPU call, so that the HIP runtime's threads and the .bin reader threads inherit it (tmae_amd/train/affinity.py)
+        from tmae_amd.train.affinity import format_cpulist, pin_rank
+        pin = pin_rank(int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', 1))))
         world, rank = common_utils.init_dist_pytorch(backend='nccl')
         local_rank = int(os.environ.get('LOCAL_RANK', 0))
     else:
@@ -119,6 +124,8 @@ def main():
     (out / 'ckpt').mkdir(parents=True, exist_ok=True)
     logger = common_utils.create_logger(out / f'log_train_{time.strftime("%Y%m%d-%H%M%S")}.txt', rank=rank)
     log_config_to_file(cfg, logger=logger)
+    if pin is not None:
+        logger.info(f'rank {rank}: host cores {format_cpulist(pin["cores"])} ({pin["source"]}, {pin["allowed"]} allowed)')
     train_loader = train_sampler = None
     if args.synthetic:
         ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=args.synthetic_points, batch_size=bs, rank=rank,

@@ -153,6 +153,9 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert 'GELU2' in d['roofline']['kernel'] and 'roofline_token_gemm_plain' in d     # the priced instance = the dual-store kernel
     assert d['roofline']['peak_measured'] == d['box_peaks']['hbm_copy_gbs'] > 1000
     assert d['roofline_step']['peak_measured'] == d['box_peaks']['mfma_bf16_tflops'] > 100
+    # each rank's launcher (and the threads it starts) is pinned to its own cores before its first GPU call (train/affinity.py)
+    print('rank cores:', d['rank_cores'])
+    assert len(d['rank_cores']['per_rank']) == 2 and d['rank_cores']['disjoint'] and d['rank_cores']['source'] != 'unpinned'
 
 
 def _syncbn_worker(rank, world, port, q):

@@ -1345,6 +1345,11 @@ def test_e2e_golden_and_oracle(oracle, name, nst):
     lo = oracle.forward_loss(Pg, g['points'], g['points_prev'], g['noise'], bs, cfg)
     lo.backward()
     assert abs(fl(lo) - fl(loss)) < 1e-4
+    # What this check covers: every gradient of the fp32 path against the oracle's.  In fp32 the decoder conv (forward, input and
+    # weight gradient: `backbone_3d.decoder_conv_out.0.weight`) is the LIBRARY's (MIOpen; ops.dense_conv3x3_ok admits bf16 only), so
+    # for that one tensor the comparison pins the glue around the conv, not csrc/dense_wgrad.hip / spconv_igemm.hip's halo kernels --
+    # those are pinned by their operator tests against torch (test_dense_conv3x3_*), and at model level by
+    # test_e2e_bf16_autocast_close_to_fp32, which compares the bf16 step's gradient of that tensor with this fp32 one.
     for n in names:
         a, b = grads[n].grad.cpu(), Pg[n].grad
         assert (a - b).abs().max().item() <= 5e-3 * max(1.0, b.abs().max().item()), n
@@ -1427,19 +1432,45 @@ def test_e2e_bf16_autocast_close_to_fp32(oracle):
         else:
             assert abs(fl(loss) - fl(l32)) < 0.01 * max(1.0, abs(fl(l32))), (fl(loss), fl(l32))
         assert all(torch.isfinite(v).all() for v in g16.values())
-        # gradient direction of the big tensors survives bf16 (cosine against the fp32 gradient)
-        # gradient direction of the big tensors survives bf16 (cosine against the fp32 gradient).  Measured, worst big tensor:
-        # conditioned head 0.950-0.953 (a stage-2 in-projection weight), default head 0.966 (a strided sparse conv).  The figure is
-        # chaotic at the third digit: round 5 rewrote the attention masks (outputs equal to the previous build's within one bf16 ulp
-        # on < 2e-5 of the elements, profiles/scripts/attn_dump.py) and it moved from 0.9532 to 0.9496 -- the bar states what the
-        # metric can resolve, 0.94, not a precision the bf16 step never had.
-        worst = (2.0, None)
-        for n, p in model.named_parameters():
-            if p.numel() >= 16384 and p.grad.norm() > 0:
-                cos = torch.nn.functional.cosine_similarity(g16[n].flatten().double(), p.grad.flatten().double(), dim=0)
-                worst = min(worst, (float(cos), n))
-        print('bf16 vs fp32 gradient cosine, worst big tensor:', worst)
-        assert worst[0] > 0.94, worst
+        # Gradient fidelity of the bf16 step, stated with metrics that can hold a bar (round 6; until then: the cosine of the WORST
+        # big tensor, a figure that is chaotic at the third digit -- it moved 0.9532 -> 0.9496 when round 5 rewrote the attention
+        # masks with outputs equal within one bf16 ulp -- and whose bar had followed it to 0.94):
+        #  (1) cosine of the CONCATENATED gradient (all parameters) against the fp32 gradient: the direction the optimizer follows;
+        #  (2) per big tensor, the relative L2 error against the fp32 gradient, measured against that tensor's own NOISE FLOOR: the
+        #      relative L2 change of the fp32 gradient when nothing but the parameters are rounded to bf16 (the smallest perturbation
+        #      any bf16 step makes, 2^-9 relative per weight, computed in fp32 throughout).  A tensor whose fp32 gradient moves by 30 %
+        #      under that rounding (the stage-2 in-projections behind ~30 layers, tau = the golden case's) cannot be asked to match to
+        #      5 %; one that moves by 1 % can.  The bar is a multiple of the floor plus the bf16 rounding of the gradient itself.
+        g32 = {n: p.grad.clone() for n, p in model.named_parameters()}
+        saved = {n: p.detach().clone() for n, p in model.named_parameters()}
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                p.copy_(p.to(torch.bfloat16).float())
+        _run_product(model, g['points'], g['points_prev'], g['noise'], int(g['batch_size']))
+        g32r = {n: p.grad.clone() for n, p in model.named_parameters()}
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                p.copy_(saved[n])
+        names = [n for n in g32 if g32[n].norm() > 0]
+        cat = lambda d: torch.cat([d[n].flatten().double() for n in names])
+        cos_all = float(torch.nn.functional.cosine_similarity(cat(g16), cat(g32), dim=0))
+        cos_floor = float(torch.nn.functional.cosine_similarity(cat(g32r), cat(g32), dim=0))
+        rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        rows = []
+        for n in names:
+            if g32[n].numel() >= 16384:
+                rows.append((rel(g16[n], g32[n]), rel(g32r[n], g32[n]), n))
+        worst = max(rows, key=lambda r: r[0] / max(r[1], 1e-3))
+        print(f'bf16 vs fp32: cosine of the concatenated gradient {cos_all:.4f} (weights-rounded fp32: {cos_floor:.4f}); worst big tensor '
+              f'rel-L2 {worst[0]:.3f} at floor {worst[1]:.3f}: {worst[2]}; largest rel-L2 {max(rows)[0]:.3f} ({max(rows)[2]})')
+        assert cos_all > 0.95, (cos_all, cos_floor)
+        for e16, floor, n in rows:
+            assert e16 <= 3.0 * floor + 0.02, (n, e16, floor)
+        # the decoder conv's weight gradient: in the fp32 run it is MIOpen's (ops.dense_conv3x3_ok admits bf16 only), in the bf16 run
+        # it is csrc/dense_wgrad.hip's -- the two agree to bf16 accuracy at model level (the operator tests compare that kernel
+        # with torch on its own)
+        n = 'backbone_3d.decoder_conv_out.0.weight'
+        assert rel(g16[n], g32[n]) <= 3.0 * rel(g32r[n], g32[n]) + 0.02, (rel(g16[n], g32[n]), rel(g32r[n], g32[n]))
 
 
 def test_vfe_bf16_keeps_far_range_coordinates(oracle):
@@ -1688,8 +1719,13 @@ def test_step_gradients_are_bit_reproducible():
             # measured: exactly {'backbone_3d.decoder_conv_out.0.weight'} (MIOpen's fp32 weight-gradient kernel).  Which library
             # kernel a box picks is not ours to pin, so the assertion is on what IS ours: nothing that only passes through this
             # repository's kernels may differ (the tau gradients, the norms), and the list stays a handful
+            # Explicit allow-list: the parameters whose fp32 gradient comes from a library kernel.  In fp32 the decoder
+            # conv runs on MIOpen (ops.dense_conv3x3_ok admits bf16 only); its weight gradient is the only gradient that is a
+            # library kernel's OUTPUT (the conv's input gradient feeds the encoder, but MIOpen's data-gradient kernel repeats bit
+            # for bit on every box measured).  A new name here must be traced to a library kernel before it is added.
             print('fp32 gradients that differ between runs:', differ)
-            assert len(differ) <= 4 and not any(('tau' in n or 'norm' in n) for n in differ), differ
+            allow = {'backbone_3d.decoder_conv_out.0.weight'}
+            assert set(differ) <= allow, differ
 
 
 def test_token_gemm_gelu_dual_store_vs_torch():
