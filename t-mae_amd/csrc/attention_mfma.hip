@@ -421,45 +421,35 @@ struct AttnBufs {          // byte sizes of the tensors for the buffer descripto
 // 28-107) but for the MFMA FORM: with a budget above 256 the compiler assumes it may need the AGPR half of the register file and
 // selects the AGPR-destination MFMAs -- every logit then travels to the VALU through a v_accvgpr_read (508 moves in the dh-32
 // 64-token forward, 16 % of its instructions).  Below 257 it selects the VGPR form and the moves are gone.
-template <int DH, int NT, bool PAIR>
-__global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
+// SPLIT (see TAU_SPLIT_BELOW): the logits from the hi/lo split of q-hat / k-hat (three MFMAs per tile) or from their bf16 values
+// alone (one MFMA, no split arithmetic).  The kernels carry both bodies and take one per launch-uniform temperature.
+//
+// What the split buys is 2^-16 instead of 2^-9 relative accuracy per normalised channel, i.e. an absolute logit error of
+// ~5e-4 / tau without it (32 products of magnitude ~1/32, rounding errors adding in quadrature, divided by tau).  The
+// probabilities that leave the softmax are rounded to bf16 for the P.V product anyway (2^-9 relative = a logit error of 2e-3):
+// at tau_c >= TAU_SPLIT_BELOW = 0.25 the un-split logit error stays below that rounding and the split is arithmetic nobody can see
+// -- ~20 VALU instructions per row fragment and two of three logit MFMAs in kernels that are bound by vector issue (DESIGN.md
+// section 6j).  The module starts at tau = 1 (cosine_msa.py:453-456); a temperature trained below 0.25 -- down to the clamp at
+// 0.01, where the un-split error would be 5 % -- takes the split body.  The reference itself runs this bmm on fp16 operands
+// under AMP (2^-11).
+#define TAU_SPLIT_BELOW 0.25f
+
+template <int DH, int NT, bool PAIR, bool SPLIT>
+__device__ __forceinline__ void win_attn_fwd_body(
     const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
-    const __hip_bfloat16* __restrict__ v, int64_t ldv, int nhead, const int32_t* __restrict__ grid_q,
-    const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx, int sy, int sx,
-    const float* __restrict__ tau, float tau_min, __hip_bfloat16* __restrict__ out, int64_t ldo,
-    float* __restrict__ lse, const int32_t* __restrict__ wl, int cls, int64_t nwin, AttnBufs nb) {
-  static_assert(!PAIR || NT == 1, "two windows per tile: single-tile class only");
+    const __hip_bfloat16* __restrict__ v, int64_t ldv, int nhead, float inv_tau, __hip_bfloat16* __restrict__ out, int64_t ldo,
+    float* __restrict__ lse, AttnBufs nb, const WinInfo& wi, int (*toks)[64], char (*vimg)[NT * 16 * (DH * 2 + 16)]) {
   constexpr int FR = DH / 4;                 // channels per lane in a row fragment
   constexpr int CT = DH / 16;                // 16-channel output tiles
   constexpr int RB = DH * 2 + 16;            // V image row pitch (bytes): 16-byte aligned, off the power of two
-  constexpr int ROWS = NT * 16;
   typedef typename Frag<DH>::T frag_t;
-  __shared__ int toks[2][64];
-  __shared__ __attribute__((aligned(16))) char vimg[4][ROWS * RB];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
   const int head = blockIdx.y * 4 + w, hoff = head * DH;
-  WinInfo wi;
-  if (!find_tokens<PAIR>(wl, cls, nwin, grid_q, grid_k, ny, nx, Wy, Wx, sy, sx, toks, lane, w, wi)) return;
   const int Tq = wi.Tq, Tk = wi.Tk;
   const __amdgpu_buffer_rsrc_t rsq = make_rsrc(q, nb.q), rsk = make_rsrc(k, nb.k), rsv = make_rsrc(v, nb.v),
                                rso = make_rsrc(out, nb.o), rsl = make_rsrc(lse, nb.lse);
   const unsigned colb = (unsigned)(hoff + FR * g) * 2u;
-  if (Tq == 0) return;                        // (dense launch only) no queries here
-  if (Tk == 0) {                              // (dense launch only) cross-attention window without keys: zero rows
-    __syncthreads();
-    const int tq = toks[0][lane];
-    if (tq >= 0) {
-      __hip_bfloat16* o = out + (int64_t)tq * ldo + hoff;
-#pragma unroll
-      for (int c = 0; c < DH; ++c) o[c] = __float2bfloat16(0.f);
-      lse[(int64_t)tq * nhead + head] = 0.f;
-    }
-    return;
-  }
-  __syncthreads();
   const int nq = PAIR ? 1 : (Tq + 15) >> 4, nk = PAIR ? 1 : (Tk + 15) >> 4;
-  const float inv_tau = fast_rcp(fmaxf(tau[0], tau_min));      // v_rcp_f32 (1 ulp; the backward uses the same instruction): an IEEE
-                                                                 // division is ~12 instructions of the ~370 a 16-token window costs
   // ---- all global row loads are issued here, one dependent round after the token ids
   frag_t kf[NT], kl[NT], qf[NT], ql[NT];
   typedef typename RawFrag<FR>::T raw_t;
@@ -481,11 +471,11 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
     if (t < nk) {                                   // wave-uniform
       unpack_row<FR>(rk[t], f);
       normalize_frag<FR>(f, 1.0f);
-      split_frag<FR>(f, kf[t], kl[t]);
+      if constexpr (SPLIT) split_frag<FR>(f, kf[t], kl[t]); else kf[t] = pack_frag<FR>(f);
       store_img_frag<DH>(&vimg[w][slot * RB], g, raw_as_frag<FR>(rv[t]));
     } else {
 #pragma unroll
-      for (int j = 0; j < FR; ++j) { kf[t][j] = 0; kl[t][j] = 0; }
+      for (int j = 0; j < FR; ++j) { kf[t][j] = 0; if constexpr (SPLIT) kl[t][j] = 0; }
       frag_t z;
 #pragma unroll
       for (int j = 0; j < FR; ++j) z[j] = 0;
@@ -494,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
     if (t < nq) {
       unpack_row<FR>(rq[t], f);
       normalize_frag<FR>(f, inv_tau);
-      split_frag<FR>(f, qf[t], ql[t]);
+      if constexpr (SPLIT) split_frag<FR>(f, qf[t], ql[t]); else qf[t] = pack_frag<FR>(f);
     }
   }
   __syncthreads();
@@ -537,9 +527,13 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
 #pragma unroll
       for (int kt = 0; kt < NT; ++kt) {
         if (kt < nk) {
-          st[kt] = mfma_s(kl[kt], qf[qt], kbias[kt]);                      // S^T tile: rows = keys 4g+r, col = query i
-          st[kt] = mfma_s(kf[kt], ql[qt], st[kt]);
-          st[kt] = mfma_s(kf[kt], qf[qt], st[kt]);
+          if constexpr (SPLIT) {
+            st[kt] = mfma_s(kl[kt], qf[qt], kbias[kt]);                    // S^T tile: rows = keys 4g+r, col = query i
+            st[kt] = mfma_s(kf[kt], ql[qt], st[kt]);
+            st[kt] = mfma_s(kf[kt], qf[qt], st[kt]);
+          } else {
+            st[kt] = mfma_s(kf[kt], qf[qt], kbias[kt]);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
           // (two v_max3_f32 in inline asm would save the canonicalising v_max_f32 the compiler puts in front of fmaxf() on an MFMA
@@ -589,6 +583,44 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mx + __logf(l)), rsl, (int)loff, 0, 0);
     }
   }
+}
+
+template <int DH, int NT, bool PAIR>
+__global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
+    const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
+    const __hip_bfloat16* __restrict__ v, int64_t ldv, int nhead, const int32_t* __restrict__ grid_q,
+    const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx, int sy, int sx,
+    const float* __restrict__ tau, float tau_min, __hip_bfloat16* __restrict__ out, int64_t ldo,
+    float* __restrict__ lse, const int32_t* __restrict__ wl, int cls, int64_t nwin, AttnBufs nb) {
+  static_assert(!PAIR || NT == 1, "two windows per tile: single-tile class only");
+  constexpr int RB = DH * 2 + 16, ROWS = NT * 16;
+  __shared__ int toks[2][64];
+  __shared__ __attribute__((aligned(16))) char vimg[4][ROWS * RB];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int head = blockIdx.y * 4 + w, hoff = head * DH;
+  WinInfo wi;
+  if (!find_tokens<PAIR>(wl, cls, nwin, grid_q, grid_k, ny, nx, Wy, Wx, sy, sx, toks, lane, w, wi)) return;
+  if (wi.Tq == 0) return;                     // (dense launch only) no queries here
+  if (wi.Tk == 0) {                           // (dense launch only) cross-attention window without keys: zero rows
+    __syncthreads();
+    const int tq = toks[0][lane];
+    if (tq >= 0) {
+      __hip_bfloat16* o = out + (int64_t)tq * ldo + hoff;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) o[c] = __float2bfloat16(0.f);
+      lse[(int64_t)tq * nhead + head] = 0.f;
+    }
+    return;
+  }
+  __syncthreads();
+  // tau is one number for the whole launch (cosine_msa.py:453-456): a scalar load, a scalar compare, one branch per wave
+  const float tau_c = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fmaxf(tau[0], tau_min))));
+  const float inv_tau = fast_rcp(tau_c);                       // v_rcp_f32 (1 ulp; the backward uses the same instruction): an IEEE
+                                                                 // division is ~12 instructions of the ~370 a 16-token window costs
+  if (tau_c < TAU_SPLIT_BELOW)
+    win_attn_fwd_body<DH, NT, PAIR, true>(q, ldq, k, ldk, v, ldv, nhead, inv_tau, out, ldo, lse, nb, wi, toks, vimg);
+  else
+    win_attn_fwd_body<DH, NT, PAIR, false>(q, ldq, k, ldk, v, ldv, nhead, inv_tau, out, ldo, lse, nb, wi, toks, vimg);
 }
 
 static int64_t class_grid(int cls, int64_t nwin, int64_t mq, int64_t mk) {
@@ -657,61 +689,43 @@ int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
 // rate of those stores was 16 % of the stage-1 kernel.)
 // NT = 4 is compiled for two waves per SIMD (the LDS images allow no more): 233 registers, no scratch.
 // ------------------------------------------------------------------------------------------------
-template <int DH, int NT, bool PAIR>
-__global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
-    const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
-    const __hip_bfloat16* __restrict__ v, int64_t ldv, const __hip_bfloat16* __restrict__ outp, int64_t ldo,
-    const __hip_bfloat16* __restrict__ dout, int64_t lddo, const float* __restrict__ lse, int nhead,
-    const int32_t* __restrict__ grid_q, const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx, int sy,
-    int sx, const float* __restrict__ tau, float tau_min, __hip_bfloat16* __restrict__ dq, int64_t lddq,
-    __hip_bfloat16* __restrict__ dk, int64_t lddk, __hip_bfloat16* __restrict__ dv, int64_t lddv,
-    float* __restrict__ dtau_partial, const int32_t* __restrict__ wl, int cls, int64_t nwin, AttnBufs nb) {
-  static_assert(!PAIR || NT == 1, "two windows per tile: single-tile class only");
-  constexpr int FR = DH / 4;
-  constexpr int CT = DH / 16;
-  constexpr int RB = DH * 2 + 16;
-  constexpr int ROWS = NT * 16;
-  typedef typename Frag<DH>::T frag_t;
-  __shared__ int toks[2][64];
-  __shared__ __attribute__((aligned(16))) char kimg[4][ROWS * RB];   // K-hat
+// the LDS of one backward workgroup (declared by the kernel, shared by its two bodies)
+template <int DH, int NT> struct BwdLds {
+  static constexpr int RB = DH * 2 + 16, ROWS = NT * 16, TP = 40;     // TP: pitch (bytes) of the 16x16 bf16 transpose tiles
+  int toks[2][64];
+  __attribute__((aligned(16))) char kimg[4][ROWS * RB];   // K-hat
   // Q-hat / tau_c and dO: ONE 16-row tile each, rewritten by its wave at the top of every query tile (round 5).  Holding all NT
   // tiles cost 41 KB of the 69 KB a dh-32 64-token workgroup used: two workgroups per CU, two waves per SIMD, in a kernel that
   // waits on latency (its first 2 us are global loads, every logit tile is an MFMA -> VALU -> exp -> MFMA chain).  With 28 KB and
   // the 168-register build the launch bounds ask for, three workgroups fit.
-  __shared__ __attribute__((aligned(16))) char qimg[4][16 * RB];     // Q-hat / tau_c of the current query tile
-  __shared__ __attribute__((aligned(16))) char gimg[4][16 * RB];     // dO of the current query tile
-  __shared__ float qnorm[4][ROWS], knorm[4][ROWS];
-  constexpr int TP = 40;                                              // pitch (bytes) of the 16x16 bf16 transpose tiles
-  __shared__ __attribute__((aligned(16))) char ptile[4][2][16 * TP];
+  __attribute__((aligned(16))) char qimg[4][16 * RB];     // Q-hat / tau_c of the current query tile
+  __attribute__((aligned(16))) char gimg[4][16 * RB];     // dO of the current query tile
+  float qnorm[4][ROWS], knorm[4][ROWS];
+  __attribute__((aligned(16))) char ptile[4][2][16 * TP];
+};
+
+template <int DH, int NT, bool PAIR, bool SPLIT>
+__device__ __forceinline__ void win_attn_bwd_body(
+    const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
+    const __hip_bfloat16* __restrict__ v, int64_t ldv, const __hip_bfloat16* __restrict__ dout, int64_t lddo,
+    const float* __restrict__ lse, int nhead, float tau_c, __hip_bfloat16* __restrict__ dq, int64_t lddq,
+    __hip_bfloat16* __restrict__ dk, int64_t lddk, __hip_bfloat16* __restrict__ dv, int64_t lddv,
+    float* __restrict__ dtau_partial, float* __restrict__ dtp, AttnBufs nb, const WinInfo& wi, BwdLds<DH, NT>& L) {
+  constexpr int FR = DH / 4;
+  constexpr int CT = DH / 16;
+  constexpr int RB = DH * 2 + 16;
+  constexpr int TP = BwdLds<DH, NT>::TP;
+  typedef typename Frag<DH>::T frag_t;
+  auto& toks = L.toks; auto& kimg = L.kimg; auto& qimg = L.qimg; auto& gimg = L.gimg; auto& qnorm = L.qnorm; auto& knorm = L.knorm;
+  auto& ptile = L.ptile;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, i = lane & 15;
   const int head = blockIdx.y * 4 + w, hoff = head * DH;
-  WinInfo wi;
-  if (!find_tokens<PAIR>(wl, cls, nwin, grid_q, grid_k, ny, nx, Wy, Wx, sy, sx, toks, lane, w, wi)) return;
   const int Tq = wi.Tq, Tk = wi.Tk;
-  float* dtp = dtau_partial + (int64_t)wi.dwin * nhead + head;
-  if (Tq == 0 || Tk == 0) {                   // (dense launch only) nothing attended here: zero gradients
-    __syncthreads();
-    if (lane == 0) *dtp = 0.f;
-    const int tq = toks[0][lane], tk = toks[1][lane];
-    if (tq >= 0) {
-      __hip_bfloat16* p = dq + (int64_t)tq * lddq + hoff;
-#pragma unroll
-      for (int c = 0; c < DH; ++c) p[c] = __float2bfloat16(0.f);
-    }
-    if (tk >= 0 && grid_q != grid_k) {
-      __hip_bfloat16* p1 = dk + (int64_t)tk * lddk + hoff;
-      __hip_bfloat16* p2 = dv + (int64_t)tk * lddv + hoff;
-#pragma unroll
-      for (int c = 0; c < DH; ++c) { p1[c] = __float2bfloat16(0.f); p2[c] = __float2bfloat16(0.f); }
-    }
-    return;
-  }
-  const float tau_c = fmaxf(tau[0], tau_min), inv_tau = fast_rcp(tau_c);
+  const float inv_tau = fast_rcp(tau_c);
   const __amdgpu_buffer_rsrc_t rsq = make_rsrc(q, nb.q), rsk = make_rsrc(k, nb.k), rsv = make_rsrc(v, nb.v),
                                rsg = make_rsrc(dout, nb.g), rsl = make_rsrc(lse, nb.lse), rsdq = make_rsrc(dq, nb.dq),
                                rsdk = make_rsrc(dk, nb.dk), rsdv = make_rsrc(dv, nb.dv);
   const unsigned colb = (unsigned)(hoff + FR * g) * 2u;
-  __syncthreads();                                   // token lists visible
   const int nq = PAIR ? 1 : (Tq + 15) >> 4, nk = PAIR ? 1 : (Tk + 15) >> 4;
   // ---- every global row load of the workgroup is issued here (one dependent round after the token ids); the
   //      row-major LDS images are written from the same 16-byte fragments: lane (g,i) owns chunk g of row tile*16+i.
@@ -739,19 +753,19 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
     if (t < nk) {                                    // wave-uniform
       unpack_row<FR>(rk[t], f);
       const float nrm = normalize_frag<FR>(f, 1.0f);
-      split_frag<FR>(f, kf[t], kl[t]);
+      if constexpr (SPLIT) split_frag<FR>(f, kf[t], kl[t]); else kf[t] = pack_frag<FR>(f);
       if (g == 0) knorm[w][slot] = nrm;
       vr[t] = raw_as_frag<FR>(rv[t]);
     } else {
 #pragma unroll
-      for (int j = 0; j < FR; ++j) { kf[t][j] = 0; kl[t][j] = 0; vr[t][j] = 0; }
+      for (int j = 0; j < FR; ++j) { kf[t][j] = 0; vr[t][j] = 0; if constexpr (SPLIT) kl[t][j] = 0; }
     }
     store_img_frag<DH>(&kimg[w][slot * RB], g, kf[t]);
     if (tokq_[t] < 0 || t >= nq) lse_i[t] = INFINITY;                      // no query: p = exp(s - inf) = 0
     if (t < nq) {
       unpack_row<FR>(rq[t], f);
       const float nrm = normalize_frag<FR>(f, inv_tau);
-      split_frag<FR>(f, qf[t], ql[t]);
+      if constexpr (SPLIT) split_frag<FR>(f, qf[t], ql[t]); else qf[t] = pack_frag<FR>(f);
       if (g == 0) qnorm[w][slot] = nrm;
       gf[t] = raw_as_frag<FR>(rg[t]);
     }
@@ -807,9 +821,14 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
         if (kt < nk) {
           // swapped: rows = keys 4g+r of this tile, column = query i; masked keys (MASKED_LOGIT through the C operand) and
           // absent queries (lse = +inf) give p = 0
-          f32x4 sT = mfma_s(kl[kt], qf[qt], kbias[kt]);
-          sT = mfma_s(kf[kt], ql[qt], sT);
-          sT = mfma_s(kf[kt], qf[qt], sT);
+          f32x4 sT;
+          if constexpr (SPLIT) {
+            sT = mfma_s(kl[kt], qf[qt], kbias[kt]);
+            sT = mfma_s(kf[kt], ql[qt], sT);
+            sT = mfma_s(kf[kt], qf[qt], sT);
+          } else {
+            sT = mfma_s(kf[kt], qf[qt], kbias[kt]);
+          }
           const f32x4 dP = mfma_s(vr[kt], gf[qt], zero4);
           if constexpr (!RECOMP) { sTk[kt] = sT; dPk[kt] = dP; }
 #pragma unroll
@@ -827,9 +846,13 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
         if (kt < nk) {
           f32x4 sT, dP, pT;
           if constexpr (RECOMP) {
-            sT = mfma_s(kl[kt], qf[qt], kbias[kt]);
-            sT = mfma_s(kf[kt], ql[qt], sT);
-            sT = mfma_s(kf[kt], qf[qt], sT);
+            if constexpr (SPLIT) {
+              sT = mfma_s(kl[kt], qf[qt], kbias[kt]);
+              sT = mfma_s(kf[kt], ql[qt], sT);
+              sT = mfma_s(kf[kt], qf[qt], sT);
+            } else {
+              sT = mfma_s(kf[kt], qf[qt], kbias[kt]);
+            }
             dP = mfma_s(vr[kt], gf[qt], f32x4{-dacc, -dacc, -dacc, -dacc});   // dP - D: D enters through the C operand
             // Round 4 masked the absent keys per element here and found that restricting the mask to the last tile (a wave-uniform
             // branch between the dP MFMA and `dP - D`) gave NaN in dK and garbage in dQ at the temperature clamp: not arithmetic --
@@ -940,6 +963,50 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
       store_row_frag<FR>(rsdv, row_off(tokk_[kt], (unsigned)lddv * 2u, colb), dvv);
     }
   }
+}
+
+template <int DH, int NT, bool PAIR>
+__global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
+    const __hip_bfloat16* __restrict__ q, int64_t ldq, const __hip_bfloat16* __restrict__ k, int64_t ldk,
+    const __hip_bfloat16* __restrict__ v, int64_t ldv, const __hip_bfloat16* __restrict__ outp, int64_t ldo,
+    const __hip_bfloat16* __restrict__ dout, int64_t lddo, const float* __restrict__ lse, int nhead,
+    const int32_t* __restrict__ grid_q, const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx, int sy,
+    int sx, const float* __restrict__ tau, float tau_min, __hip_bfloat16* __restrict__ dq, int64_t lddq,
+    __hip_bfloat16* __restrict__ dk, int64_t lddk, __hip_bfloat16* __restrict__ dv, int64_t lddv,
+    float* __restrict__ dtau_partial, const int32_t* __restrict__ wl, int cls, int64_t nwin, AttnBufs nb) {
+  static_assert(!PAIR || NT == 1, "two windows per tile: single-tile class only");
+  __shared__ BwdLds<DH, NT> L;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int head = blockIdx.y * 4 + w, hoff = head * DH;
+  WinInfo wi;
+  if (!find_tokens<PAIR>(wl, cls, nwin, grid_q, grid_k, ny, nx, Wy, Wx, sy, sx, L.toks, lane, w, wi)) return;
+  float* dtp = dtau_partial + (int64_t)wi.dwin * nhead + head;
+  if (wi.Tq == 0 || wi.Tk == 0) {             // (dense launch only) nothing attended here: zero gradients
+    __syncthreads();
+    if (lane == 0) *dtp = 0.f;
+    const int tq = L.toks[0][lane], tk = L.toks[1][lane];
+    if (tq >= 0) {
+      __hip_bfloat16* p = dq + (int64_t)tq * lddq + hoff;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) p[c] = __float2bfloat16(0.f);
+    }
+    if (tk >= 0 && grid_q != grid_k) {
+      __hip_bfloat16* p1 = dk + (int64_t)tk * lddk + hoff;
+      __hip_bfloat16* p2 = dv + (int64_t)tk * lddv + hoff;
+#pragma unroll
+      for (int c = 0; c < DH; ++c) { p1[c] = __float2bfloat16(0.f); p2[c] = __float2bfloat16(0.f); }
+    }
+    return;
+  }
+  __syncthreads();                                   // token lists visible
+  // one temperature per launch (see TAU_SPLIT_BELOW): scalar compare, one branch per wave
+  const float tau_c = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fmaxf(tau[0], tau_min))));
+  if (tau_c < TAU_SPLIT_BELOW)
+    win_attn_bwd_body<DH, NT, PAIR, true>(q, ldq, k, ldk, v, ldv, dout, lddo, lse, nhead, tau_c, dq, lddq, dk, lddk, dv, lddv,
+                                          dtau_partial, dtp, nb, wi, L);
+  else
+    win_attn_bwd_body<DH, NT, PAIR, false>(q, ldq, k, ldk, v, ldv, dout, lddo, lse, nhead, tau_c, dq, lddq, dk, lddk, dv, lddv,
+                                           dtau_partial, dtp, nb, wi, L);
 }
 
 int tmae_win_attn_bwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
