@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 17
+#define TMAE_ABI_VERSION 18
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -385,6 +385,12 @@ int tmae_bn_relu_add_fwd(const void* x, int dtype, int64_t m, int c, const float
 int tmae_bn_relu_bwd(const void* dy, const void* x, int dtype, int64_t m, int c, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, int relu, void* dx, float* dgamma, float* dbeta,
                      void* ws, size_t ws_bytes, void* stream);
+/* The same backward for a gradient that arrives in two pieces, dy + dy2 (both [m,c] in `dtype`, summed in fp32 inside the two
+ * passes): the output of a stage's last BatchNorm feeds the next stage AND, split by frame, the cross-attention block
+ * (SiamWCA_MAE.py:262-291); the caller hands over both gradients instead of adding them first. */
+int tmae_bn_relu_bwd2(const void* dy, const void* dy2, const void* x, int dtype, int64_t m, int c, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, int relu, void* dx, float* dgamma,
+                      float* dbeta, void* ws, size_t ws_bytes, void* stream);
 
 /* Split BatchNorm entry points with an explicit element count (used by the fused decoder head below): statistics
  * of the m stored rows normalised by `count` >= m (the rows that are not stored are exact zeros), the two backward
@@ -457,7 +463,7 @@ int tmae_bn_running_update(const void* bufs, int nbufs, const void* updates, con
 
 /* Token-list Linear in bf16 (fp32 accumulate):  y[m,n] = x[m,k] . w[n,k]^T (+ bias[n]) -- the in-/out-projections
  * and FFN layers of EncoderLayer (sst_basic_block.py:45-83, F.linear) and, on w^T, their input gradients.
- * k in {128, 256, 512}, n a multiple of 64; ldx / ldy = row pitches in elements (column slices of packed buffers are
+ * k in {32, 64, 128, 256, 512} (32, 64: the VFE MLP, temporal_dyn_vfe.py:110-112), n a multiple of 64; ldx / ldy = row pitches in elements (column slices of packed buffers are
  * fine); all pointers 16-byte aligned (y, bias: 8); bias [n] bf16 is required (zeros for none); y must span
  * < 2^31 bytes.  x is read once, y written once. */
 int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,

@@ -160,8 +160,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 }
 
 // partial sums of dz and dz * xhat, dz = dy * (z > 0) with z recomputed from x
-template <class T, int VEC>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// dy2 (optional, same rows): the gradient is dy + dy2, summed in fp32 where the rows are in registers anyway -- the output of a
+// stage's last BatchNorm feeds the next stage AND (split by frame) the cross-attention block (SiamWCA_MAE.py:262-291); autograd
+// used to concatenate the two frame halves of the second gradient and add the result to the first: two elementwise passes and a
+// bf16 rounding per stage.
+template <class T, int VEC, bool TWO = false>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                           const T* __restrict__ x,
                                                            int64_t m, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma,
@@ -183,6 +188,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       const int64_t r = r0 + u * RPW + sub, rc = r < m ? r : m - 1;
       load8<T>(x + rc * C + cl * 8, v[u]);                        // unconditional (clamped), masked below
       load8<T>(dy + rc * C + cl * 8, d[u]);
+      if constexpr (TWO) {
+        float e[8];
+        load8<T>(dy2 + rc * C + cl * 8, e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[u][i] += e[i];
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) d[u][i] = r < m ? d[u][i] : 0.f;
     }
@@ -220,8 +231,9 @@ __global__ __launch_bounds__(16 * BN_FIN_RL) void bn_bwd_finalize_kernel(const f
 }
 
 // dx = gamma * rstd * (dz - dbeta/m - xhat * dgamma/m)
-template <class T, int VEC>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, int64_t m,
+template <class T, int VEC, bool TWO = false>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                          const T* __restrict__ x, int64_t m,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma,
@@ -244,6 +256,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       const int64_t r = r0 + u * RPW + sub, rc = r < m ? r : m - 1;
       load8<T>(x + rc * C + cl * 8, v[u]);                        // unconditional (clamped): four loads in flight
       load8<T>(dy + rc * C + cl * 8, d[u]);
+      if constexpr (TWO) {
+        float e[8];
+        load8<T>(dy2 + rc * C + cl * 8, e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[u][i] += e[i];
+      }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -275,6 +293,19 @@ size_t tmae_bn_workspace(int64_t m, int c) { return ((size_t)bn_grid(m) * 2 * c 
     if (c == 64) hipLaunchKernelGGL((KERNEL<T, 1>), grid, block, 0, stream, __VA_ARGS__);         \
     else if (c == 128) hipLaunchKernelGGL((KERNEL<T, 2>), grid, block, 0, stream, __VA_ARGS__);   \
     else hipLaunchKernelGGL((KERNEL<T, 4>), grid, block, 0, stream, __VA_ARGS__);                 \
+  } while (0)
+// the backward kernels: with a second gradient operand (dy2 != nullptr) the TWO instantiation
+#define BN_DISPATCH2(T, KERNEL, two, ...)                                                                  \
+  do {                                                                                                      \
+    if (two) {                                                                                              \
+      if (c == 64) hipLaunchKernelGGL((KERNEL<T, 1, true>), grid, block, 0, stream, __VA_ARGS__);           \
+      else if (c == 128) hipLaunchKernelGGL((KERNEL<T, 2, true>), grid, block, 0, stream, __VA_ARGS__);     \
+      else hipLaunchKernelGGL((KERNEL<T, 4, true>), grid, block, 0, stream, __VA_ARGS__);                   \
+    } else {                                                                                                \
+      if (c == 64) hipLaunchKernelGGL((KERNEL<T, 1, false>), grid, block, 0, stream, __VA_ARGS__);          \
+      else if (c == 128) hipLaunchKernelGGL((KERNEL<T, 2, false>), grid, block, 0, stream, __VA_ARGS__);    \
+      else hipLaunchKernelGGL((KERNEL<T, 4, false>), grid, block, 0, stream, __VA_ARGS__);                  \
+    }                                                                                                       \
   } while (0)
 
 static int bn_relu_fwd(const void* x_, int dtype, int64_t m, int c, const float* gamma, const float* beta, float eps,
@@ -319,34 +350,51 @@ int tmae_bn_relu_add_fwd(const void* x, int dtype, int64_t m, int c, const float
   return bn_relu_fwd(x, dtype, m, c, gamma, beta, eps, relu, post, y, mean, var, rstd, ws, ws_bytes, stream);
 }
 
-int tmae_bn_relu_bwd(const void* dy_, const void* x_, int dtype, int64_t m, int c, const float* mean, const float* rstd,
-                     const float* gamma, const float* beta, int relu, void* dx_, float* dgamma, float* dbeta, void* wsp,
-                     size_t ws_bytes, void* stream_) {
-  (void)hipGetLastError();
+static int bn_relu_bwd(const void* dy_, const void* dy2_, const void* x_, int dtype, int64_t m, int c, const float* mean,
+                       const float* rstd, const float* gamma, const float* beta, int relu, void* dx_, float* dgamma, float* dbeta,
+                       void* wsp, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (m <= 0 || (c != 64 && c != 128 && c != 256) || !dy_ || !x_ || !mean || !rstd || !gamma || !beta || !dx_ ||
       !dgamma || !dbeta)
     return TMAE_EARG;
   if (dtype != TMAE_F32 && dtype != TMAE_BF16) return TMAE_EDTYPE;
+  if (dy2_ && ((uintptr_t)dy2_ & 15)) return TMAE_EARG;
   const int nb = bn_grid(m);
   WsCarver ws(wsp, ws_bytes);
   float* part = ws.take<float>((size_t)nb * 2 * c + c);
   if (!ws.ok) return TMAE_EWS;
   dim3 grid(nb), block(256);
+  const bool two = dy2_ != nullptr;
   if (dtype == TMAE_F32) {
-    const float *dy = (const float*)dy_, *x = (const float*)x_;
+    const float *dy = (const float*)dy_, *dy2 = (const float*)dy2_, *x = (const float*)x_;
     float* dx = (float*)dx_;
-    BN_DISPATCH(float, bn_bwd_reduce_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
+    BN_DISPATCH2(float, bn_bwd_reduce_kernel, two, dy, dy2, x, m, mean, rstd, gamma, beta, relu, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, dbeta, dgamma);
-    BN_DISPATCH(float, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, 1.0f / (float)m, dx);
+    BN_DISPATCH2(float, bn_bwd_apply_kernel, two, dy, dy2, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, 1.0f / (float)m, dx);
   } else {
-    const __hip_bfloat16 *dy = (const __hip_bfloat16*)dy_, *x = (const __hip_bfloat16*)x_;
+    const __hip_bfloat16 *dy = (const __hip_bfloat16*)dy_, *dy2 = (const __hip_bfloat16*)dy2_, *x = (const __hip_bfloat16*)x_;
     __hip_bfloat16* dx = (__hip_bfloat16*)dx_;
-    BN_DISPATCH(__hip_bfloat16, bn_bwd_reduce_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
+    BN_DISPATCH2(__hip_bfloat16, bn_bwd_reduce_kernel, two, dy, dy2, x, m, mean, rstd, gamma, beta, relu, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, dbeta, dgamma);
-    BN_DISPATCH(__hip_bfloat16, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, 1.0f / (float)m, dx);
+    BN_DISPATCH2(__hip_bfloat16, bn_bwd_apply_kernel, two, dy, dy2, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, 1.0f / (float)m, dx);
   }
   return tmae_launch_status();
+}
+
+int tmae_bn_relu_bwd(const void* dy, const void* x, int dtype, int64_t m, int c, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, int relu, void* dx, float* dgamma, float* dbeta, void* ws,
+                     size_t ws_bytes, void* stream) {
+  (void)hipGetLastError();
+  return bn_relu_bwd(dy, nullptr, x, dtype, m, c, mean, rstd, gamma, beta, relu, dx, dgamma, dbeta, ws, ws_bytes, stream);
+}
+
+// the gradient arrives in two pieces (dy + dy2, both [m, c] of x's dtype): see bn_bwd_reduce_kernel
+int tmae_bn_relu_bwd2(const void* dy, const void* dy2, const void* x, int dtype, int64_t m, int c, const float* mean,
+                      const float* rstd, const float* gamma, const float* beta, int relu, void* dx, float* dgamma, float* dbeta,
+                      void* ws, size_t ws_bytes, void* stream) {
+  (void)hipGetLastError();
+  if (!dy2) return TMAE_EARG;
+  return bn_relu_bwd(dy, dy2, x, dtype, m, c, mean, rstd, gamma, beta, relu, dx, dgamma, dbeta, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -411,10 +459,10 @@ int tmae_bn_bwd_sums(const void* dy_, const void* x_, int dtype, int64_t m, int 
   dim3 grid(nb), block(256);
   if (dtype == TMAE_F32) {
     const float *dy = (const float*)dy_, *x = (const float*)x_;
-    BN_DISPATCH(float, bn_bwd_reduce_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
+    BN_DISPATCH(float, bn_bwd_reduce_kernel, dy, (const float*)nullptr, x, m, mean, rstd, gamma, beta, relu, part);
   } else {
     const __hip_bfloat16 *dy = (const __hip_bfloat16*)dy_, *x = (const __hip_bfloat16*)x_;
-    BN_DISPATCH(__hip_bfloat16, bn_bwd_reduce_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
+    BN_DISPATCH(__hip_bfloat16, bn_bwd_reduce_kernel, dy, (const __hip_bfloat16*)nullptr, x, m, mean, rstd, gamma, beta, relu, part);
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, sum_dz, sum_dz_xhat);
   return tmae_launch_status();
@@ -433,11 +481,11 @@ int tmae_bn_bwd_apply(const void* dy_, const void* x_, int dtype, int64_t m, int
   if (dtype == TMAE_F32) {
     const float *dy = (const float*)dy_, *x = (const float*)x_;
     float* dx = (float*)dx_;
-    BN_DISPATCH(float, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, invm, dx);
+    BN_DISPATCH(float, bn_bwd_apply_kernel, dy, (const float*)nullptr, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, invm, dx);
   } else {
     const __hip_bfloat16 *dy = (const __hip_bfloat16*)dy_, *x = (const __hip_bfloat16*)x_;
     __hip_bfloat16* dx = (__hip_bfloat16*)dx_;
-    BN_DISPATCH(__hip_bfloat16, bn_bwd_apply_kernel, dy, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, invm, dx);
+    BN_DISPATCH(__hip_bfloat16, bn_bwd_apply_kernel, dy, (const __hip_bfloat16*)nullptr, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, invm, dx);
   }
   return tmae_launch_status();
 }

@@ -20,6 +20,7 @@
 //     both operands (any bijection will do as long as it is the same one);
 //   * partial sums go to fp32 slabs [split][128][9 cin], summed in a fixed order by a second small kernel (deterministic).
 #include "common.h"
+#include <cstdio>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -47,7 +48,16 @@ __device__ __forceinline__ bf16x8 dw_frag(const char* lo, const char* hi) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int DIL>
+#ifdef TMAE_AB
+// diagnostic stamps (A/B build only, TMAE_DW_VAR bit 0): per wave, summed over its stages -- s_memtime cycles from the stage's top
+// to [0] the end of its vmcnt(0) wait, [1] the barrier's release, [2] the end of group 6 (the last one that issues a transfer),
+// [3] the end of the stage; [4] stages; [5] s_memrealtime ticks (100 MHz) over the whole loop.  Written to a buffer of their own
+// that nothing else reads (MI355X_MICROARCH.md, DVFS give-back item 6).
+__device__ unsigned long long dw_stamps[256 * 8 * 8];
+#endif
+
+// VAR (A/B build only; the shipped build instantiates VAR = 0): bit 0 = stamps, bit 1 = raised priority around the MFMA groups
+template <int DIL, int VAR = 0>
 __global__ __launch_bounds__(512, 1) void dense_wgrad_halo_kernel(const __hip_bfloat16* __restrict__ dY,
                                                                  const __hip_bfloat16* __restrict__ Xin, int B, int Y, int X,
                                                                  int cin, unsigned dybytes, unsigned xbytes, int nsplit,
@@ -176,6 +186,7 @@ __global__ __launch_bounds__(512, 1) void dense_wgrad_halo_kernel(const __hip_bf
 #define DW_MFMAS(GI)                                                                                                   \
   do {                                                                                                                 \
     constexpr int ky_ = (GI) % 3, set_ = (GI) & 1;                                                                     \
+    if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(1);                                                       \
     if constexpr (ky_ == 0) {                                                                                          \
       _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_) {                                                               \
         const s16x8 v_ = {alo[a_][0], alo[a_][1], alo[a_][2], alo[a_][3], ahi[a_][0], ahi[a_][1], ahi[a_][2], ahi[a_][3]}; \
@@ -189,6 +200,7 @@ __global__ __launch_bounds__(512, 1) void dense_wgrad_halo_kernel(const __hip_bf
       _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)                                                                 \
         acc[a_][ky_ * 3 + kx_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a_], bfr_, acc[a_][ky_ * 3 + kx_], 0, 0, 0); \
     }                                                                                                                  \
+    if constexpr ((VAR & 2) != 0) __builtin_amdgcn_s_setprio(0);                                                       \
   } while (0)
   // group GI: prefetch GI + 1 (NEXT reads: 6, or 14 when GI + 1 opens a contraction step), then wait for GI's own
 #define DW_GROUP(GI, NEXT)                                                                                             \
@@ -204,19 +216,29 @@ __global__ __launch_bounds__(512, 1) void dense_wgrad_halo_kernel(const __hip_bf
     for (int jj = 0; jj < PPW; ++jj) issue_piece(jj, 0);
   }
   int buf = 0;
+  constexpr bool STAMP = (VAR & 1) != 0;
+  unsigned long long st_acc[4] = {0ull, 0ull, 0ull, 0ull}, rt0 = 0ull;
+  if constexpr (STAMP) rt0 = __builtin_amdgcn_s_memrealtime();
   for (int u = u0; u < u1; ++u) {
+    unsigned long long t0 = 0ull;
+    if constexpr (STAMP) t0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this stage's transfers (issued a stage ago)
+    if constexpr (STAMP) st_acc[0] += __builtin_amdgcn_s_memtime() - t0;
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if constexpr (STAMP) st_acc[1] += __builtin_amdgcn_s_memtime() - t0;
     const bool more = u + 1 < u1;
     if (more) origin_next(u + 1);
     DW_READS(0);
     DW_GROUP(0, 6); DW_GROUP(1, 6); DW_GROUP(2, 14);
     DW_GROUP(3, 6); DW_GROUP(4, 6); DW_GROUP(5, 14);
-    DW_GROUP(6, 6); DW_GROUP(7, 6); DW_GROUP(8, 14);
+    DW_GROUP(6, 6);
+    if constexpr (STAMP) st_acc[2] += __builtin_amdgcn_s_memtime() - t0;
+    DW_GROUP(7, 6); DW_GROUP(8, 14);
     DW_GROUP(9, 6); DW_GROUP(10, 6);
     DW_WAIT(11, 0);
     DW_MFMAS(11);
+    if constexpr (STAMP) st_acc[3] += __builtin_amdgcn_s_memtime() - t0;
     const unsigned step = buf ? 0u - (unsigned)G::STAGE : (unsigned)G::STAGE;     // the read bases follow the buffer
 #pragma unroll
     for (int a = 0; a < 4; ++a) aaddr[a] += step;
@@ -229,6 +251,15 @@ __global__ __launch_bounds__(512, 1) void dense_wgrad_halo_kernel(const __hip_bf
 #undef DW_WAIT
 #undef DW_READS
 #undef DW_TR
+#ifdef TMAE_AB
+  if constexpr (STAMP) {
+    if (lane == 0 && blockIdx.x < 256) {
+      unsigned long long* d = dw_stamps + ((size_t)blockIdx.x * 8 + w) * 8;
+      d[0] = st_acc[0]; d[1] = st_acc[1]; d[2] = st_acc[2]; d[3] = st_acc[3];
+      d[4] = (unsigned long long)(u1 - u0); d[5] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+  }
+#endif
   // rows 4 g + r of tile a = output channel (wn * 4 + a) * 16 + 4 g + r, column i = channel kc * 64 + cg * 16 + i of tap t
   float* __restrict__ sl = slab + (int64_t)s * (DW_N * 9 * cin);
   const int K = 9 * cin;
@@ -296,6 +327,44 @@ int tmae_dense_conv3x3_wgrad(const void* dy, const void* x, int batch, int ny, i
                        (const __hip_bfloat16*)x, batch, ny, nx, cin, (unsigned)dybytes, (unsigned)xbytes, nsplit, sps, \
                        (int)tot, slab);                                                                               \
   } while (0)
+#ifdef TMAE_AB
+  static const int var = TMAE_AB_INT("TMAE_DW_VAR", 0);
+  if (var != 0 && dilation == 1) {
+#define DW_LAUNCH_V(V)                                                                                                \
+  do {                                                                                                                \
+    const int lds = 2 * DwGeom<1>::STAGE;                                                                             \
+    static TmaeLdsAttr attr;                                                                                          \
+    if (int e_ = tmae_allow_lds(attr, (const void*)dense_wgrad_halo_kernel<1, V>, lds)) return e_;                    \
+    hipLaunchKernelGGL((dense_wgrad_halo_kernel<1, V>), dim3(grid), dim3(512), lds, stream, (const __hip_bfloat16*)dy, \
+                       (const __hip_bfloat16*)x, batch, ny, nx, cin, (unsigned)dybytes, (unsigned)xbytes, nsplit, sps, \
+                       (int)tot, slab);                                                                               \
+  } while (0)
+    if (var == 1) DW_LAUNCH_V(1); else if (var == 2) DW_LAUNCH_V(2); else DW_LAUNCH_V(3);
+#undef DW_LAUNCH_V
+    if (var & 1) {                       // print the stamps (diagnostic run: synchronises)
+      static int printed = 0;
+      (void)hipStreamSynchronize(stream);
+      if (printed++ == 3) {
+        static unsigned long long h[256 * 8 * 8];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(dw_stamps), sizeof(h));
+        for (int wv = 0; wv < 8; wv += 4) {
+          double a[6] = {0, 0, 0, 0, 0, 0};
+          int nb = 0;
+          for (unsigned b = 0; b < grid && b < 256; ++b) {
+            const unsigned long long* d = h + ((size_t)b * 8 + wv) * 8;
+            if (d[4] == 0) continue;
+            for (int q = 0; q < 4; ++q) a[q] += (double)d[q] / (double)d[4];
+            a[4] += (double)d[4]; a[5] += (double)d[3] / ((double)d[5] * 10.0);      // cycles per ns = GHz
+            ++nb;
+          }
+          fprintf(stderr, "dw stamps wave %d over %d blocks: stages %.0f; cycles per stage: vmcnt wait %.0f, +barrier %.0f, "
+                          "through group 6 %.0f, whole stage %.0f; in-loop clock %.2f GHz\n", wv, nb, a[4] / nb, a[0] / nb,
+                  a[1] / nb, a[2] / nb, a[3] / nb, a[5] / nb);
+        }
+      }
+    }
+  } else
+#endif
   if (dilation == 1) DW_LAUNCH(1); else DW_LAUNCH(2);
 #undef DW_LAUNCH
   hipLaunchKernelGGL(dense_wgrad_reduce_kernel, dim3(tmae_cdiv(count / 4, 256)), dim3(256), 0, stream, slab, nsplit, count, dw);

@@ -253,9 +253,9 @@ __global__ __launch_bounds__(64 * NW, 2) void token_gemm_kernel(const __hip_bflo
 static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
                              int64_t ldy, const void* aux, const void* cells, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (m < 0 || (k != 32 && k != 128 && k != 256 && k != 512) || n <= 0 || (n % 64) || ldx < k || ldy < n || (ldx % 8) || (ldy % 8))
+  if (m < 0 || (k != 32 && k != 64 && k != 128 && k != 256 && k != 512) || n <= 0 || (n % 64) || ldx < k || ldy < n || (ldx % 8) || (ldy % 8))
     return TMAE_EARG;
-  if (k == 32 && (cells || aux)) return TMAE_EARG;
+  if ((k == 32 || k == 64) && (cells || aux)) return TMAE_EARG;
   if (cells && (aux || k == 512)) return TMAE_EARG;
   if (m == 0) return TMAE_OK;
   if (!x || !w || !y || !bias) return TMAE_EARG;          // no bias: pass a zero vector (keeps the kernel branch-free)
@@ -298,6 +298,10 @@ static int token_gemm_launch(const void* x, int64_t ldx, int64_t m, int k, const
     // the VFE's first Linear on the hi | lo split point features (temporal_dyn_vfe.py:110-112; 16 + 16 columns -> 64): one
     // k-step, one 64-column chunk; the library ran this 174 MB pass at 1.4 TB/s
     if (n == 64) TG_LAUNCH(32, 2, 4, 4, 1); else TG_LAUNCH(32, 2, 4, 4, 0);
+  } else if (k == 64) {
+    // the VFE's second Linear (64 -> 128 over every point of the frame, temporal_dyn_vfe.py:110-112 with make_fc_layers):
+    // 348 MB per frame that the library moved at 3.6 TB/s
+    if (n == 128) TG_LAUNCH(64, 2, 4, 4, 2); else TG_LAUNCH(64, 2, 4, 4, 0);
   } else if (k == 128) {
     if (n == 128) TG_LAUNCH(128, 2, 4, 4, 2); else if (n == 256) TG_LAUNCH(128, 2, 4, 4, 4); else TG_LAUNCH(128, 2, 4, 4, 0);
   } else if (k == 256) {

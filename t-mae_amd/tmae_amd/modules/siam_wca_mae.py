@@ -136,7 +136,9 @@ class SiamWCA_MAE(nn.Module):
             m0 = x.groups[0][0]
             self.last_pair_tokens.append(int(x.features.shape[0]))
             ny, nx = x.spatial_shape
-            f_p, f_c = ops.split_rows(x.features, m0)
+            # the two frames' rows: outputs of the block's last norm itself when it forked them (their gradients then meet the
+            # next stage's inside the BatchNorm backward), else views whose backward is one concatenation
+            f_p, f_c = x.frame_halves if x.frame_halves is not None else ops.split_rows(x.features, m0)
             # previous frame: its rows come first, so the first B samples of the row-index grid are already its grid
             out_p[key] = SparseConvTensor(f_p, x.indices[:m0], x.spatial_shape, B, grid=x.grid[:B * ny * nx])
             out_c[key] = SparseConvTensor(f_c, x.indices[m0:] - shift, x.spatial_shape, B)

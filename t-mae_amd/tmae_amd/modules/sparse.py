@@ -21,6 +21,7 @@ class SparseConvTensor:
         self.batch_size = int(batch_size)
         self._grid = grid
         self._cache = cache if cache is not None else {}      # rulebooks keyed by conv kind, shared by replace_feature
+        self.frame_halves = None   # (features[:rows of group 0], features[rows of group 0:]) when the producing norm forked them
 
     @property
     def grid(self):
@@ -167,7 +168,14 @@ class SparseSequential(SparseModule):
                 x = m(x)
             elif isinstance(m, (nn.BatchNorm1d, nn.SyncBatchNorm)) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
                 rows = None if x.groups is None else [g[0] for g in x.groups]
-                x = x.replace_feature(ops.batch_norm_relu(x.features, m, relu=True, groups=rows))   # fused BN + ReLU
+                if rows is not None and len(rows) == 2 and i + 2 == len(mods):
+                    # two frames in one token list and this norm ends the block: its output also leaves split by frame
+                    # (SiamWCA_MAE.sparse_encode_pair) -- the halves come out of the norm's own autograd node (ops.batch_norm_relu)
+                    y, halves = ops.batch_norm_relu(x.features, m, relu=True, groups=rows, fork=True)
+                    x = x.replace_feature(y)
+                    x.frame_halves = halves
+                else:
+                    x = x.replace_feature(ops.batch_norm_relu(x.features, m, relu=True, groups=rows))   # fused BN + ReLU
                 i += 1
             elif isinstance(m, (nn.BatchNorm1d, nn.SyncBatchNorm)) and x.groups is not None:
                 x = x.replace_feature(ops.batch_norm_relu(x.features, m, relu=False, groups=[g[0] for g in x.groups]))

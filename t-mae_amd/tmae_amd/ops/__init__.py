@@ -59,7 +59,7 @@ def _tg_ok(x, k, n):
     # the W-in-registers kernel (csrc/token_gemm_wreg.hip: n = 256, >= 64 k tokens) is ahead of hipBLASLt; the chunk-streaming
     # kernel (16 tokens per wave: LDS-bound) is 10-15 % behind it on smaller token lists, which stay with the library.
     return (x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[0] >= _TOKEN_GEMM_MIN_ROWS
-            and (k in (128, 256) or (k == 512 and n == 256 and x.shape[0] >= 65536))
+            and (k in (64, 128, 256) or (k == 512 and n == 256 and x.shape[0] >= 65536))
             and n % 64 == 0 and x.shape[0] * n * 2 < 2 ** 31
             and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
 
@@ -80,9 +80,9 @@ def _zero_bias(n, device):
 def token_gemm(x, w, bias=None, force=False):
     """y [m,n] = x [m,k] @ w[n,k]^T (+ bias) in bf16, fp32 accumulation: the x-stationary streaming kernel of
     csrc/token_gemm.hip on the shapes where it is ahead of the library (force=True: whenever the kernel supports the
-    shape: k in {128,256,512}, n % 64 == 0), else the library."""
+    shape: k in {64,128,256,512}, n % 64 == 0), else the library."""
     n, k = w.shape
-    ok = _tg_ok(x, k, n) or (force and x.dtype == torch.bfloat16 and k in (128, 256, 512) and n % 64 == 0
+    ok = _tg_ok(x, k, n) or (force and x.dtype == torch.bfloat16 and k in (64, 128, 256, 512) and n % 64 == 0
                              and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
     if ok and w.dtype == torch.bfloat16 and w.is_contiguous() and (bias is None or bias.dtype == torch.bfloat16):
         m = x.shape[0]
@@ -929,11 +929,18 @@ class _BatchNormReLU(torch.autograd.Function):
     (torch.nn.SyncBatchNorm semantics: the gradients of gamma / beta stay the rank's own sums, DDP averages them)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, relu, bounds, pg=None, post=None):
-        """post [m, c] (single row range, no process group): y = relu?(norm(x)) + post; its gradient is dy itself."""
+    def forward(ctx, x, weight, bias, eps, relu, bounds, pg=None, post=None, fork=False):
+        """post [m, c] (single row range, no process group): y = relu?(norm(x)) + post; its gradient is dy itself.
+        fork (two row ranges, no process group): also returns the two row ranges of y as outputs of THIS node; what arrives for
+        them in the backward is added to dy inside the BatchNorm backward kernels (tmae_bn_relu_bwd2) -- the Siamese encoder's
+        stage output goes on to the next stage whole and to the cross-attention block split by frame (SiamWCA_MAE.py:262-291),
+        and autograd's way of joining the two (cat of the halves, then an add over [m, c]) was two elementwise passes per stage."""
         x = x.contiguous()
         m, c = x.shape
         ng = len(bounds) - 1
+        ctx.fork = bool(fork)
+        if fork:
+            assert ng == 2 and pg is None and post is None
         if post is not None:
             assert ng == 1 and pg is None and post.shape == x.shape
             post = post.to(x.dtype).contiguous()
@@ -971,17 +978,36 @@ class _BatchNormReLU(torch.autograd.Function):
         ctx.dtypes = (weight.dtype, bias.dtype)
         ctx.mark_non_differentiable(mean, var)
         ctx.set_materialize_grads(False)       # no zero-filled "gradients" for the statistics outputs (2 fills per layer)
+        if fork:
+            return y, mean, var, y[:bounds[1]], y[bounds[1]:]
         return y, mean, var
 
     @staticmethod
-    def backward(ctx, dy, _m, _v):
-        if dy is None:
-            return (None,) * 8
+    def backward(ctx, dy, _m, _v, d0=None, d1=None):
+        if dy is None and d0 is None and d1 is None:
+            return (None,) * 9
         x, mean, rstd, g32, b32 = ctx.saved_tensors
-        dy = dy.to(x.dtype).contiguous()
         m, c = x.shape
         bounds = ctx.bounds
         ng = len(bounds) - 1
+        if dy is not None:
+            dy = dy.to(x.dtype).contiguous()
+        # per row range: the gradient (first) and, with `fork`, what arrived for that range's own output (second); a range
+        # nobody sent a gradient for gets zeros
+        first = [None if dy is None else dy[bounds[g]:bounds[g + 1]] for g in range(ng)]
+        second = [None] * ng
+        if ctx.fork:
+            for g, d in enumerate((d0, d1)):
+                if d is None:
+                    continue
+                d = d.to(x.dtype).contiguous()
+                if first[g] is None:
+                    first[g] = d
+                else:
+                    second[g] = d
+        for g in range(ng):
+            if first[g] is None:
+                first[g] = torch.zeros((bounds[g + 1] - bounds[g], c), dtype=x.dtype, device=x.device)
         dx = torch.empty_like(x)
         dg = torch.empty((ng, c), dtype=torch.float32, device=x.device)
         db = torch.empty_like(dg)
@@ -990,25 +1016,30 @@ class _BatchNormReLU(torch.autograd.Function):
             wsb = lib.tmae_bn_workspace(r1 - r0, c)
             ws = _ws(wsb, x.device)
             if ctx.pg is None:
-                check(lib.tmae_bn_relu_bwd(_p(dy[r0:r1]), _p(x[r0:r1]), _dt(x), r1 - r0, c, _p(mean[g]), _p(rstd[g]), _p(g32),
+                if second[g] is not None:
+                    check(lib.tmae_bn_relu_bwd2(_p(first[g]), _p(second[g]), _p(x[r0:r1]), _dt(x), r1 - r0, c, _p(mean[g]),
+                                                _p(rstd[g]), _p(g32), _p(b32), 1 if ctx.relu else 0, _p(dx[r0:r1]), _p(dg[g]),
+                                                _p(db[g]), _p(ws), wsb, _s()), 'tmae_bn_relu_bwd2')
+                    continue
+                check(lib.tmae_bn_relu_bwd(_p(first[g]), _p(x[r0:r1]), _dt(x), r1 - r0, c, _p(mean[g]), _p(rstd[g]), _p(g32),
                                            _p(b32), 1 if ctx.relu else 0, _p(dx[r0:r1]), _p(dg[g]), _p(db[g]), _p(ws), wsb,
                                            _s()), 'tmae_bn_relu_bwd')
                 continue
             import torch.distributed as dist
-            check(lib.tmae_bn_bwd_sums(_p(dy[r0:r1]), _p(x[r0:r1]), _dt(x), r1 - r0, c, _p(mean[g]), _p(rstd[g]), _p(g32),
+            check(lib.tmae_bn_bwd_sums(_p(first[g]), _p(x[r0:r1]), _dt(x), r1 - r0, c, _p(mean[g]), _p(rstd[g]), _p(g32),
                                        _p(b32), 1 if ctx.relu else 0, _p(db[g]), _p(dg[g]), _p(ws), wsb, _s()),
                   'tmae_bn_bwd_sums')
             tot = torch.stack([db[g], dg[g]])                 # the sums of every rank enter dx; dgamma / dbeta stay local
             dist.all_reduce(tot, group=ctx.pg)
             tb, tg = tot[0].contiguous(), tot[1].contiguous()
-            check(lib.tmae_bn_bwd_apply(_p(dy[r0:r1]), _p(x[r0:r1]), _dt(x), r1 - r0, c, _p(mean[g]), _p(rstd[g]), _p(g32),
+            check(lib.tmae_bn_bwd_apply(_p(first[g]), _p(x[r0:r1]), _dt(x), r1 - r0, c, _p(mean[g]), _p(rstd[g]), _p(g32),
                                         _p(b32), 1 if ctx.relu else 0, _p(tb), _p(tg), float(ctx.counts[g]), _p(dx[r0:r1]),
                                         _s()), 'tmae_bn_bwd_apply')
         if ng > 1:
             dg, db = dg.sum(0), db.sum(0)
         else:
             dg, db = dg[0], db[0]
-        return dx, dg.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None, None, None, (dy if ctx.has_post else None)
+        return dx, dg.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None, None, None, (dy if ctx.has_post else None), None
 
 
 class _DeadBias(torch.autograd.Function):
@@ -1026,13 +1057,15 @@ class _DeadBias(torch.autograd.Function):
         return dy, torch.zeros(shape, dtype=dtype, device=device)
 
 
-def batch_norm_relu(x, bn, relu=True, groups=None, pre_bias=None, post=None):
+def batch_norm_relu(x, bn, relu=True, groups=None, pre_bias=None, post=None, fork=False):
     """nn.BatchNorm1d `bn` (+ ReLU) over the rows of x [m,c]; fused HIP kernels in training mode for c in
     {64,128,256}; updates bn's running statistics like torch does.  `groups` (row counts summing to m): each row
     range is a separate BatchNorm call (own batch statistics, running statistics updated in order).
     pre_bias [c]: the result for x + pre_bias WITHOUT adding it (a conv bias before the norm, USE_BIAS_BEFORE_NORM,
     center_head.py:19-27): the normalised output does not depend on it, its gradient is exactly zero, only the running
-    mean sees it -- saves an elementwise pass over the activation forward and a column reduction backward."""
+    mean sees it -- saves an elementwise pass over the activation forward and a column reduction backward.
+    fork (two groups): returns (y, (y[:g0], y[g0:])) -- the halves as outputs of the norm's own autograd node, see
+    _BatchNormReLU.forward; where the fused kernels do not apply the halves come from ops.split_rows."""
     if pre_bias is not None and not (x.is_cuda and x.dim() == 2 and bn.training and x.shape[1] in (64, 128, 256)
                                      and groups is None and x.shape[0] > 1 and x.dtype in (torch.float32, torch.bfloat16)):
         x, pre_bias = x + pre_bias.to(x.dtype), None
@@ -1044,9 +1077,13 @@ def batch_norm_relu(x, bn, relu=True, groups=None, pre_bias=None, post=None):
         for g in sizes:
             bounds.append(bounds[-1] + g)
         pg = _sync_group(bn)
+        halves = None
         if post is not None and (groups is not None or pg is not None):
             y, mean, var = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.eps, relu, tuple(bounds), pg)
             y = y + post
+        elif fork and len(sizes) == 2 and pg is None and post is None and pre_bias is None:
+            y, mean, var, h0, h1 = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.eps, relu, tuple(bounds), None, None, True)
+            halves = (h0, h1)
         else:
             y, mean, var = _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.eps, relu, tuple(bounds), pg, post)
         if pre_bias is not None:
@@ -1055,6 +1092,8 @@ def batch_norm_relu(x, bn, relu=True, groups=None, pre_bias=None, post=None):
         if bn.track_running_stats:
             for g, m in enumerate(_BatchNormReLU.last_counts):      # SyncBatchNorm: the rows of all ranks (unbiased variance)
                 _bn_running_update(bn, mean[g], var[g], m)
+        if fork:
+            return y, (halves if halves is not None else split_rows(y, sizes[0]))
         return y
     if _sync_group(bn) is not None:
         raise NotImplementedError('SyncBatchNorm: this layer shape has no fused kernel (channels in {64, 128, 256}, bf16 / fp32 '
@@ -1065,7 +1104,8 @@ def batch_norm_relu(x, bn, relu=True, groups=None, pre_bias=None, post=None):
     else:
         y = bn(x)
     y = torch.relu(y) if relu else y
-    return y if post is None else y + post
+    y = y if post is None else y + post
+    return (y, split_rows(y, sizes[0])) if fork else y
 
 
 class _SplitRows(torch.autograd.Function):

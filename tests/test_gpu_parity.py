@@ -965,6 +965,43 @@ def test_add_layernorm_residual_options_vs_torch():
                 assert float((got[2] * (1 - keep.float())).abs().max()) == 0.0        # masked rows of b get no gradient
 
 
+def test_batchnorm_fork_joins_the_frame_gradients_inside_its_backward():
+    """ops.batch_norm_relu(..., groups=[m0, m1], fork=True): y and its two row ranges as outputs of ONE autograd node; whichever
+    of the three receive a gradient, dx / dgamma / dbeta equal those of the unforked norm followed by ops.split_rows (autograd's
+    cat + add), up to the one bf16 rounding that path spends on the sum (tmae_bn_relu_bwd2 adds in fp32)."""
+    from tmae_amd import ops
+    torch.manual_seed(4)
+    for c, dt, tol in ((128, torch.float32, 1e-5), (256, torch.bfloat16, 2e-2), (64, torch.bfloat16, 2e-2)):
+        m0, m1 = 7001, 3999
+        x = (torch.randn(m0 + m1, c, device=dev()) * 1.3 + 0.2).to(dt)
+        ga, g0, g1 = (torch.randn(n, c, device=dev()).to(dt) for n in (m0 + m1, m0, m1))
+        for use in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 0, 0), (0, 1, 0)):
+            res = []
+            for fork in (True, False):
+                bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev())
+                with torch.no_grad():
+                    bn.weight.fill_(1.1), bn.bias.fill_(-0.1)
+                xi = x.clone().requires_grad_(True)
+                if fork:
+                    y, (h0, h1) = ops.batch_norm_relu(xi, bn, relu=True, groups=[m0, m1], fork=True)
+                else:
+                    y = ops.batch_norm_relu(xi, bn, relu=True, groups=[m0, m1])
+                    h0, h1 = ops.split_rows(y, m0)
+                assert h0.shape == (m0, c) and h1.shape == (m1, c) and torch.equal(h0, y[:m0]) and torch.equal(h1, y[m0:])
+                outs, gs = [], []
+                for flag, o, g_ in zip(use, (y, h0, h1), (ga, g0, g1)):
+                    if flag:
+                        outs.append(o), gs.append(g_)
+                torch.autograd.backward(outs, gs)
+                res.append((y.detach().float(), xi.grad.float(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+            (ya, dxa, dga, dba), (yb, dxb, dgb, dbb) = res
+            assert torch.equal(ya, yb)
+            sc = max(1.0, float(dxb.abs().max()))
+            assert (dxa - dxb).abs().max().item() <= tol * sc, (c, dt, use, (dxa - dxb).abs().max().item())
+            for a, b in ((dga, dgb), (dba, dbb)):
+                assert (a - b).abs().max().item() <= max(tol, 2e-3) * max(1.0, float(b.abs().max())), (c, dt, use)
+
+
 def test_batchnorm_relu_kernel_vs_torch():
     from tmae_amd import ops
     torch.manual_seed(2)
