@@ -286,7 +286,12 @@ __global__ __launch_bounds__(256) void dense_wgrad_reduce_kernel(const float* __
   *reinterpret_cast<float4*>(dw + e) = acc;
 }
 
-static int dw_splits(int cin) { return 256 / (cin / 64); }      // one workgroup per CU: splits x channel slices = 256
+// One workgroup per CU, and the blocks of one split share an XCD (block ids are dealt round-robin over the 8 XCDs): splits x channel
+// slices <= 256 is not enough, EVERY XCD must get at most its 32 CUs' worth -- the split count is a multiple of 8.  Until round 6
+// this was 256 / KC = 42 for the decoder conv (KC = 6): XCDs 0 and 1 were dealt 6 splits = 36 workgroups for their 32 CUs, four of
+// them waited for a free CU and the launch took two rounds (2.07 ms for a loop whose in-kernel stamps add up to 1.15 ms:
+// profiles/round6_dense_wgrad_stamps.txt); with 40 splits every XCD runs 30 workgroups in one round.
+static int dw_splits(int cin) { return 256 / (cin / 64) / 8 * 8; }
 
 size_t tmae_dense_conv3x3_wgrad_workspace(int cin, int cout) {
   if (cout != DW_N || cin <= 0 || cin % 64) return 0;
