@@ -109,18 +109,6 @@ def _pmc(key):
     return _pmc_entry(key)[2]
 
 
-def _counters(*kernels):
-    """Matrix-core / vector-ALU utilisation of the named kernels from the committed counter passes
-    (profiles/round3_pmc_counters.json <- profiles/round3_pmc_kernels.md): fractions of all SIMD-cycles of a launch."""
-    f = os.path.join(ROOT, 'profiles', 'round3_pmc_counters.json')
-    if not os.path.exists(f):
-        return None
-    tab = json.load(open(f))['kernels']
-    out = {k: {q: tab[k][q] for q in ('mfma_busy', 'valu_busy', 'wave_wait_frac', 'wave_issue_stall_frac', 'l2_hit_rate')}
-           for k in kernels if k in tab}
-    return {'kernels': out, 'source': 'profiles/round3_pmc_counters.json (rocprofv3 --pmc, MI355X_MICROARCH.md units)'} if out else None
-
-
 def box_peaks(dev, reps=5):
     """What THIS box sustains: a 16-bytes-per-lane streaming copy of 1 GiB (HBM
     bytes = read + write) and a register-resident bf16 MFMA loop on random operands, both library probes
@@ -231,8 +219,7 @@ def token_gemm_roofline(model, batch, amp_dtype, iters=20):
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
             'traffic': _pmc('token_gemm'), 'traffic_is_of_this_source': _pmc_current('token_gemm'),
             'traffic_source': _pmc_source('token_gemm'),
-            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k,
-            'utilisation': _counters('token_gemm_wreg_kernel<256, 4, 8, false, false>')}
+            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k}
 
 
 def gelu_gemm_roofline(model, batch, amp_dtype, iters=20):
@@ -301,8 +288,7 @@ def wgrad_roofline(model, batch, amp_dtype, iters=20):
             'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': _pmc('wgrad'), 'traffic_is_of_this_source': _pmc_current('wgrad'),
             'traffic_source': _pmc_source('wgrad'),
-            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k,
-            'utilisation': _counters('wgrad256_kernel<false, 1>', 'wgrad_reduce_kernel')}
+            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': m, 'n': n, 'k': k}
 
 
 def attention_roofline(model, batch, amp_dtype, iters=20):
@@ -364,9 +350,7 @@ def attention_roofline(model, batch, amp_dtype, iters=20):
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
             'traffic_is_of_this_source': _pmc_current('attention') if code == 1 else None,
             'traffic_source': _pmc_source('attention'),
-            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': int(m),
-            'utilisation': _counters('win_attn_bwd_mfma_kernel<16, 1, false>', 'win_attn_bwd_mfma_kernel<16, 1, true>',
-                                     'win_attn_bwd_mfma_kernel<16, 2, false>', 'win_attn_bwd_mfma_kernel<16, 4, false>')}
+            'ms_per_launch': round(ms, 4), 'algorithmic_bytes': int(bytes_alg), 'tokens': int(m)}
 
 
 def _cpu_now():
@@ -430,6 +414,98 @@ def igemm_roofline(batch_per_gpu, iters=10):
                       'op)', 'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(tf / MFMA_BF16_PEAK_TFLOPS, 5), 'traffic': None, 'ms_per_launch': round(ms, 4),
             'algorithmic_flops': flops, 'cells': B * Y * X}
+
+
+def dense_wgrad_roofline(batch_per_gpu, iters=10):
+    """`roofline_dense_wgrad`: the decoder conv's weight gradient (B x 468 x 468 cells, dW[128, 9 x 384]) on the halo kernel of
+    csrc/dense_wgrad.hip + its slab reduction, through the C ABI.  MFMA-bound: 2 * cells * 9 * 384 * 128 FLOPs per launch
+    against the dense bf16 MFMA peak; HIP events on the launch stream."""
+    from tmae_amd._lib import lib, check
+    dev = torch.device('cuda', torch.cuda.current_device())
+    B, Y, X, cin, cout = batch_per_gpu, 468, 468, 384, 128
+    x = torch.randn(B, Y, X, cin, device=dev).bfloat16()
+    dy = torch.randn(B, Y, X, cout, device=dev).bfloat16()
+    dw = torch.empty(cout, 9 * cin, device=dev)
+    wsb = lib.tmae_dense_conv3x3_wgrad_workspace(cin, cout)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        check(lib.tmae_dense_conv3x3_wgrad(dy.data_ptr(), x.data_ptr(), B, Y, X, cin, cout, 1, dw.data_ptr(), ws.data_ptr(), wsb, st),
+              'tmae_dense_conv3x3_wgrad')
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * B * Y * X * 9 * cin * cout
+    tf = flops / (ms * 1e-3) / 1e12
+    return {'kernel': 'dense_wgrad_halo_kernel<1> + dense_wgrad_reduce_kernel (dense decoder conv weight gradient dW[128, 9 x 384]; '
+                      'the op = both launches)', 'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': round(tf / MFMA_BF16_PEAK_TFLOPS, 5), 'traffic': None, 'ms_per_launch': round(ms, 4),
+            'algorithmic_flops': flops, 'cells': B * Y * X}
+
+
+def spconv_rooflines(model, iters=10):
+    """`roofline_spconv` / `roofline_spconv_wgrad`: the d = 256 submanifold conv of the encoder's second stage (conv_out of
+    sst_block 2: 256 -> 256, spt_backbone.py:279-304 through spconv_utils.post_act_block) over the token list of BOTH frames with
+    the batch's real rulebook -- forward on spconv_igemm_ring256_kernel<256> (+ its tail launch), weight gradient on
+    wgrad256_kernel<true> + the slab reduction.  MFMA-bound; FLOPs = 2 x ACTIVE (input, output) pairs x 256 x 256 (SURVEY 8d:
+    the kernels also multiply the zeros of absent neighbours, which is not counted).  Needs the index sets of a forward pass
+    (step_flops ran one)."""
+    from tmae_amd import ops
+    from tmae_amd._lib import lib, check
+    bb = model.backbone_3d
+    ind_p, ind_c, (ny, nx) = bb.last_stage_indices[1]
+    dev = ind_p.device
+    B = int(max(int(ind_p[:, 0].max()), int(ind_c[:, 0].max()))) + 1
+    shift = torch.tensor([B, 0, 0], dtype=torch.int32, device=dev)
+    ind = torch.cat([ind_p, ind_c + shift], 0).contiguous()
+    grid = ops.index_grid(ind, 2 * B, ny, nx)
+    nbr = ops.spconv_neighbors(ind, grid, 2 * B, ny, nx, 1)
+    m, cin, cout = int(ind.shape[0]), 256, 256
+    pairs = float((nbr >= 0).sum())
+    feat = torch.randn(m, cin, device=dev).bfloat16()
+    dy = torch.randn(m, cout, device=dev).bfloat16()
+    w = (torch.randn(cout, 9 * cin, device=dev) * 0.02).bfloat16()
+    out = torch.empty(m, cout, device=dev, dtype=torch.bfloat16)
+    dw = torch.empty(cout, 9 * cin, device=dev)
+    wsb = lib.tmae_linear_wgrad_workspace(m, cout, 9 * cin)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fwd():
+        check(lib.tmae_spconv_fwd(feat.data_ptr(), cin, m, cin, nbr.data_ptr(), m, w.data_ptr(), cout, out.data_ptr(), cout, st), 'tmae_spconv_fwd')
+
+    def wg():
+        check(lib.tmae_spconv_wgrad(dy.data_ptr(), cout, feat.data_ptr(), cin, nbr.data_ptr(), m, cout, cin, dw.data_ptr(), ws.data_ptr(), wsb, st),
+              'tmae_spconv_wgrad')
+    res = {}
+    flops = 2.0 * pairs * cin * cout
+    for key, fn, name in (('roofline_spconv', fwd, 'spconv_igemm_ring256_kernel<256> (+ the 128-column tail launch of its last round): stage-2 '
+                                                   'submanifold conv 256 -> 256 forward, both frames'),
+                          ('roofline_spconv_wgrad', wg, 'wgrad256_kernel<true> + wgrad_reduce_kernel: the same conv\'s weight gradient '
+                                                        'dW[256, 9 x 256] through the rulebook')):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        tf = flops / (ms * 1e-3) / 1e12
+        res[key] = {'kernel': name, 'bound': 'mfma', 'achieved': round(tf, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(tf / MFMA_BF16_PEAK_TFLOPS, 5), 'traffic': None, 'ms_per_launch': round(ms, 4),
+                    'algorithmic_flops': flops, 'rows': m, 'active_pairs': pairs, 'executed_flops': 2.0 * m * 9 * cin * cout}
+    return res
 
 
 def cpu_baseline(n_points, iters=3):
@@ -728,7 +804,9 @@ def main():
                           'roofline_token_gemm_plain': token_gemm_roofline(model, dict(batches[0]), amp),
                           'roofline_wgrad': wgrad_roofline(model, dict(batches[0]), amp),
                           'roofline_attention': attention_roofline(model, dict(batches[0]), amp),
-                          'roofline_igemm': igemm_roofline(args.batch_per_gpu)}), flush=True)
+                          'roofline_igemm': igemm_roofline(args.batch_per_gpu),
+                          'roofline_dense_wgrad': dense_wgrad_roofline(args.batch_per_gpu),
+                          **(spconv_rooflines(model) if (step_flops(model, dict(batches[0]), amp) and amp is not None) else {})}), flush=True)
         return
 
     def log(msg):
@@ -851,6 +929,10 @@ def main():
         line['roofline_attention'] = _with_measured(attention_roofline(model, dict(batches[0]), amp), peaks)
         if args.task == 'pretrain' and amp is not None:
             line['roofline_igemm'] = _with_measured(igemm_roofline(args.batch_per_gpu), peaks)
+            # the three MFMA-bound stragglers of the per-kernel tables: priced in the line itself
+            line['roofline_dense_wgrad'] = _with_measured(dense_wgrad_roofline(args.batch_per_gpu), peaks)
+            for key, ent in spconv_rooflines(model).items():
+                line[key] = _with_measured(ent, peaks)
         if world == 1 and not args.no_cpu_baseline:
             log('timing the CPU oracle (cpu_baseline: warm-up + 3 iterations at C2 and C1) ...')
             line['cpu_baseline'], (O, loss_cpu, case) = cpu_baseline(args.cpu_points)

@@ -49,7 +49,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     naive = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('naive_conv')]
     rows = rows[(max(naive) + 1) if naive else 0:]
     vk = [i for i, r in enumerate(rows) if 'vox_key_kernel' in r['Kernel_Name']]
-    seg = rows[vk[2 * WARM]:vk[2 * (WARM + STEPS)]]
+    seg = [r for r in rows[vk[2 * WARM]:vk[2 * (WARM + STEPS)]] if 'probe_mfma_kernel' not in r['Kernel_Name'] and 'probe_copy_kernel' not in r['Kernel_Name']]
     agg = collections.defaultdict(lambda: [0.0, 0, 0.0])
     for r in seg:
         n = clean(r['Kernel_Name'])

@@ -11,6 +11,9 @@ rest = rows[(max(naive) + 1) if naive else 0:]
 vk = [i for i, r in enumerate(rest) if 'vox_key_kernel' in r['Kernel_Name']]
 WARM, STEPS = 2, 3                  # bench.py --warmup 2 --steps 3: every step voxelises two frames (2 vox_key launches)
 seg = rest[vk[2 * WARM]:vk[2 * (WARM + STEPS)]]      # the 3 timed steps; what follows (FLOP-model forward, probes) is the tail
+# box-peak probes (csrc/probe.hip) are never step kernels, wherever a command line places them (the fine-tune profile of round 5
+# counted probe_mfma_kernel / probe_copy_kernel as 7 ms "per step")
+seg = [r for r in seg if 'probe_mfma_kernel' not in r['Kernel_Name'] and 'probe_copy_kernel' not in r['Kernel_Name']]
 t0, t1 = int(seg[0]['Start_Timestamp']), int(seg[-1]['End_Timestamp'])
 agg = collections.defaultdict(lambda: [0, 0])
 for r in seg:

@@ -74,20 +74,31 @@ template <bool G, bool CL>          // G: X rows are gathered through nbr (spars
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
                                                    const __hip_bfloat16* __restrict__ X, int64_t ldx, int64_t M,
                                                    int N, int K, int rows_per_split, float* __restrict__ slab,
-                                                   int64_t count, bool has_bias, int NB, int KB, int S,
+                                                   int64_t count, bool has_bias, int NB, int KB, int S, int per_xcd,
                                                    const int32_t* __restrict__ nbr, int cin,
                                                    const uint8_t* __restrict__ cells, int pos_n) {
   __shared__ __attribute__((aligned(16))) char lds[2][2][WG_MS * 256];
   __shared__ uint2 ldsC[2][4];         // CL: the slice's 32 cell bytes, staged with the rows (8 bytes per lane group g)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w >> 1, wk = w & 1;
-  // XCD-aware 1-D grid: block ids are dealt round-robin over the 8 XCDs (speed only, never correctness), so all
+  // XCD-aware 1-D grid: block ids are dealt round-robin over the 8 XCDs (speed only, never correctness), so the
   // (n, k) output blocks of one token chunk s get ids of the same residue: they stream the same dY / X rows at the
   // same time and share them through that XCD's L2 instead of fetching them once per block from HBM.
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  // per_xcd > 0 (round 6, the 9-block chunks of the d = 256 sparse convs): an XCD's workgroups are a CONTIGUOUS range of the list
+  // (chunk, block) instead of whole chunks dealt in turn -- whole chunks filled 27 of an XCD's 32 slots; a chunk that straddles two
+  // XCDs is fetched by both.  Measured per launch (profiles/round6_ab_wgrad_map.txt): 9 blocks -3..-7 %, 5 and 3 blocks nothing,
+  // and the 2- / 4-block shapes (where both forms use every slot) +5..+8 % with the contiguous deal: those keep the round-robin one.
   const int per_s = NB * KB;
-  const int s = (j / per_s) * 8 + xcd;
-  if (s >= S) return;
-  const int blk = j % per_s;
+  int s, blk;
+  if (per_xcd > 0) {
+    const int L = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (L >= S * per_s) return;
+    s = L / per_s; blk = L % per_s;
+  } else {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    s = (j / per_s) * 8 + xcd;
+    if (s >= S) return;
+    blk = j % per_s;
+  }
   const int n0 = (blk % NB) * WG_BN, kblk = blk / NB, k0 = kblk * WG_BK;
   const int64_t m_begin = (int64_t)s * rows_per_split;
   const int64_t m_end = min(M, m_begin + (int64_t)rows_per_split);
@@ -304,18 +315,25 @@ template <bool G, int NTL = 0, int VAR = 0, bool CL = false>      // NTL: bit 0 
 __global__ __launch_bounds__(512, 2) void wgrad256_kernel(const __hip_bfloat16* __restrict__ dY, int64_t ldy,
                                                          const __hip_bfloat16* __restrict__ X, int64_t ldx, int64_t M,
                                                          int N, int K, int rows_per_split, float* __restrict__ slab,
-                                                         int64_t count, bool has_bias, int NB, int KB, int S,
+                                                         int64_t count, bool has_bias, int NB, int KB, int S, int per_xcd,
                                                          const int32_t* __restrict__ nbr, int cin,
                                                          const uint8_t* __restrict__ cells, int pos_n) {
   static_assert(!(G && CL), "per-cell sums belong to the Linear in-projections, not to the gathered sparse-conv gradient");
   __shared__ __attribute__((aligned(16))) char lds[2][2][2][WG_MS * 256];     // [buffer][operand][column half]
   __shared__ uint2 ldsC[2][4];         // CL: the slice's 32 cell bytes, staged with the rows (8 bytes per lane group g)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w >> 2, wk = w & 3;
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int per_s = NB * KB;
-  const int s = (j / per_s) * 8 + xcd;
-  if (s >= S) return;
-  const int blk = j % per_s;
+  int s, blk;
+  if (per_xcd > 0) {                                                   // see wgrad_kernel
+    const int L = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (L >= S * per_s) return;
+    s = L / per_s; blk = L % per_s;
+  } else {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    s = (j / per_s) * 8 + xcd;
+    if (s >= S) return;
+    blk = j % per_s;
+  }
   const int n0 = (blk % NB) * WG2_B, kblk = blk / NB, k0 = kblk * WG2_B;
   const int64_t m_begin = (int64_t)s * rows_per_split;
   const int64_t m_end = min(M, m_begin + (int64_t)rows_per_split);
@@ -591,6 +609,11 @@ static bool wgrad_big_tile(int n, int k) {
 // (they share dY / X through that L2), so chunks are handed out per XCD: as many as fit the XCD's resident
 // workgroups in ONE round (32 CUs x 2 for the 128-tile kernel, x 1 for the 256-tile kernel) -- a second, partly
 // filled round costs a whole extra pass (measured: 576 workgroups on 512 slots ran 1.8x longer than 504).
+static bool wgrad_contig(int per_xcd, int nb) {
+  const int whole = 8 * (per_xcd / nb) * nb, list = (8 * per_xcd) / nb * nb;
+  return nb <= per_xcd && list * 10 >= whole * 11;
+}
+
 static void wgrad_plan(int64_t m, int n, int k, int& splits, int& rows_per_split) {
   const bool big = wgrad_big_tile(n, k);
   const int bt = big ? WG2_B : WG_BN;
@@ -600,6 +623,9 @@ static void wgrad_plan(int64_t m, int n, int k, int& splits, int& rows_per_split
   int64_t c = per_xcd / nb;
   if (c < 1) c = 1;
   int64_t s = 8 * c;
+  // whole chunks per XCD leave slots idle when nb does not divide per_xcd; where that is >= 10 % of the chip (nb = 9: 8 x 3 x 9 = 216 of
+  // 256) the chunks are dealt as one contiguous list instead (wgrad_contig): 28 x 9 = 252
+  if (wgrad_contig(per_xcd, nb)) s = (8 * per_xcd) / nb;
   const int64_t max_s = (m + 255) / 256;                  // at least 8 steps per workgroup
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -628,6 +654,9 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
   if (cells && (nbr || (!dc && !posE) || pos_n < 0 || pos_n > n || (dc && ldc < n) || (((uintptr_t)cells) & 7))) return TMAE_EARG;
   if (posE && (!cells || (((uintptr_t)posE) & 15) || !((256 % k) == 0 || (k % 256) == 0) || k < 64 || (((int64_t)n * k) % 256)))
     return TMAE_EARG;
+  // the reduction adds dcell^T E to EVERY row of dw and relies on zero cell sums for the rows >= pos_n; the kernels mask the cell sums
+  // per output tile, so the position rows must end on a tile boundary (d = 64 cross k | v would have n = 128, pos_n = 64)
+  if (posE && pos_n != n && (pos_n % (wgrad_big_tile(n, k) ? WG2_B : WG_BN))) return TMAE_EARG;
   if (m > 0 && (!dy || !x)) return TMAE_EARG;
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15)) return TMAE_EARG;
   int splits, rows;
@@ -641,10 +670,12 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
   if (!ws.ok) return TMAE_EWS;
   // without a bias the slabs' bias columns stay unwritten; the reduction discards those sums
 #define WG_ARGS (const __hip_bfloat16*)dy, ldy, (const __hip_bfloat16*)x, ldx, m, n, k, rows, slab, count, db != nullptr, NB, \
-                KB, splits, nbr, cin
+                KB, splits, per_x, nbr, cin
   if (wgrad_big_tile(n, k)) {
     const int NB = (n + WG2_B - 1) / WG2_B, KB = (k + WG2_B - 1) / WG2_B;
-    const unsigned nblocks = 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
+    // per_x > 0: blocks per XCD residue, a contiguous range of (chunk, block); 0: whole chunks dealt round-robin
+    const int per_x = wgrad_contig(32, NB * KB) ? (splits * NB * KB + 7) / 8 : 0;
+    const unsigned nblocks = per_x ? 8u * (unsigned)per_x : 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
     if (nbr) hipLaunchKernelGGL((wgrad256_kernel<true>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS, cells, pos_n);
     else if (cl) {                 // per-cell sums inside the 256-tile kernel (dY non-temporal when nobody re-reads it)
       if (KB == 1) hipLaunchKernelGGL((wgrad256_kernel<false, 1, 0, true>), dim3(nblocks), dim3(512), 0, stream, WG_ARGS, cells, pos_n);
@@ -670,7 +701,8 @@ static int wgrad_launch(const void* dy, int64_t ldy, const void* x, int64_t ldx,
     }
   } else {
     const int NB = (n + WG_BN - 1) / WG_BN, KB = (k + WG_BK - 1) / WG_BK;
-    const unsigned nblocks = 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
+    const int per_x = wgrad_contig(64, NB * KB) ? (splits * NB * KB + 7) / 8 : 0;
+    const unsigned nblocks = per_x ? 8u * (unsigned)per_x : 8u * (unsigned)((splits + 7) / 8) * (unsigned)(NB * KB);
     if (nbr) hipLaunchKernelGGL((wgrad_kernel<true, false>), dim3(nblocks), dim3(256), 0, stream, WG_ARGS, cells, pos_n);
     else if (cl) hipLaunchKernelGGL((wgrad_kernel<false, true>), dim3(nblocks), dim3(256), 0, stream, WG_ARGS, cells, pos_n);
     else hipLaunchKernelGGL((wgrad_kernel<false, false>), dim3(nblocks), dim3(256), 0, stream, WG_ARGS, cells, pos_n);

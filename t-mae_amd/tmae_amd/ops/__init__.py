@@ -379,8 +379,11 @@ def linear_wgrad(dy, x, want_bias=True, out_w=None, out_b=None, cells=None, pos_
     wsb = lib.tmae_linear_wgrad_workspace(m, n, k)
     ws = _ws(wsb, dy.device)
     if cells is not None:
+        # (the kernels zero the cell sums per OUTPUT TILE, the reduction adds dcell^T E to every row: the position rows must end on a
+        #  tile boundary -- 256 rows for the 256-tile kernel, 128 otherwise -- or cover all rows; else the unfolded form below)
+        tile = 256 if (n >= 256 and k >= 256 and ((n + 255) // 256) * ((k + 255) // 256) >= 2) else 128
         fold = (pos_e is not None and pos_e.dtype == torch.float32 and pos_e.is_contiguous() and pos_e.shape == (16, k)
-                and k >= 64 and (256 % k == 0 or k % 256 == 0) and (n * k) % 256 == 0)
+                and k >= 64 and (256 % k == 0 or k % 256 == 0) and (n * k) % 256 == 0 and (pos_n % tile == 0 or pos_n == n))
         dcell = None if fold else torch.empty((16, n), dtype=torch.float32, device=dy.device)
         check(lib.tmae_linear_wgrad_cells(_p(dy), dy.stride(0), _p(x), x.stride(0), m, n, k, _p(cells), int(pos_n),
                                           _p(pos_e) if fold else None, _p(dw), _p(db), _p(dcell), _p(ws), wsb, _s()),
@@ -1175,22 +1178,36 @@ class HostCopy:
     and records an event behind it; `.get()` waits for that event and returns the values.  Between the two the caller enqueues
     work that does not need the values: by the time they are read the copy has long happened, the host does not stall and keeps
     its lead over the GPU (the strided convs' output counts are enqueued before the first stage and read after it)."""
-    _pool = {}
+    _free = {}         # (device, dtype) -> [(pinned buffer, event), ...] not in flight
 
     def __init__(self, t, tag):
+        """Every copy in flight owns its pinned buffer and event: they come from a free list and go back to it in get().  (Until
+        round 6 one buffer per `tag` was shared: a second HostCopy of the same tag made before the first one's get() -- two models
+        or forwards interleaved, an abandoned prefetch -- overwrote the first one's values in place.)  `tag` only names the copy."""
         t = t.detach()
-        key = (tag, t.device, t.dtype)
-        ent = HostCopy._pool.get(key)
-        if ent is None or ent[0].numel() < t.numel():
-            ent = HostCopy._pool[key] = (torch.empty((max(t.numel(), 64),), dtype=t.dtype).pin_memory(), torch.cuda.Event())
+        self.tag = tag
+        self.key = (t.device, t.dtype)
+        free = HostCopy._free.setdefault(self.key, [])
+        ent = None
+        for j, e in enumerate(free):
+            if e[0].numel() >= t.numel():
+                ent = free.pop(j)
+                break
+        if ent is None:
+            ent = (torch.empty((max(t.numel(), 64),), dtype=t.dtype).pin_memory(), torch.cuda.Event())
+        self.ent = ent
         self.buf = ent[0][:t.numel()].view(t.shape)
-        self.event = ent[1]
         self.buf.copy_(t, non_blocking=True)
-        self.event.record(torch.cuda.current_stream(t.device))
+        ent[1].record(torch.cuda.current_stream(t.device))
 
     def get(self):
-        self.event.synchronize()
-        return self.buf.clone()
+        if self.ent is None:
+            raise RuntimeError(f'HostCopy({self.tag!r}).get() called twice')
+        self.ent[1].synchronize()
+        out = self.buf.clone()
+        HostCopy._free[self.key].append(self.ent)       # an abandoned copy simply never returns its buffer (64 pinned elements)
+        self.ent = self.buf = None
+        return out
 
 
 def voxelize_finish(out, counts_host):

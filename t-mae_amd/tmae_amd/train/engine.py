@@ -45,10 +45,24 @@ def settle_gc():
     _GC_SETTLED = True
 
 
+def unsettle_gc():
+    """Undo settle_gc(): the frozen objects go back under the collector (gc.unfreeze) and the next train_one_step(settle=True)
+    freezes again.  For a long-lived process that builds model after model (a sweep, a notebook): call it when a model and its
+    optimizer are dropped, or their reference cycles stay in the permanent generation for the life of the process."""
+    global _GC_SETTLED
+    import gc
+    gc.unfreeze()
+    _GC_SETTLED = False
+
+
 def train_one_step(model, optimizer, scheduler, batch_dict, it, model_func, amp_dtype=torch.bfloat16,
-                   grad_norm_clip=None):
+                   grad_norm_clip=None, settle=None):
     """lr_scheduler.step -> zero_grad -> autocast forward -> backward (DDP all-reduce overlaps) ->
-    [clip, non-AMP branch only: train_utils.py:88-93] -> optimizer.step."""
+    [clip, non-AMP branch only: train_utils.py:88-93] -> optimizer.step.
+    settle: freeze the interpreter's long-lived objects out of the cyclic collector after the first step (settle_gc: a
+    process-wide, one-way change until unsettle_gc()).  None = the TMAE_SETTLE_GC environment switch, default ON -- the
+    training drivers (tools/train.py, bench.py) are one-model processes; a host that builds many models passes False or calls
+    unsettle_gc() between them."""
     if scheduler is not None:
         scheduler.step(it)
     optimizer.zero_grad(set_to_none=True)
@@ -65,5 +79,9 @@ def train_one_step(model, optimizer, scheduler, batch_dict, it, model_func, amp_
     if use_amp:
         from .. import ops
         ops.refresh_param_copies(optimizer.params if hasattr(optimizer, 'params') else model.parameters(), amp_dtype)
-    settle_gc()                                     # first call only
+    if settle is None:
+        import os
+        settle = os.environ.get('TMAE_SETTLE_GC', '1') != '0'
+    if settle:
+        settle_gc()                                 # first call only
     return loss, tb_dict, disp_dict

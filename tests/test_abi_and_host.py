@@ -44,6 +44,16 @@ def test_binding_table_matches_header_prototypes():
     assert int(m.group(1)) == _lib.ABI_VERSION
 
 
+def test_docs_quote_the_current_abi():
+    """INTEGRATION.md / DESIGN.md name the ABI version and the number of entry points (both had gone stale)."""
+    hdr = open(os.path.join(ROOT, 'include', 'tmae_hip.h')).read()
+    ver = int(re.search(r'#define\s+TMAE_ABI_VERSION\s+(\d+)', hdr).group(1))
+    n = len(_declared_symbols())
+    for doc in ('INTEGRATION.md', 'DESIGN.md'):
+        text = open(os.path.join(ROOT, doc)).read()
+        assert f'{n} entry points, ABI version {ver}' in text, (doc, n, ver)
+
+
 def test_entry_points_refuse_a_wrong_argument_count():
     """ctypes lets a cdecl call carry EXTRA arguments (converted to 32-bit ints): the binding's wrappers do not."""
     from tmae_amd import _lib

@@ -965,6 +965,42 @@ def test_add_layernorm_residual_options_vs_torch():
                 assert float((got[2] * (1 - keep.float())).abs().max()) == 0.0        # masked rows of b get no gradient
 
 
+def test_ffn_residual_out_of_the_gemm_vs_added_in_the_norm():
+    """_EncoderTail with `src + linear2(act)` written by linear2's GEMM (tmae_token_gemm_res, the default) against the same tail
+    with the sum taken inside norm2 from two tensors (TMAE_FFN_RESIDUAL=add): the fused form rounds the residual
+    stream to bf16 once more per layer (2^-9 relative on the norm's INPUT).  Stated tolerance, bf16 autocast, 70 k tokens, d = 256:
+    norm2 output 2^-6 absolute on unit-variance rows (two bf16 roundings of a normalised value), input gradient and the FFN weight
+    gradients 2 % of their largest element."""
+    from tmae_amd.modules import sst
+    torch.manual_seed(11)
+    d, m = 256, 70000
+    layer = sst._EncoderTail(torch.nn.Identity(), d, 2 * d, 'gelu').to(dev())
+    src0 = torch.randn(m, d, device=dev())
+    attn0 = torch.randn(m, d, device=dev()) * 0.5
+    go = torch.randn(m, d, device=dev())
+    res = []
+    for fused in (True, False):
+        saved = sst._FFN_RESIDUAL_FUSED
+        sst._FFN_RESIDUAL_FUSED = fused
+        try:
+            layer.zero_grad()
+            src = src0.clone().requires_grad_(True)
+            attn = attn0.clone().requires_grad_(True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                out = layer.tail(src, attn)
+            out.backward(go.to(out.dtype))
+            res.append((out.detach().float(), src.grad.float(), attn.grad.float(), layer.linear1.weight.grad.float().clone(),
+                        layer.linear2.weight.grad.float().clone(), layer.norm2.weight.grad.float().clone()))
+        finally:
+            sst._FFN_RESIDUAL_FUSED = saved
+    a, b = res
+    assert (a[0] - b[0]).abs().max().item() <= 2.0 ** -6 * max(1.0, float(b[0].abs().max())), (a[0] - b[0]).abs().max().item()
+    assert (a[0] - b[0]).abs().mean().item() <= 2e-3
+    for k in (1, 2, 3, 4, 5):
+        lim = 2e-2 * max(1.0, float(b[k].abs().max()))
+        assert (a[k] - b[k]).abs().max().item() <= lim, (k, (a[k] - b[k]).abs().max().item(), lim)
+
+
 def test_batchnorm_fork_joins_the_frame_gradients_inside_its_backward():
     """ops.batch_norm_relu(..., groups=[m0, m1], fork=True): y and its two row ranges as outputs of ONE autograd node; whichever
     of the three receive a gradient, dx / dgamma / dbeta equal those of the unforked norm followed by ops.split_rows (autograd's
