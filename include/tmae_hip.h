@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 18
+#define TMAE_ABI_VERSION 19
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -391,6 +391,16 @@ int tmae_bn_relu_bwd(const void* dy, const void* x, int dtype, int64_t m, int c,
 int tmae_bn_relu_bwd2(const void* dy, const void* dy2, const void* x, int dtype, int64_t m, int c, const float* mean,
                       const float* rstd, const float* gamma, const float* beta, int relu, void* dx, float* dgamma,
                       float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of the same norm over the rows of a DENSE map x [batch, ny, nx, c] whose output is read at m sites only -- the decoder's
+ * last BatchNorm2d + ReLU, read back by the gather at the current frame's voxels (SiamWCA_MAE.py:100-115, 303-312).  dyc [m, c]: the
+ * gradient at site indices[j] = (b, y, x) (int32 [m, 3], unique); rowmap [batch * ny * nx] int32: the site's row in dyc or -1
+ * (tmae_index_grid of `indices`); all other cells carry zero gradient.  The two sums run over the m rows, dx [batch * ny * nx, c]
+ * is written for every cell; workspace: tmae_bn_workspace(m, c). */
+int tmae_bn_relu_bwd_gathered(const void* dyc, const int32_t* indices, const int32_t* rowmap, int64_t m, const void* x, int dtype,
+                              int batch, int ny, int nx, int c, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, int relu, void* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                              void* stream);
 
 /* Split BatchNorm entry points with an explicit element count (used by the fused decoder head below): statistics
  * of the m stored rows normalised by `count` >= m (the rows that are not stored are exact zeros), the two backward

@@ -279,6 +279,97 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of BatchNorm(+ReLU) over the rows of a DENSE map whose output is read at m << cells sites only -- the decoder's last
+// norm, whose [B, 468, 468, 128] output reaches the loss through the gather at the current frame's voxels (SiamWCA_MAE.py:303-312:
+// 21 % of the cells).  The gradient that arrives is the compact [m, c] one; scattering it into a dense, mostly zero dy first
+// (tmae_sparse_to_dense) cost a 448 MB write, and both passes below then read those zeros back.  Here:
+//   * the two sums run over the m gathered rows only (x read at their cells);
+//   * the apply pass walks all cells and takes dz from the compact rows through the cell -> row map (-1: no gradient).
+// ------------------------------------------------------------------------------------------------
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_rows_kernel(const T* __restrict__ dyc, const int32_t* __restrict__ ind,
+                                                                const T* __restrict__ x, int64_t m, int ny, int nx,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                int relu, float* __restrict__ part) {
+  BN_LAYOUT;
+  __shared__ float red[4][2][C];
+  float mu[8], rs[8], g[8], bt[8], s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ch = cl * 8 + i;
+    mu[i] = mean[ch]; rs[i] = rstd[ch]; g[i] = gamma[ch]; bt[i] = beta[ch];
+    s1[i] = 0.f; s2[i] = 0.f;
+  }
+  for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
+    float v[2][8], d[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub, rc = r < m ? r : m - 1;
+      const int64_t cell = ((int64_t)ind[rc * 3] * ny + ind[rc * 3 + 1]) * nx + ind[rc * 3 + 2];
+      load8<T>(x + cell * C + cl * 8, v[u]);                      // unconditional (clamped row), masked below
+      load8<T>(dyc + rc * C + cl * 8, d[u]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[u][i] = r < m ? d[u][i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (v[u][i] - mu[i]) * rs[i];
+        const float dz = (relu && !(xh * g[i] + bt[i] > 0.f)) ? 0.f : d[u][i];
+        s1[i] += dz;
+        s2[i] += dz * xh;
+      }
+  }
+  bn_block_partial<C, LPR>(s1, s2, red, w, sub, cl, part);
+}
+
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_map_kernel(const T* __restrict__ dyc, const int32_t* __restrict__ rowmap,
+                                                              const T* __restrict__ x, int64_t cells,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int relu, const float* __restrict__ dbeta,
+                                                              const float* __restrict__ dgamma, float invm, T* __restrict__ dx) {
+  BN_LAYOUT;
+  float mu[8], rs[8], g[8], bt[8], a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ch = cl * 8 + i;
+    mu[i] = mean[ch]; rs[i] = rstd[ch]; g[i] = gamma[ch]; bt[i] = beta[ch];
+    a[i] = dbeta[ch] * invm; b[i] = dgamma[ch] * invm;
+  }
+  for (int64_t r0 = wave * (2 * RPW); r0 < cells; r0 += nwaves * (2 * RPW)) {
+    float v[2][8], d[2][8];
+    int src[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub, rc = r < cells ? r : cells - 1;
+      src[u] = rowmap[rc];
+      load8<T>(x + rc * C + cl * 8, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      load8<T>(dyc + (int64_t)(src[u] < 0 ? 0 : src[u]) * C + cl * 8, d[u]);      // unconditional (row 0 for "no gradient"), masked below
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub;
+      if (r < cells) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xh = (v[u][i] - mu[i]) * rs[i];
+          const float dz = (src[u] < 0 || (relu && !(xh * g[i] + bt[i] > 0.f))) ? 0.f : d[u][i];
+          d[u][i] = g[i] * rs[i] * (dz - a[i] - xh * b[i]);
+        }
+        store8<T>(dx + r * C + cl * 8, d[u]);
+      }
+    }
+  }
+}
+
 static int bn_grid(int64_t m) {
   int64_t g = (m + 255) / 256;          // >= 64 rows per wave
   if (g > 1024) g = 1024;
@@ -486,6 +577,40 @@ int tmae_bn_bwd_apply(const void* dy_, const void* x_, int dtype, int64_t m, int
     const __hip_bfloat16 *dy = (const __hip_bfloat16*)dy_, *x = (const __hip_bfloat16*)x_;
     __hip_bfloat16* dx = (__hip_bfloat16*)dx_;
     BN_DISPATCH(__hip_bfloat16, bn_bwd_apply_kernel, dy, (const __hip_bfloat16*)nullptr, x, m, mean, rstd, gamma, beta, relu, dbeta, dgamma, invm, dx);
+  }
+  return tmae_launch_status();
+}
+
+// dx [cells, c], dgamma, dbeta of y = relu?(BatchNorm(x)) over the rows of a dense map x [batch, ny, nx, c] whose gradient is given at
+// m sites only: dyc [m, c] (row j = site indices[j] = (b, y, x), int32 [m, 3]), rowmap [batch * ny * nx] int32 = the site's row in dyc
+// or -1 (tmae_index_grid of `indices`); every other cell has zero gradient.  Statistics over all `cells` rows, as the forward's.
+int tmae_bn_relu_bwd_gathered(const void* dyc_, const int32_t* indices, const int32_t* rowmap, int64_t m, const void* x_, int dtype,
+                              int batch, int ny, int nx, int c, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, int relu, void* dx_, float* dgamma, float* dbeta, void* wsp, size_t ws_bytes,
+                              void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t cells = (int64_t)batch * ny * nx;
+  if (!bn_args_ok(cells, c, dtype) || batch <= 0 || ny <= 0 || nx <= 0 || m <= 0 || !dyc_ || !indices || !rowmap || !x_ || !mean ||
+      !rstd || !gamma || !beta || !dx_ || !dgamma || !dbeta || ((uintptr_t)dyc_ & 15) || ((uintptr_t)x_ & 15) || ((uintptr_t)dx_ & 15))
+    return TMAE_EARG;
+  const int nb = bn_grid(m);
+  WsCarver ws(wsp, ws_bytes);
+  float* part = ws.take<float>((size_t)nb * 2 * c + c);
+  if (!ws.ok) return TMAE_EWS;
+  const float invm = (float)(1.0 / (double)cells);
+  if (dtype == TMAE_F32) {
+    const float *dyc = (const float*)dyc_, *x = (const float*)x_;
+    float* dx = (float*)dx_;
+    { dim3 grid(nb), block(256); BN_DISPATCH(float, bn_bwd_reduce_rows_kernel, dyc, indices, x, m, ny, nx, mean, rstd, gamma, beta, relu, part); }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, dbeta, dgamma);
+    { dim3 grid(bn_grid(cells)), block(256); BN_DISPATCH(float, bn_bwd_apply_map_kernel, dyc, rowmap, x, cells, mean, rstd, gamma, beta, relu, dbeta, dgamma, invm, dx); }
+  } else {
+    const __hip_bfloat16 *dyc = (const __hip_bfloat16*)dyc_, *x = (const __hip_bfloat16*)x_;
+    __hip_bfloat16* dx = (__hip_bfloat16*)dx_;
+    { dim3 grid(nb), block(256); BN_DISPATCH(__hip_bfloat16, bn_bwd_reduce_rows_kernel, dyc, indices, x, m, ny, nx, mean, rstd, gamma, beta, relu, part); }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, dbeta, dgamma);
+    { dim3 grid(bn_grid(cells)), block(256); BN_DISPATCH(__hip_bfloat16, bn_bwd_apply_map_kernel, dyc, rowmap, x, cells, mean, rstd, gamma, beta, relu, dbeta, dgamma, invm, dx); }
   }
   return tmae_launch_status();
 }

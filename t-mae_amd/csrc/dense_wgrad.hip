@@ -279,7 +279,15 @@ __global__ __launch_bounds__(256) void dense_wgrad_reduce_kernel(const float* __
   const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (e >= count) return;
   float4 acc = *reinterpret_cast<const float4*>(slab + e);
-  for (int s = 1; s < nsplit; ++s) {
+  int s = 1;
+  for (; s + 3 < nsplit; s += 4) {                 // four slabs in flight, summed in slab order (the rolled loop: one round trip each)
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(slab + (int64_t)(s + q) * count + e);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w; }
+  }
+  for (; s < nsplit; ++s) {
     const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)s * count + e);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }

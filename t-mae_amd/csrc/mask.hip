@@ -50,9 +50,28 @@ __global__ __launch_bounds__(MASK_THREADS) void mask_select_kernel(const float* 
     for (int i = threadIdx.x; i < 256; i += MASK_THREADS) hist[i] = 0;
     __syncthreads();
     const unsigned prefix = s_prefix;
-    for (int i = threadIdx.x; i < L; i += MASK_THREADS) {
-      const unsigned bits = __float_as_uint(noise[lo + i]);
-      if ((bits & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(bits >> shift) & 255u], 1);
+    if (pass == 3) {
+      // the top byte of uniform noise in [0, 1) is sign + 7 exponent bits: three values hold 7/8 of the elements, and 1024 threads
+      // adding to the same LDS word serialise (this pass alone took ~100 of the kernel's 160 us).  A wave counts its lanes per
+      // distinct digit with ballots first -- one atomic per (wave, digit), 1-4 rounds for such data; the loop bound is wave-uniform
+      for (int i0 = 0; i0 < L; i0 += MASK_THREADS) {
+        const int i = i0 + (int)threadIdx.x;
+        const bool in = i < L;
+        const unsigned digit = in ? (__float_as_uint(noise[lo + i]) >> 24) & 255u : 0u;
+        unsigned long long todo = __ballot(in);
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const unsigned dl = (unsigned)__shfl((int)digit, leader, 64);
+          const unsigned long long same = __ballot(in && digit == dl) & todo;
+          if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[dl], __popcll(same));
+          todo &= ~same;
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < L; i += MASK_THREADS) {
+        const unsigned bits = __float_as_uint(noise[lo + i]);
+        if ((bits & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(bits >> shift) & 255u], 1);
+      }
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -234,7 +234,28 @@ __global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict
   float s[VFE_MAXF];
 #pragma unroll
   for (int c = 0; c < VFE_MAXF; ++c) s[c] = 0.f;
-  for (int j = lo; j < hi; ++j) {            // ascending point id: deterministic sum
+  // ascending point id: deterministic sum.  Four points per round: their ids, then their rows, are loaded side by side and added
+  // in order -- the rolled loop was two dependent round trips per POINT, and the launch lasted as long as its fullest voxel
+  // (~100 points next to the sensor: 127 us for 18 MB).
+  int j = lo;
+  for (; j + 3 < hi; j += 4) {
+    int id[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) id[q] = perm[j + q];
+    float t[4][VFE_MAXF];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* p = pts + (int64_t)id[q] * row;
+#pragma unroll
+      for (int c = 0; c < VFE_MAXF; ++c) t[q][c] = c < F ? p[1 + c] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int c = 0; c < VFE_MAXF; ++c)
+        if (c < F) s[c] = add_rn(s[c], t[q][c]);
+  }
+  for (; j < hi; ++j) {
     const float* p = pts + (int64_t)perm[j] * row;
 #pragma unroll
     for (int c = 0; c < VFE_MAXF; ++c)

@@ -553,7 +553,17 @@ __global__ __launch_bounds__(64 * WG_RG) void wgrad_reduce_kernel(const float* _
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float cacc = 0.f;
   if (e < count) {
-    for (int s = w; s < splits; s += WG_RG) {
+    // four slabs in flight per wave (round 6: the rolled loop waited for every load before it issued the next -- 8 to 16 dependent
+    // round trips per wave); the sums are taken in the same order as before
+    int s = w;
+    for (; s + 3 * WG_RG < splits; s += 4 * WG_RG) {
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(slab + (int64_t)(s + q * WG_RG) * count + e);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w; }
+    }
+    for (; s < splits; s += WG_RG) {
       const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)s * count + e);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }

@@ -79,6 +79,7 @@ SIGNATURES = {
     'tmae_bn_relu_add_fwd': (I, [P, I, L, I, P, P, F, I, P, P, P, P, P, P, Z, P]),
     'tmae_bn_relu_bwd': (I, [P, P, I, L, I, P, P, P, P, I, P, P, P, P, Z, P]),
     'tmae_bn_relu_bwd2': (I, [P, P, P, I, L, I, P, P, P, P, I, P, P, P, P, Z, P]),
+    'tmae_bn_relu_bwd_gathered': (I, [P, P, P, L, P, I, I, I, I, I, P, P, P, P, I, P, P, P, P, Z, P]),
     'tmae_bn_stats': (I, [P, I, L, I, D, F, P, P, P, P, Z, P]),
     'tmae_bn_apply': (I, [P, I, L, I, P, P, P, P, I, P, P]),
     'tmae_bn_bwd_sums': (I, [P, P, I, L, I, P, P, P, P, I, P, P, P, Z, P]),
@@ -140,7 +141,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     setattr(lib, _name, _strict(_fn, _name, len(_args)))
 
-ABI_VERSION = 18            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
+ABI_VERSION = 19            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError(f'libtmae_hip.so ABI version {lib.tmae_abi_version()} != binding {ABI_VERSION}; rebuild with '
                       f't-mae_amd/build.py')

@@ -152,7 +152,10 @@ class SiamWCA_MAE(nn.Module):
         return feats
 
     # ------------------------------------------------------------------ decoder (SiamWCA_MAE.py:231-253)
-    def dense_conv(self, feats, strides):
+    def dense_conv(self, feats, strides, gather=None):
+        """gather = (rowmap, indices) of the sites whose decoder feature the caller wants (forward(): every current voxel): returns
+        (spatial, stride, rows) with rows = spatial at those sites, taken inside the last norm's autograd node
+        (ops.batch_norm_relu_gather) when that norm runs on the fused row kernels."""
         out_strides, sources = [], []
         for i, src in enumerate(self.model_cfg.FEATURES_SOURCE):
             sp = feats[src]
@@ -177,10 +180,16 @@ class SiamWCA_MAE(nn.Module):
                 and y.shape[1] in (64, 128, 256) and isinstance(self.decoder_conv_out[2], nn.ReLU)):
             # BatchNorm2d + ReLU over a channels-last tensor = the row kernels over [B*Y*X, C]
             b, c, ny, nx = y.shape
+            if gather is not None:
+                rows, picked = ops.batch_norm_relu_gather(y.permute(0, 2, 3, 1).reshape(b * ny * nx, c), bn, True, gather[0], gather[1],
+                                                          b, ny, nx)
+                return rows.view(b, ny, nx, c).permute(0, 3, 1, 2), out_strides[0], picked
             rows = ops.batch_norm_relu(y.permute(0, 2, 3, 1).reshape(b * ny * nx, c), bn, relu=True)
             spatial = rows.view(b, ny, nx, c).permute(0, 3, 1, 2)
         else:
             spatial = self.decoder_conv_out[2](bn(y))
+        if gather is not None:
+            return spatial, out_strides[0], ops.dense_gather(spatial.permute(0, 2, 3, 1), gather[0], gather[1])
         return spatial, out_strides[0]
 
     # ------------------------------------------------------------------ targets (SiamWCA_MAE.py:124-152)
@@ -216,17 +225,15 @@ class SiamWCA_MAE(nn.Module):
             self.last_stage_indices = [(feats_prev[k].indices, feats[k].indices, tuple(feats[k].spatial_shape))
                                        for k in feats]
         feats = self.sparse_cross_attn(feats, feats_prev, dtime=batch_dict.get('dt', 0))
-        spatial, spatial_stride = self.dense_conv(feats, strides)
+        all_ind = _byx(all_coords)
+        grid_all = ops.index_grid(all_ind, bs, self.sparse_shape[0], self.sparse_shape[1])
+        spatial, spatial_stride, pyramid = self.dense_conv(feats, strides, gather=(grid_all, all_ind))   # decoder feature at EVERY current voxel
         batch_dict['multi_scale_3d_features'] = feats
         batch_dict['multi_scale_3d_strides'] = strides
         batch_dict['spatial_features'] = spatial
         batch_dict['spatial_features_stride'] = spatial_stride
         assert spatial.shape[0] == bs and spatial.shape[2] == self.grid_size[1] and spatial.shape[3] == self.grid_size[0]
 
-        all_ind = _byx(all_coords)
-        grid_all = ops.index_grid(all_ind, bs, self.sparse_shape[0], self.sparse_shape[1])
-        nhwc = spatial.permute(0, 2, 3, 1)
-        pyramid = ops.dense_gather(nhwc, grid_all, all_ind)         # decoder feature at EVERY current voxel
         batch_dict.update({
             'voxel_features': pyramid, 'voxel_coords': all_coords,
             'voxel_shuffle_inds': torch.arange(all_coords.shape[0], device=all_coords.device, dtype=torch.long)})

@@ -1111,6 +1111,81 @@ def batch_norm_relu(x, bn, relu=True, groups=None, pre_bias=None, post=None, for
     return (y, split_rows(y, sizes[0])) if fork else y
 
 
+class _BNReLUGather(torch.autograd.Function):
+    """y = relu?(BatchNorm(x)) over the rows of a dense map x [cells, c] AND rows = y at m sites, one autograd node
+    (SiamWCA_MAE.py:100-115 then :303-312: the decoder's last norm, read back at the current frame's voxels).  When only `rows`
+    carries a gradient -- pre-training: nothing else reads the dense map -- the backward never builds the dense, 79 % zero dy:
+    its sums run over the m gathered rows and the apply pass picks dz through the cell -> row map (tmae_bn_relu_bwd_gathered)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, relu, rowmap, indices, batch, ny, nx):
+        x = x.contiguous()
+        cells, c = x.shape
+        assert cells == batch * ny * nx
+        y = torch.empty_like(x)
+        mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+        var, rstd = torch.empty_like(mean), torch.empty_like(mean)
+        g32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        wsb = lib.tmae_bn_workspace(cells, c)
+        ws = _ws(wsb, x.device)
+        check(lib.tmae_bn_relu_fwd(_p(x), _dt(x), cells, c, _p(g32), _p(b32), float(eps), 1 if relu else 0, _p(y), _p(mean), _p(var),
+                                   _p(rstd), _p(ws), wsb, _s()), 'tmae_bn_relu_fwd')
+        m = indices.shape[0]
+        rows = torch.empty((m, c), dtype=x.dtype, device=x.device)
+        check(lib.tmae_dense_gather(_p(y), _dt(y), batch, ny, nx, c, _p(indices), m, _p(rows), _s()), 'tmae_dense_gather')
+        ctx.save_for_backward(x, mean, rstd, g32, b32, rowmap, indices)
+        ctx.meta = (bool(relu), int(batch), int(ny), int(nx), weight.dtype, bias.dtype)
+        ctx.mark_non_differentiable(mean, var)
+        ctx.set_materialize_grads(False)
+        return y, rows, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, drows, _m, _v):
+        if dy is None and drows is None:
+            return (None,) * 10
+        x, mean, rstd, g32, b32, rowmap, indices = ctx.saved_tensors
+        relu, batch, ny, nx, wdt, bdt = ctx.meta
+        cells, c = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty((c,), dtype=torch.float32, device=x.device)
+        db = torch.empty_like(dg)
+        if dy is None:
+            drows = drows.to(x.dtype).contiguous()
+            wsb = lib.tmae_bn_workspace(drows.shape[0], c)
+            ws = _ws(wsb, x.device)
+            check(lib.tmae_bn_relu_bwd_gathered(_p(drows), _p(indices), _p(rowmap), drows.shape[0], _p(x), _dt(x), batch, ny, nx, c,
+                                                _p(mean), _p(rstd), _p(g32), _p(b32), 1 if relu else 0, _p(dx), _p(dg), _p(db),
+                                                _p(ws), wsb, _s()), 'tmae_bn_relu_bwd_gathered')
+        else:                                        # the dense map has a reader of its own: the plain backward on the sum
+            dy = dy.to(x.dtype).contiguous()
+            if drows is not None:
+                sc = torch.empty_like(x)
+                check(lib.tmae_sparse_to_dense(_p(drows.to(x.dtype).contiguous()), _dt(x), drows.shape[0], c, _p(rowmap), batch, ny, nx,
+                                               _p(sc), _s()), 'tmae_sparse_to_dense')
+                dy = dy + sc
+            wsb = lib.tmae_bn_workspace(cells, c)
+            ws = _ws(wsb, x.device)
+            check(lib.tmae_bn_relu_bwd(_p(dy), _p(x), _dt(x), cells, c, _p(mean), _p(rstd), _p(g32), _p(b32), 1 if relu else 0,
+                                       _p(dx), _p(dg), _p(db), _p(ws), wsb, _s()), 'tmae_bn_relu_bwd')
+        return dx, dg.to(wdt), db.to(bdt), None, None, None, None, None, None, None
+
+
+def batch_norm_relu_gather(x_rows, bn, relu, rowmap, indices, batch, ny, nx):
+    """(y, rows): ops.batch_norm_relu over the rows of a dense map [batch * ny * nx, c] and ops.dense_gather of the result at
+    `indices` ([m, 3] int32 unique sites; rowmap = ops.index_grid(indices, ...)), as one autograd node (_BNReLUGather).  Falls
+    back to the two ops where the fused kernels do not apply."""
+    cells, c = x_rows.shape
+    ok = (x_rows.is_cuda and bn.training and c in (64, 128, 256) and cells > 1 and _sync_group(bn) is None
+          and x_rows.dtype in (torch.float32, torch.bfloat16) and indices.shape[0] > 0)
+    if not ok:
+        y = batch_norm_relu(x_rows, bn, relu=relu)
+        return y, dense_gather(y.view(batch, ny, nx, c), rowmap, indices)
+    y, rows, mean, var = _BNReLUGather.apply(x_rows, bn.weight, bn.bias, bn.eps, relu, rowmap, indices, batch, ny, nx)
+    if bn.track_running_stats:
+        _bn_running_update(bn, mean, var, float(cells))
+    return y, rows
+
+
 class _SplitRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, m0):

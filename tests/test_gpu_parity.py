@@ -965,6 +965,51 @@ def test_add_layernorm_residual_options_vs_torch():
                 assert float((got[2] * (1 - keep.float())).abs().max()) == 0.0        # masked rows of b get no gradient
 
 
+def test_batchnorm_gather_backward_without_the_dense_gradient():
+    """ops.batch_norm_relu_gather (the decoder's last norm + the gather at the current frame's voxels as one node,
+    tmae_bn_relu_bwd_gathered) against ops.batch_norm_relu followed by ops.dense_gather: same outputs bit for bit; dx / dgamma /
+    dbeta equal whether the gradient arrives at the gathered rows only (the pre-training step), at the dense map too, or at the
+    dense map alone."""
+    from tmae_amd import ops
+    torch.manual_seed(6)
+    B, ny, nx = 2, 37, 53
+    for c, dt, tol in ((128, torch.float32, 2e-5), (128, torch.bfloat16, 2e-2), (64, torch.bfloat16, 2e-2)):
+        cells = B * ny * nx
+        x0 = (torch.randn(cells, c, device=dev()) * 1.4 - 0.3).to(dt)
+        pick = torch.randperm(cells, device=dev())[:cells // 5].sort().values
+        ind = torch.stack([pick // (ny * nx), (pick // nx) % ny, pick % nx], 1).int().contiguous()
+        rowmap = ops.index_grid(ind, B, ny, nx)
+        g_rows = torch.randn(ind.shape[0], c, device=dev()).to(dt)
+        g_map = torch.randn(cells, c, device=dev()).to(dt)
+        for use_rows, use_map in ((True, False), (True, True), (False, True)):
+            res = []
+            for fused in (True, False):
+                bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev())
+                with torch.no_grad():
+                    bn.weight.fill_(0.9), bn.bias.fill_(0.05)
+                x = x0.clone().requires_grad_(True)
+                if fused:
+                    y, rows = ops.batch_norm_relu_gather(x, bn, True, rowmap, ind, B, ny, nx)
+                else:
+                    y = ops.batch_norm_relu(x, bn, relu=True)
+                    rows = ops.dense_gather(y.view(B, ny, nx, c), rowmap, ind)
+                outs, gs = [], []
+                if use_rows:
+                    outs.append(rows), gs.append(g_rows)
+                if use_map:
+                    outs.append(y), gs.append(g_map)
+                torch.autograd.backward(outs, gs)
+                res.append((y.detach().float(), rows.detach().float(), x.grad.float(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                            bn.running_mean.clone(), bn.running_var.clone()))
+            a, b = res
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+            assert torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])
+            sc = max(1.0, float(b[2].abs().max()))
+            assert (a[2] - b[2]).abs().max().item() <= tol * sc, (c, dt, use_rows, use_map, (a[2] - b[2]).abs().max().item())
+            for k in (3, 4):
+                assert (a[k] - b[k]).abs().max().item() <= max(tol, 2e-3) * max(1.0, float(b[k].abs().max())), (c, dt, k)
+
+
 def test_ffn_residual_out_of_the_gemm_vs_added_in_the_norm():
     """_EncoderTail with `src + linear2(act)` written by linear2's GEMM (tmae_token_gemm_res, the default) against the same tail
     with the sum taken inside norm2 from two tensors (TMAE_FFN_RESIDUAL=add): the fused form rounds the residual
