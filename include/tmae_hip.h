@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 19
+#define TMAE_ABI_VERSION 22
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -254,6 +254,14 @@ int tmae_dense_conv3x3_dilated(const void* in, int batch, int ny, int nx, int ci
  * arrives through its shortcut (autograd's gradient accumulation at `out` in sst_bev_backbone.py:35-41), one rounding. */
 int tmae_dense_conv3x3_add(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, int dilation,
                            const void* post, void* out, void* stream);
+/* The decoder conv's two heavy launches with the column sums of their output taken in the epilogue (sums of the bf16 values the
+ * kernel stores; fixed summation order): moments = 1 (cin 128, cout 384: the input gradient of the conv, summed by the BatchNorm
+ * backward of the three deconvolutions in front of it, SiamWCA_MAE.py:85-99) -> sums [cout]; moments = 2 (cin 384, cout 128: the
+ * forward, SiamWCA_MAE.py:100-115, whose BatchNorm2d needs mean and variance) -> sums [2][cout] = sum, sum of squares.  post:
+ * optional residual operand as in tmae_dense_conv3x3_add.  Any other shape: TMAE_EARG. */
+size_t tmae_dense_conv3x3_sums_workspace(int cout);
+int tmae_dense_conv3x3_sums(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, const void* post,
+                            int moments, void* out, float* sums, void* ws, size_t ws_bytes, void* stream);
 /* Weight gradient of that convolution (SiamWCA_MAE.py:100-115, sst_bev_backbone.py:20-30; torch's conv2d weight gradient in
  * the reference): dw [cout, 9*cin] fp32 (the weight's layout) from dy [batch, ny, nx, cout] and x [batch, ny, nx, cin], bf16,
  * contiguous.  Halo-tiled like the forward (the nine shifted copies of x are read out of one staged image), fixed-order
@@ -415,6 +423,11 @@ int tmae_bn_apply(const void* x, int dtype, int64_t m, int c, const float* mean,
 int tmae_bn_bwd_sums(const void* dy, const void* x, int dtype, int64_t m, int c, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, int relu, float* sum_dz, float* sum_dz_xhat, void* ws,
                      size_t ws_bytes, void* stream);
+/* The same pass with a third total, sum_dy [c] = the column sums of dy before the ReLU mask (what tmae_deblock_bn_tail needs to
+ * price the inactive cells of a dense map; it was a separate tmae_column_sums pass over dy).  Workspace: 2 x tmae_bn_workspace(m, c). */
+int tmae_bn_bwd_sums3(const void* dy, const void* x, int dtype, int64_t m, int c, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, int relu, float* sum_dy, float* sum_dz, float* sum_dz_xhat,
+                      void* ws, size_t ws_bytes, void* stream);
 int tmae_bn_bwd_apply(const void* dy, const void* x, int dtype, int64_t m, int c, const float* mean,
                       const float* rstd, const float* gamma, const float* beta, int relu, const float* dbeta,
                       const float* dgamma, double count, void* dx, void* stream);
@@ -442,6 +455,17 @@ int tmae_column_sums(const void* x, int dtype, int64_t rows, int c, float* out, 
 int tmae_deblock_bn_tail(const float* mean, const float* rstd, const float* gamma, const float* beta, const float* s_all,
                          const float* s_act, const float* sum_dz, const float* sum_dzx, int c, float* dbeta, float* dgamma,
                          void* stream);
+/* The whole BatchNorm backward of one source of the fused decoder head (the backward of tmae_deblock_scatter up to the
+ * deconvolution's rows), reading the source's gradient rows IN PLACE from the gradient of the concat buffer: v [m s^2, cout] the
+ * deconvolution's rows at the m active voxels indices [m, 3], dcat [batch, ys s, xs s, ldc] (this source at channel offset coff),
+ * s_all [cout] the column sums of dcat over all cells for these channels, count = batch * ys s * xs s.  Outputs dv [m s^2, cout]
+ * (gradient of v), dgamma, dbeta.  s in {1, 2, 4}, cout in {64, 128, 256}.  Replaces tmae_deblock_gather + tmae_column_sums +
+ * tmae_bn_bwd_sums + tmae_deblock_bn_tail + tmae_bn_bwd_apply.  ws: tmae_deblock_bn_bwd_workspace(m, s, cout). */
+size_t tmae_deblock_bn_bwd_workspace(int64_t m, int s, int cout);
+int tmae_deblock_bn_bwd(const void* dcat, int dtype, int64_t ldc, int coff, const int32_t* indices, int64_t m, int ys, int xs, int s,
+                        int cout, const void* v, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        const float* s_all, double count, void* dv, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                        void* stream);
 
 /* bf16 copies of fp32 parameter matrices after the optimizer step (what autocast reads: torch casts a weight on every
  * use; the dX GEMMs of the token-list Linears additionally want W^T): ONE launch for a list of matrices.

@@ -230,6 +230,97 @@ __global__ __launch_bounds__(16 * BN_FIN_RL) void bn_bwd_finalize_kernel(const f
   }
 }
 
+// The same two sums plus the UNMASKED column sum of dy (the fused decoder head's BatchNorm backward, csrc/deblock.hip, needs it to
+// price the inactive cells: tmae_deblock_bn_tail) in one pass over dy and x -- it used to be a separate tmae_column_sums pass
+// over dy (three launches of 82 us per step).  part [grid][3][C] (+ unused pivot row).
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce3_kernel(const T* __restrict__ dy, const T* __restrict__ x, int64_t m,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            int relu, float* __restrict__ part) {
+  BN_LAYOUT;
+  __shared__ float red[4][3][C];
+  float mu[8], rs[8], g[8], bt[8], s0[8], s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ch = cl * 8 + i;
+    mu[i] = mean[ch]; rs[i] = rstd[ch]; g[i] = gamma[ch]; bt[i] = beta[ch];
+    s0[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f;
+  }
+  for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
+    float v[2][8], d[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub, rc = r < m ? r : m - 1;
+      load8<T>(x + rc * C + cl * 8, v[u]);                        // unconditional (clamped), masked below
+      load8<T>(dy + rc * C + cl * 8, d[u]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[u][i] = r < m ? d[u][i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (v[u][i] - mu[i]) * rs[i];
+        const float dz = (relu && !(xh * g[i] + bt[i] > 0.f)) ? 0.f : d[u][i];
+        s0[i] += d[u][i];
+        s1[i] += dz;
+        s2[i] += dz * xh;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s0[i] = cross_group_sum<LPR>(s0[i]); s1[i] = cross_group_sum<LPR>(s1[i]); s2[i] = cross_group_sum<LPR>(s2[i]); }
+  if (sub == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[w][0][cl * 8 + i] = s0[i]; red[w][1][cl * 8 + i] = s1[i]; red[w][2][cl * 8 + i] = s2[i]; }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 3 * C; e += 256) {
+    const int which = e / C, c = e % C;
+    part[(int64_t)blockIdx.x * 3 * C + e] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+  }
+}
+
+// the three totals from part [nblocks][3][c]: double accumulation in a fixed order, 16 channels x 64 partial rows per workgroup
+__global__ __launch_bounds__(16 * BN_FIN_RL) void bn_bwd_finalize3_kernel(const float* __restrict__ part, int nblocks, int c,
+                                                                         float* __restrict__ sum_dy, float* __restrict__ dbeta,
+                                                                         float* __restrict__ dgamma) {
+  __shared__ double red[BN_FIN_RL][17][3];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double a[3] = {0.0, 0.0, 0.0};
+  if (ch < c) {
+    int k = rl;
+    for (; k + 3 * BN_FIN_RL < nblocks; k += 4 * BN_FIN_RL) {
+      float u[4][3];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) u[q][t] = part[((int64_t)(k + q * BN_FIN_RL) * 3 + t) * c + ch];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a[t] += u[q][t];
+    }
+    for (; k < nblocks; k += BN_FIN_RL)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) a[t] += part[((int64_t)k * 3 + t) * c + ch];
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) red[rl][cl][t] = a[t];
+  __syncthreads();
+  if (rl == 0 && ch < c) {
+    double s[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < BN_FIN_RL; ++r)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) s[t] += red[r][cl][t];
+    sum_dy[ch] = (float)s[0];
+    dbeta[ch] = (float)s[1];
+    dgamma[ch] = (float)s[2];
+  }
+}
+
 // dx = gamma * rstd * (dz - dbeta/m - xhat * dgamma/m)
 template <class T, int VEC, bool TWO = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
@@ -559,6 +650,32 @@ int tmae_bn_bwd_sums(const void* dy_, const void* x_, int dtype, int64_t m, int 
   return tmae_launch_status();
 }
 
+// tmae_bn_bwd_sums plus sum_dy [c] = the unmasked column sums of dy, in the same pass (workspace: 3/2 of tmae_bn_workspace: the
+// caller passes tmae_bn_workspace(m, c) * 2)
+int tmae_bn_bwd_sums3(const void* dy_, const void* x_, int dtype, int64_t m, int c, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, int relu, float* sum_dy, float* sum_dz, float* sum_dz_xhat, void* wsp,
+                      size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!bn_args_ok(m, c, dtype) || !dy_ || !x_ || !mean || !rstd || !gamma || !beta || !sum_dy || !sum_dz || !sum_dz_xhat)
+    return TMAE_EARG;
+  const int nb = bn_grid(m);
+  WsCarver ws(wsp, ws_bytes);
+  float* part = ws.take<float>((size_t)nb * 3 * c + c);
+  if (!ws.ok) return TMAE_EWS;
+  dim3 grid(nb), block(256);
+  if (dtype == TMAE_F32) {
+    const float *dy = (const float*)dy_, *x = (const float*)x_;
+    BN_DISPATCH(float, bn_bwd_reduce3_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
+  } else {
+    const __hip_bfloat16 *dy = (const __hip_bfloat16*)dy_, *x = (const __hip_bfloat16*)x_;
+    BN_DISPATCH(__hip_bfloat16, bn_bwd_reduce3_kernel, dy, x, m, mean, rstd, gamma, beta, relu, part);
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize3_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, sum_dy, sum_dz,
+                     sum_dz_xhat);
+  return tmae_launch_status();
+}
+
 int tmae_bn_bwd_apply(const void* dy_, const void* x_, int dtype, int64_t m, int c, const float* mean,
                       const float* rstd, const float* gamma, const float* beta, int relu, const float* dbeta,
                       const float* dgamma, double count, void* dx_, void* stream_) {
@@ -611,6 +728,164 @@ int tmae_bn_relu_bwd_gathered(const void* dyc_, const int32_t* indices, const in
     { dim3 grid(nb), block(256); BN_DISPATCH(__hip_bfloat16, bn_bwd_reduce_rows_kernel, dyc, indices, x, m, ny, nx, mean, rstd, gamma, beta, relu, part); }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, dbeta, dgamma);
     { dim3 grid(bn_grid(cells)), block(256); BN_DISPATCH(__hip_bfloat16, bn_bwd_apply_map_kernel, dyc, rowmap, x, cells, mean, rstd, gamma, beta, relu, dbeta, dgamma, invm, dx); }
+  }
+  return tmae_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward of one deconvolution of the fused decoder head (csrc/deblock.hip) with its gradient rows read IN PLACE from
+// the dense concat gradient: row R = (active voxel j, sub-cell q of its s x s block) of v [m s^2, c] corresponds to the c channels
+// at offset coff of cell ((b ys + y) s + q / s, x s + q % s) of dcat [B, ys s, xs s, ldc].  Rounds 1-5 gathered those rows into a
+// tensor g first (tmae_deblock_gather: 353 MB written for the stride-4 source, then read by two passes).
+// ------------------------------------------------------------------------------------------------
+struct DbRows {
+  const int32_t* ind;       // [m, 3] (b, y, x) of the active voxels
+  int ys, xs, s, ls2;       // source grid, stride, log2(s * s)
+  int64_t ldc;              // row pitch of dcat in elements
+  __device__ __forceinline__ int64_t off(int64_t row) const {        // element offset of row's first channel (without coff)
+    const int64_t j = row >> ls2;
+    const int q = (int)(row & ((1 << ls2) - 1));
+    const int b = ind[j * 3], y = ind[j * 3 + 1], x = ind[j * 3 + 2];
+    const int64_t cell = ((int64_t)b * ys * s + (int64_t)y * s + q / s) * ((int64_t)xs * s) + (int64_t)x * s + q % s;
+    return cell * ldc;
+  }
+};
+
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void db_bwd_reduce3_kernel(const T* __restrict__ dcat, DbRows map, const T* __restrict__ x, int64_t m,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ part) {
+  BN_LAYOUT;
+  __shared__ float red[4][3][C];
+  float mu[8], rs[8], g[8], bt[8], s0[8], s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ch = cl * 8 + i;
+    mu[i] = mean[ch]; rs[i] = rstd[ch]; g[i] = gamma[ch]; bt[i] = beta[ch];
+    s0[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f;
+  }
+  for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
+    float v[2][8], d[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub, rc = r < m ? r : m - 1;
+      load8<T>(x + rc * C + cl * 8, v[u]);                        // unconditional (clamped), masked below
+      load8<T>(dcat + map.off(rc) + cl * 8, d[u]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[u][i] = r < m ? d[u][i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (v[u][i] - mu[i]) * rs[i];
+        const float dz = !(xh * g[i] + bt[i] > 0.f) ? 0.f : d[u][i];
+        s0[i] += d[u][i];
+        s1[i] += dz;
+        s2[i] += dz * xh;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s0[i] = cross_group_sum<LPR>(s0[i]); s1[i] = cross_group_sum<LPR>(s1[i]); s2[i] = cross_group_sum<LPR>(s2[i]); }
+  if (sub == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[w][0][cl * 8 + i] = s0[i]; red[w][1][cl * 8 + i] = s1[i]; red[w][2][cl * 8 + i] = s2[i]; }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 3 * C; e += 256) {
+    const int which = e / C, c = e % C;
+    part[(int64_t)blockIdx.x * 3 * C + e] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+  }
+}
+
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void db_bwd_apply_kernel(const T* __restrict__ dcat, DbRows map, const T* __restrict__ x, int64_t m,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                                                          float invm, T* __restrict__ dx) {
+  BN_LAYOUT;
+  float mu[8], rs[8], g[8], bt[8], a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ch = cl * 8 + i;
+    mu[i] = mean[ch]; rs[i] = rstd[ch]; g[i] = gamma[ch]; bt[i] = beta[ch];
+    a[i] = dbeta[ch] * invm; b[i] = dgamma[ch] * invm;
+  }
+  for (int64_t r0 = wave * (2 * RPW); r0 < m; r0 += nwaves * (2 * RPW)) {
+    float v[2][8], d[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub, rc = r < m ? r : m - 1;
+      load8<T>(x + rc * C + cl * 8, v[u]);                        // unconditional (clamped): four loads in flight
+      load8<T>(dcat + map.off(rc) + cl * 8, d[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t r = r0 + u * RPW + sub;
+      if (r < m) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float xh = (v[u][i] - mu[i]) * rs[i];
+          const float dz = !(xh * g[i] + bt[i] > 0.f) ? 0.f : d[u][i];
+          d[u][i] = g[i] * rs[i] * (dz - a[i] - xh * b[i]);
+        }
+        store8<T>(dx + r * C + cl * 8, d[u]);
+      }
+    }
+  }
+}
+
+extern "C" int tmae_deblock_bn_tail(const float* mean, const float* rstd, const float* gamma, const float* beta, const float* s_all,
+                                    const float* s_act, const float* sum_dz, const float* sum_dzx, int c, float* dbeta, float* dgamma,
+                                    void* stream_);
+
+size_t tmae_deblock_bn_bwd_workspace(int64_t m, int s, int cout) {
+  return ((size_t)bn_grid(m * s * s) * 3 * cout + 4 * (size_t)cout) * 4 + 512;
+}
+
+// dv [m s^2, cout], dgamma, dbeta of relu(BatchNorm2d(deconv)) for one source of the fused decoder head (tmae_deblock_scatter's
+// backward): v [m s^2, cout] = the deconvolution's rows at the m active voxels (indices [m, 3] int32), dcat [batch, ys s, xs s, ldc]
+// the gradient of the concat buffer (this source's channels at coff), s_all [cout] its column sums over ALL cells (tmae_column_sums,
+// or the producing conv's epilogue), count = batch * ys s * xs s.  One pass for the three sums, the inactive cells' share
+// (tmae_deblock_bn_tail), one pass for dv; s in {1, 2, 4}.
+int tmae_deblock_bn_bwd(const void* dcat_, int dtype, int64_t ldc, int coff, const int32_t* indices, int64_t m, int ys, int xs, int s,
+                        int cout, const void* v_, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        const float* s_all, double count, void* dv_, float* dgamma, float* dbeta, void* wsp, size_t ws_bytes,
+                        void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  const int c = cout;
+  const int64_t rows = m * s * s;
+  if (!bn_args_ok(rows, c, dtype) || (s != 1 && s != 2 && s != 4) || ys <= 0 || xs <= 0 || ldc < coff + cout || (ldc % 8) || (coff % 8) ||
+      !dcat_ || !indices || !v_ || !mean || !rstd || !gamma || !beta || !s_all || !dv_ || !dgamma || !dbeta || count < 1.0 ||
+      ((uintptr_t)dcat_ & 15) || ((uintptr_t)v_ & 15) || ((uintptr_t)dv_ & 15))
+    return TMAE_EARG;
+  const int nb = bn_grid(rows);
+  WsCarver ws(wsp, ws_bytes);
+  float* part = ws.take<float>((size_t)nb * 3 * c);
+  float* sums = ws.take<float>((size_t)3 * c);          // s_act | sum_dz | sum_dz_xhat
+  if (!ws.ok) return TMAE_EWS;
+  DbRows map{indices, ys, xs, s, s == 1 ? 0 : (s == 2 ? 2 : 4), ldc};
+  const float invm = (float)(1.0 / count);
+  dim3 grid(nb), block(256);
+  if (dtype == TMAE_F32) {
+    const float *dcat = (const float*)dcat_ + coff, *x = (const float*)v_;
+    BN_DISPATCH(float, db_bwd_reduce3_kernel, dcat, map, x, rows, mean, rstd, gamma, beta, part);
+  } else {
+    const __hip_bfloat16 *dcat = (const __hip_bfloat16*)dcat_ + coff, *x = (const __hip_bfloat16*)v_;
+    BN_DISPATCH(__hip_bfloat16, db_bwd_reduce3_kernel, dcat, map, x, rows, mean, rstd, gamma, beta, part);
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize3_kernel, dim3(tmae_cdiv(c, 16)), dim3(16 * BN_FIN_RL), 0, stream, part, nb, c, sums, sums + c,
+                     sums + 2 * c);
+  if (int e = tmae_deblock_bn_tail(mean, rstd, gamma, beta, s_all, sums, sums + c, sums + 2 * c, c, dbeta, dgamma, stream_)) return e;
+  if (dtype == TMAE_F32) {
+    const float *dcat = (const float*)dcat_ + coff, *x = (const float*)v_;
+    BN_DISPATCH(float, db_bwd_apply_kernel, dcat, map, x, rows, mean, rstd, gamma, beta, dbeta, dgamma, invm, (float*)dv_);
+  } else {
+    const __hip_bfloat16 *dcat = (const __hip_bfloat16*)dcat_ + coff, *x = (const __hip_bfloat16*)v_;
+    BN_DISPATCH(__hip_bfloat16, db_bwd_apply_kernel, dcat, map, x, rows, mean, rstd, gamma, beta, dbeta, dgamma, invm, (__hip_bfloat16*)dv_);
   }
   return tmae_launch_status();
 }

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(MASK_THREADS) void mask_select_kernel(const float* 
   __shared__ int hist[256];
   __shared__ int wtot[16];
   __shared__ unsigned s_prefix;
-  __shared__ int s_k;
+  __shared__ int s_k, s_neq;
   const int b = blockIdx.x;
   const int lo = sample_offsets[b], hi = sample_offsets[b + 1];
   const int L = hi - lo;
@@ -44,27 +44,45 @@ __global__ __launch_bounds__(MASK_THREADS) void mask_select_kernel(const float* 
     return;
   }
   if (threadIdx.x == 0) { s_prefix = 0u; s_k = len_keep; }
+  // One workgroup per sample = 16 waves on one CU: every pass over the sample's noise used to be ~46 dependent load -> LDS-atomic
+  // round trips per thread (5 passes x ~35 us for 190 KB that sit in L2; round 6).  Samples of up to MASK_REGS x 1024 voxels are
+  // read ONCE, all loads in flight together, and the four digit passes run on registers.
+  constexpr int MASK_REGS = 64;
+  const bool in_regs = L <= MASK_REGS * MASK_THREADS;                    // workgroup-uniform
+  unsigned vals[MASK_REGS];
+  if (in_regs) {
+#pragma unroll
+    for (int q = 0; q < MASK_REGS; ++q) {
+      const int i = q * MASK_THREADS + (int)threadIdx.x;
+      vals[q] = (q * MASK_THREADS < L) ? __float_as_uint(noise[lo + min(i, L - 1)]) : 0u;
+    }
+  }
   for (int pass = 3; pass >= 0; --pass) {
     const int shift = pass * 8;
     const unsigned hi_mask = (pass == 3) ? 0u : (0xFFFFFFFFu << (shift + 8));
     for (int i = threadIdx.x; i < 256; i += MASK_THREADS) hist[i] = 0;
     __syncthreads();
     const unsigned prefix = s_prefix;
-    if (pass == 3) {
-      // the top byte of uniform noise in [0, 1) is sign + 7 exponent bits: three values hold 7/8 of the elements, and 1024 threads
-      // adding to the same LDS word serialise (this pass alone took ~100 of the kernel's 160 us).  A wave counts its lanes per
-      // distinct digit with ballots first -- one atomic per (wave, digit), 1-4 rounds for such data; the loop bound is wave-uniform
-      for (int i0 = 0; i0 < L; i0 += MASK_THREADS) {
-        const int i = i0 + (int)threadIdx.x;
-        const bool in = i < L;
-        const unsigned digit = in ? (__float_as_uint(noise[lo + i]) >> 24) & 255u : 0u;
-        unsigned long long todo = __ballot(in);
-        while (todo) {
-          const int leader = __ffsll((long long)todo) - 1;
-          const unsigned dl = (unsigned)__shfl((int)digit, leader, 64);
-          const unsigned long long same = __ballot(in && digit == dl) & todo;
-          if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[dl], __popcll(same));
-          todo &= ~same;
+    if (in_regs) {
+#pragma unroll
+      for (int q = 0; q < MASK_REGS; ++q) {
+        if (q * MASK_THREADS < L) {                                      // workgroup-uniform
+          const bool in = q * MASK_THREADS + (int)threadIdx.x < L && (vals[q] & hi_mask) == (prefix & hi_mask);
+          const unsigned digit = (vals[q] >> shift) & 255u;
+          if (pass == 3) {
+            // the top byte of uniform noise in [0, 1) is sign + 7 exponent bits: three values hold 7/8 of the elements -- a wave
+            // counts its lanes per distinct digit with ballots and adds once per (wave, digit)
+            unsigned long long todo = __ballot(in);
+            while (todo) {
+              const int leader = __ffsll((long long)todo) - 1;
+              const unsigned dl = (unsigned)__shfl((int)digit, leader, 64);
+              const unsigned long long same = __ballot(in && digit == dl) & todo;
+              if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[dl], __popcll(same));
+              todo &= ~same;
+            }
+          } else if (in) {
+            atomicAdd(&hist[digit], 1);
+          }
         }
       }
     } else {
@@ -81,12 +99,27 @@ __global__ __launch_bounds__(MASK_THREADS) void mask_select_kernel(const float* 
         cum += hist[d];
       }
       s_k = k - cum;
+      s_neq = hist[d];                 // after the last pass: how many elements equal the threshold value
       s_prefix = prefix | ((unsigned)d << shift);
     }
     __syncthreads();
   }
   const unsigned kth = s_prefix;   // bits of the len_keep-th smallest value
   const int k_eq = s_k;            // how many elements equal to it are kept (lowest indices first)
+  if (in_regs && k_eq == s_neq) {
+    // every element that equals the threshold is kept (with float noise: there is exactly one) -- no tie ranks: coalesced
+    // stores from the registers.  (The ranked path below walks a contiguous chunk per thread: 64 cache lines per wave-load.)
+#pragma unroll
+    for (int q = 0; q < MASK_REGS; ++q) {
+      const int i = q * MASK_THREADS + (int)threadIdx.x;
+      if (q * MASK_THREADS < L && i < L) {
+        const bool keep = vals[q] <= kth;
+        mask[lo + i] = keep ? 0.f : 1.f;
+        keepflag[lo + i] = keep ? 1 : 0;
+      }
+    }
+    return;
+  }
   // contiguous chunk per thread keeps index order for the tie ranks
   const int chunk = (L + MASK_THREADS - 1) / MASK_THREADS;
   const int c0 = min((int)threadIdx.x * chunk, L), c1 = min(c0 + chunk, L);

@@ -593,15 +593,85 @@ int tmae_spconv_bwd_data(const void* dout, int64_t lddo, int64_t m_out, int cout
 // ------------------------------------------------------------------------------------------------
 // DIL = dilation (1: 18 x 18 halo = 41 pieces of 8 rows, 41 KB per image; 2 -- the third conv of SSTBEVBackbone,
 // sst_bev_backbone.py:20-30 with t_mae.yaml:107-112 -- 20 x 20 = 50 pieces, 50 KB: 2 images + 3 weight slots = 149 KB).
+// sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane
+__device__ __forceinline__ float ig_row16_sum(float v) {
+#define IG_ROR(n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xF, 0xF, false))
+  v += IG_ROR(8);
+  v += IG_ROR(4);
+  v += IG_ROR(2);
+  v += IG_ROR(1);
+#undef IG_ROR
+  return v;
+}
+
+// Reduce-scatter of 16 per-lane values over the 16 lanes of a DPP row: returns, in lane i, the sum over the row's lanes of a[i].
+// Steps s = 1, 2, 4, 8: a lane keeps the values whose index agrees with its own lane id in bit s and adds what lane i + s (row
+// rotation: same low bits, bit s flipped) holds for them -- every (lane, value) term is counted once; 15 selects-and-adds.
+__device__ __forceinline__ float ig_row16_scatter_sum(const float* a, int i) {
+  float v8[8], v4[4], v2[2];
+#define IG_RS(dst, lo, hi, S)                                                                                   \
+  {                                                                                                             \
+    const bool up_ = (i & (S)) != 0;                                                                            \
+    const float keep_ = up_ ? (hi) : (lo), send_ = up_ ? (lo) : (hi);                                           \
+    dst = keep_ + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send_), 0x120 + (S), 0xF, 0xF, false)); \
+  }
+  // (row_ror:S reads lane (i + S) mod 16 of the row.)  value index j = 8 b3 + 4 b2 + 2 b1 + b0; step 1 pairs (j, j ^ 1) ...
+#pragma unroll
+  for (int q = 0; q < 8; ++q) IG_RS(v8[q], a[2 * q], a[2 * q + 1], 1)        // v8[q]: index bits 3..1 = q, bit 0 = lane's
+#pragma unroll
+  for (int q = 0; q < 4; ++q) IG_RS(v4[q], v8[2 * q], v8[2 * q + 1], 2)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) IG_RS(v2[q], v4[2 * q], v4[2 * q + 1], 4)
+  float r;
+  IG_RS(r, v2[0], v2[1], 8)
+#undef IG_RS
+  return r;
+}
+
+// out[c] = sum over the `rows` (block, wave) rows of part [rows][ncol], in a fixed order: 16 columns x 64 row lanes per workgroup,
+// four loads in flight per thread, double accumulation (the 2 048 x 384 partials of a launch: ~5 us)
+__global__ __launch_bounds__(1024) void dense_colsum_finish_kernel(const float* __restrict__ part, int rows, int ncol,
+                                                                  float* __restrict__ out) {
+  __shared__ double red[64][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double acc = 0.0;
+  if (c < ncol) {
+    int r = rl;
+    for (; r + 3 * 64 < rows; r += 4 * 64) {
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = part[(int64_t)(r + q * 64) * ncol + c];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc += (double)v[q];
+    }
+    for (; r < rows; r += 64) acc += (double)part[(int64_t)r * ncol + c];
+  }
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < ncol) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) t += red[q][cl];
+    out[c] = (float)t;
+  }
+}
+
 template <int DIL> struct HaloGeom {
   static constexpr int HW = 16 + 2 * DIL, NH = HW * HW, NP = (NH + 7) / 8, ABYTES = NP * 8 * 128, PQ = (NP + 7) / 8;
 };
 
-template <int CIN, int DIL = 1>
+// CS (round 6): the kernel also leaves, per wave, the COLUMN SUMS of what it stored (the bf16-rounded outputs; CS = 2: and of their
+// squares) in cs_part [blocks][8 waves][CS][cout] -- the decoder conv's input gradient is column-summed by the BatchNorm backward
+// of the three deconvolutions in front of it (a 1.35 GB pass over [cells, 384]: tmae_column_sums), and its forward output by the
+// statistics pass of the norm behind it (448 MB).  The sums ride in an LDS row per wave (every wave owns its row: no atomics, fixed
+// order); dense_colsum_finish_kernel adds the rows up in a fixed order.
+template <int CIN, int DIL = 1, int CS = 0>
 __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_bfloat16* __restrict__ in, int B, int Y,
                                                                    int X, const __hip_bfloat16* __restrict__ W, int cout,
                                                                    __hip_bfloat16* __restrict__ out, int nunits,
-                                                                   const __hip_bfloat16* __restrict__ post) {
+                                                                   const __hip_bfloat16* __restrict__ post,
+                                                                   float* __restrict__ cs_part) {
   // post (optional, the shape of out): out = conv + post -- the gradient that reaches a residual block's input through its
   // shortcut, added where the input gradient of its conv is in registers (sst_bev_backbone.py:35-41 backwards)
   constexpr int KC = CIN / 64;
@@ -611,6 +681,7 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   constexpr int BRING = 2 * HC_ABYTES;                 // 2 halo images (channel slices kc, kc+1), then 3 weight slots of 16 KB
   constexpr int SCRATCH = BRING + 3 * (IG_BN * 128);   // 1 KB sink of the dummy transfers
+  constexpr int CSOFF = SCRATCH + 1024;                // CS: [8 waves][CS][cout] floats
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, i = lane & 15;
   // ALLCT (cin = 128: the two halo images hold the WHOLE input of the tile): one unit of work = a cell block with ALL its column
   // tiles -- the halo is fetched once instead of once per column tile (the decoder conv's input gradient, 128 -> 384: 1.50 ->
@@ -655,6 +726,10 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
   }
   int unit = blockIdx.x;
   if (unit >= nunits) return;
+  float* colacc = reinterpret_cast<float*>(lds + CSOFF) + (CS ? w * CS * cout : 0);      // this wave's row(s)
+  if constexpr (CS > 0) {
+    for (int c = lane; c < CS * cout; c += 64) colacc[c] = 0.f;
+  }
   decode(unit);
   halo_sources();
 #pragma unroll
@@ -784,6 +859,13 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
         wk[1] = wnx[1];
       }
       const int n0 = (ALLCT ? cti : uct) * IG_BN;
+      float cs1[4][4], cs2[CS == 2 ? 4 : 1][4];
+      if constexpr (CS > 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { cs1[nt][r] = 0.f; if constexpr (CS == 2) cs2[nt][r] = 0.f; }
+      }
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int y = uy0 + 4 * wm + mt, x = ux0 + i;
@@ -811,10 +893,32 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
             v[2] = ig_bf16_bits(acc[2 * h + 1][mt][0]) | (ig_bf16_bits(acc[2 * h + 1][mt][1]) << 16);
             v[3] = ig_bf16_bits(acc[2 * h + 1][mt][2]) | (ig_bf16_bits(acc[2 * h + 1][mt][3]) << 16);
             *reinterpret_cast<u32x4*>(p + 32 * h) = v;
+            if constexpr (CS > 0) {                              // sums of the STORED (bf16-rounded) values
+#pragma unroll
+              for (int q2 = 0; q2 < 2; ++q2) {
+                const float f0 = __uint_as_float(v[2 * q2] << 16), f1 = __uint_as_float(v[2 * q2] & 0xFFFF0000u);
+                const float f2 = __uint_as_float(v[2 * q2 + 1] << 16), f3 = __uint_as_float(v[2 * q2 + 1] & 0xFFFF0000u);
+                cs1[2 * h + q2][0] += f0; cs1[2 * h + q2][1] += f1; cs1[2 * h + q2][2] += f2; cs1[2 * h + q2][3] += f3;
+                if constexpr (CS == 2) {
+                  cs2[2 * h + q2][0] += f0 * f0; cs2[2 * h + q2][1] += f1 * f1; cs2[2 * h + q2][2] += f2 * f2; cs2[2 * h + q2][3] += f3 * f3;
+                }
+              }
+            }
           }
         }
       }
+      if constexpr (CS > 0) {
+        // over the 16 cells (lanes i) of the wave's rows: a reduce-scatter -- lane i ends up with the total of value i = (nt, r) =
+        // (i >> 2, i & 3) -- in 15 DPP adds instead of 16 full reductions (64), then ONE add per lane into the wave's own LDS row
+        const int chl = n0 + wn * 64 + 32 * (i >> 3) + 8 * g + 4 * ((i >> 2) & 1) + (i & 3);
+        colacc[chl] += ig_row16_scatter_sum(&cs1[0][0], i);
+        if constexpr (CS == 2) colacc[cout + chl] += ig_row16_scatter_sum(&cs2[0][0], i);
+      }
     }
+  }
+  if constexpr (CS > 0) {
+    // (LDS operations of a wave execute in order: the row is complete)
+    for (int c = lane; c < CS * cout; c += 64) cs_part[((int64_t)blockIdx.x * 8 + w) * (CS * cout) + c] = colacc[c];
   }
 #undef HC_MFMAS
 #undef HC_STEP
@@ -828,7 +932,8 @@ __global__ __launch_bounds__(512, 1) void dense_conv3x3_halo_kernel(const __hip_
 // cout % 128 == 0, dilation in {1, 2}.  The input gradient of such a conv is the same call on dout with
 // weight_t[c, (2-ky)*3 + (2-kx), n] = weight[n, ky, kx, c].
 static int dense_conv3x3_launch(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, int dil,
-                                const void* post, void* out, hipStream_t stream) {
+                                const void* post, void* out, hipStream_t stream, int cs = 0, float* sums = nullptr,
+                                void* wsp = nullptr, size_t ws_bytes = 0) {
   if (batch <= 0 || ny <= 0 || nx <= 0 || (cin != 128 && cin != 256 && cin != 384) || cout <= 0 || (cout % IG_BN) ||
       (dil != 1 && dil != 2))
     return TMAE_EARG;
@@ -839,22 +944,47 @@ static int dense_conv3x3_launch(const void* in, int batch, int ny, int nx, int c
   if (units >= ((int64_t)1 << 31)) return TMAE_EARG;
   const int ncu = tmae_num_cus();
   const int64_t blocks = units < ncu ? units : ncu;
-#define HC_LAUNCH(C, D)                                                                                               \
+  float* part = nullptr;
+  if (cs) {                       // the two shapes of the decoder conv (SiamWCA_MAE.py:100-115): forward 384 -> 128, input gradient 128 -> 384
+    if (dil != 1 || !sums || !((cs == 2 && cin == 384 && cout == 128) || (cs == 1 && cin == 128 && cout == 384))) return TMAE_EARG;
+    WsCarver ws(wsp, ws_bytes);
+    part = ws.take<float>((size_t)blocks * 8 * cs * cout);
+    if (!ws.ok) return TMAE_EWS;
+  }
+#define HC_LAUNCH(C, D, S)                                                                                            \
   do {                                                                                                                \
-    const int lds = 2 * HaloGeom<D>::ABYTES + 3 * (IG_BN * 128) + 1024;                                               \
+    const int lds = 2 * HaloGeom<D>::ABYTES + 3 * (IG_BN * 128) + 1024 + 8 * (S) * cout * 4;                          \
     static TmaeLdsAttr attr;                                                                                          \
-    if (int e_ = tmae_allow_lds(attr, (const void*)dense_conv3x3_halo_kernel<C, D>, lds)) return e_;                  \
-    hipLaunchKernelGGL((dense_conv3x3_halo_kernel<C, D>), dim3((unsigned)blocks), dim3(512), lds, stream,            \
+    if (int e_ = tmae_allow_lds(attr, (const void*)dense_conv3x3_halo_kernel<C, D, S>, lds)) return e_;               \
+    hipLaunchKernelGGL((dense_conv3x3_halo_kernel<C, D, S>), dim3((unsigned)blocks), dim3(512), lds, stream,         \
                        (const __hip_bfloat16*)in, batch, ny, nx, (const __hip_bfloat16*)weight, cout,                 \
-                       (__hip_bfloat16*)out, (int)units, (const __hip_bfloat16*)post);                                \
+                       (__hip_bfloat16*)out, (int)units, (const __hip_bfloat16*)post, part);                          \
   } while (0)
-  if (dil == 1) {
-    if (cin == 128) HC_LAUNCH(128, 1); else if (cin == 256) HC_LAUNCH(256, 1); else HC_LAUNCH(384, 1);
+  if (cs == 2) HC_LAUNCH(384, 1, 2);
+  else if (cs == 1) HC_LAUNCH(128, 1, 1);
+  else if (dil == 1) {
+    if (cin == 128) HC_LAUNCH(128, 1, 0); else if (cin == 256) HC_LAUNCH(256, 1, 0); else HC_LAUNCH(384, 1, 0);
   } else {
-    if (cin == 128) HC_LAUNCH(128, 2); else if (cin == 256) HC_LAUNCH(256, 2); else HC_LAUNCH(384, 2);
+    if (cin == 128) HC_LAUNCH(128, 2, 0); else if (cin == 256) HC_LAUNCH(256, 2, 0); else HC_LAUNCH(384, 2, 0);
   }
 #undef HC_LAUNCH
+  if (cs)
+    hipLaunchKernelGGL(dense_colsum_finish_kernel, dim3(tmae_cdiv(cs * cout, 16)), dim3(1024), 0, stream, part, (int)blocks * 8,
+                       cs * cout, sums);
   return tmae_launch_status();
+}
+
+size_t tmae_dense_conv3x3_sums_workspace(int cout) { return tmae_align((size_t)tmae_num_cus() * 8 * 2 * (cout > 0 ? cout : 0) * 4) + 256; }
+
+// tmae_dense_conv3x3 / _add that also returns column sums of the stored output, taken in the conv's epilogue:
+//   moments = 1: sums [cout]       = sum over all cells of out[., n]             (cin = 128, cout = 384: the decoder conv's input gradient)
+//   moments = 2: sums [2][cout]    = ... and of out[., n]^2                      (cin = 384, cout = 128: its forward)
+// post may be NULL.  ws: tmae_dense_conv3x3_sums_workspace(cout) bytes.  Other shapes: TMAE_EARG (run the conv, then tmae_column_sums).
+int tmae_dense_conv3x3_sums(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, const void* post,
+                            int moments, void* out, float* sums, void* ws, size_t ws_bytes, void* stream_) {
+  (void)hipGetLastError();
+  if ((moments != 1 && moments != 2) || !sums || (post && ((uintptr_t)post & 15))) return TMAE_EARG;
+  return dense_conv3x3_launch(in, batch, ny, nx, cin, weight, cout, 1, post, out, (hipStream_t)stream_, moments, sums, ws, ws_bytes);
 }
 
 int tmae_dense_conv3x3(const void* in, int batch, int ny, int nx, int cin, const void* weight, int cout, void* out,

@@ -54,6 +54,8 @@ SIGNATURES = {
     'tmae_dense_conv3x3': (I, [P, I, I, I, I, P, I, P, P]),
     'tmae_dense_conv3x3_dilated': (I, [P, I, I, I, I, P, I, I, P, P]),
     'tmae_dense_conv3x3_add': (I, [P, I, I, I, I, P, I, I, P, P, P]),
+    'tmae_dense_conv3x3_sums_workspace': (Z, [I]),
+    'tmae_dense_conv3x3_sums': (I, [P, I, I, I, I, P, I, P, I, P, P, P, Z, P]),
     'tmae_dense_conv3x3_wgrad_workspace': (Z, [I, I]),
     'tmae_dense_conv3x3_wgrad': (I, [P, P, I, I, I, I, I, I, P, P, Z, P]),
     'tmae_conv3x3_c64_workspace': (Z, []),
@@ -83,6 +85,9 @@ SIGNATURES = {
     'tmae_bn_stats': (I, [P, I, L, I, D, F, P, P, P, P, Z, P]),
     'tmae_bn_apply': (I, [P, I, L, I, P, P, P, P, I, P, P]),
     'tmae_bn_bwd_sums': (I, [P, P, I, L, I, P, P, P, P, I, P, P, P, Z, P]),
+    'tmae_bn_bwd_sums3': (I, [P, P, I, L, I, P, P, P, P, I, P, P, P, P, Z, P]),
+    'tmae_deblock_bn_bwd_workspace': (Z, [L, I, I]),
+    'tmae_deblock_bn_bwd': (I, [P, I, L, I, P, L, I, I, I, I, P, P, P, P, P, P, D, P, P, P, P, Z, P]),
     'tmae_bn_bwd_apply': (I, [P, P, I, L, I, P, P, P, P, I, P, P, D, P, P]),
     'tmae_deblock_scatter': (I, [P, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P]),
     'tmae_deblock_gather': (I, [P, I, I, I, P, L, I, I, I, I, P, P]),
@@ -141,7 +146,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     setattr(lib, _name, _strict(_fn, _name, len(_args)))
 
-ABI_VERSION = 19            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
+ABI_VERSION = 22            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError(f'libtmae_hip.so ABI version {lib.tmae_abi_version()} != binding {ABI_VERSION}; rebuild with '
                       f't-mae_amd/build.py')

@@ -171,9 +171,12 @@ class SiamWCA_MAE(nn.Module):
                              for i, src in enumerate(self.model_cfg.FEATURES_SOURCE)], dim=1)
         conv, bn = self.decoder_conv_out[0], self.decoder_conv_out[1]
         nhwc = cat.permute(0, 2, 3, 1)
+        moments = None
         if (self.training and nhwc.is_contiguous() and ops.dense_conv3x3_ok(nhwc, conv)
                 and os.environ.get('TMAE_DENSE_CONV', 'native') != 'miopen'):
-            y = ops.dense_conv3x3(nhwc, conv.weight).permute(0, 3, 1, 2)     # weight gradient: our token-split kernel
+            # (the conv's epilogue also returns the column sums of y and y^2: the norm below needs no statistics pass over y)
+            y, moments = ops.dense_conv3x3(nhwc, conv.weight, moments=True)
+            y = y.permute(0, 3, 1, 2)
         else:
             y = conv(cat)
         if (self.training and y.is_cuda and y.is_contiguous(memory_format=torch.channels_last)
@@ -182,7 +185,7 @@ class SiamWCA_MAE(nn.Module):
             b, c, ny, nx = y.shape
             if gather is not None:
                 rows, picked = ops.batch_norm_relu_gather(y.permute(0, 2, 3, 1).reshape(b * ny * nx, c), bn, True, gather[0], gather[1],
-                                                          b, ny, nx)
+                                                          b, ny, nx, moments=moments)
                 return rows.view(b, ny, nx, c).permute(0, 3, 1, 2), out_strides[0], picked
             rows = ops.batch_norm_relu(y.permute(0, 2, 3, 1).reshape(b * ny * nx, c), bn, relu=True)
             spatial = rows.view(b, ny, nx, c).permute(0, 3, 1, 2)

@@ -1118,18 +1118,29 @@ class _BNReLUGather(torch.autograd.Function):
     its sums run over the m gathered rows and the apply pass picks dz through the cell -> row map (tmae_bn_relu_bwd_gathered)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, relu, rowmap, indices, batch, ny, nx):
+    def forward(ctx, x, weight, bias, eps, relu, rowmap, indices, batch, ny, nx, moments=None):
+        """moments [2, c] f32 (optional): the column sums of x and x^2, already taken by x's producer (the decoder conv's epilogue):
+        mean / variance come from them (double precision, a handful of [c]-sized launches) and the statistics pass over x is skipped."""
         x = x.contiguous()
         cells, c = x.shape
         assert cells == batch * ny * nx
         y = torch.empty_like(x)
-        mean = torch.empty((c,), dtype=torch.float32, device=x.device)
-        var, rstd = torch.empty_like(mean), torch.empty_like(mean)
         g32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
-        wsb = lib.tmae_bn_workspace(cells, c)
-        ws = _ws(wsb, x.device)
-        check(lib.tmae_bn_relu_fwd(_p(x), _dt(x), cells, c, _p(g32), _p(b32), float(eps), 1 if relu else 0, _p(y), _p(mean), _p(var),
-                                   _p(rstd), _p(ws), wsb, _s()), 'tmae_bn_relu_fwd')
+        if moments is not None:
+            mo = moments.double() / float(cells)
+            mean64 = mo[0]
+            var64 = (mo[1] - mean64 * mean64).clamp_(min=0.0)
+            mean, var = mean64.float(), var64.float()
+            rstd = torch.rsqrt(var64 + float(eps)).float()
+            check(lib.tmae_bn_apply(_p(x), _dt(x), cells, c, _p(mean), _p(rstd), _p(g32), _p(b32), 1 if relu else 0, _p(y), _s()),
+                  'tmae_bn_apply')
+        else:
+            mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+            var, rstd = torch.empty_like(mean), torch.empty_like(mean)
+            wsb = lib.tmae_bn_workspace(cells, c)
+            ws = _ws(wsb, x.device)
+            check(lib.tmae_bn_relu_fwd(_p(x), _dt(x), cells, c, _p(g32), _p(b32), float(eps), 1 if relu else 0, _p(y), _p(mean), _p(var),
+                                       _p(rstd), _p(ws), wsb, _s()), 'tmae_bn_relu_fwd')
         m = indices.shape[0]
         rows = torch.empty((m, c), dtype=x.dtype, device=x.device)
         check(lib.tmae_dense_gather(_p(y), _dt(y), batch, ny, nx, c, _p(indices), m, _p(rows), _s()), 'tmae_dense_gather')
@@ -1142,7 +1153,7 @@ class _BNReLUGather(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, drows, _m, _v):
         if dy is None and drows is None:
-            return (None,) * 10
+            return (None,) * 11
         x, mean, rstd, g32, b32, rowmap, indices = ctx.saved_tensors
         relu, batch, ny, nx, wdt, bdt = ctx.meta
         cells, c = x.shape
@@ -1167,10 +1178,10 @@ class _BNReLUGather(torch.autograd.Function):
             ws = _ws(wsb, x.device)
             check(lib.tmae_bn_relu_bwd(_p(dy), _p(x), _dt(x), cells, c, _p(mean), _p(rstd), _p(g32), _p(b32), 1 if relu else 0,
                                        _p(dx), _p(dg), _p(db), _p(ws), wsb, _s()), 'tmae_bn_relu_bwd')
-        return dx, dg.to(wdt), db.to(bdt), None, None, None, None, None, None, None
+        return dx, dg.to(wdt), db.to(bdt), None, None, None, None, None, None, None, None
 
 
-def batch_norm_relu_gather(x_rows, bn, relu, rowmap, indices, batch, ny, nx):
+def batch_norm_relu_gather(x_rows, bn, relu, rowmap, indices, batch, ny, nx, moments=None):
     """(y, rows): ops.batch_norm_relu over the rows of a dense map [batch * ny * nx, c] and ops.dense_gather of the result at
     `indices` ([m, 3] int32 unique sites; rowmap = ops.index_grid(indices, ...)), as one autograd node (_BNReLUGather).  Falls
     back to the two ops where the fused kernels do not apply."""
@@ -1180,7 +1191,9 @@ def batch_norm_relu_gather(x_rows, bn, relu, rowmap, indices, batch, ny, nx):
     if not ok:
         y = batch_norm_relu(x_rows, bn, relu=relu)
         return y, dense_gather(y.view(batch, ny, nx, c), rowmap, indices)
-    y, rows, mean, var = _BNReLUGather.apply(x_rows, bn.weight, bn.bias, bn.eps, relu, rowmap, indices, batch, ny, nx)
+    if moments is not None and (moments.numel() != 2 * c or not _DENSE_SUMS):
+        moments = None
+    y, rows, mean, var = _BNReLUGather.apply(x_rows, bn.weight, bn.bias, bn.eps, relu, rowmap, indices, batch, ny, nx, moments)
     if bn.track_running_stats:
         _bn_running_update(bn, mean, var, float(cells))
     return y, rows
@@ -1852,10 +1865,12 @@ class _DeblocksToDense(torch.autograd.Function):
         if not dcat.is_contiguous():
             dcat = dcat.contiguous()
         nrows = batch * ny * nx
-        s_all = torch.empty((ctot,), dtype=torch.float32, device=dev)
-        wsb = lib.tmae_column_sums_workspace(nrows, ctot)
-        ws = _ws(wsb, dev)
-        check(lib.tmae_column_sums(_p(dcat), _dt(dcat), nrows, ctot, _p(s_all), _p(ws), wsb, _s()), 'tmae_column_sums')
+        s_all = colsum_tail(dcat, ctot)                      # the producing conv kernel summed its own output (dense_conv3x3_halo)
+        if s_all is None:
+            s_all = torch.empty((ctot,), dtype=torch.float32, device=dev)
+            wsb = lib.tmae_column_sums_workspace(nrows, ctot)
+            ws = _ws(wsb, dev)
+            check(lib.tmae_column_sums(_p(dcat), _dt(dcat), nrows, ctot, _p(s_all), _p(ws), wsb, _s()), 'tmae_column_sums')
         grads = []
         coff = 0
         for i in range(n_src):
@@ -1864,19 +1879,40 @@ class _DeblocksToDense(torch.autograd.Function):
             cout = couts[i]
             m = v.shape[0]
             rows = m * s * s
+            if ctx.pg is None and s in (1, 2, 4):
+                # the norm's whole backward with the gradient rows read in place from dcat (no gathered copy: 353 MB for the
+                # stride-4 source), three sums in one pass, the inactive cells' share, one pass for dv
+                dv = torch.empty_like(v)
+                dbeta = torch.empty((cout,), dtype=torch.float32, device=dev)
+                dgamma = torch.empty_like(dbeta)
+                wsb = lib.tmae_deblock_bn_bwd_workspace(m, s, cout)
+                ws = _ws(wsb, dev)
+                check(lib.tmae_deblock_bn_bwd(_p(dcat), _dt(dcat), ctot, coff, _p(indices), m, ys, xs, s, cout, _p(v), _p(mean), _p(rstd),
+                                              _p(g32), _p(b32), s_all.data_ptr() + 4 * coff, float(count), _p(dv), _p(dgamma), _p(dbeta),
+                                              _p(ws), wsb, _s()), 'tmae_deblock_bn_bwd')
+                dfeat = token_gemm_dx(dv, wmat) if ctx.needs_input_grad[6 + 4 * i] else None
+                dwmat = None
+                if ctx.needs_input_grad[6 + 4 * i + 1]:
+                    if _wgrad_ok(dv, x_c):
+                        dwmat, _ = linear_wgrad(dv, x_c, want_bias=False)
+                    else:
+                        dwmat = dv.float().t() @ x_c.float()
+                    cin = x_c.shape[1]
+                    dwmat = dwmat.view(s, s, cout, cin).permute(3, 2, 0, 1).to(dts[i][1])
+                grads += [None if dfeat is None else dfeat.to(dts[i][0]), dwmat, dgamma.to(dts[i][2]), dbeta.to(dts[i][3])]
+                coff += cout
+                continue
             g = torch.empty_like(v)
             check(lib.tmae_deblock_gather(_p(dcat), _dt(dcat), ctot, coff, _p(indices), m, ys, xs, s, cout, _p(g), _s()),
                   'tmae_deblock_gather')
+            # the unmasked column sums of g (for the inactive cells' share below) and the two masked sums: one pass over g and v
             s_act = torch.empty((cout,), dtype=torch.float32, device=dev)
-            wsb = lib.tmae_column_sums_workspace(rows, cout)
-            ws = _ws(wsb, dev)
-            check(lib.tmae_column_sums(_p(g), _dt(g), rows, cout, _p(s_act), _p(ws), wsb, _s()), 'tmae_column_sums')
             sum_dz = torch.empty((cout,), dtype=torch.float32, device=dev)
             sum_dzx = torch.empty_like(sum_dz)
-            wsb = lib.tmae_bn_workspace(rows, cout)
+            wsb = 2 * lib.tmae_bn_workspace(rows, cout)
             ws = _ws(wsb, dev)
-            check(lib.tmae_bn_bwd_sums(_p(g), _p(v), _dt(v), rows, cout, _p(mean), _p(rstd), _p(g32), _p(b32), 1,
-                                       _p(sum_dz), _p(sum_dzx), _p(ws), wsb, _s()), 'tmae_bn_bwd_sums')
+            check(lib.tmae_bn_bwd_sums3(_p(g), _p(v), _dt(v), rows, cout, _p(mean), _p(rstd), _p(g32), _p(b32), 1,
+                                        _p(s_act), _p(sum_dz), _p(sum_dzx), _p(ws), wsb, _s()), 'tmae_bn_bwd_sums3')
             # inactive cells: z = beta - mean*rstd*gamma (constant per channel), xhat = -mean*rstd: their share of the sums
             dbeta, dgamma = torch.empty_like(sum_dz), torch.empty_like(sum_dz)
             check(lib.tmae_deblock_bn_tail(_p(mean), _p(rstd), _p(g32), _p(b32), s_all.data_ptr() + 4 * coff, _p(s_act),
@@ -1975,6 +2011,7 @@ def _dense_rulebook(batch, ny, nx, device, dil=1):
 
 _DENSE_WGRAD = _os.environ.get('TMAE_DENSE_WGRAD', 'halo')   # halo: csrc/dense_wgrad.hip; rulebook: tmae_spconv_wgrad over the full grid
 _DENSE_CONV = _os.environ.get('TMAE_DENSE_CONV', 'halo')     # native: all three passes on our kernels; wgrad: only dW; miopen
+_DENSE_SUMS = _os.environ.get('TMAE_DENSE_SUMS', '1') != '0'    # column sums / moments out of the decoder conv's epilogues (round 6)
 
 
 class _DenseConv3x3(torch.autograd.Function):
@@ -1984,10 +2021,12 @@ class _DenseConv3x3(torch.autograd.Function):
     im2col(X), never materialised).  The library's implicit GEMMs ran at 0.52-0.68 PFLOP/s on this shape."""
 
     @staticmethod
-    def forward(ctx, x_nhwc, weight, dil=1, fork=False):
+    def forward(ctx, x_nhwc, weight, dil=1, fork=False, moments=False):
         """fork: also returns an alias of the input for a residual shortcut (SSTBEVBackbone, sst_bev_backbone.py:35-41); the
         gradient that arrives for the alias is added to the input gradient INSIDE the conv's input-gradient kernel
-        (tmae_dense_conv3x3_add) instead of by autograd's accumulation pass."""
+        (tmae_dense_conv3x3_add) instead of by autograd's accumulation pass.
+        moments: the last output is [2, cout] f32, the column sums of y and y^2 from the conv's epilogue (None-valued zeros tensor
+        of shape [0] where the shape has no such kernel): what the BatchNorm behind the conv needs (ops.batch_norm_relu_gather)."""
         cdt = compute_dtype(x_nhwc)
         x = x_nhwc.to(cdt).contiguous()
         w = cast_param(weight, cdt)
@@ -1998,8 +2037,12 @@ class _DenseConv3x3(torch.autograd.Function):
         ctx.dil = dil
         if ctx.native:
             w2d = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
+            mom = None
             if _DENSE_CONV == 'halo' or dil != 1:
-                y = dense_conv3x3_halo(x, w2d, dil)
+                if moments and dil == 1:
+                    y, mom = dense_conv3x3_halo(x, w2d, dil, moments=2)
+                else:
+                    y = dense_conv3x3_halo(x, w2d, dil)
             else:
                 y = spconv_fwd(x.view(n, cin), _dense_rulebook(B, Y, X, x.device), w2d).view(B, Y, X, cout)
             ctx.save_for_backward(x, w2d)
@@ -2009,6 +2052,13 @@ class _DenseConv3x3(torch.autograd.Function):
             ctx.save_for_backward(x, w)
         ctx.meta = (x_nhwc.dtype, weight.dtype)
         ctx.fork = bool(fork)
+        if moments:
+            assert not fork
+            if not ctx.native or mom is None:
+                mom = torch.empty((0,), dtype=torch.float32, device=x.device)
+            ctx.mark_non_differentiable(mom)
+            ctx.set_materialize_grads(False)
+            return y, mom
         if fork:
             ctx.set_materialize_grads(False)
             return y, x_nhwc.view_as(x_nhwc)
@@ -2017,8 +2067,10 @@ class _DenseConv3x3(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy_nhwc, dalias=None):
         x, w = ctx.saved_tensors
+        if not ctx.fork:
+            dalias = None                                    # (the second output is the moments tensor: no gradient)
         if dy_nhwc is None:                                  # only the alias was used downstream
-            return (None if dalias is None else dalias.to(ctx.meta[0])), None, None, None
+            return (None if dalias is None else dalias.to(ctx.meta[0])), None, None, None, None
         skip = None if dalias is None else dalias.to(x.dtype).contiguous()
         B, Y, X, cin = x.shape
         cout = w.shape[0]
@@ -2031,7 +2083,9 @@ class _DenseConv3x3(torch.autograd.Function):
             if ctx.native and (_DENSE_CONV == 'halo' or dil != 1) and cout in (128, 256, 384) and cin % 128 == 0:
                 # weight_t[c, 2-ky, 2-kx, n] = w[n, ky, kx, c]: the input gradient is a conv of dY with the flipped taps
                 wt = w.view(cout, 3, 3, cin).flip(1, 2).permute(3, 1, 2, 0).reshape(cin, 9 * cout).contiguous()
-                dx = dense_conv3x3_halo(dy, wt, dil, post=skip).to(ctx.meta[0])
+                # (128 -> 384: the decoder conv's input gradient leaves with its column sums behind it -- the BatchNorm backward of
+                #  the deconvolutions in front of the conv wants them, _DeblocksToDense.backward)
+                dx = dense_conv3x3_halo(dy, wt, dil, post=skip, tail_sums=(dil == 1 and (cout, cin) == (128, 384))).to(ctx.meta[0])
                 skip = None                                  # added inside the kernel
             elif ctx.native:
                 nbr_t = _DENSE_NBR.get(('t', B, Y, X, dil, x.device))
@@ -2052,13 +2106,13 @@ class _DenseConv3x3(torch.autograd.Function):
                 ws = _ws(wsb, x.device)
                 check(lib.tmae_dense_conv3x3_wgrad(_p(dy), _p(x), B, Y, X, cin, cout, int(dil), _p(dw), _p(ws), wsb, _s()),
                       'tmae_dense_conv3x3_wgrad')
-                return dx, dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2).to(ctx.meta[1]), None, None
+                return dx, dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2).to(ctx.meta[1]), None, None, None
         wsb = lib.tmae_linear_wgrad_workspace(n, cout, 9 * cin)
         ws = _ws(wsb, x.device)
         check(lib.tmae_spconv_wgrad(_p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(nbr), n, cout, cin, _p(dw), _p(ws),
                                     wsb, _s()), 'tmae_spconv_wgrad')
         dw = dw.view(cout, 3, 3, cin).permute(0, 3, 1, 2).to(ctx.meta[1])
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 def _channel_sums(dy):
@@ -2280,11 +2334,51 @@ def conv3x3_channel_bias(x, conv):
     return _ConvOwnBiasGrad.apply(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation)
 
 
-def dense_conv3x3_halo(x_nhwc, w2d, dil=1, post=None):
+_COLSUM_TAIL = 2048       # bf16 elements behind a gradient map that carries its own column sums (dense_conv3x3_halo(tail_sums=True))
+
+
+def colsum_tail(t, ncol):
+    """The fp32 column sums [ncol] that ride behind the data of `t` ([..., ncol] bf16, contiguous, the whole of its storage) when
+    `t` came out of dense_conv3x3_halo(..., tail_sums=True); None for any other tensor.  The storage size is the signature: the
+    data followed by exactly _COLSUM_TAIL spare elements is an allocation only that call makes, and a tensor autograd has summed
+    with another gradient, cast or copied is a new allocation without it."""
+    if not (_DENSE_SUMS and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.storage_offset() == 0
+            and t.shape[-1] == ncol and ncol * 4 <= _COLSUM_TAIL * 2):
+        return None
+    st = t.untyped_storage()
+    if st.nbytes() != (t.numel() + _COLSUM_TAIL) * 2:
+        return None
+    return torch.empty(0, dtype=torch.float32, device=t.device).set_(st, t.numel() * 2 // 4, (ncol,))
+
+
+def dense_conv3x3_halo(x_nhwc, w2d, dil=1, post=None, moments=0, tail_sums=False):
     """[B, Y, X, cin] bf16 (contiguous) x w2d [cout, 9*cin] bf16 -> [B, Y, X, cout] (csrc/spconv_igemm.hip, halo kernel);
-    padding = dilation in {1, 2}; post [B, Y, X, cout] bf16: added to the result inside the kernel."""
+    padding = dilation in {1, 2}; post [B, Y, X, cout] bf16: added to the result inside the kernel.
+    moments = 2 (cin 384 -> cout 128, dil 1): returns (y, sums [2, cout] f32 = column sums of y and of y^2, from the conv's epilogue).
+    tail_sums (cin 128 -> cout 384, dil 1): y's allocation carries its fp32 column sums behind the data (read them with
+    colsum_tail(y, cout)); the return value is y alone."""
     B, Y, X, cin = x_nhwc.shape
     cout = w2d.shape[0]
+    if (moments == 2 or tail_sums) and dil == 1 and _DENSE_SUMS and ((moments == 2 and (cin, cout) == (384, 128)) or (tail_sums and (cin, cout) == (128, 384))):
+        if post is not None:
+            assert post.shape == (B, Y, X, cout) and post.dtype == torch.bfloat16 and post.is_contiguous()
+        n = B * Y * X * cout
+        wsb = lib.tmae_dense_conv3x3_sums_workspace(cout)
+        ws = _ws(wsb, x_nhwc.device)
+        if tail_sums:
+            buf = torch.empty((n + _COLSUM_TAIL,), dtype=torch.bfloat16, device=x_nhwc.device)
+            y = buf[:n].view(B, Y, X, cout)
+            sums = torch.empty(0, dtype=torch.float32, device=x_nhwc.device).set_(buf.untyped_storage(), n * 2 // 4, (cout,))
+            check(lib.tmae_dense_conv3x3_sums(_p(x_nhwc), B, Y, X, cin, _p(w2d), cout, _p(post), 1, _p(y), _p(sums), _p(ws), wsb, _s()),
+                  'tmae_dense_conv3x3_sums')
+            return y
+        y = torch.empty((B, Y, X, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+        sums = torch.empty((2, cout), dtype=torch.float32, device=x_nhwc.device)
+        check(lib.tmae_dense_conv3x3_sums(_p(x_nhwc), B, Y, X, cin, _p(w2d), cout, _p(post), 2, _p(y), _p(sums), _p(ws), wsb, _s()),
+              'tmae_dense_conv3x3_sums')
+        return y, sums
+    if moments == 2:
+        return dense_conv3x3_halo(x_nhwc, w2d, dil, post), None
     y = torch.empty((B, Y, X, cout), dtype=torch.bfloat16, device=x_nhwc.device)
     if post is not None:
         assert post.shape == y.shape and post.dtype == torch.bfloat16 and post.is_contiguous()
@@ -2306,9 +2400,10 @@ def dense_conv3x3_ok(x_nhwc, conv):
             and conv.out_channels % 8 == 0 and x_nhwc.shape[0] * x_nhwc.shape[1] * x_nhwc.shape[2] >= 4096)
 
 
-def dense_conv3x3(x_nhwc, weight, dilation=1, fork=False):
-    """fork: returns (y, alias of x_nhwc) -- see _DenseConv3x3.forward."""
-    return _DenseConv3x3.apply(x_nhwc, weight, int(dilation), bool(fork))
+def dense_conv3x3(x_nhwc, weight, dilation=1, fork=False, moments=False):
+    """fork: returns (y, alias of x_nhwc); moments: returns (y, [2, cout] column sums of y and y^2, or an empty tensor) -- see
+    _DenseConv3x3.forward."""
+    return _DenseConv3x3.apply(x_nhwc, weight, int(dilation), bool(fork), bool(moments))
 
 
 class _DenseGather(torch.autograd.Function):

@@ -965,6 +965,73 @@ def test_add_layernorm_residual_options_vs_torch():
                 assert float((got[2] * (1 - keep.float())).abs().max()) == 0.0        # masked rows of b get no gradient
 
 
+def test_dense_conv_epilogue_sums_and_their_two_consumers():
+    """tmae_dense_conv3x3_sums: the decoder conv's two heavy launches with the column sums of their OUTPUT from the epilogue.
+    (1) operator level: outputs bit-equal to tmae_dense_conv3x3(_add), sums equal to fp64 sums of the stored bf16 values to fp32
+    accuracy, on a grid with ragged 16 x 16 tiles; (2) the input gradient carries its sums behind its data (ops.colsum_tail) and
+    only there; (3) model level: one decoder pass (deblocks -> conv -> norm + gather) with and without the epilogue sums gives the
+    same outputs and gradients (the statistics of the last norm come from the conv's moments, the column sum of the concat
+    gradient from its tail)."""
+    from tmae_amd import ops
+    from tmae_amd._lib import lib, check
+    torch.manual_seed(8)
+    B, Y, X = 2, 41, 50
+    st = torch.cuda.current_stream().cuda_stream
+    for cin, cout, mom in ((384, 128, 2), (128, 384, 1)):
+        x = torch.randn(B, Y, X, cin, device=dev()).bfloat16()
+        w = (torch.randn(cout, 9 * cin, device=dev()) * 0.03).bfloat16()
+        post = torch.randn(B, Y, X, cout, device=dev()).bfloat16() if mom == 1 else None
+        ref = ops.dense_conv3x3_halo(x, w, 1, post=post)
+        y = torch.empty_like(ref)
+        sums = torch.empty(mom, cout, device=dev())
+        wsb = lib.tmae_dense_conv3x3_sums_workspace(cout)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+        check(lib.tmae_dense_conv3x3_sums(x.data_ptr(), B, Y, X, cin, w.data_ptr(), cout, None if post is None else post.data_ptr(), mom,
+                                          y.data_ptr(), sums.data_ptr(), ws.data_ptr(), wsb, st), 'sums')
+        assert torch.equal(y, ref)
+        rows = ref.view(-1, cout).double()
+        want = [rows.sum(0)] + ([(rows * rows).sum(0)] if mom == 2 else [])
+        for got, w_ in zip(sums, want):
+            assert (got.double() - w_).abs().max().item() <= 2e-5 * max(1.0, float(w_.abs().max())) + 1e-3, (cin, cout)
+        # refusals: other shapes, a missing sums pointer
+        assert lib.tmae_dense_conv3x3_sums(x.data_ptr(), B, Y, X, cin, w.data_ptr(), cout, None, 3 - mom, y.data_ptr(), sums.data_ptr(),
+                                           ws.data_ptr(), wsb, st) != 0
+    x = torch.randn(B, Y, X, 128, device=dev()).bfloat16()
+    w = (torch.randn(384, 9 * 128, device=dev()) * 0.03).bfloat16()
+    y = ops.dense_conv3x3_halo(x, w, 1, tail_sums=True)
+    tail = ops.colsum_tail(y, 384)
+    assert tail is not None and torch.allclose(tail.double(), y.view(-1, 384).double().sum(0), rtol=2e-5, atol=1e-3)
+    assert ops.colsum_tail(y.clone(), 384) is None and ops.colsum_tail(ops.dense_conv3x3_halo(x, w, 1), 384) is None
+    assert ops.colsum_tail(y.permute(0, 3, 1, 2).permute(0, 2, 3, 1), 384) is not None        # the views autograd hands on
+
+
+def test_decoder_with_and_without_epilogue_sums(oracle):
+    """The whole model step (F10 golden case, bf16 autocast) with TMAE_DENSE_SUMS on and off: same loss to 1e-4, same decoder
+    gradients to bf16 accuracy -- the conv-epilogue moments / tail sums replace passes, not results."""
+    from tmae_amd import ops
+    g = golden('F10_e2e_3stage')
+    cfg = oracle.default_model_cfg(3)
+    P = oracle.init_params(cfg, seed=int(g['param_seed']), tau=float(g['tau']), pred_scale=float(g['pred_scale']))
+    res = []
+    for on in (True, False):
+        saved = ops._DENSE_SUMS
+        ops._DENSE_SUMS = on
+        try:
+            model, _, _ = build_product_model(3, params=P, device=dev())
+            model.train()
+            loss, _ = _run_product(model, g['points'], g['points_prev'], g['noise'], int(g['batch_size']), amp=True)
+            res.append((fl(loss), {n: p.grad.float().clone() for n, p in model.named_parameters() if 'decoder' in n},
+                        {n: b.clone() for n, b in model.named_buffers() if 'decoder_conv_out' in n and 'running' in n}))
+        finally:
+            ops._DENSE_SUMS = saved
+    (la, ga, ba), (lb, gb, bb) = res
+    assert abs(la - lb) < 1e-4, (la, lb)
+    for n in gb:
+        assert (ga[n] - gb[n]).abs().max().item() <= 2e-2 * max(1e-3, float(gb[n].abs().max())), n
+    for n in bb:
+        assert torch.allclose(ba[n], bb[n], rtol=1e-4, atol=1e-5), n
+
+
 def test_batchnorm_gather_backward_without_the_dense_gradient():
     """ops.batch_norm_relu_gather (the decoder's last norm + the gather at the current frame's voxels as one node,
     tmae_bn_relu_bwd_gathered) against ops.batch_norm_relu followed by ops.dense_gather: same outputs bit for bit; dx / dgamma /
