@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 22
+#define TMAE_ABI_VERSION 23
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -443,6 +443,13 @@ int tmae_bn_bwd_apply(const void* dy, const void* x, int dtype, int64_t m, int c
 int tmae_deblock_scatter(const void* v, int dtype, const int32_t* grid, int batch, int ys, int xs, int s, int cout,
                          const float* mean, const float* rstd, const float* gamma, const float* beta, void* out,
                          int ldc, int coff, void* stream);
+/* All sources of the concat buffer in ONE launch (whole ldc-wide rows per store burst instead of one channel slice per launch):
+ * HOST arrays of n_src <= 4 entries -- v[i], grid[i], ys[i], xs[i], s[i], cout[i], mean[i], rstd[i], gamma[i], beta[i] as in
+ * tmae_deblock_scatter; the slices lie side by side in source order (sum of cout = ldc), every source covers the same dense
+ * grid (ys[i] s[i] = Y, xs[i] s[i] = X). */
+int tmae_deblock_scatter_multi(int n_src, const void* const* v, int dtype, const int32_t* const* grid, int batch, const int* ys,
+                               const int* xs, const int* s, const int* cout, const float* const* mean, const float* const* rstd,
+                               const float* const* gamma, const float* const* beta, void* out, int ldc, void* stream);
 int tmae_deblock_gather(const void* dcat, int dtype, int ldc, int coff, const int32_t* indices, int64_t m, int ys,
                         int xs, int s, int cout, void* g, void* stream);
 size_t tmae_column_sums_workspace(int64_t rows, int c);

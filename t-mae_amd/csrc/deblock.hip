@@ -57,6 +57,63 @@ __global__ __launch_bounds__(256) void deblock_scatter_kernel(const T* __restric
   }
 }
 
+// The same for ALL sources of the concat buffer in one launch (round 6): a workgroup's threads cover whole ldc-wide rows -- thread t
+// owns chunk t % (ldc / VEC) of the row, i.e. one 16-byte chunk of ONE source for the whole kernel -- so every cell's row leaves as
+// one contiguous 768-byte store burst.  One launch per source wrote its 256-byte slice of each row: three passes of partial lines
+// over the 1.35 GB buffer (3 x 126 us at 3.5 TB/s).
+#define DS_MAXSRC 4
+struct DbSrc {
+  const void* v;
+  const int32_t* grid;
+  const float *mean, *rstd, *gamma, *beta;
+  int ys, xs, s, cout, coff;
+};
+struct DbSrcs { DbSrc src[DS_MAXSRC]; int n; };
+
+template <class T>
+__global__ __launch_bounds__(256) void deblock_scatter_multi_kernel(DbSrcs P, int batch, int Yi, int Xi, T* __restrict__ out, int ldc) {
+  constexpr int VEC = 16 / sizeof(T);
+  const unsigned chunks = (unsigned)(ldc / VEC);                // chunks per row (<= 256: launcher)
+  const unsigned cpp = 256u / chunks;                           // cells per pass of the block
+  const unsigned Y = (unsigned)Yi, X = (unsigned)Xi;
+  const unsigned ncell = (unsigned)batch * Y * X;
+  const unsigned ch = threadIdx.x % chunks, sub = threadIdx.x / chunks;
+  if (sub >= cpp) return;                                       // 256 % chunks spare threads
+  const int c0g = (int)ch * VEC;                                // channel of the chunk in the concat row
+  int si = 0;
+#pragma unroll
+  for (int k = 1; k < DS_MAXSRC; ++k)
+    if (k < P.n && c0g >= P.src[k].coff) si = k;
+  const DbSrc S = P.src[si];
+  const int c0 = c0g - S.coff;
+  const T* __restrict__ v = (const T*)S.v;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    sc[k] = S.rstd[c0 + k] * S.gamma[c0 + k];
+    sh[k] = S.beta[c0 + k] - S.mean[c0 + k] * sc[k];
+  }
+  const unsigned s = (unsigned)S.s, ys = (unsigned)S.ys, xs = (unsigned)S.xs;
+  const unsigned cell0 = blockIdx.x * (cpp * DS_CPT) + sub;
+#pragma unroll
+  for (int it = 0; it < DS_CPT; ++it) {
+    const unsigned cell = cell0 + (unsigned)it * cpp;
+    if (cell >= ncell) break;
+    const unsigned x = cell % X, yb = cell / X, y = yb % Y, b = yb / Y;
+    const int idx = S.grid[(b * ys + y / s) * xs + x / s];
+    T tmp[VEC];
+    if (idx >= 0)
+      *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(
+          v + ((int64_t)idx * s * s + (y % s) * s + (x % s)) * S.cout + c0);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float z = (idx >= 0 ? ld_f<T>(&tmp[k]) * sc[k] : 0.f) + sh[k];
+      st_f<T>(&tmp[k], fmaxf(z, 0.f));
+    }
+    *reinterpret_cast<uint4*>(out + (int64_t)cell * ldc + c0g) = *reinterpret_cast<uint4*>(tmp);
+  }
+}
+
 // g[row, sub, c] = dcat[cell(row, sub), coff + c]
 template <class T>
 __global__ __launch_bounds__(256) void deblock_gather_kernel(const T* __restrict__ dcat, int ldc, int coff,
@@ -137,6 +194,45 @@ int tmae_deblock_scatter(const void* v, int dtype, const int32_t* grid, int batc
     hipLaunchKernelGGL(deblock_scatter_kernel<__hip_bfloat16>, dim3(tmae_cdiv(ncell, per_block)), dim3(256), 0, stream,
                        (const __hip_bfloat16*)v, grid, batch, ys, xs, s, cout, mean, rstd, gamma, beta,
                        (__hip_bfloat16*)out, ldc, coff);
+  return tmae_launch_status();
+}
+
+// n_src <= 4 sources written in one launch: host arrays v[i], grid[i], mean[i] ... and ys[i], xs[i], s[i], cout[i] (the channel
+// slices are laid side by side in source order: coff[i] = cout[0] + ... + cout[i-1], their sum = ldc); every source must cover the
+// same dense grid (ys[i] * s[i] = Y, xs[i] * s[i] = X).
+int tmae_deblock_scatter_multi(int n_src, const void* const* v, int dtype, const int32_t* const* grid, int batch, const int* ys,
+                               const int* xs, const int* s, const int* cout, const float* const* mean, const float* const* rstd,
+                               const float* const* gamma, const float* const* beta, void* out, int ldc, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  const int es = esz(dtype);
+  if (!es) return TMAE_EDTYPE;
+  if (n_src < 1 || n_src > DS_MAXSRC || !v || !grid || !ys || !xs || !s || !cout || !mean || !rstd || !gamma || !beta || !out || batch <= 0 ||
+      ldc <= 0 || (ldc * es) % 16)
+    return TMAE_EARG;
+  DbSrcs P;
+  P.n = n_src;
+  int coff = 0;
+  const int Y = ys[0] * s[0], X = xs[0] * s[0];
+  for (int i = 0; i < n_src; ++i) {
+    if (!v[i] || !grid[i] || !mean[i] || !rstd[i] || !gamma[i] || !beta[i] || ys[i] <= 0 || xs[i] <= 0 || s[i] <= 0 || cout[i] <= 0 ||
+        (cout[i] * es) % 16 || ys[i] * s[i] != Y || xs[i] * s[i] != X)
+      return TMAE_EARG;
+    P.src[i] = DbSrc{v[i], grid[i], mean[i], rstd[i], gamma[i], beta[i], ys[i], xs[i], s[i], cout[i], coff};
+    coff += cout[i];
+  }
+  for (int i = n_src; i < DS_MAXSRC; ++i) P.src[i] = P.src[0];
+  if (coff != ldc) return TMAE_EARG;
+  const int chunks = ldc * es / 16;
+  const int64_t ncell = (int64_t)batch * Y * X;
+  if (chunks > 256 || ncell >= ((int64_t)1 << 31)) return TMAE_EARG;
+  const int64_t per_block = (int64_t)(256 / chunks) * DS_CPT;
+  if (dtype == TMAE_F32)
+    hipLaunchKernelGGL(deblock_scatter_multi_kernel<float>, dim3(tmae_cdiv(ncell, per_block)), dim3(256), 0, stream, P, batch, Y, X,
+                       (float*)out, ldc);
+  else
+    hipLaunchKernelGGL(deblock_scatter_multi_kernel<__hip_bfloat16>, dim3(tmae_cdiv(ncell, per_block)), dim3(256), 0, stream, P, batch,
+                       Y, X, (__hip_bfloat16*)out, ldc);
   return tmae_launch_status();
 }
 

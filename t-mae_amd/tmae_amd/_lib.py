@@ -90,6 +90,7 @@ SIGNATURES = {
     'tmae_deblock_bn_bwd': (I, [P, I, L, I, P, L, I, I, I, I, P, P, P, P, P, P, D, P, P, P, P, Z, P]),
     'tmae_bn_bwd_apply': (I, [P, P, I, L, I, P, P, P, P, I, P, P, D, P, P]),
     'tmae_deblock_scatter': (I, [P, I, P, I, I, I, I, I, P, P, P, P, P, I, I, P]),
+    'tmae_deblock_scatter_multi': (I, [I, P, I, P, I, P, P, P, P, P, P, P, P, P, I, P]),
     'tmae_deblock_gather': (I, [P, I, I, I, P, L, I, I, I, I, P, P]),
     'tmae_column_sums_workspace': (Z, [L, I]),
     'tmae_column_sums': (I, [P, I, L, I, P, P, Z, P]),
@@ -146,7 +147,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     setattr(lib, _name, _strict(_fn, _name, len(_args)))
 
-ABI_VERSION = 22            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
+ABI_VERSION = 23            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError(f'libtmae_hip.so ABI version {lib.tmae_abi_version()} != binding {ABI_VERSION}; rebuild with '
                       f't-mae_amd/build.py')

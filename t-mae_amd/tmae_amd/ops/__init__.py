@@ -1838,11 +1838,29 @@ class _DeblocksToDense(torch.autograd.Function):
             if pg is not None:                    # SyncBatchNorm: every rank counts batch * ny * nx cells
                 gm, gv, _ = _merge_stats(mean, var, count, pg)
                 mean.copy_(gm), var.copy_(gv), rstd.copy_(torch.rsqrt(gv + float(eps[i])))
-            check(lib.tmae_deblock_scatter(_p(v), _dt(v), _p(grid), batch, ys, xs, s, cout, _p(mean), _p(rstd), _p(g32),
-                                           _p(b32), _p(cat), ctot, coff, _s()), 'tmae_deblock_scatter')
             saved += [x_c, wmat, v, mean, rstd, g32, b32, grid, indices]
             stats += [mean, var]
             coff += cout
+        if n_src <= 4 and len({(ys * s, xs * s) for (_, _, ys, xs, s) in metas}) == 1:
+            # all channel slices of the concat buffer in one launch (whole rows per store burst): HOST tables of the sources
+            import ctypes as _ct
+            vp = _ct.c_void_p
+            def tab(vals, ty):
+                return (ty * n_src)(*vals)
+            ptrs = lambda k: _ct.cast(tab([saved[9 * i + k].data_ptr() for i in range(n_src)], vp), vp)
+            ints = lambda k: _ct.cast(tab([int(metas[i][k]) for i in range(n_src)], _ct.c_int), vp)
+            t_v, t_mean, t_rstd, t_g, t_b, t_grid = ptrs(2), ptrs(3), ptrs(4), ptrs(5), ptrs(6), ptrs(7)
+            t_ys, t_xs, t_s = ints(2), ints(3), ints(4)
+            t_c = _ct.cast(tab(couts, _ct.c_int), vp)
+            check(lib.tmae_deblock_scatter_multi(n_src, t_v, _dt(saved[2]), t_grid, batch, t_ys, t_xs, t_s, t_c, t_mean, t_rstd, t_g, t_b,
+                                                 _p(cat), ctot, _s()), 'tmae_deblock_scatter_multi')
+        else:
+            coff = 0
+            for i, (grid, indices, ys, xs, s) in enumerate(metas):
+                x_c, wmat, v, mean, rstd, g32, b32 = saved[9 * i:9 * i + 7]
+                check(lib.tmae_deblock_scatter(_p(v), _dt(v), _p(grid), batch, ys, xs, s, couts[i], _p(mean), _p(rstd), _p(g32),
+                                               _p(b32), _p(cat), ctot, coff, _s()), 'tmae_deblock_scatter')
+                coff += couts[i]
         ctx.save_for_backward(*saved)
         ctx.meta = (n_src, [(ys, xs, s) for (_, _, ys, xs, s) in metas], batch, ny, nx, couts, count,
                     [(args[4 * i].dtype, args[4 * i + 1].dtype, args[4 * i + 2].dtype, args[4 * i + 3].dtype)
