@@ -52,6 +52,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the short fine-tune / Waymo-shape runs that fill the `secondary` field of the N = 1 line')
+    ap.add_argument('--no-vfe-prefetch', action='store_true',
+                    help='voxelise every batch inside its own step (the default hands a step the batch that follows it, see step()); '
+                         'for kernel traces: under rocprofv3 the slowed-down host turns the lookahead into idle gaps')
     ap.add_argument('--skip-unread-gradients', action='store_true',
                     help='variant, not the reference step: no gradients for the parameters its optimizer never owns')
     ap.add_argument('--cpu-points', type=int, default=120000)
@@ -795,8 +798,17 @@ def main():
         if 'gt_boxes' in b:
             batches[-1]['gt_boxes'] = torch.from_numpy(b['gt_boxes']).to(dev)
 
+    # the batch a step will consume is handed to the step before it as `next_batch`: its voxelisation (index work, no gradients)
+    # is enqueued between that step's forward and backward, and its counts are on the host when its own step begins
+    # (TemporalDynVFE.prefetch).  Every step still voxelises exactly one batch -- the next one.
+    upcoming = {}
+
     def step(i):
-        return train_one_step(ddp, opt, sched, dict(batches[i % nb]), i, model_func, amp_dtype=amp)[0]
+        if args.no_vfe_prefetch:
+            return train_one_step(ddp, opt, sched, dict(batches[i % nb]), i, model_func, amp_dtype=amp)[0]
+        cur = upcoming.pop(i, None) or dict(batches[i % nb])
+        nxt = upcoming[i + 1] = dict(batches[(i + 1) % nb])
+        return train_one_step(ddp, opt, sched, cur, i, model_func, amp_dtype=amp, next_batch=nxt)[0]
 
     if args.probe_only:
         print(json.dumps({'box_peaks': box_peaks(dev),

@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=${1:-p}; shift
 export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python3 "${BENCH_PY:-$GRAFT_REPO_ROOT/bench.py}" --steps 3 --warmup 2 --no-cpu-baseline "$@" > "$GRAFT_REPO_ROOT/gpurun_out/${TAG}.log" 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python3 "${BENCH_PY:-$GRAFT_REPO_ROOT/bench.py}" --steps 3 --warmup 2 --no-cpu-baseline --no-vfe-prefetch "$@" > "$GRAFT_REPO_ROOT/gpurun_out/${TAG}.log" 2>&1 )
 TRACE=$(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1)
 STATS=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
 echo "trace: $TRACE stats: $STATS"

@@ -89,11 +89,32 @@ class TemporalDynVFE(VFETemplate):
         x_max, _ = ops.scatter_max(x, inv_rows, perm_rows, offsets, m)
         return x_max
 
+    _PREFETCH = '_vfe_prefetch'
+
+    def prefetch(self, batch_dict):
+        """Voxelise both frames of a batch that a LATER forward() will consume and start the copy of their counts to the host
+        (train_one_step(next_batch=...): enqueued between the current step's forward and backward).  forward() then finds the
+        counts on the host instead of stalling for them at the top of the step -- the launching thread was parked there until the
+        GPU had finished the whole previous step, and the small index kernels behind the wait arrived one by one on an empty
+        queue (0.67 ms of idle GPU per step, profiles/round6_i_kernel_stats.md).  Index work only: nothing here needs gradients."""
+        pts = batch_dict.get('points', None)
+        if self._PREFETCH in batch_dict or not (torch.is_tensor(pts) and pts.is_cuda):
+            return
+        bs = int(batch_dict['batch_size'])
+        with torch.no_grad():
+            launched = [ops.voxelize_launch(batch_dict[k], bs, self.point_cloud_range, self.voxel_size, self.grid_size)
+                        for k in ('points', 'points_prev')]
+            batch_dict[self._PREFETCH] = (launched, ops.HostCopy(torch.stack([o['counts'] for o in launched]), 'vfe_counts'))
+
     def forward(self, batch_dict, **kwargs):
         bs = int(batch_dict['batch_size'])
-        launched = [ops.voxelize_launch(batch_dict[k], bs, self.point_cloud_range, self.voxel_size, self.grid_size)
-                    for k in ('points', 'points_prev')]
-        counts = ops.to_host(torch.stack([o['counts'] for o in launched]))     # the one host sync of the VFE
+        pre = batch_dict.pop(self._PREFETCH, None)
+        if pre is not None:
+            launched, counts = pre[0], pre[1].get()
+        else:
+            launched = [ops.voxelize_launch(batch_dict[k], bs, self.point_cloud_range, self.voxel_size, self.grid_size)
+                        for k in ('points', 'points_prev')]
+            counts = ops.to_host(torch.stack([o['counts'] for o in launched]))     # the one host sync of the VFE
         for suffix, out, cnt in (('', launched[0], counts[0]), ('_prev', launched[1], counts[1])):
             vox = ops.voxelize_finish(out, cnt)
             x = self._features(vox)

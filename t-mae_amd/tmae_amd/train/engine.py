@@ -56,19 +56,25 @@ def unsettle_gc():
 
 
 def train_one_step(model, optimizer, scheduler, batch_dict, it, model_func, amp_dtype=torch.bfloat16,
-                   grad_norm_clip=None, settle=None):
+                   grad_norm_clip=None, settle=None, next_batch=None):
     """lr_scheduler.step -> zero_grad -> autocast forward -> backward (DDP all-reduce overlaps) ->
     [clip, non-AMP branch only: train_utils.py:88-93] -> optimizer.step.
     settle: freeze the interpreter's long-lived objects out of the cyclic collector after the first step (settle_gc: a
     process-wide, one-way change until unsettle_gc()).  None = the TMAE_SETTLE_GC environment switch, default ON -- the
     training drivers (tools/train.py, bench.py) are one-model processes; a host that builds many models passes False or calls
-    unsettle_gc() between them."""
+    unsettle_gc() between them.
+    next_batch: the batch_dict the NEXT call will be given (the same dict object): its voxelisation is enqueued between this
+    step's forward and backward (TemporalDynVFE.prefetch), so that the next step does not begin with a host stall."""
     if scheduler is not None:
         scheduler.step(it)
     optimizer.zero_grad(set_to_none=True)
     use_amp = amp_dtype is not None
     with torch.autocast('cuda', dtype=amp_dtype if use_amp else torch.bfloat16, enabled=use_amp):
         loss, tb_dict, disp_dict = model_func(model, batch_dict)
+    if next_batch is not None:
+        vfe = getattr(getattr(model, 'module', model), 'vfe', None)
+        if vfe is not None and hasattr(vfe, 'prefetch'):
+            vfe.prefetch(next_batch)
     loss.backward()
     if not use_amp and grad_norm_clip:
         torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm_clip)

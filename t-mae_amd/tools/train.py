@@ -174,9 +174,18 @@ def main():
             train_sampler.set_epoch(epoch)
             ds.set_epoch(epoch)
         batches = (ds.batch(epoch * iters_per_epoch + i) for i in range(iters_per_epoch)) if train_loader is None else train_loader
-        for i, batch in enumerate(batches):
+        # one batch of lookahead: the step is told which batch comes next and voxelises it between its forward and backward
+        # (TemporalDynVFE.prefetch), so that no step begins by waiting for its voxel counts
+        feed = iter(batches)
+        batch = next(feed, None)
+        i = -1
+        while batch is not None:
+            i += 1
+            nxt = next(feed, None)
             loss, tb, _ = train_one_step(ddp, opt, sched, batch, it, model_func, amp_dtype=amp,
-                                         grad_norm_clip=cfg.OPTIMIZATION.get('GRAD_NORM_CLIP', None))
+                                         grad_norm_clip=cfg.OPTIMIZATION.get('GRAD_NORM_CLIP', None),
+                                         next_batch=nxt if isinstance(nxt, dict) and torch.is_tensor(nxt.get('points', None)) else None)
+            batch = nxt
             it += 1
             if rank == 0 and (i % 10 == 0 or i == iters_per_epoch - 1):
                 logger.info(f'epoch {epoch} it {i}/{iters_per_epoch} loss {float(loss):.5f} lr {opt.lr:.2e}')

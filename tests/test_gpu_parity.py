@@ -1867,6 +1867,40 @@ def test_bf16_trains_like_fp32():
     assert abs(a[-10:].mean() - b[-10:].mean()) <= 0.03 * a[-10:].mean()
 
 
+def test_vfe_prefetch_one_step_ahead_changes_nothing():
+    """train_one_step(next_batch=...): the next batch's voxelisation enqueued between this step's forward and backward
+    (TemporalDynVFE.prefetch) -- three optimizer steps with and without the lookahead give bit-identical losses and weights."""
+    from pcdet.config import EasyDict, cfg_from_yaml_file
+    from pcdet.models import model_fn_decorator
+    from tmae_amd.train import SyntheticTemporalDataset, build_model_from_cfg, build_optimizer, build_scheduler, train_one_step
+    import bench
+    cfg = cfg_from_yaml_file(os.path.join(bench.ROOT, 't-mae_amd', 'tools', 'cfgs', 'once_models', 't_mae_ssl.yaml'), EasyDict())
+    ds = SyntheticTemporalDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_points=12000, batch_size=2)
+    raw = [ds.batch(i) for i in range(3)]
+    res = []
+    for ahead in (True, False):
+        torch.manual_seed(7)
+        model = build_model_from_cfg(cfg, ds).to(dev()).train()
+        opt = build_optimizer(model, cfg.OPTIMIZATION)
+        sched, _ = build_scheduler(opt, 100, cfg.OPTIMIZATION.NUM_EPOCHS, -1, cfg.OPTIMIZATION)
+        mk = lambda b: {'points': torch.from_numpy(b['points']).to(dev()), 'points_prev': torch.from_numpy(b['points_prev']).to(dev()),
+                        'batch_size': b['batch_size']}
+        dicts = [mk(b) for b in raw]
+        losses = []
+        for i in range(3):
+            torch.manual_seed(100 + i)                                           # the masking noise
+            nxt = dicts[i + 1] if (ahead and i + 1 < 3) else None
+            loss, _, _ = train_one_step(model, opt, sched, dicts[i], i, model_fn_decorator(), amp_dtype=torch.bfloat16, settle=False,
+                                        next_batch=nxt)
+            if ahead and i + 1 < 3:
+                assert '_vfe_prefetch' in dicts[i + 1]
+            losses.append(loss.detach().clone())
+        res.append((losses, torch.cat([p.detach().flatten() for p in model.parameters()]).clone()))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b), (a, b)
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def test_step_gradients_are_bit_reproducible():
     """One forward + backward of the full model (B = 2 x 20 k-point pairs) three times from identical state and masking noise:
     under bf16 autocast (the benched path) EVERY gradient repeats bit for bit -- all reductions of this repository run in a fixed
