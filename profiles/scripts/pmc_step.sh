@@ -9,7 +9,7 @@ TAG=${1:-r4}
 OUT=/tmp/pmc_step_$TAG
 rm -rf $OUT; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-secondary > "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_step_$c.log" 2>&1 )
+  ( cd /tmp && timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-vfe-prefetch > "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_step_$c.log" 2>&1 )
   echo "$c rc $?"
 done
 python3 profiles/scripts/pmc_step_summary.py $OUT gpurun_out/${TAG}_step_bytes.json > gpurun_out/${TAG}_step_bytes.md

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 TAG=${1:-r4}
 OUT=/tmp/pmc_sq_$TAG
 rm -rf $OUT; mkdir -p $OUT
-( cd /tmp && timeout -k 10 500 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/p -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-secondary > "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_sq.log" 2>&1 )
+( cd /tmp && timeout -k 10 500 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/p -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-vfe-prefetch > "$GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_sq.log" 2>&1 )
 echo "rc $?"
 python3 - "$OUT" > gpurun_out/${TAG}_step_sq.md <<'PY'
 import collections, csv, glob, re, sys
