@@ -457,7 +457,7 @@ def dense_wgrad_roofline(batch_per_gpu, iters=10):
 def spconv_rooflines(model, iters=10):
     """`roofline_spconv` / `roofline_spconv_wgrad`: the d = 256 submanifold conv of the encoder's second stage (conv_out of
     sst_block 2: 256 -> 256, spt_backbone.py:279-304 through spconv_utils.post_act_block) over the token list of BOTH frames with
-    the batch's real rulebook -- forward on spconv_igemm_ring256_kernel<256> (+ its tail launch), weight gradient on
+    the batch's real rulebook -- forward on spconv_igemm_ring256_kernel<256>, weight gradient on
     wgrad256_kernel<true> + the slab reduction.  MFMA-bound; FLOPs = 2 x ACTIVE (input, output) pairs x 256 x 256 (SURVEY 8d:
     the kernels also multiply the zeros of absent neighbours, which is not counted).  Needs the index sets of a forward pass
     (step_flops ran one)."""
@@ -490,7 +490,7 @@ def spconv_rooflines(model, iters=10):
               'tmae_spconv_wgrad')
     res = {}
     flops = 2.0 * pairs * cin * cout
-    for key, fn, name in (('roofline_spconv', fwd, 'spconv_igemm_ring256_kernel<256> (+ the 128-column tail launch of its last round): stage-2 '
+    for key, fn, name in (('roofline_spconv', fwd, 'spconv_igemm_ring256_kernel<256>: stage-2 '
                                                    'submanifold conv 256 -> 256 forward, both frames'),
                           ('roofline_spconv_wgrad', wg, 'wgrad256_kernel<true> + wgrad_reduce_kernel: the same conv\'s weight gradient '
                                                         'dW[256, 9 x 256] through the rulebook')):

@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 23
+#define TMAE_ABI_VERSION 24
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -103,6 +103,13 @@ int tmae_vfe_point_features_bf16x2(const float* points, int row, const int64_t* 
 int tmae_segment_max_fwd(const void* x, int dtype, int64_t n, int64_t m, int c,
                          const int32_t* perm, const int32_t* offsets,
                          void* out, int32_t* argmax, void* stream);
+/* tmae_segment_max_fwd over the rows of relu?(BatchNorm(x)) without writing them: the VFE's last Linear -> BatchNorm1d -> ReLU ->
+ * scatter_max (temporal_dyn_vfe.py:110-113) with the norm's statistics given (tmae_bn_stats).  out / argmax are bit for bit those
+ * of tmae_bn_apply followed by tmae_segment_max_fwd.  c in {64, 128, 256}; the backward is tmae_segment_max_bwd then
+ * tmae_bn_relu_bwd. */
+int tmae_segment_max_bn_fwd(const void* x, int dtype, int64_t n, int64_t m, int c, const int32_t* perm, const int32_t* offsets,
+                            const float* mean, const float* rstd, const float* gamma, const float* beta, int relu, void* out,
+                            int32_t* argmax, void* stream);
 int tmae_segment_max_bwd(const void* dout, int dtype, int64_t n, int64_t m, int c,
                          const int64_t* inverse_i64, const int32_t* argmax, void* dx, void* stream);
 
@@ -446,7 +453,7 @@ int tmae_deblock_scatter(const void* v, int dtype, const int32_t* grid, int batc
 /* All sources of the concat buffer in ONE launch (whole ldc-wide rows per store burst instead of one channel slice per launch):
  * HOST arrays of n_src <= 4 entries -- v[i], grid[i], ys[i], xs[i], s[i], cout[i], mean[i], rstd[i], gamma[i], beta[i] as in
  * tmae_deblock_scatter; the slices lie side by side in source order (sum of cout = ldc), every source covers the same dense
- * grid (ys[i] s[i] = Y, xs[i] s[i] = X). */
+ * grid (ys[i] s[i] = Y, xs[i] s[i] = X); strides are powers of two. */
 int tmae_deblock_scatter_multi(int n_src, const void* const* v, int dtype, const int32_t* const* grid, int batch, const int* ys,
                                const int* xs, const int* s, const int* cout, const float* const* mean, const float* const* rstd,
                                const float* const* gamma, const float* const* beta, void* out, int ldc, void* stream);

@@ -93,18 +93,20 @@ __global__ __launch_bounds__(256) void deblock_scatter_multi_kernel(DbSrcs P, in
     sc[k] = S.rstd[c0 + k] * S.gamma[c0 + k];
     sh[k] = S.beta[c0 + k] - S.mean[c0 + k] * sc[k];
   }
-  const unsigned s = (unsigned)S.s, ys = (unsigned)S.ys, xs = (unsigned)S.xs;
+  // the stride differs from lane group to lane group here (one source per chunk range): shifts and masks, not per-lane integer
+  // divisions (the launcher admits powers of two only) -- the first version divided and ran 471 us against 3 x 126 us
+  const unsigned ls = (unsigned)S.s, ys = (unsigned)S.ys, xs = (unsigned)S.xs, sm = (1u << ls) - 1u;   // S.s holds log2(stride)
   const unsigned cell0 = blockIdx.x * (cpp * DS_CPT) + sub;
 #pragma unroll
   for (int it = 0; it < DS_CPT; ++it) {
     const unsigned cell = cell0 + (unsigned)it * cpp;
     if (cell >= ncell) break;
     const unsigned x = cell % X, yb = cell / X, y = yb % Y, b = yb / Y;
-    const int idx = S.grid[(b * ys + y / s) * xs + x / s];
+    const int idx = S.grid[(b * ys + (y >> ls)) * xs + (x >> ls)];
     T tmp[VEC];
     if (idx >= 0)
       *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(
-          v + ((int64_t)idx * s * s + (y % s) * s + (x % s)) * S.cout + c0);
+          v + ((((int64_t)idx << (2 * ls)) + (((y & sm) << ls) | (x & sm))) * S.cout + c0));
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       const float z = (idx >= 0 ? ld_f<T>(&tmp[k]) * sc[k] : 0.f) + sh[k];
@@ -216,9 +218,11 @@ int tmae_deblock_scatter_multi(int n_src, const void* const* v, int dtype, const
   const int Y = ys[0] * s[0], X = xs[0] * s[0];
   for (int i = 0; i < n_src; ++i) {
     if (!v[i] || !grid[i] || !mean[i] || !rstd[i] || !gamma[i] || !beta[i] || ys[i] <= 0 || xs[i] <= 0 || s[i] <= 0 || cout[i] <= 0 ||
-        (cout[i] * es) % 16 || ys[i] * s[i] != Y || xs[i] * s[i] != X)
-      return TMAE_EARG;
-    P.src[i] = DbSrc{v[i], grid[i], mean[i], rstd[i], gamma[i], beta[i], ys[i], xs[i], s[i], cout[i], coff};
+        (cout[i] * es) % 16 || ys[i] * s[i] != Y || xs[i] * s[i] != X || (s[i] & (s[i] - 1)))
+      return TMAE_EARG;                                       // (strides: powers of two -- the kernel shifts)
+    int ls = 0;
+    while ((1 << ls) < s[i]) ++ls;
+    P.src[i] = DbSrc{v[i], grid[i], mean[i], rstd[i], gamma[i], beta[i], ys[i], xs[i], ls, cout[i], coff};
     coff += cout[i];
   }
   for (int i = n_src; i < DS_MAXSRC; ++i) P.src[i] = P.src[0];

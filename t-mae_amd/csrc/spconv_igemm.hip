@@ -505,15 +505,10 @@ static int igemm_launch(const void* feat, int64_t ldf, int64_t m_in, int cin, co
     const int64_t fbytes = ((m_in - 1) * ldf + cin) * 2;
     static const int gen2 = TMAE_AB_INT("TMAE_IGEMM_RING2", 1);
     if (bn == 256 && gen2 != 0 && fbytes < (int64_t)IR2_OOB && ldf * 2 < (1 << 24) && m_in < (1 << 24)) {
-      // Tile quantisation (round 6).  One 512-thread workgroup per CU, 256 CUs: `rts` row tiles run in ceil(rts / 256) rounds, and a
-      // last round that is mostly empty costs as much as a full one (86 k rows: 337 tiles = 1.3 rounds run as 2; 148 k: 2.25 as 3).
-      // When the last round holds at most 128 row tiles, its rows go to the 128-column kernel above instead -- two column tiles per
-      // row tile, i.e. at most 256 workgroups of about half the work each, in a second launch: the round costs ~0.55 of a full one.
-      static const int tail_split = TMAE_AB_INT("TMAE_IGEMM_TAIL", 1);
-      const int64_t whole = (rts / 256) * 256, rem = rts - whole;
-      const bool split = tail_split != 0 && cout == 256 && whole > 0 && rem > 0 && rem <= 128;
-      const int64_t m_main = split ? whole * IR_BM : m_out;
-      const int64_t grid_main = split ? whole : grid;
+      // (Round 6 tried to run a last, mostly empty round of row tiles -- 86 k rows = 337 tiles = 1.3 rounds of 256 workgroups -- on the
+      //  128-column kernel in a second launch: that kernel gathers the same rows for half the columns and took 0.7 of a full round plus
+      //  its own launch; ring256 2.66 -> 2.34 ms, tail launches +0.29 ms: nothing.  profiles/round6_ab_spconv_tail.txt.)
+      const int64_t m_main = m_out, grid_main = grid;
 #define IR2_LAUNCH(C)                                                                                                 \
   do {                                                                                                                \
     static TmaeLdsAttr attr;                                                                                          \
@@ -524,22 +519,6 @@ static int igemm_launch(const void* feat, int64_t ldf, int64_t m_in, int cin, co
   } while (0)
       if (cin == 128) IR2_LAUNCH(128); else if (cin == 256) IR2_LAUNCH(256); else IR2_LAUNCH(384);
 #undef IR2_LAUNCH
-      if (split) {
-        const int64_t m_tail = m_out - m_main;
-        const int32_t* nbr_t = nbr + m_main * 9;
-        __hip_bfloat16* out_t = (__hip_bfloat16*)out + m_main * ldo;
-        const int64_t grid_t = ((rem + 7) / 8) * 8 * 2;
-        const int lds_t = 3 * (IR_BM * 128 + 128 * 128) + IR_BM * 9 * 4;
-#define IR_TAIL(C)                                                                                                    \
-  do {                                                                                                                \
-    static TmaeLdsAttr attr;                                                                                          \
-    if (int e_ = tmae_allow_lds(attr, (const void*)spconv_igemm_ring_kernel<C, 128>, lds_t)) return e_;               \
-    hipLaunchKernelGGL((spconv_igemm_ring_kernel<C, 128>), dim3((unsigned)grid_t), dim3(512), lds_t, stream,          \
-                       (const __hip_bfloat16*)feat, ldf, nbr_t, m_tail, (const __hip_bfloat16*)w, cout, out_t, ldo);   \
-  } while (0)
-        if (cin == 128) IR_TAIL(128); else if (cin == 256) IR_TAIL(256); else IR_TAIL(384);
-#undef IR_TAIL
-      }
     } else if (bn == 256) {
       if (cin == 128) IR_LAUNCH(128, 256); else if (cin == 256) IR_LAUNCH(256, 256); else IR_LAUNCH(384, 256);
     } else {

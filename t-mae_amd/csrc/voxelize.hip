@@ -419,11 +419,21 @@ __global__ __launch_bounds__(256) void segmax_bwd_kernel(const T* __restrict__ d
 
 // 16-byte variants (c a multiple of 8 with c/8 a power of two <= 64): c/8 adjacent lanes per voxel / point row, 8
 // channels per lane.  A voxel holds ~2-3 points, so one wavefront per voxel left most of the wave's width idle.
-template <class T, int LPV>
+template <class T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<__hip_bfloat16>(float v) { return __bfloat162float(__float2bfloat16(v)); }
+
+// AFF (round 6): the rows are normalised on the way in -- val = relu?(x * sc + sh) with sc = rstd gamma, sh = beta - mean sc, rounded
+// to T like the tensor a separate BatchNorm + ReLU pass would have written -- so the VFE's last norm needs no apply pass of its
+// own over every point of the frame (temporal_dyn_vfe.py:110-113: Linear, BatchNorm1d, ReLU, scatter_max).
+template <class T, int LPV, bool AFF = false>
 __global__ __launch_bounds__(256) void segmax_fwd8_kernel(const T* __restrict__ x, int64_t m,
                                                          const int32_t* __restrict__ perm,
                                                          const int32_t* __restrict__ offsets, T* __restrict__ out,
-                                                         int32_t* __restrict__ argmax) {
+                                                         int32_t* __restrict__ argmax, const float* __restrict__ mean = nullptr,
+                                                         const float* __restrict__ rstd = nullptr,
+                                                         const float* __restrict__ gamma = nullptr,
+                                                         const float* __restrict__ beta = nullptr, int relu = 0) {
   constexpr int C = LPV * 8, VPW = 64 / LPV;
   const int lane = threadIdx.x & 63, sub = lane / LPV, cl = lane % LPV;
   const int64_t v = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * VPW + sub;
@@ -433,6 +443,15 @@ __global__ __launch_bounds__(256) void segmax_fwd8_kernel(const T* __restrict__ 
   int arg[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; arg[i] = -1; }
+  float sc[8], sh[8];
+  if constexpr (AFF) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int ch = cl * 8 + i;
+      sc[i] = rstd[ch] * gamma[ch];
+      sh[i] = beta[ch] - mean[ch] * sc[i];
+    }
+  }
   // four rows per round, all four loads in flight before the first comparison (a voxel holds 2-3 points: one dependent load
   // per point left this kernel waiting for memory latency, not bandwidth); rows past the segment re-read its last row
   for (int j0 = lo; j0 < hi; j0 += 4) {
@@ -445,6 +464,15 @@ __global__ __launch_bounds__(256) void segmax_fwd8_kernel(const T* __restrict__ 
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) load8<T>(x + (int64_t)rows[u] * C + cl * 8, val[u]);
+    if constexpr (AFF) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float z = val[u][i] * sc[i] + sh[i];            // the expression of bn_apply_kernel, then its store's rounding
+          val[u][i] = round_to<T>(relu ? fmaxf(z, 0.f) : z);
+        }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (j0 + u < hi) {
@@ -524,6 +552,29 @@ int tmae_segment_max_fwd(const void* x, int dtype, int64_t n, int64_t m, int c, 
                        perm, offsets, (__hip_bfloat16*)out, argmax);
   else
     return TMAE_EDTYPE;
+  return tmae_launch_status();
+}
+
+// tmae_segment_max_fwd over relu?(BatchNorm(x)) with the norm's statistics given: out / argmax as if the normalised rows had been
+// written (in x's dtype) and then reduced.  c in {64, 128, 256} with 16-byte aligned rows; anything else TMAE_EARG (normalise first).
+int tmae_segment_max_bn_fwd(const void* x, int dtype, int64_t n, int64_t m, int c, const int32_t* perm, const int32_t* offsets,
+                            const float* mean, const float* rstd, const float* gamma, const float* beta, int relu, void* out,
+                            int32_t* argmax, void* stream_) {
+  (void)hipGetLastError();
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || m < 0 || (c != 64 && c != 128 && c != 256)) return TMAE_EARG;
+  if (m == 0) return TMAE_OK;
+  if (!x || !offsets || !out || !argmax || !mean || !rstd || !gamma || !beta) return TMAE_EARG;
+  if (!segmax_vec_ok(c, x, out) || ((uintptr_t)argmax & 15) || (dtype != TMAE_F32 && dtype != TMAE_BF16)) return TMAE_EARG;
+  const dim3 g8(tmae_cdiv(m, 4 * (512 / c))), blk(256);
+#define SEGMAX8_AFF(T)                                                                                                  \
+  do {                                                                                                                  \
+    if (c == 64) hipLaunchKernelGGL((segmax_fwd8_kernel<T, 8, true>), g8, blk, 0, stream, (const T*)x, m, perm, offsets, (T*)out, argmax, mean, rstd, gamma, beta, relu); \
+    else if (c == 128) hipLaunchKernelGGL((segmax_fwd8_kernel<T, 16, true>), g8, blk, 0, stream, (const T*)x, m, perm, offsets, (T*)out, argmax, mean, rstd, gamma, beta, relu); \
+    else hipLaunchKernelGGL((segmax_fwd8_kernel<T, 32, true>), g8, blk, 0, stream, (const T*)x, m, perm, offsets, (T*)out, argmax, mean, rstd, gamma, beta, relu); \
+  } while (0)
+  if (dtype == TMAE_F32) SEGMAX8_AFF(float); else SEGMAX8_AFF(__hip_bfloat16);
+#undef SEGMAX8_AFF
   return tmae_launch_status();
 }
 

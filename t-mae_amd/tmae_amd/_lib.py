@@ -30,6 +30,7 @@ SIGNATURES = {
     'tmae_vfe_point_features_bf16x2': (I, [P, I, P, P, P, P, L, L, F, F, F, F, F, F, P, P, P, P]),
     'tmae_segment_max_fwd': (I, [P, I, L, L, I, P, P, P, P, P]),
     'tmae_segment_max_bwd': (I, [P, I, L, L, I, P, P, P, P]),
+    'tmae_segment_max_bn_fwd': (I, [P, I, L, L, I, P, P, P, P, P, P, I, P, P, P]),
     'tmae_group_points': (I, [P, I, P, P, P, L, I, F, F, F, F, F, F, P, P, P]),
     'tmae_random_mask_workspace': (Z, [L, I]),
     'tmae_random_mask': (I, [P, P, L, I, D, P, P, P, P, Z, P]),
@@ -147,7 +148,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     setattr(lib, _name, _strict(_fn, _name, len(_args)))
 
-ABI_VERSION = 23            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
+ABI_VERSION = 24            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError(f'libtmae_hip.so ABI version {lib.tmae_abi_version()} != binding {ABI_VERSION}; rebuild with '
                       f't-mae_amd/build.py')

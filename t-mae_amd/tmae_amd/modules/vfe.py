@@ -76,6 +76,8 @@ class TemporalDynVFE(VFETemplate):
         else:
             _, x = ops.vfe_point_features(vox['points'], vox['point_coords'], vox['inverse'], perm, offsets, m,
                                           self.point_cloud_range, self.voxel_size)
+        norms = [i for i, layer in enumerate(layers) if isinstance(layer, (nn.BatchNorm1d, nn.SyncBatchNorm))]
+        last_norm = norms[-1] if norms and not any(isinstance(layer, nn.Linear) for layer in layers[norms[-1]:]) else -1
         for i, layer in enumerate(layers):
             if isinstance(layer, nn.Linear):
                 w = layer.weight
@@ -85,6 +87,10 @@ class TemporalDynVFE(VFETemplate):
                     w = torch.nn.functional.pad(w, (0, pad))
                 x = ops.linear(x, w, None)
             elif isinstance(layer, (nn.BatchNorm1d, nn.SyncBatchNorm)):
+                if i == last_norm:
+                    # the MLP's last norm + ReLU are applied by the voxel max as it reads the rows: no normalised [points, c] tensor
+                    x_max, _ = ops.bn_relu_scatter_max(x, layer, inv_rows, perm_rows, offsets, m)
+                    return x_max
                 x = ops.batch_norm_relu(x, layer, relu=True)         # the ReLU that follows is fused
         x_max, _ = ops.scatter_max(x, inv_rows, perm_rows, offsets, m)
         return x_max

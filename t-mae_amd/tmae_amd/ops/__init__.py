@@ -1438,6 +1438,64 @@ class _SegmentMax(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+class _BNReLUSegMax(torch.autograd.Function):
+    """scatter_max(relu(BatchNorm1d(x))) -- the tail of the VFE's MLP (temporal_dyn_vfe.py:110-113) -- without the normalised
+    [points, c] tensor: one statistics pass over x, then the segment max normalises the rows as it reads them
+    (tmae_segment_max_bn_fwd: values and argmax bit-equal to the two-op form).  Backward: the max's gradient scattered to its
+    argmax rows, then the norm's backward with the ReLU mask recomputed from x, as before."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, inverse, perm, offsets, m):
+        x = x.contiguous()
+        n, c = x.shape
+        mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+        var, rstd = torch.empty_like(mean), torch.empty_like(mean)
+        g32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        wsb = lib.tmae_bn_workspace(n, c)
+        ws = _ws(wsb, x.device)
+        check(lib.tmae_bn_stats(_p(x), _dt(x), n, c, float(n), float(eps), _p(mean), _p(var), _p(rstd), _p(ws), wsb, _s()), 'tmae_bn_stats')
+        out = torch.empty((m, c), dtype=x.dtype, device=x.device)
+        argmax = torch.empty((m, c), dtype=torch.int32, device=x.device)
+        check(lib.tmae_segment_max_bn_fwd(_p(x), _dt(x), n, m, c, _p(perm), _p(offsets), _p(mean), _p(rstd), _p(g32), _p(b32), 1, _p(out),
+                                          _p(argmax), _s()), 'tmae_segment_max_bn_fwd')
+        ctx.save_for_backward(x, mean, rstd, g32, b32, inverse, argmax)
+        ctx.dtypes = (weight.dtype, bias.dtype)
+        ctx.mark_non_differentiable(argmax, mean, var)
+        ctx.set_materialize_grads(False)
+        return out, argmax, mean, var
+
+    @staticmethod
+    def backward(ctx, dout, _a, _m, _v):
+        if dout is None:
+            return (None,) * 8
+        x, mean, rstd, g32, b32, inverse, argmax = ctx.saved_tensors
+        n, c = x.shape
+        dout = dout.to(x.dtype).contiguous()
+        dy = torch.empty((n, c), dtype=x.dtype, device=x.device)
+        check(lib.tmae_segment_max_bwd(_p(dout), _dt(dout), n, dout.shape[0], c, _p(inverse), _p(argmax), _p(dy), _s()), 'tmae_segment_max_bwd')
+        dx = torch.empty_like(x)
+        dg = torch.empty((c,), dtype=torch.float32, device=x.device)
+        db = torch.empty_like(dg)
+        wsb = lib.tmae_bn_workspace(n, c)
+        ws = _ws(wsb, x.device)
+        check(lib.tmae_bn_relu_bwd(_p(dy), _p(x), _dt(x), n, c, _p(mean), _p(rstd), _p(g32), _p(b32), 1, _p(dx), _p(dg), _p(db), _p(ws), wsb,
+                                   _s()), 'tmae_bn_relu_bwd')
+        return dx, dg.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None, None, None, None
+
+
+def bn_relu_scatter_max(x, bn, inverse, perm, offsets, m):
+    """scatter_max(relu(bn(x)), inverse) -> (out [m, c], argmax) with bn's running statistics updated as torch does; the fused
+    form (_BNReLUSegMax) for training-mode norms over 64 / 128 / 256 channels on the GPU, else the two ops."""
+    n, c = x.shape
+    if (x.is_cuda and bn.training and c in (64, 128, 256) and n > 1 and _sync_group(bn) is None and x.dtype in (torch.float32, torch.bfloat16)
+            and x.is_contiguous() and x.data_ptr() % 16 == 0):
+        out, argmax, mean, var = _BNReLUSegMax.apply(x, bn.weight, bn.bias, bn.eps, inverse, perm, offsets, m)
+        if bn.track_running_stats:
+            _bn_running_update(bn, mean, var, float(n))
+        return out, argmax
+    return scatter_max(batch_norm_relu(x, bn, relu=True), inverse, perm, offsets, m)
+
+
 def scatter_max(src, inverse, perm, offsets, m):
     """torch_scatter.scatter_max(src, index, dim=0) -> (out, argmax) (temporal_dyn_vfe.py:113)."""
     return _SegmentMax.apply(src, inverse, perm, offsets, m)
@@ -1841,7 +1899,7 @@ class _DeblocksToDense(torch.autograd.Function):
             saved += [x_c, wmat, v, mean, rstd, g32, b32, grid, indices]
             stats += [mean, var]
             coff += cout
-        if n_src <= 4 and len({(ys * s, xs * s) for (_, _, ys, xs, s) in metas}) == 1:
+        if n_src <= 4 and len({(ys * s, xs * s) for (_, _, ys, xs, s) in metas}) == 1 and all(s & (s - 1) == 0 for (_, _, _, _, s) in metas):
             # all channel slices of the concat buffer in one launch (whole rows per store burst): HOST tables of the sources
             import ctypes as _ct
             vp = _ct.c_void_p

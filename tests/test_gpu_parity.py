@@ -1032,6 +1032,39 @@ def test_decoder_with_and_without_epilogue_sums(oracle):
         assert torch.allclose(ba[n], bb[n], rtol=1e-4, atol=1e-5), n
 
 
+def test_bn_relu_scatter_max_equals_the_two_ops():
+    """ops.bn_relu_scatter_max (the VFE's last BatchNorm + ReLU applied by the voxel max as it reads the rows,
+    tmae_segment_max_bn_fwd) against ops.batch_norm_relu followed by ops.scatter_max: values, argmax, running statistics and
+    all gradients bit for bit (the fused kernel rounds the normalised value exactly as the separate pass stores it)."""
+    from tmae_amd import ops
+    torch.manual_seed(9)
+    n, m = 60000, 21000
+    inv = torch.randint(0, m, (n,), device=dev()).sort().values          # rows in voxel order (perm = None), some voxels empty
+    perm_, offs = ops.segment_csr(inv, m)
+    for c, dt in ((128, torch.bfloat16), (64, torch.float32), (256, torch.bfloat16)):
+        x0 = (torch.randn(n, c, device=dev()) * 1.7 + 0.4).to(dt)
+        go = torch.randn(m, c, device=dev()).to(dt)
+        res = []
+        for fused in (True, False):
+            bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev())
+            with torch.no_grad():
+                bn.weight.normal_(1.0, 0.3), bn.bias.normal_(0.0, 0.3)
+                bn.weight[0] = -0.7                                              # a negative scale: the max is taken AFTER the affine map
+            if len(res):
+                bn.load_state_dict(keep)
+            keep = {k: v.clone() for k, v in bn.state_dict().items()}
+            x = x0.clone().requires_grad_(True)
+            if fused:
+                out, arg = ops.bn_relu_scatter_max(x, bn, inv, None, offs, m)
+            else:
+                out, arg = ops.scatter_max(ops.batch_norm_relu(x, bn, relu=True), inv, None, offs, m)
+            out.backward(go)
+            res.append((out.detach().clone(), arg.clone(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(),
+                        bn.running_mean.clone(), bn.running_var.clone()))
+        for k, (a, b) in enumerate(zip(*res)):
+            assert torch.equal(a, b), (c, dt, k)
+
+
 def test_batchnorm_gather_backward_without_the_dense_gradient():
     """ops.batch_norm_relu_gather (the decoder's last norm + the gather at the current frame's voxels as one node,
     tmae_bn_relu_bwd_gathered) against ops.batch_norm_relu followed by ops.dense_gather: same outputs bit for bit; dx / dgamma /
