@@ -519,8 +519,8 @@ int tmae_token_gemm(const void* x, int64_t ldx, int64_t m, int k, const void* w,
 /* In-place form  y[m,n] += x[m,k] . w[n,k]^T + bias[n]  -- torch.Tensor.addmm_ of the Linear input gradients whose input has
  * a second consumer (ops.proj_fork: the FFN's first Linear, sst_basic_block.py:81-83, autograd's AccumulateGrad add in
  * the reference) and of the attention in-projections (sst_basic_block.py:45-47 backwards).  Shapes: (k, n) = (512, 256),
- * (256, 128), (768, 256) or (384, 128), m >= 32768; anything else returns TMAE_EARG and the caller keeps the library's
- * addmm_.  Same pointer rules as tmae_token_gemm; y is read and written once. */
+ * (256, 128), (768, 256), (384, 128), (256, 256) or (128, 128), m >= 32768; anything else returns TMAE_EARG and the caller
+ * keeps the library's addmm_.  Same pointer rules as tmae_token_gemm; y is read and written once. */
 int tmae_token_gemm_acc(const void* x, int64_t ldx, int64_t m, int k, const void* w, int n, const void* bias, void* y,
                         int64_t ldy, void* stream);
 /* Residual form  y[m,n] = res[m,n] + x[m,k] . w[n,k]^T + bias[n]  (res: the pitch of y, 16-byte aligned; res != y) -- `src +

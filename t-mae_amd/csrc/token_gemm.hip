@@ -327,8 +327,10 @@ int tmae_token_gemm_acc(const void* x, int64_t ldx, int64_t m, int k, const void
   if (m < 0) return TMAE_EARG;
   if (m == 0) return TMAE_OK;
   // the in-place form exists in the W-in-registers kernel only (the y tile travels through its LDS ring):
-  // [m, 256] += [m, 512] W^T and [m, 128] += [m, 256] W^T -- the FFN-1 input gradients of the d = 256 / d = 128 stages
-  if (m < 32768 || !((k == 512 && n == 256) || (k == 256 && n == 128) || (k == 768 && n == 256) || (k == 384 && n == 128)))
+  // [m, 256] += [m, 512] W^T and [m, 128] += [m, 256] W^T -- the FFN-1 input gradients of the d = 256 / d = 128 stages --, the
+  // in-projections' (768 -> 256, 384 -> 128) and the square ones (256 -> 256, 128 -> 128)
+  if (m < 32768 || !((k == 512 && n == 256) || (k == 256 && n == 128) || (k == 768 && n == 256) || (k == 384 && n == 128) ||
+                     (k == 256 && n == 256) || (k == 128 && n == 128)))
     return TMAE_EARG;
   return tmae_token_gemm_wreg(x, ldx, m, k, w, n, bias, nullptr, y, ldy, 1, stream_);
 }

@@ -64,6 +64,8 @@ __device__ __forceinline__ float tgw_dgelu(float x) {
 // tokens per ring slot: 32 KB of x (DG: 16 KB); contraction 384 / 768 (the attention in-projections' input gradients,
 // W = 96 / 192 registers per lane): 24 KB
 __host__ __device__ constexpr int tgw_step(int k, bool dg) { return k == 768 ? 16 : (k == 384 ? 32 : (dg ? 8192 : 16384) / k); }
+// ACC at contraction 128 takes the half step too: its y tile (128 columns) is as large as the x tile
+__host__ __device__ constexpr bool tgw_half(int k, bool acc, bool dg) { return dg || (acc && k == 128); }
 
 #define TGW_OOB 0x7FFFFFF0u          // voffset past every buffer: loads return zeros, stores are dropped
 #define TGW_NT 2                     // cache policy of the y stores (written once, streamed)
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void token_gemm_wreg_kernel(const __hip_bfl
                                                                 __hip_bfloat16* __restrict__ y2) {
   static_assert(!(DG && (ACC || GELU2 || POS)), "DG is a mode of its own");
   constexpr int TEAMS = 8 / NWC;                  // teams of NWC waves; a team covers all columns of the group
-  constexpr int STEP = tgw_step(K, DG);           // tokens per ring slot (32 KB of x; DG 16 KB): 128 / 64 / 32 for K = 128 / 256 / 512
+  constexpr int STEP = tgw_step(K, tgw_half(K, ACC, DG));   // tokens per ring slot (32 KB of x; DG 16 KB): 128 / 64 / 32 for K = 128 / 256 / 512
   constexpr int TGW = (STEP / 16) / TEAMS;        // 16-token groups per wave and step
   constexpr int KX = K / 32, KA = K + (POS ? 32 : 0), KS = KA / 32;
   constexpr int ROWB = K * 2;                     // bytes per x row
@@ -324,7 +326,7 @@ template <int K, int NTC, int NWC, bool POS, bool ACC = false, bool GELU2 = fals
 static int tgw_launch(const void* x, int64_t ldx, int64_t m, const void* w, int n, const void* bias, void* y, int64_t ldy,
                       const void* cells, hipStream_t stream, void* y2 = nullptr) {
   constexpr int NG = NWC * NTC * 16;
-  constexpr int STEP = tgw_step(K, DG);
+  constexpr int STEP = tgw_step(K, tgw_half(K, ACC, DG));
   constexpr int lds = ((ACC || DG) ? 3 : 4) * (STEP * K * 2 + (POS ? STEP * 4 : 0) + ((ACC || DG) ? STEP * NG * 2 : 0)) + 8 * 16 * NTC * 32;
   const int ncg = n / NG;
   static TmaeLdsAttr attr;
@@ -356,6 +358,10 @@ int tmae_token_gemm_wreg(const void* x, int64_t ldx, int64_t m, int k, const voi
     if (k == 256 && n == 128) return tgw_launch<256, 4, 2, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
     if (k == 768 && n == 256) return tgw_launch<768, 2, 8, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
     if (k == 384 && n == 128) return tgw_launch<384, 2, 4, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
+    // the square ones (the cross layers' query input gradient into the alias gradient, the out-projections'): 256 -> 256 as two
+    // column groups of the 256 -> 128 instance (x read twice, the second time from the cache), 128 -> 128 on half steps
+    if (k == 256 && n == 256) return tgw_launch<256, 4, 2, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
+    if (k == 128 && n == 128) return tgw_launch<128, 4, 2, false, true>(x, ldx, m, w, n, bias, y, ldy, nullptr, stream);
     return TMAE_EARG;
   }
   if (n % 128 || (k != 128 && k != 256)) return TMAE_EARG;

@@ -101,7 +101,7 @@ class SiamWCA_MAE(nn.Module):
         offs_dev = torch.from_numpy(offs).pin_memory().to(dev, non_blocking=True)      # (a pageable copy is synchronous)
         mask, vis_index, _ = ops.random_mask(noise, offs_dev, batch_size, keep_frac)
         vis = vis_index[:n_vis].long()
-        return all_voxel_features[vis], all_voxel_coords[vis], mask
+        return ops.gather_rows(all_voxel_features, vis), all_voxel_coords[vis], mask       # vis: distinct rows
 
     # ------------------------------------------------------------------ encoder (SiamWCA_MAE.py:184-218)
     def sparse_encode(self, voxel_features, voxel_coords, batch_size, previous_sstblock=False):

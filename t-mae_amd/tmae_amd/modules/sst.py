@@ -150,26 +150,29 @@ class WindowCrossAttention(nn.Module):
                                                    tau_min=layer_cfg.get('tau_min', 0.01),
                                                    non_shared_tau=layer_cfg.get('non_shared_tau', False))
 
-    def forward(self, x, plan, x_prv, plan_prv, pos_table, window_shape, shift):
+    def forward(self, x, plan, x_prv, plan_prv, pos_table, window_shape, shift, prv_alias=False):
         """q = cur + pos, k = prev + pos_prev, v = prev (wca_block.py:26-67).  Query tokens whose window is
-        empty in the previous frame come back as zero rows (= not in keep_inds, wca_block.py:93-96)."""
+        empty in the previous frame come back as zero rows (= not in keep_inds, wca_block.py:93-96).
+        prv_alias: a third result, what the next cross layer should take as ITS x_prv (ops._PosProjCross kv_alias; x_prv itself
+        where that node is not used)."""
         a = self.cross_attn
         d = a.embed_dim
         w, b = a.in_proj_weight, a.in_proj_bias
         if _POS_FOLD and ops._pos_proj_ok(x, d, d) and ops._pos_proj_ok(x_prv, d, 2 * d):
             E = ops.pos_axes(pos_table, window_shape)
-            q, kv, x_res = ops.pos_proj_cross(x, x_prv, w, b, plan.cells(shift, window_shape),
-                                              plan_prv.cells(shift, window_shape), E, inplace_dx=True)
+            res = ops.pos_proj_cross(x, x_prv, w, b, plan.cells(shift, window_shape),
+                                     plan_prv.cells(shift, window_shape), E, inplace_dx=True, kv_alias=prv_alias)
+            q, kv, x_res = res[:3]
             o = ops.win_attn(q, kv, 'kv', a.tau, plan.grid_q(shift), plan.grid_k(shift), self.nhead, plan.batch, plan.ny,
                              plan.nx, shift, a.tau_min, worklist=plan.worklist(shift), covered=plan.covered(shift))
-            return o, x_res
+            return (o, x_res, res[3]) if prv_alias else (o, x_res)
         q, x_res = ops.proj_fork(x, w, b, ((0, d, True),), pos=(plan.indices, pos_table, window_shape, shift), fork=True,
                                  inplace_dx=True)
         k, v = ops.proj_fork(x_prv, w, b, ((d, 2 * d, True), (2 * d, 3 * d, False)),
                              pos=(plan_prv.indices, pos_table, window_shape, shift))
         o = ops.win_attn(q, k, v, a.tau, plan.grid_q(shift), plan.grid_k(shift), self.nhead, plan.batch, plan.ny, plan.nx,
                          shift, a.tau_min, worklist=plan.worklist(shift), covered=plan.covered(shift))
-        return o, x_res
+        return (o, x_res, x_prv) if prv_alias else (o, x_res)
 
 
 def _activation(name):
@@ -267,13 +270,16 @@ class WCAEncoderLayer(_EncoderTail):
     def __init__(self, d_model, nhead, dim_feedforward, dropout, activation, layer_cfg):
         super().__init__(WindowCrossAttention(d_model, nhead, dropout, layer_cfg), d_model, dim_feedforward, activation)
 
-    def forward(self, src, plan, src_prv, plan_prv, pos_table, window_shape, shift, kept, passthrough=False, post=None):
+    def forward(self, src, plan, src_prv, plan_prv, pos_table, window_shape, shift, kept, passthrough=False, post=None,
+                prv_alias=False):
+        """prv_alias: the result becomes (result, what the next cross layer takes as src_prv) -- see WindowCrossAttention."""
         a = self.win_attn.cross_attn
-        o, src_res = self.win_attn(src, plan, src_prv, plan_prv, pos_table, window_shape, shift)
+        o, src_res, *nxt_prv = self.win_attn(src, plan, src_prv, plan_prv, pos_table, window_shape, shift, prv_alias=prv_alias)
         # src[keep] += out_proj(attn): kept = query rows whose window also holds previous-frame tokens (the out-proj
         # bias must not reach the other rows): a 0/1 row weight of the update inside the fused add + norm
         upd = ops.linear(o, a.out_proj.weight, a.out_proj.bias)
-        return self.tail(src_res, upd, bmask=kept, passthrough=passthrough, post=post)
+        out = self.tail(src_res, upd, bmask=kept, passthrough=passthrough, post=post)
+        return (out, nxt_prv[0]) if prv_alias else out
 
 
 class BasicShiftBlock_WCA(nn.Module):
@@ -290,9 +296,13 @@ class BasicShiftBlock_WCA(nn.Module):
         assert len(self.encoder_list) >= 2 or not residual, 'residual folding needs >= 2 cross layers'
         for i, layer in enumerate(self.encoder_list):
             last = i == len(self.encoder_list) - 1
+            # every layer but the last hands the previous frame's rows on through its in-projection node: the layers' gradients for
+            # them then meet inside the earlier layer's input-gradient GEMM instead of in an autograd add (ops._PosProjCross)
             if residual and i == 0:
-                src, alias = layer(src, plan, src_prv, plan_prv, pos_table, window_shape, i == 1, kept_list[i],
-                                   passthrough=True)
+                (src, alias), src_prv = layer(src, plan, src_prv, plan_prv, pos_table, window_shape, i == 1, kept_list[i],
+                                              passthrough=True, prv_alias=True)
+            elif not last:
+                src, src_prv = layer(src, plan, src_prv, plan_prv, pos_table, window_shape, i == 1, kept_list[i], prv_alias=True)
             else:
                 src = layer(src, plan, src_prv, plan_prv, pos_table, window_shape, i == 1, kept_list[i],
                             post=alias if (residual and last) else None)

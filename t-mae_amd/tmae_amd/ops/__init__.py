@@ -112,11 +112,11 @@ def token_gemm_gelu(x, w, bias):
 
 def addmm_inplace(dx, dy, w, wt=None):
     """dx += dy @ w in place (w [n,k]: dx [m,k], dy [m,n]): the W-in-registers kernel's accumulate form on the shapes it
-    covers (tmae_token_gemm_acc: contraction 512 -> 256, 256 -> 128 and -- the attention in-projections -- 768 -> 256,
-    384 -> 128; >= 32 k tokens), torch's addmm_ otherwise.  wt: w^T contiguous if the caller keeps one (else made here)."""
+    covers (tmae_token_gemm_acc: contraction 512 -> 256, 256 -> 128, the attention in-projections' 768 -> 256 and 384 -> 128,
+    the square 256 -> 256 and 128 -> 128; >= 32 k tokens), torch's addmm_ otherwise.  wt: w^T contiguous if the caller keeps one (else made here)."""
     n, k = w.shape
     m = dx.shape[0]
-    if (m >= (65536 if n in (512, 768) else 32768) and (n, k) in ((512, 256), (256, 128), (768, 256), (384, 128))
+    if (m >= (65536 if n in (512, 768) else 32768) and (n, k) in ((512, 256), (256, 128), (768, 256), (384, 128), (256, 256), (128, 128))
             and dx.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
             and w.dtype == torch.bfloat16 and dx.is_contiguous() and dy.stride(1) == 1 and dy.stride(0) % 8 == 0
             and dy.data_ptr() % 16 == 0 and dx.data_ptr() % 16 == 0 and m * max(n, k) * 2 < 2 ** 31):
@@ -669,10 +669,14 @@ class _PosProjCross(torch.autograd.Function):
         kv [mk, 2d] = [(x_kv + pos) W[d:2d]^T | x_kv W[2d:]^T] + b[d:]
     plus x_q's alias for the residual branch.  Two position-folded GEMMs forward; backward writes the two row ranges of ONE
     [3d, d] weight gradient (as two separate nodes each returned a zero-padded full-size gradient that autograd then
-    added: two fills and two adds per layer and parameter)."""
+    added: two fills and two adds per layer and parameter).
+    kv_alias: a fourth output, an alias of x_kv, for the NEXT cross layer to take as its x_kv (both layers of a block read the
+    same previous-frame rows, wca_block.py:106-145): that layer's input gradient then arrives here through the alias and this
+    layer's k | v input gradient is accumulated into it by the GEMM itself -- autograd no longer adds two [m_prev, d] gradients
+    (one elementwise pass per stage) in front of the previous frame's last norm."""
 
     @staticmethod
-    def forward(ctx, x_q, x_kv, weight, bias, cells_q, cells_k, E, inplace_dx):
+    def forward(ctx, x_q, x_kv, weight, bias, cells_q, cells_k, E, inplace_dx, kv_alias=False):
         xq, xk = x_q.to(torch.bfloat16).contiguous(), x_kv.to(torch.bfloat16).contiguous()
         d = xq.shape[1]
         wq = pos_fold_weight(weight, 0, d, (0, d), E)
@@ -690,10 +694,12 @@ class _PosProjCross(torch.autograd.Function):
         ctx.has_bias, ctx.inplace_dx = bias is not None, bool(inplace_dx)
         ctx.dtypes = (x_q.dtype, x_kv.dtype, weight.dtype, None if bias is None else bias.dtype)
         ctx.set_materialize_grads(False)
+        if kv_alias:
+            return q, kv, x_q.view_as(x_q), x_kv.view_as(x_kv)
         return q, kv, x_q.view_as(x_q)
 
     @staticmethod
-    def backward(ctx, dq, dkv, dalias):
+    def backward(ctx, dq, dkv, dalias, dkalias=None):
         xq, xk, wq, wkv, cells_q, cells_k, E = ctx.saved_tensors
         qdt, kdt, wdt, bdt = ctx.dtypes
         d = xq.shape[1]
@@ -712,8 +718,15 @@ class _PosProjCross(torch.autograd.Function):
                 addmm_inplace(dxq, dq, wq[:, :d])              # see _ProjFork.backward
             else:
                 dxq = torch.addmm(dxq, dq, wq[:, :d])
+        if ctx.needs_input_grad[1] and dkalias is not None:
+            dxk = dkalias.to(torch.bfloat16)
+            if not dxk.is_contiguous():
+                dxk = dxk.contiguous()
         if ctx.needs_input_grad[1] and dkv is not None:
-            dxk = token_gemm(dkv, ctx.wkvT) if _tg_ok(dkv, 2 * d, d) else dkv @ wkv[:, :d]
+            if dxk is not None:
+                addmm_inplace(dxk, dkv, wkv[:, :d], ctx.wkvT)      # into the later layer's gradient (see kv_alias)
+            else:
+                dxk = token_gemm(dkv, ctx.wkvT) if _tg_ok(dkv, 2 * d, d) else dkv @ wkv[:, :d]
         dW = dB = None
         if ctx.needs_input_grad[2]:
             mk = torch.empty if (dq is not None and dkv is not None) else torch.zeros
@@ -725,12 +738,12 @@ class _PosProjCross(torch.autograd.Function):
             if dkv is not None:
                 linear_wgrad(dkv, xk, want_b, out_w=dW[d:], out_b=None if dB is None else dB[d:], cells=cells_k, pos_n=d, pos_e=E)
         return (None if dxq is None else dxq.to(qdt), None if dxk is None else dxk.to(kdt),
-                None if dW is None else dW.to(wdt), None if dB is None else dB.to(bdt), None, None, None, None)
+                None if dW is None else dW.to(wdt), None if dB is None else dB.to(bdt), None, None, None, None, None)
 
 
-def pos_proj_cross(x_q, x_kv, weight, bias, cells_q, cells_k, E, inplace_dx=False):
-    """See _PosProjCross: (q [mq,d], kv [mk,2d], alias of x_q)."""
-    return _PosProjCross.apply(x_q, x_kv, weight, bias, cells_q, cells_k, E, bool(inplace_dx))
+def pos_proj_cross(x_q, x_kv, weight, bias, cells_q, cells_k, E, inplace_dx=False, kv_alias=False):
+    """See _PosProjCross: (q [mq,d], kv [mk,2d], alias of x_q[, alias of x_kv])."""
+    return _PosProjCross.apply(x_q, x_kv, weight, bias, cells_q, cells_k, E, bool(inplace_dx), bool(kv_alias))
 
 
 def pos_proj(x, weight, bias, lo, hi, p0, p1, cells, E, fork=False, inplace_dx=False):
@@ -1012,8 +1025,8 @@ class _BatchNormReLU(torch.autograd.Function):
             if first[g] is None:
                 first[g] = torch.zeros((bounds[g + 1] - bounds[g], c), dtype=x.dtype, device=x.device)
         dx = torch.empty_like(x)
-        dg = torch.empty((ng, c), dtype=torch.float32, device=x.device)
-        db = torch.empty_like(dg)
+        dgb = torch.empty((ng, 2, c), dtype=torch.float32, device=x.device)     # [group][gamma | beta]: one sum over the groups below
+        dg, db = dgb[:, 0], dgb[:, 1]
         for g in range(ng):
             r0, r1 = bounds[g], bounds[g + 1]
             wsb = lib.tmae_bn_workspace(r1 - r0, c)
@@ -1039,7 +1052,7 @@ class _BatchNormReLU(torch.autograd.Function):
                                         _p(b32), 1 if ctx.relu else 0, _p(tb), _p(tg), float(ctx.counts[g]), _p(dx[r0:r1]),
                                         _s()), 'tmae_bn_bwd_apply')
         if ng > 1:
-            dg, db = dg.sum(0), db.sum(0)
+            dg, db = dgb.sum(0)
         else:
             dg, db = dg[0], db[0]
         return dx, dg.to(ctx.dtypes[0]), db.to(ctx.dtypes[1]), None, None, None, None, (dy if ctx.has_post else None), None
@@ -1532,6 +1545,30 @@ def random_mask(noise, sample_offsets, batch_size, keep_frac):
 
 
 # ----------------------------------------------------------------------------- windows (A4/A5/A10)
+
+class _GatherRows(torch.autograd.Function):
+    """x[idx] for DISTINCT row indices (the visible voxels of the masked frame, SiamWCA_MAE.py:166-182).  The backward writes each
+    gradient row to its place in a zeroed tensor; autograd's own backward of x[idx] has to allow repeated indices and sorts them
+    first (an accumulating index_put: 100 us for 94 k of 376 k rows, profiles/round6 census)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.rows = x.shape[0]
+        return x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, = ctx.saved_tensors
+        dx = dy.new_zeros((ctx.rows,) + tuple(dy.shape[1:]))
+        dx.index_copy_(0, idx, dy)
+        return dx, None
+
+
+def gather_rows(x, idx):
+    """x[idx], idx int64 [n] without repeats -- see _GatherRows."""
+    return _GatherRows.apply(x, idx)
+
 
 def index_grid(indices, batch_size, ny, nx):
     """Dense row-index grid [batch*ny*nx] int32 (-1 = inactive) of a sparse tensor's indices [m,3] (b,y,x)."""

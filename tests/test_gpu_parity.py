@@ -696,7 +696,8 @@ def test_token_gemm_wreg_kernel_every_instantiation_vs_torch():
     # (contraction 768 / 384: the attention in-projections' input gradients; their weight is a column slice of the
     # position-augmented weight, pitch k + 32)
     for (m, n, k) in ((65536 + 33, 512, 256), (120001, 512, 256), (32768 + 5, 256, 128), (470001, 256, 128),
-                      (65536 + 17, 768, 256), (200003, 768, 256), (32768 + 9, 384, 128), (150001, 384, 128)):
+                      (65536 + 17, 768, 256), (200003, 768, 256), (32768 + 9, 384, 128), (150001, 384, 128),
+                      (32768 + 41, 256, 256), (147403, 256, 256), (32768 + 3, 128, 128), (94022, 128, 128)):     # square: two column groups / half steps
         dy = torch.randn(m, n, device=dev()).bfloat16()
         w = (torch.randn(n, k + 32, device=dev()) * 0.1).bfloat16()[:, :k] if n in (768, 384) else (torch.randn(n, k, device=dev()) * 0.1).bfloat16()
         dx0 = torch.randn(m, k, device=dev()).bfloat16()
@@ -783,6 +784,46 @@ def test_pos_folded_in_projection_vs_materialised(shift):
             out3 = ops.pos_proj(xin, wp, bp, lo, hi, p0, p1, cells, E)
         ref3 = (ref - br[lo:hi]) * 0.5 + br[lo:hi]
         assert (out3.float() - ref3).abs().max().item() <= 1e-2 * scale
+
+
+def test_cross_in_projection_chains_the_previous_frame_gradient():
+    """ops.pos_proj_cross(kv_alias=True): the two cross layers of a block (wca_block.py:106-145) read the same previous-frame rows;
+    the second takes them through the first one's alias, so its input gradient arrives at the first node and that node's k | v
+    input-gradient GEMM accumulates into it (tmae_token_gemm_acc above 32 k / 64 k rows, the library's in-place addmm below) instead
+    of autograd adding two [m_prev, d] tensors.  Against the same two nodes reading x_prev independently: identical outputs, the same
+    gradient for x_prev up to one bf16 rounding (the chained sum is rounded once, the added one twice), weight gradients equal."""
+    from tmae_amd import ops
+    for (mq, mk, d) in ((5000, 7001, 128), (20011, 40003, 128), (30000, 70001, 256)):
+        indq, table, xq = _pos_case(mq, d, 3)
+        indk, _, xk = _pos_case(mk, d, 4)
+        cq, ck = ops.window_cells(indq, [8, 8, 1], False), ops.window_cells(indk, [8, 8, 1], False)
+        E = ops.pos_axes(table, [8, 8, 1])
+        gens = torch.Generator(device=dev()).manual_seed(mq)
+        W = [torch.randn(3 * d, d, device=dev(), generator=gens) * 0.1 for _ in range(2)]
+        Bv = [torch.randn(3 * d, device=dev(), generator=gens) for _ in range(2)]
+        gq = [torch.randn(mq, d, device=dev(), generator=gens).bfloat16() for _ in range(2)]
+        gkv = [torch.randn(mk, 2 * d, device=dev(), generator=gens).bfloat16() for _ in range(2)]
+
+        def run(chain):
+            wp = [torch.nn.Parameter(w.clone()) for w in W]
+            bp = [torch.nn.Parameter(b.clone()) for b in Bv]
+            a, k = xq.clone().requires_grad_(True), xk.clone().requires_grad_(True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                r0 = ops.pos_proj_cross(a, k, wp[0], bp[0], cq, ck, E, inplace_dx=True, kv_alias=chain)
+                r1 = ops.pos_proj_cross(a, r0[3] if chain else k, wp[1], bp[1], cq, ck, E, inplace_dx=True)
+            torch.autograd.backward([r0[0], r0[1], r1[0], r1[1]], [gq[0], gkv[0], gq[1], gkv[1]])
+            return (r0[0], r0[1], r1[0], r1[1]), k.grad, [p.grad for p in wp + bp]
+        o1, dk1, g1 = run(True)
+        o0, dk0, g0 = run(False)
+        for u, v in zip(o1, o0):
+            assert torch.equal(u, v)
+        for u, v in zip(g1, g0):
+            assert torch.equal(u, v)
+        scale = float(dk0.float().abs().max())
+        assert (dk1.float() - dk0.float()).abs().max().item() <= 2.0 ** -7 * scale, (mq, mk, d)
+        # and against fp32: d x_prev = sum over the two layers of dkv W[d:3d] (the position rows add nothing to dx)
+        ref = sum(gkv[j].float() @ W[j][d:].bfloat16().float() for j in range(2))
+        assert (dk1.float() - ref).abs().max().item() <= 2e-2 * float(ref.abs().max())
 
 
 def test_refresh_param_copies_casts_and_transposes_in_one_launch():
