@@ -14,7 +14,8 @@ torch.distributed.launch with 16 DataLoader workers per rank.)
 import glob
 import os
 
-__all__ = ['parse_cpulist', 'format_cpulist', 'gpu_local_cpus', 'plan_rank_cores', 'pin_rank']
+__all__ = ['parse_cpulist', 'format_cpulist', 'gpu_local_cpus', 'plan_rank_cores', 'pin_rank', 'MIN_PIN_CORES']
+MIN_PIN_CORES = 4
 
 
 def parse_cpulist(text):
@@ -61,15 +62,20 @@ def _core_order(cpus):
 def _kfd_gpu_nodes():
     """PCI addresses 'dddd:bb:dd.f' of the GPUs in KFD (= ROCr / HIP enumeration) order, [] when sysfs does not show them."""
     nodes = []
-    for d in sorted(glob.glob('/sys/class/kfd/kfd/topology/nodes/*'), key=lambda p: int(os.path.basename(p))):
-        try:
-            props = dict(line.split() for line in open(os.path.join(d, 'properties')) if len(line.split()) == 2)
-        except OSError:
-            continue
-        if int(props.get('simd_count', '0')) == 0:          # a CPU node
-            continue
-        loc, dom = int(props.get('location_id', '0')), int(props.get('domain', '0'))
-        nodes.append('%04x:%02x:%02x.%x' % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7))
+    try:
+        dirs = sorted((p for p in glob.glob('/sys/class/kfd/kfd/topology/nodes/*') if os.path.basename(p).isdigit()),
+                      key=lambda p: int(os.path.basename(p)))
+        for d in dirs:
+            try:
+                props = dict(line.split() for line in open(os.path.join(d, 'properties')) if len(line.split()) == 2)
+            except OSError:
+                continue
+            if int(props.get('simd_count', '0')) == 0:          # a CPU node
+                continue
+            loc, dom = int(props.get('location_id', '0')), int(props.get('domain', '0'))
+            nodes.append('%04x:%02x:%02x.%x' % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7))
+    except (OSError, ValueError):                                # a sysfs this code does not understand: no locality, even split
+        return []
     return nodes
 
 
@@ -149,7 +155,9 @@ def pin_rank(local_rank, local_world, device_indices=None, apply=True):
     """Pin this process (and every thread it starts afterwards) to its slice of the node's cores.  Call before the first GPU
     call.  device_indices[r] = the HIP device of local rank r (default: r) -- every rank must pass the same list, the plan is
     computed by each rank on its own.  Returns {'cores': [...], 'source': 'gpu-local' | 'even-split' | 'unpinned', 'allowed': n}.
-    TMAE_PIN_CORES=0 turns the pinning off; with one rank on the node nothing is pinned unless TMAE_PIN_CORES=1."""
+    TMAE_PIN_CORES=0 turns the pinning off; with one rank on the node nothing is pinned unless TMAE_PIN_CORES=1.
+    A slice below MIN_PIN_CORES (4; TMAE_PIN_MIN_CORES) is not applied: besides the launching thread a rank runs the HIP runtime's
+    helper threads and RCCL's proxy thread, which polls -- all of them on one or two cores is worse than floating."""
     allowed = sorted(os.sched_getaffinity(0))
     env = os.environ.get('TMAE_PIN_CORES', '')
     if env == '0' or (local_world <= 1 and env != '1'):
@@ -160,8 +168,15 @@ def pin_rank(local_rank, local_world, device_indices=None, apply=True):
     mine = plan_rank_cores(allowed, locs)[local_rank]
     loc = locs[local_rank]
     source = 'gpu-local' if loc and set(mine) <= set(loc) else 'even-split'
-    if len(mine) == len(allowed):
-        source = 'unpinned'
-    elif apply and mine:
-        os.sched_setaffinity(0, mine)
+    try:
+        floor = int(os.environ.get('TMAE_PIN_MIN_CORES', str(MIN_PIN_CORES)))
+    except ValueError:
+        floor = MIN_PIN_CORES
+    if len(mine) == len(allowed) or len(mine) < floor:
+        return {'cores': allowed, 'source': 'unpinned', 'allowed': len(allowed)}
+    if apply:
+        try:
+            os.sched_setaffinity(0, mine)
+        except OSError:                                          # a cpuset that moved under us: stay where the OS put us
+            return {'cores': allowed, 'source': 'unpinned', 'allowed': len(allowed)}
     return {'cores': mine, 'source': source, 'allowed': len(allowed)}

@@ -83,7 +83,7 @@ def test_two_ranks_pin_themselves_to_disjoint_cores():
         pytest.skip('one core')
     outs = []
     for r in range(2):
-        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE='2')
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE='2', TMAE_PIN_MIN_CORES='1')
         env.pop('TMAE_PIN_CORES', None)
         res = subprocess.run([sys.executable, '-c', _CHILD, AFF], env=env, capture_output=True, text=True, timeout=60)
         assert res.returncode == 0, res.stderr
@@ -100,3 +100,15 @@ def test_single_rank_keeps_its_allowance():
     before = sorted(os.sched_getaffinity(0))
     pin = m.pin_rank(0, 1)
     assert pin['source'] == 'unpinned' and pin['cores'] == before and sorted(os.sched_getaffinity(0)) == before
+
+
+def test_a_slice_below_the_floor_is_not_applied(monkeypatch):
+    """8 ranks on a node that allows this job 8 cores would get one core each -- launcher, HIP helper threads and RCCL's polling
+    proxy thread on one core: the plan is then reported as unpinned and nothing is applied (MIN_PIN_CORES, TMAE_PIN_MIN_CORES)."""
+    m = _mod()
+    before = sorted(os.sched_getaffinity(0))
+    monkeypatch.setenv('TMAE_PIN_MIN_CORES', str(len(before) + 1))
+    monkeypatch.delenv('TMAE_PIN_CORES', raising=False)
+    pin = m.pin_rank(0, 2, device_indices=[0, 0])
+    assert pin['source'] == 'unpinned' and pin['cores'] == before and sorted(os.sched_getaffinity(0)) == before
+    assert m.MIN_PIN_CORES >= 2
