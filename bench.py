@@ -58,12 +58,15 @@ def parse():
     ap.add_argument('--skip-unread-gradients', action='store_true',
                     help='variant, not the reference step: no gradients for the parameters its optimizer never owns')
     ap.add_argument('--cpu-points', type=int, default=120000)
-    ap.add_argument('--probe-only', action='store_true', help='only time the roofline kernel (for PMC runs)')
+    ap.add_argument('--probe-only', action='store_true', help='only time the roofline kernels')
+    ap.add_argument('--probe-hbm-only', action='store_true',
+                    help='only the four HBM-priced probes (token GEMMs, weight gradient, attention): the command of the counter '
+                         'passes, whose per-kernel averages must not mix with the other probes\' launches of the same kernels')
     return ap.parse_args()
 
 
 def _pmc_files():
-    """Committed counter passes of `bench.py --probe-only` (profiles/roundN_pmc.json), latest round first."""
+    """Committed counter passes of `bench.py --probe-hbm-only` (profiles/roundN_pmc.json), latest round first."""
     import glob
     import re
     fs = glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc.json'))
@@ -91,7 +94,7 @@ def _pmc_source(key):
     if f is None:
         return None
     return (f'profiles/{os.path.basename(f)} (FETCH_SIZE x2 + WRITE_SIZE, bytes per op; a committed counter pass of '
-            f'`bench.py --probe-only`, not measured in this run)')
+            f'`bench.py --probe-hbm-only`, not measured in this run)')
 
 
 def _pmc_current(key):
@@ -810,6 +813,12 @@ def main():
         nxt = upcoming[i + 1] = dict(batches[(i + 1) % nb])
         return train_one_step(ddp, opt, sched, cur, i, model_func, amp_dtype=amp, next_batch=nxt)[0]
 
+    if args.probe_hbm_only:
+        print(json.dumps({'roofline': gelu_gemm_roofline(model, dict(batches[0]), amp),
+                          'roofline_token_gemm_plain': token_gemm_roofline(model, dict(batches[0]), amp),
+                          'roofline_wgrad': wgrad_roofline(model, dict(batches[0]), amp),
+                          'roofline_attention': attention_roofline(model, dict(batches[0]), amp)}), flush=True)
+        return
     if args.probe_only:
         print(json.dumps({'box_peaks': box_peaks(dev),
                           'roofline': gelu_gemm_roofline(model, dict(batches[0]), amp),

@@ -1,8 +1,8 @@
-"""HBM traffic of the roofline kernels from two rocprofv3 PMC passes of `bench.py --probe-only`.
+"""HBM traffic of the roofline kernels from two rocprofv3 PMC passes of `bench.py --probe-hbm-only` (round 6; --probe-only before).
 
   cd /tmp && export TMPDIR=/tmp
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d <out>/pmc_$c -- python3 bench.py --probe-only
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d <out>/pmc_$c -- python3 bench.py --probe-hbm-only
   done
   python profiles/scripts/pmc_summary.py <out> > profiles/<round>_pmc.json
 
@@ -10,7 +10,7 @@ Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM / rocprofv3 sect
 FETCH_SIZE reports half of the bytes of wide coalesced reads on gfx950 and is doubled; WRITE_SIZE is exact.
 An op = one launch of every kernel of its group (wgrad: the kernel + two slab reductions; attention: the three
 tile-class launches NT = 1, 2, 4 of the stage-1 backward; token GEMMs: their one launch); bytes per op = sum of the per-launch
-averages.  The training step itself is not run by --probe-only, so every launch of these kernels belongs to a probe -- except the
+averages.  The training step itself is not run by the probe command, so every launch of these kernels belongs to a probe -- except the
 token GEMMs, which also run in the forward pass that measures the token count: their probe is the LAST 23 launches of the instance.
 
 Kernels are matched by base name + identifying template arguments (profiles/scripts/_kernels.py); a group that matches NO kernel
@@ -44,7 +44,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         agg[r['_name']][1] += 1
     raw[c] = {k: v[0] / v[1] for k, v in agg.items()}
 res = {'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py '
-                  '--probe-only (one pass per counter)',
+                  '--probe-hbm-only (one pass per counter)',
        'unit_note': 'counter unit = KB; gfx950: FETCH_SIZE counts half of the bytes of wide coalesced reads -> doubled; '
                     'WRITE_SIZE exact (MI355X_MICROARCH.md, HBM section)'}
 for g, matchers in groups.items():
