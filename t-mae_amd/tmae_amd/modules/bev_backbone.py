@@ -12,11 +12,22 @@ import torch.nn as nn
 from .. import ops
 
 
-def conv_bn_relu_nhwc(seq, x, shortcut=False):
+def conv_bn_relu_nhwc(seq, x, shortcut=False, chain=False):
     """seq = Sequential(Conv2d, BatchNorm2d, ReLU) on a channels-last tensor; fused norm+ReLU in training.
+    chain: returns (result, what the next module that reads the same x should read instead) -- an alias of x through which the
+    readers' input gradients accumulate (ops._Conv3x3C64) where the 64 -> 64 kernel takes the conv, x itself otherwise.
     shortcut: returns seq(x) + x (sst_bev_backbone.py:35-41).  On the halo-conv path the shortcut is added inside the norm's apply
     kernel forward and inside the conv's input-gradient kernel backward (TMAE_BEV_SHORTCUT=add: as separate elementwise passes)."""
+    if chain:
+        assert not shortcut
+        res = _conv_bn_relu_nhwc(seq, x, False, True)
+        return res if isinstance(res, tuple) else (res, x)
+    return _conv_bn_relu_nhwc(seq, x, shortcut, False)
+
+
+def _conv_bn_relu_nhwc(seq, x, shortcut, chain):
     conv, bn = seq[0], seq[1]
+    chained = None
     nhwc = x.permute(0, 2, 3, 1)
     if (bn.training and os.environ.get('TMAE_DENSE_CONV', 'halo') != 'miopen' and nhwc.is_contiguous()
             and ops.dense_conv3x3_ok(nhwc, conv) and conv.out_channels % 128 == 0):
@@ -32,7 +43,11 @@ def conv_bn_relu_nhwc(seq, x, shortcut=False):
     elif bn.training and not shortcut and ops.conv3x3_c64_ok(nhwc, conv):
         # CenterHead's 64 -> 64 stems (center_head.py:28-31): csrc/headconv.hip (a bias is folded into the norm below, as in the
         # library branch)
-        y = ops.conv3x3_c64(nhwc, conv.weight).permute(0, 3, 1, 2)
+        if chain:
+            y, nxt = ops.conv3x3_c64(nhwc, conv.weight, chain=True)
+            y, chained = y.permute(0, 3, 1, 2), nxt.permute(0, 3, 1, 2)
+        else:
+            y = ops.conv3x3_c64(nhwc, conv.weight).permute(0, 3, 1, 2)
         fused = True
     elif bn.training and not shortcut and ops.conv3x3_c128to64_ok(nhwc, conv):
         y = ops.conv3x3_c128to64(nhwc, conv.weight).permute(0, 3, 1, 2)         # CenterHead's shared conv (center_head.py:85-89)
@@ -48,6 +63,8 @@ def conv_bn_relu_nhwc(seq, x, shortcut=False):
         b, c, ny, nx = y.shape
         rows = ops.batch_norm_relu(y.permute(0, 2, 3, 1).reshape(b * ny * nx, c), bn, relu=True, pre_bias=conv.bias)
         out = rows.view(b, ny, nx, c).permute(0, 3, 1, 2)
+        if chained is not None:
+            return out, chained
         return out + x if shortcut else out
     if fused and conv.bias is not None:
         y = y + conv.bias.view(1, -1, 1, 1).to(y.dtype)

@@ -41,10 +41,14 @@ class SeparateHead(nn.Module):
 
     def forward(self, x):
         ret = {}
-        for name in self.sep_head_dict:
-            y = x
-            for layer in getattr(self, name):
-                y = conv_bn_relu_nhwc(layer, y) if isinstance(layer, nn.Sequential) else ops.conv3x3_channel_bias(y, layer)
+        src = x          # what the next branch reads: x, or x's alias out of the previous branch's stem conv (its input gradient
+        for name in self.sep_head_dict:      # then accumulates into the later branches' instead of meeting them in autograd adds)
+            y = src
+            for j, layer in enumerate(getattr(self, name)):
+                if j == 0 and isinstance(layer, nn.Sequential) and self.training:
+                    y, src = conv_bn_relu_nhwc(layer, y, chain=True)
+                else:
+                    y = conv_bn_relu_nhwc(layer, y) if isinstance(layer, nn.Sequential) else ops.conv3x3_channel_bias(y, layer)
             ret[name] = y
         return ret
 

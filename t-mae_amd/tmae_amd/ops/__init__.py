@@ -723,8 +723,10 @@ class _PosProjCross(torch.autograd.Function):
             if not dxk.is_contiguous():
                 dxk = dxk.contiguous()
         if ctx.needs_input_grad[1] and dkv is not None:
-            if dxk is not None:
+            if dxk is not None and ctx.inplace_dx:
                 addmm_inplace(dxk, dkv, wkv[:, :d], ctx.wkvT)      # into the later layer's gradient (see kv_alias)
+            elif dxk is not None:
+                dxk = torch.addmm(dxk, dkv, wkv[:, :d])
             else:
                 dxk = token_gemm(dkv, ctx.wkvT) if _tg_ok(dkv, 2 * d, d) else dkv @ wkv[:, :d]
         dW = dB = None
@@ -2321,10 +2323,13 @@ class _NarrowConv3x3(torch.autograd.Function):
 class _Conv3x3C64(torch.autograd.Function):
     """Conv2d(64, 64, 3, padding=1, bias=False) on a channels-last bf16 activation [B, Y, X, 64] -- the stem convs of CenterHead's
     branches (center_head.py:28-31) -- forward, input gradient (the same kernel on dY with flipped, transposed weights) and
-    weight gradient on csrc/headconv.hip (tmae_conv3x3_c64, tmae_conv3x3_c64_wgrad)."""
+    weight gradient on csrc/headconv.hip (tmae_conv3x3_c64, tmae_conv3x3_c64_wgrad).
+    chain: a second output, an alias of the input, for the NEXT branch to read instead of the shared tensor: the five branches'
+    input gradients then arrive one through the other and every input-gradient launch accumulates into what came in (the kernel's
+    accumulate form) -- autograd otherwise joins them with four adds over [B, Y, X, 64]."""
 
     @staticmethod
-    def forward(ctx, x_nhwc, weight):
+    def forward(ctx, x_nhwc, weight, chain=False):
         x = x_nhwc.to(torch.bfloat16).contiguous()
         B, Y, X, cin = x.shape
         w2 = _derived(weight, ('c64_3x3',), lambda t: t.detach().permute(0, 2, 3, 1).reshape(64, 9 * 64).to(torch.bfloat16).contiguous())
@@ -2334,25 +2339,31 @@ class _Conv3x3C64(torch.autograd.Function):
         check(lib.tmae_conv3x3_c64(_p(x), 64, B, Y, X, _p(w2), 0, 0, _p(y), 64, _p(ws), wsb, _s()), 'tmae_conv3x3_c64')
         ctx.save_for_backward(x, w2)
         ctx.meta = (x_nhwc.dtype, weight.dtype)
+        ctx.set_materialize_grads(False)
+        if chain:
+            return y, x_nhwc.view_as(x_nhwc)
         return y
 
     @staticmethod
-    def backward(ctx, dy_nhwc):
+    def backward(ctx, dy_nhwc, dalias=None):
         x, w2 = ctx.saved_tensors
         B, Y, X, _ = x.shape
+        if dy_nhwc is None:                               # only the alias was used downstream
+            return (None if dalias is None else dalias.to(ctx.meta[0])), None, None
         dy = dy_nhwc.to(torch.bfloat16).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            acc = dalias is not None
+            dx = dalias.to(torch.bfloat16).contiguous() if acc else torch.empty_like(x)
             wsb = lib.tmae_conv3x3_c64_workspace()
             ws = _ws(wsb, x.device)
-            check(lib.tmae_conv3x3_c64(_p(dy), 64, B, Y, X, _p(w2), 1, 0, _p(dx), 64, _p(ws), wsb, _s()), 'tmae_conv3x3_c64')
+            check(lib.tmae_conv3x3_c64(_p(dy), 64, B, Y, X, _p(w2), 1, 1 if acc else 0, _p(dx), 64, _p(ws), wsb, _s()), 'tmae_conv3x3_c64')
             dx = dx.to(ctx.meta[0])
         dw = torch.empty((64, 9 * 64), dtype=torch.float32, device=x.device)
         wsb = lib.tmae_conv3x3_c64_wgrad_workspace()
         ws = _ws(wsb, x.device)
         check(lib.tmae_conv3x3_c64_wgrad(_p(dy), 64, _p(x), 64, B, Y, X, _p(dw), _p(ws), wsb, _s()), 'tmae_conv3x3_c64_wgrad')
-        return dx, dw.view(64, 3, 3, 64).permute(0, 3, 1, 2).to(ctx.meta[1])
+        return dx, dw.view(64, 3, 3, 64).permute(0, 3, 1, 2).to(ctx.meta[1]), None
 
 
 class _Conv3x3C128to64(torch.autograd.Function):
@@ -2424,8 +2435,9 @@ def conv3x3_c64_ok(x_nhwc, conv):
             and x_nhwc.numel() * 2 < (1 << 31) and _os.environ.get('TMAE_HEAD_CONV', 'native') == 'native')
 
 
-def conv3x3_c64(x_nhwc, weight):
-    return _Conv3x3C64.apply(x_nhwc, weight)
+def conv3x3_c64(x_nhwc, weight, chain=False):
+    """See _Conv3x3C64; chain=True: (y, alias of x_nhwc for the next reader of the same tensor)."""
+    return _Conv3x3C64.apply(x_nhwc, weight, bool(chain))
 
 
 def narrow_conv3x3_ok(x, conv):

@@ -284,6 +284,47 @@ def test_narrow_head_conv_kernels_vs_torch():
     torch.cuda.synchronize()
 
 
+def test_branch_stems_chain_their_input_gradients():
+    """SeparateHead (center_head.py:11-45): the branches' 64 -> 64 stem convs read one shared map.  Each stem hands the next branch
+    an alias of its input (ops.conv3x3_c64(chain=True)), so a branch's input gradient accumulates into the later branches' inside
+    the conv kernel (accumulate form) instead of autograd adding one [B, Y, X, 64] tensor per branch.  Against the same stems reading
+    the map independently: identical outputs and weight gradients, the map's gradient equal up to the bf16 roundings the separate
+    adds make (the chained sum is rounded once per branch as well: same count, different order)."""
+    import torch.nn as nn
+    from tmae_amd.modules.bev_backbone import conv_bn_relu_nhwc
+    torch.manual_seed(21)
+    B, Y, X, nb = 2, 52, 37, 4
+    seqs = [nn.Sequential(nn.Conv2d(64, 64, 3, padding=1, bias=True), nn.BatchNorm2d(64, eps=1e-3, momentum=0.01),
+                          nn.ReLU(inplace=True)).cuda().train() for _ in range(nb)]
+    x0 = torch.randn(B, Y, X, 64, device='cuda').bfloat16().permute(0, 3, 1, 2)
+    gos = [torch.randn(B, Y, X, 64, device='cuda').bfloat16().permute(0, 3, 1, 2) for _ in range(nb)]
+
+    def run(chain):
+        for q in seqs:
+            q.zero_grad()
+            q[1].running_mean.zero_(); q[1].running_var.fill_(1.0)
+        xa = x0.clone().requires_grad_(True)
+        src, outs = xa, []
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            for q in seqs:
+                if chain:
+                    y, src = conv_bn_relu_nhwc(q, src, chain=True)
+                    assert src is not xa                        # the 64 -> 64 kernel took the conv: the alias is handed on
+                else:
+                    y = conv_bn_relu_nhwc(q, xa)
+                outs.append(y)
+        torch.autograd.backward(outs, gos)
+        return [o.detach() for o in outs], xa.grad.float(), [p.grad.clone() for q in seqs for p in q.parameters()]
+    o1, dx1, g1 = run(True)
+    o0, dx0, g0 = run(False)
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
+    assert float((dx1 - dx0).abs().max()) <= 2.0 ** -6 * float(dx0.abs().max())
+    assert float((dx1 - dx0).norm() / dx0.norm()) < 4e-3
+
+
 def test_c64_stem_conv_kernels_vs_torch():
     """csrc/headconv.hip, 64 -> 64: Conv2d(64, 64, 3, padding=1, bias=False) forward, input gradient (the same kernel with flipped,
     transposed weights) and weight gradient on channels-last bf16 maps (CenterHead's stem convs, center_head.py:28-31) against
