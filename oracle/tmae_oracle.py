@@ -332,13 +332,16 @@ def sst_input_layer_temporal(coords, coords_prv, grid_xyz, cfg):
     return cur, prv
 
 
-def pos_embed(coors_in_win, feat_dim, window_shape, pos_temperature):
-    """SSTInputLayer.get_pos_embed, spt_backbone.py:186-224 (NORMALIZE_POS False).
+def pos_embed(coors_in_win, feat_dim, window_shape, pos_temperature, normalize_pos=False):
+    """SSTInputLayer.get_pos_embed, spt_backbone.py:186-224 (normalize_pos: NORMALIZE_POS, :202-204).
     coors_in_win [N,3] (z,y,x) -> [N, feat_dim] float32."""
     wx, wy = window_shape[:2]
     c = torch.as_tensor(coors_in_win)
     y = c[:, 1] - wy / 2
     x = c[:, 2] - wx / 2
+    if normalize_pos:
+        x = x / wx * 2 * 3.1415
+        y = y / wy * 2 * 3.1415
     pos_length = feat_dim // 2
     inv_freq = torch.arange(pos_length, dtype=torch.float32)
     inv_freq = pos_temperature ** (2 * torch.div(inv_freq, 2, rounding_mode='floor') / pos_length)

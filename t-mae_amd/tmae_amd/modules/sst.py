@@ -315,8 +315,6 @@ def _check_preprocess(pre):
         raise NotImplementedError('window attention kernels are built for 8x8x1 windows (t_mae_ssl.yaml:61)')
     if pre.get('SHUFFLE_VOXELS', False):
         raise NotImplementedError('SHUFFLE_VOXELS is False in the T-MAE configs')
-    if pre.get('NORMALIZE_POS', False):
-        raise NotImplementedError('NORMALIZE_POS is False in the T-MAE configs')
     if max(int(v['max_tokens']) for v in pre.DROP_INFO['train'].values()) > ws[0] * ws[1]:
         raise NotImplementedError('DROP_INFO max_tokens above the 64 cells of a window')
 
@@ -363,8 +361,8 @@ class SSTBlockV1(nn.Module):
             BasicShiftBlockV2(d_model, enc.NHEAD, enc.DIM_FEEDFORWARD, enc.DROPOUT, enc.ACTIVATION, enc.LAYER_CFG)
             for _ in range(enc.NUM_BLOCKS)])
         self.conv_out = post_act_block(d_model, d_model, 3, norm_fn=norm_fn, indice_key=f'{indice_key}_subm', dim=2)
-        self.register_buffer('pos_table', pos_embed_table(d_model, self.window_shape,
-                                                          model_cfg.PREPROCESS.POS_TEMPERATURE), persistent=False)
+        self.register_buffer('pos_table', pos_embed_table(d_model, self.window_shape, model_cfg.PREPROCESS.POS_TEMPERATURE,
+                                                          bool(model_cfg.PREPROCESS.get('NORMALIZE_POS', False))), persistent=False)
 
     def kept_rows(self, sp: SparseConvTensor):
         """Rows that survive SSTInputLayer.drop_voxel (spt_backbone.py:73-135): in shift 0 a voxel whose in-window rank
@@ -442,8 +440,8 @@ class WCABlock(nn.Module):
         self.encoder_blocks = nn.ModuleList([
             BasicShiftBlock_WCA(d_model, enc.NHEAD, enc.DIM_FEEDFORWARD, enc.DROPOUT, enc.ACTIVATION, enc.LAYER_CFG)])
         self.conv_out = post_act_block(d_model, d_model, 3, norm_fn=norm_fn, indice_key=f'{indice_key}_subm', dim=2)
-        self.register_buffer('pos_table', pos_embed_table(d_model, self.window_shape,
-                                                          model_cfg.PREPROCESS.POS_TEMPERATURE), persistent=False)
+        self.register_buffer('pos_table', pos_embed_table(d_model, self.window_shape, model_cfg.PREPROCESS.POS_TEMPERATURE,
+                                                          bool(model_cfg.PREPROCESS.get('NORMALIZE_POS', False))), persistent=False)
 
     def encoder_forward(self, sp: SparseConvTensor, sp_prev: SparseConvTensor, residual=False):
         """WCABlock.encoder_forward (SiamWCA.py:342-396): joint bucketing of the two frames, two cross layers."""

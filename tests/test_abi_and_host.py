@@ -147,6 +147,26 @@ def test_pos_table_matches_golden():
         np.testing.assert_allclose(t[ciw[:, 1] * 8 + ciw[:, 2]], g[f'pos_{d}'], atol=1e-6)
 
 
+def test_pos_table_normalised_matches_golden():
+    """NORMALIZE_POS: True (spt_backbone.py:202-204; off in the shipped YAMLs): the in-window offsets scaled to [-pi, pi) before the
+    sin / cos -- the reference's get_pos_embed with the option on (F14), the oracle, the module's table, and that a stage built from a
+    config with the option carries that table."""
+    import copy
+    from tmae_amd.modules.sst import pos_embed_table
+    g = golden('F14_options')
+    ciw = g['coors_in_win']
+    temp = float(g['pos_temperature'])
+    for d in (128, 256):
+        t = pos_embed_table(d, [8, 8, 1], temp, normalize_pos=True).numpy()
+        np.testing.assert_allclose(t[ciw[:, 1] * 8 + ciw[:, 2]], g[f'pos_norm_{d}'], atol=1e-6)
+        assert np.abs(t - pos_embed_table(d, [8, 8, 1], temp).numpy()).max() > 0.1
+    cfg = load_cfg(1)
+    from tmae_amd.modules import sst
+    blk_cfg = copy.deepcopy(cfg.MODEL.BACKBONE_3D.SST_BLOCK_LIST[0])
+    blk_cfg.PREPROCESS.NORMALIZE_POS = True
+    sst._check_preprocess(blk_cfg.PREPROCESS)                       # no longer refused
+
+
 def test_synthetic_dataset_shards_by_rank():
     from tmae_amd.train import SyntheticTemporalDataset
     cfg = load_cfg(3)

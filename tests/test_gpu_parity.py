@@ -720,7 +720,7 @@ def _pos_case(m, d, seed):
     g = torch.Generator().manual_seed(seed)
     ind = torch.stack([torch.zeros(m, dtype=torch.int64), torch.randint(0, 468, (m,), generator=g),
                        torch.randint(0, 468, (m,), generator=g)], 1).int().to(dev())
-    table = pos_embed_table(d, [8, 8, 1], 10000).to(dev())
+    table = pos_embed_table(d, [8, 8, 1], 10000, normalize_pos=bool(seed % 2)).to(dev())     # both forms of the table (NORMALIZE_POS)
     x = torch.randn(m, d, generator=g).to(dev()).bfloat16()
     return ind, table, x
 

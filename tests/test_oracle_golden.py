@@ -88,6 +88,14 @@ def test_f6_pos_embed(oracle):
         np.testing.assert_allclose(pe, g[f'pos_{d}'], atol=1e-6)
 
 
+def test_f14_pos_embed_normalised(oracle):
+    """NORMALIZE_POS: True (spt_backbone.py:202-204) -- the reference's values (oracle/gen_golden_options.py) vs the oracle."""
+    g = golden('F14_options')
+    for d in (128, 256):
+        pe = oracle.pos_embed(g['coors_in_win'], d, (8, 8, 1), float(g['pos_temperature']), normalize_pos=True).numpy()
+        np.testing.assert_allclose(pe, g[f'pos_norm_{d}'], atol=1e-6)
+
+
 def test_f7_attention(oracle):
     g = golden('F7_attention')
     for case in range(4):
