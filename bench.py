@@ -328,13 +328,13 @@ def attention_roofline(model, batch, amp_dtype, iters=20):
     q_, k_ = qk.data_ptr(), qk.data_ptr() + d * es
     check(lib.tmae_win_attn_fwd(q_, 2 * d, k_, 2 * d, v.data_ptr(), d, code, m, m, H, dh, grid.data_ptr(),
                                 grid.data_ptr(), bs, 468, 468, 0, tau.data_ptr(), 0.01, out.data_ptr(), d,
-                                lse.data_ptr(), wlp, st), 'fwd')
+                                lse.data_ptr(), wlp, 0, st), 'fwd')
 
     def bwd():
         check(lib.tmae_win_attn_bwd(q_, 2 * d, k_, 2 * d, v.data_ptr(), d, out.data_ptr(), d, dout.data_ptr(), d,
                                     lse.data_ptr(), code, m, m, H, dh, grid.data_ptr(), grid.data_ptr(), bs, 468, 468,
                                     0, tau.data_ptr(), 0.01, dqk.data_ptr(), 2 * d, dqk.data_ptr() + d * es, 2 * d,
-                                    dv.data_ptr(), d, part.data_ptr(), wlp, st), 'bwd')
+                                    dv.data_ptr(), d, part.data_ptr(), wlp, 0, st), 'bwd')
     for _ in range(3):
         bwd()
     torch.cuda.synchronize()

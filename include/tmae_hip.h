@@ -40,7 +40,7 @@ extern "C" {
  * entry point does with its arguments; tmae_abi_hash() is the fingerprint of THIS header's prototypes (name, return class and
  * argument classes in order: tmae_amd/_abi.py) that the build compiled in.  The Python binding compares both at import, so a
  * stale library, or a binding row that disagrees with its prototype, fails there and not inside a launch. */
-#define TMAE_ABI_VERSION 24
+#define TMAE_ABI_VERSION 25
 int tmae_abi_version(void);
 int tmae_abi_hash(void);
 
@@ -166,12 +166,14 @@ int tmae_window_bucket(const int32_t* indices, int64_t m, const int32_t* grid, c
  * softmax over the window's keys, P.V.  Self-attention: grid_k == grid_q.  Cross-attention
  * (wca_block.py:26-67): grid_q = current frame, grid_k = previous frame; query tokens whose
  * window has no key get a zero row (they are not "kept", wca_block.py:93-96).
- * lse [mq, nhead] f32 is saved for the backward.  dh in {16, 32}; 8x8 windows. */
+ * lse [mq, nhead] f32 is saved for the backward.  dh in {16, 32}; 8x8 windows.
+ * tau_per_head 0: tau[0] is the layer's one temperature (cosine_msa.py:455-456); 1: tau [nhead], one per head
+ * (non_shared_tau, cosine_msa.py:453-454, :155-158). */
 int tmae_win_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                       int dtype, int64_t mq, int64_t mk, int nhead, int dh,
                       const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx,
                       int do_shift, const float* tau, float tau_min,
-                      void* out, int64_t ldo, float* lse, const int32_t* worklist, void* stream);
+                      void* out, int64_t ldo, float* lse, const int32_t* worklist, int tau_per_head, void* stream);
 /* Backward.  dq/dk/dv are fully written for every token that sits in an attended window and
  * zero-filled otherwise.  dtau_partial [n_windows*nhead/heads_per_block] f32 partial sums of
  * d loss / d max(tau,tau_min) (summed by the caller; n entries = tmae_win_attn_num_blocks). */
@@ -180,16 +182,17 @@ int64_t tmae_win_attn_num_blocks(int batch, int ny, int nx, int nhead, int dh);
  * clamp(tau, min=tau_min) of cosine_msa.py:150-152; fixed-order sum over up to 64 strips, one launch.  Calls must be
  * ordered on one stream (a module-scope ticket counter picks the block that finishes).  worklist (may be NULL): the work list the
  * backward ran with -- windows that are in none of its lists wrote no partial and count as zero (no pre-zeroing of dtau_partial);
- * NULL: every entry is read. */
+ * NULL: every entry is read.  tau_per_head 1: tau / dtau [nhead], dtau[h] from the partials of head h (n = windows x nhead,
+ * one launch per head). */
 int tmae_win_attn_dtau(const float* dtau_partial, int64_t n, const float* tau, float tau_min, float* dtau,
-                       const int32_t* worklist, int nhead, void* stream);
+                       const int32_t* worklist, int nhead, int tau_per_head, void* stream);
 int tmae_win_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                       const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
                       int dtype, int64_t mq, int64_t mk, int nhead, int dh,
                       const int32_t* grid_q, const int32_t* grid_k, int batch, int ny, int nx,
                       int do_shift, const float* tau, float tau_min,
                       void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
-                      float* dtau_partial, const int32_t* worklist, void* stream);
+                      float* dtau_partial, const int32_t* worklist, int tau_per_head, void* stream);
 
 /* Window work lists -- the reference's region batching (drop levels 16/32/64 tokens, spt_backbone.py:47-71,
  * t_mae_ssl.yaml:63-67) as three index lists instead of padded tensors: windows of one shift that hold both queries

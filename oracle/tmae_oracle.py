@@ -391,7 +391,7 @@ def cosine_mha(q_in, k_in, v_in, kpm, p, prefix, nhead, tau_min):
     """cosine_msa.py:178-438 (+ _scaled_cosine_attention :114-176).  q_in/k_in/v_in:
     [nW, T, E] (batch-first here; the reference permutes to (T, nW, E)); kpm [nW, T]
     True = padded key.  Three chunks of the packed in-proj weight (:57-62); per-head
-    L2-normalised q,k (F.normalize eps 1e-12); logits / clamp(tau, tau_min); -inf on
+    L2-normalised q,k (F.normalize eps 1e-12); logits / clamp(tau, tau_min) (one tau, or one per head); -inf on
     padded keys; softmax; PV; out-proj."""
     nW, Tq, E = q_in.shape
     Tk = k_in.shape[1]
@@ -406,7 +406,8 @@ def cosine_mha(q_in, k_in, v_in, kpm, p, prefix, nhead, tau_min):
     q = F.normalize(q, dim=-1)
     k = F.normalize(k, dim=-1)
     attn = q @ k.transpose(-2, -1)
-    attn = attn / p[prefix + 'tau'].view(1, 1, 1, 1).clamp(min=tau_min)
+    tau = p[prefix + 'tau']                      # (1,1,1) shared, or (1, nhead, 1, 1) with non_shared_tau (cosine_msa.py:155-161, :453-456)
+    attn = attn / (tau.view(1, nhead, 1, 1) if tau.dim() == 4 else tau.view(1, 1, 1, 1)).clamp(min=tau_min)
     attn = attn.masked_fill(kpm.view(nW, 1, 1, Tk), float('-inf'))
     attn = attn.softmax(dim=-1)
     o = (attn @ v).transpose(1, 2).reshape(nW, Tq, E)

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64 * (64 / DH)) void win_attn_fwd_kernel(
     const T* __restrict__ q, int64_t ldq, const T* __restrict__ k, int64_t ldk, const T* __restrict__ v, int64_t ldv,
     int nhead, const int32_t* __restrict__ grid_q, const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx,
     int sy, int sx, const float* __restrict__ tau, float tau_min, T* __restrict__ out, int64_t ldo,
-    float* __restrict__ lse) {
+    float* __restrict__ lse, int tau_stride) {
   constexpr int HG = 64 / DH;
   constexpr int LD = DH + ROWPAD;
   __shared__ __attribute__((aligned(16))) float Ks[HG][64][LD];
@@ -83,7 +83,8 @@ __global__ __launch_bounds__(64 * (64 / DH)) void win_attn_fwd_kernel(
   }
   __syncthreads();
   if (tq < 0) return;
-  const float inv_tau = 1.0f / fmaxf(tau[0], tau_min);      // attn / tau.clamp(min=tau_min) (cosine_msa.py:161)
+  // attn / tau.clamp(min=tau_min) (cosine_msa.py:155-161); tau_stride 1: one temperature per head (non_shared_tau, :453-454)
+  const float inv_tau = 1.0f / fmaxf(tau[head * tau_stride], tau_min);
   float qh[DH], o[DH];
   load_row<T, DH>(q + (int64_t)tq * ldq + hoff, qh);
   float ss = 0.f;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(64 * (64 / DH)) void win_attn_bwd_kernel(
     const T* __restrict__ outp, int64_t ldo, const T* __restrict__ dout, int64_t lddo, const float* __restrict__ lse,
     int nhead, const int32_t* __restrict__ grid_q, const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx,
     int sy, int sx, const float* __restrict__ tau, float tau_min, T* __restrict__ dq, int64_t lddq,
-    T* __restrict__ dk, int64_t lddk, T* __restrict__ dv, int64_t lddv, float* __restrict__ dtau_partial) {
+    T* __restrict__ dk, int64_t lddk, T* __restrict__ dv, int64_t lddv, float* __restrict__ dtau_partial, int tau_stride) {
   constexpr int HG = 64 / DH;
   constexpr int LD = DH + ROWPAD;
   __shared__ __attribute__((aligned(16))) float Ks[HG][64][LD];
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(64 * (64 / DH)) void win_attn_bwd_kernel(
     }
     return;
   }
-  const float inv_tau = 1.0f / fmaxf(tau[0], tau_min);
+  const float inv_tau = 1.0f / fmaxf(tau[head * tau_stride], tau_min);
   float kh[DH], vj[DH];
   float knorm = 1.f;
   if (tk >= 0) {
@@ -289,13 +290,13 @@ __global__ __launch_bounds__(64 * (64 / DH)) void win_attn_bwd_kernel(
 int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                            int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
                            int batch, int ny, int nx, int do_shift, const float* tau, float tau_min, void* out,
-                           int64_t ldo, float* lse, const int32_t* worklist, hipStream_t stream);
+                           int64_t ldo, float* lse, const int32_t* worklist, int tau_stride, hipStream_t stream);
 int tmae_win_attn_bwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                            const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, int64_t mq,
                            int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k, int batch,
                            int ny, int nx, int do_shift, const float* tau, float tau_min, void* dq, int64_t lddq,
                            void* dk, int64_t lddk, void* dv, int64_t lddv, float* dtau_partial,
-                           const int32_t* worklist, hipStream_t stream);
+                           const int32_t* worklist, int tau_stride, hipStream_t stream);
 // bf16 inputs take the MFMA kernels; TMAE_ATTN_VALU=1 (debug build only, common.h) sends them to the fp32-style VALU kernels
 static bool use_mfma() {
   static const int valu = TMAE_AB_INT("TMAE_ATTN_VALU", 0);
@@ -318,13 +319,19 @@ __device__ float dtau_strip_sum[DTAU_MAX_BLOCKS];
 
 // listed (may be NULL) / per: the class byte of window e / per from the work list (attention_mfma.hip: win_class_kernel) -- a
 // window that is in no list wrote no partial and counts as zero, so the caller need not pre-zero the partials.
+// off / stride: the partials e * stride + off, e < n (one temperature per head: stride = heads, off = the head, n = windows; one
+// launch per head, ordered on the stream like any other two calls); shared temperature: off 0, stride 1, n = windows x heads
 __global__ __launch_bounds__(1024) void dtau_finish_kernel(const float* __restrict__ part_raw, int64_t n,
                                                           const float* __restrict__ tau, float tau_min,
-                                                          float* __restrict__ dtau, const int8_t* __restrict__ listed, int heads) {
+                                                          float* __restrict__ dtau, const int8_t* __restrict__ listed, int heads,
+                                                          int off, int stride) {
   struct Part {
-    const float* p; const int8_t* l; int per;
-    __device__ __forceinline__ float operator[](int64_t e) const { return (l == nullptr || l[e / per] >= 0) ? p[e] : 0.f; }
-  } part{part_raw, listed, heads};
+    const float* p; const int8_t* l; int per, off, stride;
+    __device__ __forceinline__ float operator[](int64_t e) const {
+      const int64_t f = e * stride + off;
+      return (l == nullptr || l[f / per] >= 0) ? p[f] : 0.f;
+    }
+  } part{part_raw, listed, heads, off, stride};
   __shared__ float red[1024];
   __shared__ bool last;
   const int nb = gridDim.x;
@@ -350,23 +357,29 @@ __global__ __launch_bounds__(1024) void dtau_finish_kernel(const float* __restri
     __threadfence();
     float tot = 0.f;
     for (int b = 0; b < nb; ++b) tot += __hip_atomic_load(&dtau_strip_sum[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float t = tau[0];
-    dtau[0] = t >= tau_min ? -tot / t : 0.f;
+    const int ti = stride > 1 ? off : 0;
+    const float t = tau[ti];
+    dtau[ti] = t >= tau_min ? -tot / t : 0.f;
     dtau_ticket = 0;                                           // ready for the next call on the stream
   }
 }
 
 int tmae_win_attn_dtau(const float* dtau_partial, int64_t n, const float* tau, float tau_min, float* dtau,
-                       const int32_t* worklist, int nhead, void* stream_) {
+                       const int32_t* worklist, int nhead, int tau_per_head, void* stream_) {
   (void)hipGetLastError();
   if (n < 0 || !tau || !dtau || (n > 0 && !dtau_partial) || (worklist && (nhead <= 0 || n % nhead))) return TMAE_EARG;
+  if (tau_per_head != 0 && tau_per_head != 1) return TMAE_EARG;
+  if (tau_per_head && (nhead <= 0 || n % nhead)) return TMAE_EARG;
   // the class bytes behind the four lists (tmae_window_worklist_size: counts | lists | class bytes); n = windows x heads
   const int8_t* listed = worklist ? reinterpret_cast<const int8_t*>(worklist + 8 + 4 * (n / nhead)) : nullptr;
-  int64_t nb = (n + 8191) / 8192;                              // >= 8 elements per thread and block
+  const int launches = tau_per_head ? nhead : 1, stride = tau_per_head ? nhead : 1;
+  const int64_t cnt = n / stride;
+  int64_t nb = (cnt + 8191) / 8192;                            // >= 8 elements per thread and block
   if (nb < 1) nb = 1;
   if (nb > DTAU_MAX_BLOCKS) nb = DTAU_MAX_BLOCKS;
-  hipLaunchKernelGGL(dtau_finish_kernel, dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream_, dtau_partial, n, tau,
-                     tau_min, dtau, listed, nhead > 0 ? nhead : 1);
+  for (int h = 0; h < launches; ++h)
+    hipLaunchKernelGGL(dtau_finish_kernel, dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream_, dtau_partial, cnt, tau,
+                       tau_min, dtau, listed, nhead > 0 ? nhead : 1, h, stride);
   return tmae_launch_status();
 }
 
@@ -387,13 +400,14 @@ static int attn_check(int64_t mq, int64_t mk, int nhead, int dh, int batch, int 
 int tmae_win_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, int dtype,
                       int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
                       int batch, int ny, int nx, int do_shift, const float* tau, float tau_min, void* out, int64_t ldo,
-                      float* lse, const int32_t* worklist, void* stream_) {
+                      float* lse, const int32_t* worklist, int tau_per_head, void* stream_) {
   (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   int r = attn_check(mq, mk, nhead, dh, batch, ny, nx);
   if (r) return r;
   if (mq == 0) return TMAE_OK;
   if (!q || !grid_q || !grid_k || !tau || !out || !lse || (mk > 0 && (!k || !v))) return TMAE_EARG;
+  if (tau_per_head != 0 && tau_per_head != 1) return TMAE_EARG;
   int Wy, Wx;
   attn_dims(ny, nx, Wy, Wx);
   const int s = do_shift ? WIN / 2 : WIN;
@@ -401,13 +415,13 @@ int tmae_win_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
   dim3 block(64 * (64 / dh));
 #define FWD(T, DH)                                                                                                   \
   hipLaunchKernelGGL((win_attn_fwd_kernel<T, DH>), grid, block, 0, stream, (const T*)q, ldq, (const T*)k, ldk,       \
-                     (const T*)v, ldv, nhead, grid_q, grid_k, ny, nx, Wy, Wx, s, s, tau, tau_min, (T*)out, ldo, lse)
+                     (const T*)v, ldv, nhead, grid_q, grid_k, ny, nx, Wy, Wx, s, s, tau, tau_min, (T*)out, ldo, lse, tau_per_head)
   if (dtype == TMAE_F32) { if (dh == 16) FWD(float, 16); else FWD(float, 32); }
   else if (dtype == TMAE_BF16) {
     if (use_mfma() && nhead % 4 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && !((uintptr_t)q & 15) &&
         !((uintptr_t)k & 15) && !((uintptr_t)v & 15))
       return tmae_win_attn_fwd_mfma(q, ldq, k, ldk, v, ldv, mq, mk, nhead, dh, grid_q, grid_k, batch, ny, nx, do_shift,
-                                    tau, tau_min, out, ldo, lse, worklist, stream);
+                                    tau, tau_min, out, ldo, lse, worklist, tau_per_head, stream);
     if (dh == 16) FWD(__hip_bfloat16, 16); else FWD(__hip_bfloat16, 32);
   }
   else return TMAE_EDTYPE;
@@ -420,12 +434,12 @@ int tmae_win_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
                       int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
                       int batch, int ny, int nx, int do_shift, const float* tau, float tau_min, void* dq, int64_t lddq,
                       void* dk, int64_t lddk, void* dv, int64_t lddv, float* dtau_partial, const int32_t* worklist,
-                      void* stream_) {
+                      int tau_per_head, void* stream_) {
   (void)hipGetLastError();   // drop stale errors of other runtime users: the return code is about OUR launches
   hipStream_t stream = (hipStream_t)stream_;
   int r = attn_check(mq, mk, nhead, dh, batch, ny, nx);
   if (r) return r;
-  if (!grid_q || !grid_k || !tau || !dtau_partial) return TMAE_EARG;
+  if (!grid_q || !grid_k || !tau || !dtau_partial || (tau_per_head != 0 && tau_per_head != 1)) return TMAE_EARG;
   if (mq > 0 && (!q || !out || !dout || !lse || !dq)) return TMAE_EARG;
   if (mk > 0 && (!k || !v || !dk || !dv)) return TMAE_EARG;
   int Wy, Wx;
@@ -436,7 +450,7 @@ int tmae_win_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
 #define BWD(T, DH)                                                                                                   \
   hipLaunchKernelGGL((win_attn_bwd_kernel<T, DH>), grid, block, 0, stream, (const T*)q, ldq, (const T*)k, ldk,       \
                      (const T*)v, ldv, (const T*)out, ldo, (const T*)dout, lddo, lse, nhead, grid_q, grid_k, ny, nx, \
-                     Wy, Wx, s, s, tau, tau_min, (T*)dq, lddq, (T*)dk, lddk, (T*)dv, lddv, dtau_partial)
+                     Wy, Wx, s, s, tau, tau_min, (T*)dq, lddq, (T*)dk, lddk, (T*)dv, lddv, dtau_partial, tau_per_head)
   if (dtype == TMAE_F32) { if (dh == 16) BWD(float, 16); else BWD(float, 32); }
   else if (dtype == TMAE_BF16) {
     const bool al = !(ldq % 8) && !(ldk % 8) && !(ldv % 8) && !(ldo % 8) && !(lddo % 8) && !((uintptr_t)q & 15) &&
@@ -444,7 +458,7 @@ int tmae_win_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, co
     if (use_mfma() && nhead % 4 == 0 && al && mq > 0 && mk > 0)
       return tmae_win_attn_bwd_mfma(q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, lse, mq, mk, nhead, dh, grid_q, grid_k,
                                     batch, ny, nx, do_shift, tau, tau_min, dq, lddq, dk, lddk, dv, lddv, dtau_partial,
-                                    worklist, stream);
+                                    worklist, tau_per_head, stream);
     if (dh == 16) BWD(__hip_bfloat16, 16); else BWD(__hip_bfloat16, 32);
   }
   else return TMAE_EDTYPE;

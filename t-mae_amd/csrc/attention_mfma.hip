@@ -433,6 +433,14 @@ struct AttnBufs {          // byte sizes of the tensors for the buffer descripto
 // 0.01, where the un-split error would be 5 % -- takes the split body.  The reference itself runs this bmm on fp16 operands
 // under AMP (2^-11).
 #define TAU_SPLIT_BELOW 0.25f
+// the smallest clamped temperature among the four heads of this workgroup (blockIdx.y * 4 ..): the wave's own one when shared
+__device__ __forceinline__ float block_min_tau(const float* __restrict__ tau, float tau_min, int tau_stride, float own) {
+  if (tau_stride == 0) return own;
+  float m = own;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) m = fminf(m, fmaxf(tau[(blockIdx.y * 4 + j) * tau_stride], tau_min));
+  return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(m)));
+}
 
 template <int DH, int NT, bool PAIR, bool SPLIT>
 __device__ __forceinline__ void win_attn_fwd_body(
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
     const __hip_bfloat16* __restrict__ v, int64_t ldv, int nhead, const int32_t* __restrict__ grid_q,
     const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx, int sy, int sx,
     const float* __restrict__ tau, float tau_min, __hip_bfloat16* __restrict__ out, int64_t ldo,
-    float* __restrict__ lse, const int32_t* __restrict__ wl, int cls, int64_t nwin, AttnBufs nb) {
+    float* __restrict__ lse, const int32_t* __restrict__ wl, int cls, int64_t nwin, AttnBufs nb, int tau_stride) {
   static_assert(!PAIR || NT == 1, "two windows per tile: single-tile class only");
   constexpr int RB = DH * 2 + 16, ROWS = NT * 16;
   __shared__ int toks[2][64];
@@ -613,11 +621,14 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
     return;
   }
   __syncthreads();
-  // tau is one number for the whole launch (cosine_msa.py:453-456): a scalar load, a scalar compare, one branch per wave
-  const float tau_c = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fmaxf(tau[0], tau_min))));
+  // tau is one number for the whole launch (cosine_msa.py:453-456; tau_stride 0): a scalar load, a scalar compare, one branch per
+  // wave -- or one per head (non_shared_tau, tau_stride 1): the wave's own head scales its logits, the SMALLEST temperature of the
+  // workgroup's four heads picks the body, because both bodies hold workgroup barriers (the split body is the more exact one)
+  const float tau_c = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fmaxf(tau[head * tau_stride], tau_min))));
   const float inv_tau = fast_rcp(tau_c);                       // v_rcp_f32 (1 ulp; the backward uses the same instruction): an IEEE
                                                                  // division is ~12 instructions of the ~370 a 16-token window costs
-  if (tau_c < TAU_SPLIT_BELOW)
+  const float tau_b = block_min_tau(tau, tau_min, tau_stride, tau_c);
+  if (tau_b < TAU_SPLIT_BELOW)
     win_attn_fwd_body<DH, NT, PAIR, true>(q, ldq, k, ldk, v, ldv, nhead, inv_tau, out, ldo, lse, nb, wi, toks, vimg);
   else
     win_attn_fwd_body<DH, NT, PAIR, false>(q, ldq, k, ldk, v, ldv, nhead, inv_tau, out, ldo, lse, nb, wi, toks, vimg);
@@ -637,7 +648,7 @@ static unsigned attn_bytes(int64_t rows, int64_t ld, int width) { return rows > 
 int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                            int64_t mq, int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k,
                            int batch, int ny, int nx, int do_shift, const float* tau, float tau_min, void* out,
-                           int64_t ldo, float* lse, const int32_t* worklist, hipStream_t stream) {
+                           int64_t ldo, float* lse, const int32_t* worklist, int tau_stride, hipStream_t stream) {
   if (nhead % 4 || (dh != 16 && dh != 32)) return TMAE_EARG;
   // 16-byte row fragments / V rows: bases and pitches must keep every head slice 16-byte aligned
   if ((ldq % 8) || (ldk % 8) || (ldv % 8) || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15))
@@ -656,7 +667,7 @@ int tmae_win_attn_fwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
   hipLaunchKernelGGL((win_attn_fwd_mfma_kernel<DH, NT, PAIR>), dim3((unsigned)(GX), (unsigned)(nhead / 4)), dim3(256), \
                      0, stream, (const __hip_bfloat16*)q, ldq, (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v, \
                      ldv, nhead, grid_q, grid_k, ny, nx, Wy, Wx, s, s, tau, tau_min, (__hip_bfloat16*)out, ldo, lse, \
-                     worklist, CLS, nwin, nb)
+                     worklist, CLS, nwin, nb, tau_stride)
   if (!worklist) {
     if (dh == 32) FWDM(32, 4, false, 0, nwin); else FWDM(16, 4, false, 0, nwin);
   } else {
@@ -973,7 +984,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
     const int32_t* __restrict__ grid_q, const int32_t* __restrict__ grid_k, int ny, int nx, int Wy, int Wx, int sy,
     int sx, const float* __restrict__ tau, float tau_min, __hip_bfloat16* __restrict__ dq, int64_t lddq,
     __hip_bfloat16* __restrict__ dk, int64_t lddk, __hip_bfloat16* __restrict__ dv, int64_t lddv,
-    float* __restrict__ dtau_partial, const int32_t* __restrict__ wl, int cls, int64_t nwin, AttnBufs nb) {
+    float* __restrict__ dtau_partial, const int32_t* __restrict__ wl, int cls, int64_t nwin, AttnBufs nb, int tau_stride) {
   static_assert(!PAIR || NT == 1, "two windows per tile: single-tile class only");
   __shared__ BwdLds<DH, NT> L;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -999,9 +1010,11 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
     return;
   }
   __syncthreads();                                   // token lists visible
-  // one temperature per launch (see TAU_SPLIT_BELOW): scalar compare, one branch per wave
-  const float tau_c = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fmaxf(tau[0], tau_min))));
-  if (tau_c < TAU_SPLIT_BELOW)
+  // one temperature per launch or per head (see the forward kernel): scalar compare, one branch per wave, the same for the four
+  // waves of the workgroup
+  const float tau_c = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fmaxf(tau[head * tau_stride], tau_min))));
+  const float tau_b = block_min_tau(tau, tau_min, tau_stride, tau_c);
+  if (tau_b < TAU_SPLIT_BELOW)
     win_attn_bwd_body<DH, NT, PAIR, true>(q, ldq, k, ldk, v, ldv, dout, lddo, lse, nhead, tau_c, dq, lddq, dk, lddk, dv, lddv,
                                           dtau_partial, dtp, nb, wi, L);
   else
@@ -1014,7 +1027,7 @@ int tmae_win_attn_bwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
                            int64_t mk, int nhead, int dh, const int32_t* grid_q, const int32_t* grid_k, int batch,
                            int ny, int nx, int do_shift, const float* tau, float tau_min, void* dq, int64_t lddq,
                            void* dk, int64_t lddk, void* dv, int64_t lddv, float* dtau_partial,
-                           const int32_t* worklist, hipStream_t stream) {
+                           const int32_t* worklist, int tau_stride, hipStream_t stream) {
   if (nhead % 4 || (dh != 16 && dh != 32)) return TMAE_EARG;
   if (!attn_sizes_ok(mq, ldq) || !attn_sizes_ok(mk, ldk) || !attn_sizes_ok(mk, ldv) || !attn_sizes_ok(mq, lddo) ||
       !attn_sizes_ok(mq, lddq) || !attn_sizes_ok(mk, lddk) || !attn_sizes_ok(mk, lddv) ||
@@ -1035,7 +1048,7 @@ int tmae_win_attn_bwd_mfma(const void* q, int64_t ldq, const void* k, int64_t ld
                      0, stream, (const __hip_bfloat16*)q, ldq, (const __hip_bfloat16*)k, ldk, (const __hip_bfloat16*)v, \
                      ldv, (const __hip_bfloat16*)out, ldo, (const __hip_bfloat16*)dout, lddo, lse, nhead, grid_q,     \
                      grid_k, ny, nx, Wy, Wx, s, s, tau, tau_min, (__hip_bfloat16*)dq, lddq, (__hip_bfloat16*)dk, lddk, \
-                     (__hip_bfloat16*)dv, lddv, dtau_partial, worklist, CLS, nwin, nb)
+                     (__hip_bfloat16*)dv, lddv, dtau_partial, worklist, CLS, nwin, nb, tau_stride)
   if (!worklist) {
     if (dh == 32) BWDM(32, 4, false, 0, nwin); else BWDM(16, 4, false, 0, nwin);
   } else {

@@ -37,14 +37,14 @@ SIGNATURES = {
     'tmae_index_grid': (I, [P, L, I, I, I, P, P]),
     'tmae_window_bucket_workspace': (Z, [I, I, I, I, I, I]),
     'tmae_window_bucket': (I, [P, L, P, P, I, I, I, I, I, I, P, I, P, P, P, P, P, P, P, P, Z, P]),
-    'tmae_win_attn_fwd': (I, [P, L, P, L, P, L, I, L, L, I, I, P, P, I, I, I, I, P, F, P, L, P, P, P]),
+    'tmae_win_attn_fwd': (I, [P, L, P, L, P, L, I, L, L, I, I, P, P, I, I, I, I, P, F, P, L, P, P, I, P]),
     'tmae_win_attn_zero_orphans': (I, [P, P, I, I, I, I, P, L, I, P, I, P, L, P, L, I, P]),
     'tmae_window_worklist_size': (Z, [I, I, I]),
     'tmae_window_worklist': (I, [P, P, I, I, I, I, P, P]),
-    'tmae_win_attn_dtau': (I, [P, L, P, F, P, P, I, P]),
+    'tmae_win_attn_dtau': (I, [P, L, P, F, P, P, I, I, P]),
     'tmae_win_attn_num_blocks': (L, [I, I, I, I, I]),
     'tmae_win_attn_bwd': (I, [P, L, P, L, P, L, P, L, P, L, P, I, L, L, I, I, P, P, I, I, I, I, P, F,
-                              P, L, P, L, P, L, P, P, P]),
+                              P, L, P, L, P, L, P, P, I, P]),
     'tmae_add_pos_embed': (I, [P, I, L, I, P, I, I, I, P, P, P]),
     'tmae_spconv_down_outputs_workspace': (Z, [I, I, I]),
     'tmae_spconv_down_outputs': (I, [P, I, I, I, I, I, P, P, P, P, Z, P]),
@@ -148,7 +148,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
     setattr(lib, _name, _strict(_fn, _name, len(_args)))
 
-ABI_VERSION = 24            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
+ABI_VERSION = 25            # = TMAE_ABI_VERSION of include/tmae_hip.h (hand-bumped with every change of the export list / a signature)
 if lib.tmae_abi_version() != ABI_VERSION:
     raise ImportError(f'libtmae_hip.so ABI version {lib.tmae_abi_version()} != binding {ABI_VERSION}; rebuild with '
                       f't-mae_amd/build.py')

@@ -42,17 +42,18 @@ def pos_embed_table(feat_dim, window_shape, pos_temperature, normalize_pos=False
 
 class CosineMultiheadAttention(nn.Module):
     """Parameter container with nn.MultiheadAttention's names (cosine_msa.py:441-458): packed in-proj,
-    out_proj, learnable temperature tau (1,1,1) clamped at tau_min."""
+    out_proj, learnable temperature tau clamped at tau_min: (1,1,1) shared by the heads, or (1, num_heads, 1, 1) with
+    non_shared_tau (cosine_msa.py:453-456)."""
 
     def __init__(self, embed_dim, num_heads, dropout=0.0, tau_min=0.01, cosine=True, non_shared_tau=False):
         super().__init__()
-        if dropout != 0.0 or not cosine or non_shared_tau:
-            raise NotImplementedError('T-MAE configs use cosine attention, shared tau, dropout 0')
+        if dropout != 0.0 or not cosine:
+            raise NotImplementedError('T-MAE configs use cosine attention, dropout 0')
         self.embed_dim, self.num_heads, self.tau_min = embed_dim, num_heads, tau_min
         self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
         self.out_proj = nn.Linear(embed_dim, embed_dim)
-        self.tau = nn.Parameter(torch.ones(1, 1, 1))
+        self.tau = nn.Parameter(torch.ones(1, num_heads, 1, 1) if non_shared_tau else torch.ones(1, 1, 1))
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.0)
 

@@ -1683,6 +1683,8 @@ class _WinAttn(torch.autograd.Function):
         q, ldq, k, ldk, v, ldv = _WinAttn._ptrs(a, b, c, d)
         cross = ctx.layout in ('q_kv', 'q_k_v')
         tau32 = tau.detach().reshape(-1).float().contiguous()
+        per_head = tau32.numel() > 1                     # non_shared_tau: tau [1, nhead, 1, 1] (cosine_msa.py:453-454)
+        assert tau32.numel() == (nhead if per_head else 1), (tuple(tau.shape), nhead)
         if a.dtype != torch.bfloat16:
             worklist = None                                  # the fp32 kernels walk the dense windows
         # cross mode starts from zeros: with a work list, tokens of windows in no list are not written; and under token
@@ -1698,7 +1700,7 @@ class _WinAttn(torch.autograd.Function):
                                                  nhead, None, 0, None, 0, 0, _s()), 'tmae_win_attn_zero_orphans')
         check(lib.tmae_win_attn_fwd(q, ldq, k, ldk, v, ldv, _dt(a), mq, mk, nhead, dh, _p(grid_q), _p(grid_k),
                                     batch, ny, nx, 1 if do_shift else 0, _p(tau32), float(tau_min), _p(out), d,
-                                    _p(lse), _p(worklist), _s()), 'tmae_win_attn_fwd')
+                                    _p(lse), _p(worklist), 1 if per_head else 0, _s()), 'tmae_win_attn_fwd')
         ctx.cross = cross
         ctx.orphans = orphans
         ctx.has_wl = worklist is not None
@@ -1735,11 +1737,12 @@ class _WinAttn(torch.autograd.Function):
         check(lib.tmae_win_attn_bwd(q, ldq, k, ldk, v, ldv, _p(out), d, _p(dout), d, _p(lse), _dt(a), mq, mk,
                                     nhead, dh, _p(grid_q), _p(grid_k), batch, ny, nx, 1 if do_shift else 0,
                                     _p(tau32), float(tau_min), dq, lddq, dk, lddk, dv, lddv, _p(part), _p(worklist),
-                                    _s()), 'tmae_win_attn_bwd')
+                                    1 if tau32.numel() > 1 else 0, _s()), 'tmae_win_attn_bwd')
         # d/d tau of logits = cos / max(tau, tau_min): -(1/tau_c) * sum dS*s, zero in the clamped branch
-        dtau = torch.empty((1,), dtype=torch.float32, device=a.device)
-        # fixed-order multi-block sum of the partials + the clamp rule, one launch
-        check(lib.tmae_win_attn_dtau(_p(part), nblk, _p(tau32), float(tau_min), _p(dtau), _p(worklist), nhead, _s()), 'tmae_win_attn_dtau')
+        dtau = torch.empty((tau32.numel(),), dtype=torch.float32, device=a.device)
+        # fixed-order multi-block sum of the partials + the clamp rule, one launch (one per head with per-head temperatures)
+        check(lib.tmae_win_attn_dtau(_p(part), nblk, _p(tau32), float(tau_min), _p(dtau), _p(worklist), nhead,
+                                     1 if tau32.numel() > 1 else 0, _s()), 'tmae_win_attn_dtau')
         dtau = dtau.reshape(tshape).to(tdtype)
         return da, db, (dc if torch.is_tensor(dc) else None), dtau, None, None, None, None, None, None, None, None, None, None
 

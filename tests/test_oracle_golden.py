@@ -116,6 +116,30 @@ def test_f7_attention(oracle):
         np.testing.assert_allclose(p['a.tau'].grad.numpy(), g[pre + 'dtau'], atol=1e-3 * max(1.0, np.abs(g[pre + 'dtau']).max()))
 
 
+def test_f14_attention_one_temperature_per_head(oracle):
+    """CosineMultiheadAttention(non_shared_tau=True), cosine_msa.py:453-454 / :155-158: the reference's outputs and gradients (three
+    cases, temperatures on both sides of the clamp at 0.01) vs the oracle with tau [1, H, 1, 1]."""
+    g = golden('F14_options')
+    for case in range(3):
+        pre = f'h{case}_'
+        E, H, T, nW, cross = [int(v) for v in g[pre + 'meta']]
+        p = {'a.' + k[len(pre) + 2:].replace('__', '.'): torch.from_numpy(g[k]) for k in g.files if k.startswith(pre + 'w_')}
+        assert tuple(p['a.tau'].shape) == (1, H, 1, 1)
+        q = torch.from_numpy(g[pre + 'q']).transpose(0, 1).clone().requires_grad_(True)
+        v = torch.from_numpy(g[pre + 'v']).transpose(0, 1).clone().requires_grad_(True)
+        k = torch.from_numpy(g[pre + 'k']).transpose(0, 1).clone().requires_grad_(True) if cross else q
+        kpm = torch.from_numpy(g[pre + 'kpm'])
+        qvalid = (torch.arange(T)[None, :] < torch.from_numpy(g[pre + 'qlens'])[:, None]).unsqueeze(-1).float()
+        p = {n: t.clone().requires_grad_(True) for n, t in p.items()}
+        out = oracle.cosine_mha(q, k, v, kpm, p, 'a.', H, 0.01)
+        (out * torch.from_numpy(g[pre + 'gout']).transpose(0, 1) * qvalid).sum().backward()
+        np.testing.assert_allclose((out * qvalid).detach().transpose(0, 1).numpy(), g[pre + 'out'], atol=1e-4)
+        np.testing.assert_allclose(q.grad.transpose(0, 1).numpy(), g[pre + 'dq'], atol=2e-4)
+        np.testing.assert_allclose(v.grad.transpose(0, 1).numpy(), g[pre + 'dv'], atol=2e-4)
+        np.testing.assert_allclose(p['a.tau'].grad.numpy(), g[pre + 'dtau'], atol=1e-3 * max(1.0, np.abs(g[pre + 'dtau']).max()))
+        assert float(np.abs(g[pre + 'dtau']).reshape(-1).min()) == 0.0          # the head below the clamp takes no gradient
+
+
 def test_f8_encoder_blocks(oracle):
     g = golden('F8_encoder_blocks')
     cfg = oracle.default_model_cfg(3)
