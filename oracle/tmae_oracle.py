@@ -456,7 +456,7 @@ def sst_encoder(x, coords, grid_xyz, p, prefix, stage, cfg, capture=None):
     per_shift = []
     for i in range(2):
         f2w = info[f'flat2win_inds_shift{i}']
-        pos = pos_embed(info[f'coors_in_win_shift{i}'], d, cfg['window_shape'], cfg['pos_temperature'])
+        pos = pos_embed(info[f'coors_in_win_shift{i}'], d, cfg['window_shape'], cfg['pos_temperature'], cfg.get('normalize_pos', False))
         per_shift.append((pos, f2w, key_padding_mask(f2w, cfg['drop_info'], xk.shape[0])))
     out = xk
     for blk in range(stage['num_blocks']):
@@ -582,8 +582,8 @@ def wca_encoder_layer(src, src_prv, cur, prv, shift, p, prefix, nhead, cfg):
     f2w, f2w_p = cur[f'flat2win_inds_shift{shift}'], prv[f'flat2win_inds_shift{shift}']
     if keep.numel() > 0:
         sel, sel_p = src[keep], src_prv[keep_p]
-        pos = pos_embed(cur[f'coors_in_win_shift{shift}'], d, cfg['window_shape'], cfg['pos_temperature'])
-        pos_p = pos_embed(prv[f'coors_in_win_shift{shift}'], d, cfg['window_shape'], cfg['pos_temperature'])
+        pos = pos_embed(cur[f'coors_in_win_shift{shift}'], d, cfg['window_shape'], cfg['pos_temperature'], cfg.get('normalize_pos', False))
+        pos_p = pos_embed(prv[f'coors_in_win_shift{shift}'], d, cfg['window_shape'], cfg['pos_temperature'], cfg.get('normalize_pos', False))
         q3, qp3 = flat2window(sel, f2w, di), flat2window(pos, f2w, di)
         k3, kp3 = flat2window(sel_p, f2w_p, di), flat2window(pos_p, f2w_p, di)
         kpm = key_padding_mask(f2w_p, di, sel_p.shape[0])
@@ -770,7 +770,8 @@ def init_params(cfg, seed=0, num_point_features=4, tau=None, pred_scale=1.0):
         a = f'{pre}win_attn.{attn_name}.'
         P[a + 'in_proj_weight'] = (torch.rand(3 * d, d, generator=g) * 2 - 1) * math.sqrt(6.0 / (4 * d))
         P[a + 'in_proj_bias'] = 0.02 * torch.randn(3 * d, generator=g)
-        P[a + 'tau'] = torch.ones(1, 1, 1)
+        # (1,1,1) shared; cfg['non_shared_tau']: one per head (cosine_msa.py:453-456), here drawn away from 1 so that heads differ
+        P[a + 'tau'] = (0.3 + 1.7 * torch.rand(1, cfg['stages'][0]['nhead'], 1, 1, generator=g)) if cfg.get('non_shared_tau', False) else torch.ones(1, 1, 1)
         lin(a + 'out_proj', d, d)
         lin(pre + 'linear1', dff, d)
         lin(pre + 'linear2', d, dff)
@@ -812,7 +813,7 @@ def init_params(cfg, seed=0, num_point_features=4, tau=None, pred_scale=1.0):
     lin('backbone_3d.decoder_pred', cfg['num_prd_points'] * 3, cmid)
     P['backbone_3d.decoder_pred.weight'] *= pred_scale
     P['backbone_3d.decoder_pred.bias'] *= pred_scale
-    if tau is not None:
+    if tau is not None and not cfg.get('non_shared_tau', False):
         for n_, t_ in P.items():
             if n_.endswith('tau'):
                 t_.fill_(tau)

@@ -52,11 +52,14 @@ def build_finetune_model(params=None, device='cpu', n_points=1000, batch_size=2)
 
 
 def build_product_model(num_stages=3, params=None, device='cpu', n_points=1000, batch_size=2, partial=False,
-                        waymo_shape=False):
-    """TMAE through the pcdet registry path; `params` = oracle-style state dict (reference key names)."""
+                        waymo_shape=False, cfg_edit=None):
+    """TMAE through the pcdet registry path; `params` = oracle-style state dict (reference key names); cfg_edit(cfg): changes
+    to the YAML's config before the model is built (options the shipped YAMLs leave off)."""
     from pcdet.models import build_network
     from tmae_amd.train import SyntheticTemporalDataset
     cfg = load_cfg(num_stages)
+    if cfg_edit is not None:
+        cfg_edit(cfg)
     npf = 5
     if waymo_shape:      # BASELINE configs[3]: 5 point features (x,y,z,intensity,elongation), z range [-2,4), 6 m pillars
         cfg.DATA_CONFIG.POINT_CLOUD_RANGE = [-74.88, -74.88, -2.0, 74.88, 74.88, 4.0]

@@ -1683,6 +1683,45 @@ def test_e2e_golden_and_oracle(oracle, name, nst):
         assert (a - b).abs().max().item() <= 5e-3 * max(1.0, b.abs().max().item()), n
 
 
+@pytest.mark.parametrize('amp', [False, True])
+def test_e2e_per_head_temperature_and_normalised_positions_vs_oracle(oracle, amp):
+    """The two options round 6 added (LAYER_CFG.non_shared_tau, PREPROCESS.NORMALIZE_POS; off in the shipped YAMLs) through the WHOLE
+    step of the 3-stage model built from the YAML with the options switched on: loss and every gradient (one per head for the
+    temperatures) against the CPU oracle with the same options, fp32 at the golden tests' bars; under bf16 autocast the loss within
+    3e-3 and the temperatures' gradients -- what the option adds -- direction-equal to the fp32 ones."""
+    g = golden('F10_e2e_3stage')                       # its inputs (points of both frames, masking noise); the parameters are drawn here
+    nst, bs = 3, int(g['batch_size'])
+    cfg = oracle.default_model_cfg(nst)
+    cfg['non_shared_tau'], cfg['normalize_pos'] = True, True
+    P = oracle.init_params(cfg, seed=5, pred_scale=float(g['pred_scale']))
+    taus = [k for k in P if k.endswith('.tau')]
+    assert taus and all(tuple(P[k].shape) == (1, 8, 1, 1) for k in taus)
+
+    def edit(c):
+        for blk in c.MODEL.BACKBONE_3D.SST_BLOCK_LIST:
+            blk.PREPROCESS.NORMALIZE_POS = True
+            blk.ENCODER.LAYER_CFG['non_shared_tau'] = True
+    model, _, _ = build_product_model(nst, params=P, device=dev(), cfg_edit=edit)
+    model.train()
+    loss, bd = _run_product(model, g['points'], g['points_prev'], g['noise'], bs, amp=True if amp else None)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lo = oracle.forward_loss(Pg, g['points'], g['points_prev'], g['noise'], bs, cfg)
+    lo.backward()
+    grads = dict(model.named_parameters())
+    assert all(tuple(grads[k].grad.shape) == (1, 8, 1, 1) for k in taus)
+    if not amp:
+        assert abs(fl(lo) - fl(loss)) < 1e-4, (fl(lo), fl(loss))
+        for n, p in grads.items():
+            if n in Pg and Pg[n].grad is not None and p.grad is not None:
+                a, b = p.grad.cpu(), Pg[n].grad
+                assert (a - b).abs().max().item() <= 5e-3 * max(1.0, b.abs().max().item()), n
+    else:
+        assert abs(fl(lo) - fl(loss)) < 3e-3, (fl(lo), fl(loss))
+        a = torch.cat([grads[k].grad.float().reshape(-1).cpu() for k in taus])
+        b = torch.cat([Pg[k].grad.reshape(-1) for k in taus])
+        assert float(torch.nn.functional.cosine_similarity(a, b, dim=0)) > 0.95
+
+
 def test_pair_encode_equals_two_encoder_calls(oracle):
     """Running both frames through the Siamese encoder as one token list (SiamWCA_MAE.sparse_encode_pair, per-frame
     BatchNorm groups) gives the results of the reference's two calls: loss, gradients, BatchNorm running statistics."""
