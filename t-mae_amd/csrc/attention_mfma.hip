@@ -433,13 +433,25 @@ struct AttnBufs {          // byte sizes of the tensors for the buffer descripto
 // 0.01, where the un-split error would be 5 % -- takes the split body.  The reference itself runs this bmm on fp16 operands
 // under AMP (2^-11).
 #define TAU_SPLIT_BELOW 0.25f
-// the smallest clamped temperature among the four heads of this workgroup (blockIdx.y * 4 ..): the wave's own one when shared
-__device__ __forceinline__ float block_min_tau(const float* __restrict__ tau, float tau_min, int tau_stride, float own) {
-  if (tau_stride == 0) return own;
-  float m = own;
+// own = max(tau of wave w's head, tau_min): scales the wave's logits; blk = the smallest clamped temperature of the workgroup's
+// four heads (blockIdx.y * 4 ..): picks the body for all four waves, because both bodies hold workgroup barriers (the split body is
+// the more exact one).  tau_stride 0 (the layer's one temperature, every shipped configuration) runs exactly the instructions it
+// ran before the per-head form existed -- one scalar load of tau[0] behind the token search; issuing four loads at the top of the
+// kernel, or one vector load of tau[head] here, cost the short classes 5-19 % (+0.25 ms per step, same-box A/B).  tau_stride 1
+// (non_shared_tau): scalar loads as well, the head index made wave-uniform first.
+struct TauPick { float own, blk; };
+__device__ __forceinline__ TauPick pick_tau(const float* __restrict__ tau, float tau_min, int tau_stride, int w) {
+  if (tau_stride == 0) {
+    const float t = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fmaxf(tau[0], tau_min))));
+    return TauPick{t, t};
+  }
+  const int h0 = (int)blockIdx.y * 4, ws = __builtin_amdgcn_readfirstlane(w);
+  const float own = fmaxf(tau[(h0 + ws) * tau_stride], tau_min);
+  float blk = own;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) m = fminf(m, fmaxf(tau[(blockIdx.y * 4 + j) * tau_stride], tau_min));
-  return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(m)));
+  for (int j = 0; j < 4; ++j) blk = fminf(blk, fmaxf(tau[(h0 + j) * tau_stride], tau_min));
+  return TauPick{__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(own))),
+                 __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(blk)))};
 }
 
 template <int DH, int NT, bool PAIR, bool SPLIT>
@@ -624,11 +636,11 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_mfma_kernel(
   // tau is one number for the whole launch (cosine_msa.py:453-456; tau_stride 0): a scalar load, a scalar compare, one branch per
   // wave -- or one per head (non_shared_tau, tau_stride 1): the wave's own head scales its logits, the SMALLEST temperature of the
   // workgroup's four heads picks the body, because both bodies hold workgroup barriers (the split body is the more exact one)
-  const float tau_c = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fmaxf(tau[head * tau_stride], tau_min))));
+  const TauPick tp = pick_tau(tau, tau_min, tau_stride, w);
+  const float tau_c = tp.own;
   const float inv_tau = fast_rcp(tau_c);                       // v_rcp_f32 (1 ulp; the backward uses the same instruction): an IEEE
                                                                  // division is ~12 instructions of the ~370 a 16-token window costs
-  const float tau_b = block_min_tau(tau, tau_min, tau_stride, tau_c);
-  if (tau_b < TAU_SPLIT_BELOW)
+  if (tp.blk < TAU_SPLIT_BELOW)
     win_attn_fwd_body<DH, NT, PAIR, true>(q, ldq, k, ldk, v, ldv, nhead, inv_tau, out, ldo, lse, nb, wi, toks, vimg);
   else
     win_attn_fwd_body<DH, NT, PAIR, false>(q, ldq, k, ldk, v, ldv, nhead, inv_tau, out, ldo, lse, nb, wi, toks, vimg);
@@ -1012,9 +1024,9 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(
   __syncthreads();                                   // token lists visible
   // one temperature per launch or per head (see the forward kernel): scalar compare, one branch per wave, the same for the four
   // waves of the workgroup
-  const float tau_c = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(fmaxf(tau[head * tau_stride], tau_min))));
-  const float tau_b = block_min_tau(tau, tau_min, tau_stride, tau_c);
-  if (tau_b < TAU_SPLIT_BELOW)
+  const TauPick tp = pick_tau(tau, tau_min, tau_stride, w);
+  const float tau_c = tp.own;
+  if (tp.blk < TAU_SPLIT_BELOW)
     win_attn_bwd_body<DH, NT, PAIR, true>(q, ldq, k, ldk, v, ldv, dout, lddo, lse, nhead, tau_c, dq, lddq, dk, lddk, dv, lddv,
                                           dtau_partial, dtp, nb, wi, L);
   else
