@@ -438,6 +438,25 @@ def test_attention_one_temperature_per_head_golden(case, dtype):
                 assert abs(mine[h] - dtau[h]) <= 0.3 * max(1.0, abs(dtau[h])), (h, mine[h], dtau[h])
 
 
+def test_gather_rows_scatters_its_gradient():
+    """ops.gather_rows (the visible voxels of the masked frame, SiamWCA_MAE.py:166-182): x[idx] for distinct indices; the backward puts
+    every gradient row in its place of a zeroed tensor -- equal to autograd's own (sorting, accumulating) backward of x[idx]; empty
+    index lists and a single row included."""
+    from tmae_amd import ops
+    g = torch.Generator(device=dev()).manual_seed(4)
+    for (m, c, n, dt) in ((1000, 128, 250, torch.bfloat16), (37, 16, 37, torch.float32), (50, 8, 0, torch.float32), (1, 128, 1, torch.bfloat16)):
+        x = torch.randn(m, c, device=dev(), generator=g).to(dt)
+        idx = torch.randperm(m, device=dev(), generator=g)[:n]
+        go = torch.randn(n, c, device=dev(), generator=g).to(dt)
+        a = x.clone().requires_grad_(True)
+        y = ops.gather_rows(a, idx)
+        y.backward(go)
+        b = x.clone().requires_grad_(True)
+        yr = b[idx]
+        yr.backward(go)
+        assert torch.equal(y, yr) and torch.equal(a.grad, b.grad) and a.grad.shape == x.shape
+
+
 def test_attention_bf16_and_softmax_property():
     """bf16 I/O (fp32 softmax/normalise) stays within bf16 tolerance of the fp32 kernel; with V = 1 every
     attended row must come back as exactly-normalised ones (rows of P sum to 1) -- at stage-1 size."""
